@@ -1,0 +1,610 @@
+"""Literal, object-by-object CPU restatement of the k-mer hot path of danielmoney/kmers.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under kmers_amd/ may import this module; only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the checker.
+
+PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors for this path and
+there is no JVM in the build container, so Kmers.jar could not be executed.  This restatement
+is pinned only by the hand-derived known-answer vectors of SURVEY.md Appendix B
+(tests/test_oracle_kat.py) and by agreement with the independent C restatement
+(oracle/kmers_oracle.c).  tools/jar_crosscheck.sh diffs against Kmers.jar when `java` exists.
+
+Every function cites the reference file:line it follows (paths relative to /root/reference/src,
+`jar:` = behaviour recovered from out/Kmers.jar bytecode).
+Pure-Python loops: use for small inputs only.
+"""
+import struct
+from collections import OrderedDict
+
+# ----------------------------------------------------------------------------- Kmers/Base.java
+# Base.java:7-10  A=0 C=1 T=2 G=3 ; Base.java:22-41 fromCharacterByte accepts upper and lower case
+_CHAR2CODE = {ord('A'): 0, ord('a'): 0, ord('C'): 1, ord('c'): 1,
+              ord('T'): 2, ord('t'): 2, ord('G'): 3, ord('g'): 3}
+_CODE2CHAR = "ACTG"
+
+
+class InvalidBaseException(Exception):
+    pass
+
+
+class InconsistentDataException(Exception):
+    pass
+
+
+def _sbyte(c):
+    """Java (byte) cast of an int."""
+    c &= 0xFF
+    return c - 256 if c >= 128 else c
+
+
+def _sshort(v):
+    """Java (short) cast of an int (KmersFromFile.java:165)."""
+    v &= 0xFFFF
+    return v - 65536 if v >= 32768 else v
+
+
+# ------------------------------------------------------------------------- Kmers/Sequence.java
+class Kmer:
+    """Kmers/Kmer.java + Kmers/Sequence.java.  `chars` = list of base codes 0..3."""
+
+    def __init__(self, chars):
+        # Sequence.java:15-35: first byte > 4 => ASCII letters, convert each (may throw);
+        # otherwise the bytes are codes already and any byte > 4 throws.  Bytes are signed.
+        chars = [_sbyte(c) for c in chars]
+        if chars[0] > 4:
+            out = []
+            for c in chars:
+                code = _CHAR2CODE.get(c & 0xFF) if c >= 0 else None
+                if code is None:
+                    raise InvalidBaseException()
+                out.append(code)
+            chars = out
+        else:
+            for c in chars:
+                if c > 4:
+                    raise InvalidBaseException()
+        self.chars = chars
+
+    def copy(self):
+        k = Kmer.__new__(Kmer)
+        k.chars = list(self.chars)
+        return k
+
+    def length(self):
+        return len(self.chars)
+
+    def key(self, num):  # Kmer.java:47-55
+        key = 0
+        for i in range(num):
+            key = key * 4 + self.chars[i]
+        return key
+
+    def cbytes(self):  # Sequence.java:90-115
+        n = len(self.chars)
+        l = (n - 1) // 4 + 1
+        r = bytearray(l)
+        c = 0
+        cb = 0
+        cc = 0
+        for i in range(n):
+            cb = ((cb << 2) + self.chars[i]) & 0xFF
+            cc += 1
+            if cc == 4:
+                r[c] = cb
+                c += 1
+                cc = 0
+                cb = 0
+        if cc != 0:
+            cb = (cb << ((4 - cc) * 2)) & 0xFF
+            r[c] = cb
+        return bytes(r)
+
+    def compressed_bytes(self):  # Kmer.java:90-97  [len byte][packed]
+        return bytes([len(self.chars) & 0xFF]) + self.cbytes()
+
+    @staticmethod
+    def from_compressed_seq(seq_bytes, length):  # Sequence.java:236-257
+        b = [0] * length
+        l = (length - 1) // 4 + 1
+        for i in range(l):
+            cb = seq_bytes[i]
+            for j in range(4):
+                p = i * 4 + (3 - j)
+                if p < length:
+                    b[p] = cb & 3
+                cb >>= 2
+        return b
+
+    @staticmethod
+    def create_from_compressed(data):  # Kmer.java:326-345
+        length = data[0]
+        return Kmer(Kmer.from_compressed_seq(data[1:], length)) if length > 0 else None
+
+    def inplace_rc(self):  # Kmer.java:142-208: A<->T, C<->G  == code ^ 2, reversed
+        comp = {0: 2, 1: 3, 2: 0, 3: 1}
+        ch = self.chars
+        n = len(ch)
+        for i in range(n // 2):
+            temp = comp[ch[i]]
+            ch[i] = comp[ch[n - i - 1]]
+            ch[n - i - 1] = temp
+        if n % 2 == 1:
+            ch[n // 2] = comp[ch[n // 2]]
+
+    def is_own_rc(self):  # Kmer.java:210-225: a *palindrome* test, even lengths only
+        n = len(self.chars)
+        if n % 2 == 1:
+            return False
+        for i in range(n // 2):
+            if self.chars[i] != self.chars[n - i - 1]:
+                return False
+        return True
+
+    def compare_to(self, other):  # Sequence.java:165-187
+        a, b = self.chars, other.chars
+        for i in range(min(len(a), len(b))):
+            if a[i] < b[i]:
+                return -1
+            if a[i] > b[i]:
+                return 1
+        if len(a) < len(b):
+            return -1
+        if len(a) > len(b):
+            return 1
+        return 0
+
+    def sort_key(self):
+        # tuple order == compare_to order (element-wise, shorter-prefix first)
+        return tuple(self.chars)
+
+    def __str__(self):  # Sequence.java:117-134
+        return "".join(_CODE2CHAR[c] for c in self.chars)
+
+    def __eq__(self, o):
+        return isinstance(o, Kmer) and self.chars == o.chars
+
+    def __hash__(self):
+        return hash(tuple(self.chars))
+
+
+# ------------------------------------------------- OtherFiles/KmersFromFileStateChanger.java
+ID, KMER, OTHER = "ID", "KMER", "OTHER"
+
+
+def fa_state_changer():  # KmersFromFileStateChanger.java:46-58
+    return OTHER, {(ID, ord(' ')): OTHER, (ID, ord('\n')): KMER, (OTHER, ord('\n')): KMER,
+                   (KMER, ord('\n')): OTHER, (OTHER, ord('>')): ID}
+
+
+def fq_state_changer():  # KmersFromFileStateChanger.java:60-68
+    return OTHER, {(OTHER, ord('@')): ID, (KMER, ord('@')): ID, (ID, ord('\n')): KMER,
+                   (KMER, ord('+')): OTHER}
+
+
+class ReadIDMapping:  # OtherFiles/ReadIDMapping.java:5-28
+    def __init__(self):
+        self.names = []          # what `out.println(id)` writes, in order
+        self.cur_s = ""
+        self.cur_i = -1
+
+    def ge_next(self, rid):      # ReadIDMapping.java:14-23
+        if rid != self.cur_s:
+            self.names.append(rid)
+            self.cur_s = rid
+            self.cur_i += 1
+        return self.cur_i
+
+
+def kmers_from_file(data, state_changer, min_k, max_k, mapper):
+    """KmersFromFile.KmersFromFileSpliterator (KmersFromFile.java:65-243) driven to exhaustion.
+
+    `data`: bytes of the (already gunzipped) file.  `mapper(id_str, short_pos)` as the
+    BiFunction at KmersFromFile.java:39-52.  Returns the list of (Kmer, payload) in stream order.
+    One loop iteration below == one iteration of the do/while at KmersFromFile.java:88-192;
+    the outer `while True` == repeated tryAdvance calls.
+    """
+    start_state, table = state_changer
+    out = []
+    kmerbytes = [0] * max_k
+    state = start_state
+    idb = []
+    ending = False
+    end_file = False
+    cur_k = 0
+    oldid = ""
+    pos = 0
+    kwd = None
+    ip = 0
+    n = len(data)
+    while True:                                    # one tryAdvance per outer iteration
+        while True:                                # do { ... } while (kwd == null ...)
+            broke = False
+            if ending:                             # :90-111
+                if cur_k < min_k:
+                    ending = False
+                    kwd = None
+                else:
+                    newbytes = kmerbytes[max_k - cur_k:max_k]
+                    try:
+                        kwd = (Kmer(newbytes), mapper(oldid, _sshort(pos - cur_k)))
+                    except InvalidBaseException:
+                        pass
+                    cur_k -= 1
+            else:
+                if ip >= n:                        # in.read() == -1  :116-123
+                    ending = True
+                    oldid = "".join(idb)
+                    cur_k = min(pos - 1, max_k - 1)
+                    end_file = True
+                    broke = True
+                else:
+                    c = data[ip]
+                    ip += 1
+                    new_state = table.get((state, c))
+                    if new_state is not None:      # :126-148
+                        if state == KMER and pos >= min_k:
+                            oldid = "".join(idb)
+                            ending = True
+                            cur_k = min(pos, max_k - 1)
+                        state = new_state
+                        if state == KMER:
+                            pos = 0
+                        elif state == ID:
+                            idb = []
+                            kwd = None
+                        else:
+                            kwd = None
+                    else:                          # :149-189
+                        if state == KMER:
+                            if c > 32:
+                                pos += 1
+                                kmerbytes = kmerbytes[1:] + [c]
+                                if pos >= max_k:
+                                    try:
+                                        k = Kmer(list(kmerbytes))
+                                        kwd = (k, mapper("".join(idb), _sshort(pos - max_k)))
+                                    except InvalidBaseException:
+                                        kwd = None
+                                        if pos > min_k:
+                                            ending = True
+                                            oldid = "".join(idb)
+                                            cur_k = min(pos - 1, max_k - 1)
+                            else:
+                                kwd = None
+                        elif state == ID:
+                            idb.append(chr(c))
+            if broke:
+                break
+            if kwd is not None:                    # while ((kwd == null) && (true))
+                break
+        if kwd is None:
+            return out
+        out.append((kwd[0].copy(), kwd[1]))
+        # NB: kwd is a *field* and survives into the next tryAdvance (quirk C.7: a file that
+        # lacks its final newline emits its last k-mer twice) -- so it is not reset here.
+
+
+def fa_to_refdb_mapper(id_str, pos):  # KmersFromFile.java:39-42
+    return int(id_str)  # Integer.parseInt: raises ValueError like NumberFormatException
+
+
+def make_fq_mapper(read_map):  # KmersFromFile.java:49-52
+    return lambda s, i: (read_map.ge_next(s), i)
+
+
+# -------------------------------------------------------------------- codecs (App. A.4, src/)
+def int_compress(v):  # jar:Compression.IntCompressor  4 B big-endian
+    return struct.pack(">i", v)
+
+
+def readpos_compress(rp):  # Reads/ReadPosDataType.java:22-28
+    return struct.pack(">ih", rp[0], rp[1])
+
+
+def count_compress(cmap):  # Counts/CountDataType.java:31-46  (cmap: dict taxon->count)
+    b = struct.pack(">h", _sshort(len(cmap)))
+    for t in sorted(cmap):
+        b += struct.pack(">iB", t, min(cmap[t], 255))
+    return b
+
+
+def count_decompress(buf, off):  # CountDataType.java:83-95 + :48-67
+    (n,) = struct.unpack_from(">h", buf, off)
+    off += 2
+    m = OrderedDict()
+    for _ in range(n):
+        t, c = struct.unpack_from(">iB", buf, off)
+        off += 5
+        m[t] = c
+    return m, off
+
+
+def readset_compress(rps):  # jar:Compression.SetCompressor [int n] + n x child
+    b = struct.pack(">i", len(rps))
+    for rp in rps:
+        b += readpos_compress(rp)
+    return b
+
+
+def readset_decompress(buf, off):
+    (n,) = struct.unpack_from(">i", buf, off)
+    off += 4
+    out = []
+    for _ in range(n):
+        out.append(struct.unpack_from(">ih", buf, off))
+        off += 6
+    return out, off
+
+
+def byte_id(ids):  # jar:Compression.Compressor.getByteID
+    return struct.pack(">i", len(ids)) + b"".join(struct.pack(">i", i) for i in ids)
+
+
+REF_ID = [2048]          # CountDataType.java:115-121
+READ_ID = [257, 2052]    # jar SetCompressor [257] ++ ReadPosDataType.java:57-62
+
+
+def kwd_compress(kmer, payload_bytes):  # Kmers/KmerWithDataDataType.java:62-72
+    return kmer.compressed_bytes() + payload_bytes
+
+
+# ------------------------------------------------------------------ KmerFiles/FileCreator.java
+class FileCreator:
+    """FileCreator.java:31-438 without the disk: the temp bucket file is a dict key -> bytes.
+
+    kind = 'ref'  : DataCollector.getCountInstance  (IntDataType, CountDataType, TreeCountMap)
+    kind = 'read' : DataCollector.getReadInstance   (ReadPosDataType, SetDataType, toSet)
+    (DataTypes/DataCollector.java:63-81)
+    """
+
+    def __init__(self, key_length, kind, rc):
+        self.key_length = key_length
+        self.maxkey = 4 ** key_length            # FileCreator.java:40-44
+        self.kind = kind
+        self.rc = rc
+        self.min_k = -1
+        self.max_k = -1
+        self.buckets = {}
+
+    def _payload(self, d):
+        return int_compress(d) if self.kind == "ref" else readpos_compress(d)
+
+    def add_kmers(self, kwds, min_k, max_k):     # FileCreator.java:65-110
+        if self.min_k == -1:
+            self.min_k, self.max_k = min_k, max_k
+        if self.min_k != min_k or self.max_k != max_k:
+            raise InconsistentDataException(
+                "New stream does not have the same min or max kmer length as a previous stream")
+        for kmer, d in kwds:
+            self.buckets.setdefault(kmer.key(self.key_length), bytearray()).extend(
+                kwd_compress(kmer, self._payload(d)))
+            if self.rc and not kmer.is_own_rc():  # :83-87
+                kmer.inplace_rc()
+                self.buckets.setdefault(kmer.key(self.key_length), bytearray()).extend(
+                    kwd_compress(kmer, self._payload(d)))
+
+    def meta(self):                              # FileCreator.java:153-164
+        ids = REF_ID if self.kind == "ref" else READ_ID
+        return bytes([self.min_k & 0xFF, self.max_k & 0xFF, self.key_length & 0xFF]) + \
+            byte_id(ids) + bytes([1 if self.rc else 0])
+
+    def make_key(self, index):
+        """MakeAndWriteKey.call (FileCreator.java:271-406), non-hr.  Returns
+        (block_bytes, entries) with entries = [(Kmer, collection)] ascending."""
+        buf = bytes(self.buckets.get(index, b""))
+        kmers = {}
+        off = 0
+        while off < len(buf):                    # :280-303
+            length = buf[off]
+            l = (length - 1) // 4 + 1
+            k = Kmer.create_from_compressed(buf[off:off + l + 1])
+            off += l + 1
+            if self.kind == "ref":
+                (d,) = struct.unpack_from(">i", buf, off)
+                off += 4
+            else:
+                d = struct.unpack_from(">ih", buf, off)
+                off += 6
+            sk = k.sort_key()
+            cm = kmers.get(sk)
+            if cm is None:
+                cm = (k, {} if self.kind == "ref" else [])
+                kmers[sk] = cm
+            if self.kind == "ref":               # jar:TreeCountMap.add
+                cm[1][d] = cm[1].get(d, 0) + 1
+            else:                                # HashSet<ReadPos>.add, identity-hashed objects
+                cm[1].append(d)
+        entries = []
+        out = bytearray()
+        prev = bytes(1)                          # :315
+        for sk in sorted(kmers):                 # TreeMap ascending, Sequence.compareTo
+            k, coll = kmers[sk]
+            kc = k.compressed_bytes()
+            s = 0                                # shared(): FileCreator.java:244-252
+            while s < len(prev) and s < len(kc) and prev[s] == kc[s]:
+                s += 1
+            prev = kc
+            out.append(s & 0xFF)
+            out.extend(kc if s == 0 else kc[s:])
+            if self.kind == "ref":
+                out.extend(count_compress(coll))
+            else:
+                # Java order is HashSet iteration order (nondeterministic); canonical = ascending
+                coll.sort()
+                out.extend(readset_compress(coll))
+            entries.append((k, coll))
+        return bytes(out), entries
+
+    def create(self):
+        """FileCreator.create (:117-217) minus the container: {-1: meta, key: block} for all keys."""
+        blocks = {-1: self.meta()}
+        for i in range(self.maxkey):             # every key gets a (possibly empty) block
+            blocks[i] = self.make_key(i)[0]
+        return blocks
+
+
+# ---------------------------------------------------------------------- KmerFiles/KmerFile.java
+def parse_meta(meta):  # KmerFile.java:275-289 (binary branch)
+    min_k, max_k, key_len = meta[0], meta[1], meta[2]
+    (n,) = struct.unpack_from(">i", meta, 3)
+    ids = list(struct.unpack_from(">%di" % n, meta, 7))
+    rc = meta[7 + 4 * n] == 1
+    return min_k, max_k, key_len, ids, rc
+
+
+def decode_block(block, kind):
+    """CompressedKmerSpliterator.tryAdvance (KmerFile.java:200-250) over one key's bytes."""
+    out = []
+    off = 0
+    prevkb = b""
+    while off < len(block):
+        copy = _sbyte(block[off])
+        off += 1
+        if copy == 0:
+            length = block[off]
+            off += 1
+        else:
+            length = prevkb[0]
+        l = (length - 1) // 4 + 1
+        if copy > 0:
+            kb = prevkb[:copy] + block[off:off + l - copy + 1]
+            off += l - copy + 1
+        else:
+            kb = bytes([length]) + block[off:off + l]
+            off += l
+        prevkb = kb
+        k = Kmer.create_from_compressed(kb)
+        if kind == "ref":
+            data, off = count_decompress(block, off)
+        else:
+            data, off = readset_decompress(block, off)
+        out.append((k, data))
+    return out
+
+
+# ---------------------------------------------------------------------------- Database/DB.java
+class DB:
+    """Database/DB.java over one or more decoded reference DBs (each = blocks dict)."""
+
+    def __init__(self, files):
+        metas = [parse_meta(f[-1]) for f in files]
+        for m in metas:                          # DB.java:36-42
+            if m[3] != metas[0][3]:
+                raise InconsistentDataException("Files contain different datatypes")
+        self.min_k, self.max_k, self.key_length = metas[0][0], metas[0][1], metas[0][2]
+        for m in metas:                          # DB.java:57-64
+            if (m[0], m[1], m[2]) != (self.min_k, self.max_k, self.key_length) or not m[4]:
+                raise InconsistentDataException(
+                    "Files contains different kmer parameters (min/max length, key length or "
+                    "reverse complement included")
+        self.files = files
+        self.max_key = 4 ** self.key_length
+
+    def kmers(self, key):
+        """DB.kmers (DB.java:99-109): k-way merge (jar:StreamUtils.mergeSortedStreams, ties by
+        source index) + groupAndReduce with merger addAll (counts add as longs, quirk C.9)."""
+        merged = []
+        for si, f in enumerate(self.files):
+            for k, data in decode_block(f.get(key, b""), "ref"):
+                merged.append((k.sort_key(), si, k, data))
+        merged.sort(key=lambda t: (t[0], t[1]))
+        out = []
+        for sk, _, k, data in merged:
+            if out and out[-1][0].sort_key() == sk:
+                for t, c in data.items():
+                    out[-1][1][t] = out[-1][1].get(t, 0) + c
+            else:
+                out.append((k, dict(data)))
+        return out
+
+    def quick_match(self, search):
+        """getNearestKmers quick branch (DB.java:76-90,129-137): group the ascending search
+        stream by key; per group two-pointer inner join (jar:StreamUtils.matchTwoStreams --
+        both sides advance on a hit) against kmers(key)."""
+        res = []
+        i = 0
+        n = len(search)
+        while i < n:
+            key = search[i][0].key(self.key_length)
+            j = i
+            while j < n and search[j][0].key(self.key_length) == key:
+                j += 1
+            ref = self.kmers(key)
+            a, b = i, 0
+            while a < j and b < len(ref):
+                c = search[a][0].compare_to(ref[b][0])
+                if c == 0:
+                    res.append((search[a][0], search[a][1], ref[b][1]))
+                    a += 1
+                    b += 1
+                elif c < 0:
+                    a += 1
+                else:
+                    b += 1
+            i = j
+        return res
+
+
+def match_lines(search_blocks, db):
+    """Matcher.doMatching (Matcher.java:235-250), read-vs-reference, maxDiff 0, one search file.
+    Line text: ResultsDataType.java:15-35 -> KMER \\t r:p|r:p \\t -|TxC|TxC
+    (KmerWithDataDataType.java:74-82, DataPairDataType.java:43-50, KmerDiff.java:54-67,
+    ReadPosDataType.java:46-49, CountDataType.java:109-113 with separators "x" and "|")."""
+    min_k, max_k, key_len, ids, rc = parse_meta(search_blocks[-1])
+    kind = "read" if ids == READ_ID else "ref"
+    search = []
+    for key in range(4 ** key_len):
+        search.extend(decode_block(search_blocks.get(key, b""), kind))
+    lines = []
+    for kmer, sdata, rdata in db.quick_match(search):
+        if kind == "read":
+            s = "|".join("%d:%d" % (r, p) for r, p in sorted(sdata))  # canonical order
+        else:
+            s = "|".join("%dx%d" % (t, sdata[t]) for t in sorted(sdata))
+        r = "|".join("%dx%d" % (t, rdata[t]) for t in sorted(rdata))
+        lines.append("%s\t%s\t-|%s" % (kmer, s, r))
+    return lines
+
+
+# --------------------------------------------------------------------- Utils/TaxaCounts.java
+def taxa_counts(db):
+    """TaxaCounts default mode (TaxaCounts.java:119-150, 355-360, 386-395, 427-436)."""
+    match, unique = {}, {}
+    for key in range(db.max_key):
+        for _, data in db.kmers(key):
+            for t in data:
+                match[t] = match.get(t, 0) + 1
+            if len(data) == 1:
+                t = next(iter(data))
+                unique[t] = unique.get(t, 0) + 1
+    return ["%d\t%d\t%d" % (t, match[t], unique.get(t, 0)) for t in sorted(match)]
+
+
+# ----------------------------------------------------------------- Kmers/Dust.java, RunOfSame
+def dust_test(kmer, threshold):  # Dust.java:12-30
+    counts = [0] * 64
+    ch = kmer.chars
+    for i in range(len(ch) - 2):
+        counts[ch[i] * 16 + ch[i + 1] * 4 + ch[i + 2]] += 1
+    score = sum(c * (c - 1) for c in counts)
+    return score < threshold * len(ch) * 2
+
+
+# --------------------------------------------------------------------- convenience pipelines
+def build_ref_db(fasta_bytes, k, key_length, min_k=None, rc=True):
+    """MakeDatabase -a (MakeDatabase.java:127-163): FASTA -> reference DB blocks."""
+    min_k = k if min_k is None else min_k
+    fc = FileCreator(key_length, "ref", rc)
+    fc.add_kmers(kmers_from_file(fasta_bytes, fa_state_changer(), min_k, k, fa_to_refdb_mapper),
+                 min_k, k)
+    return fc.create()
+
+
+def build_read_db(fastq_bytes, k, key_length, min_k=None):
+    """MakeDatabase -q (MakeDatabase.java:165-185): FASTQ -> read DB blocks + read-name map."""
+    min_k = k if min_k is None else min_k
+    rm = ReadIDMapping()
+    fc = FileCreator(key_length, "read", False)
+    fc.add_kmers(kmers_from_file(fastq_bytes, fq_state_changer(), min_k, k, make_fq_mapper(rm)),
+                 min_k, k)
+    return fc.create(), rm.names
