@@ -1,0 +1,120 @@
+"""ctypes wrapper around oracle/kmers_oracle.c (TEST INFRASTRUCTURE ONLY -- see that file's header)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libkmers_oracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    u64, vp = C.c_uint64, C.c_void_p
+    lib.ko_build.restype = vp
+    lib.ko_build.argtypes = [C.c_char_p, u64, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.ko_free.argtypes = [vp]
+    for n in ("U", "V", "n_windows", "n_records", "n_reads"):
+        f = getattr(lib, "ko_" + n)
+        f.restype, f.argtypes = u64, [vp]
+    for n in ("keys", "val_off", "val_a", "val_b", "bucket_off", "name_off", "names"):
+        f = getattr(lib, "ko_" + n)
+        f.restype, f.argtypes = vp, [vp]
+    lib.ko_encode_blocks.restype = u64
+    lib.ko_encode_blocks.argtypes = [vp, vp, u64, vp]
+    lib.ko_match.restype = u64
+    lib.ko_match.argtypes = [vp, vp, vp, C.c_int]
+    lib.ko_match_lines.restype = u64
+    lib.ko_match_lines.argtypes = [vp, vp, vp, vp, u64]
+    lib.ko_taxacounts.restype = u64
+    lib.ko_taxacounts.argtypes = [vp, vp, vp, vp, u64]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+class OracleDB:
+    """Result of MakeDatabase (-a: mode 0, -q: mode 1) as CSR arrays."""
+
+    def __init__(self, data: bytes, mode: int, k: int, key_len: int, threads: int = 1):
+        L = lib()
+        self._h = L.ko_build(data, len(data), mode, k, key_len, threads)
+        if not self._h:
+            raise ValueError("ko_build rejected the parameters")
+        h = self._h
+        self.k, self.key_len, self.kind = k, key_len, mode
+        self.U, self.V = L.ko_U(h), L.ko_V(h)
+        self.n_windows, self.n_records = L.ko_n_windows(h), L.ko_n_records(h)
+        self.keys = _arr(L.ko_keys(h), self.U, np.uint64)
+        self.val_off = _arr(L.ko_val_off(h), self.U + 1, np.uint64)
+        self.val_a = _arr(L.ko_val_a(h), self.V, np.int32)
+        self.val_b = _arr(L.ko_val_b(h), self.V, np.int32)
+        self.bucket_off = _arr(L.ko_bucket_off(h), 4 ** key_len + 1, np.uint64)
+        self.names = []
+        if mode == 1:
+            nr = L.ko_n_reads(h)
+            off = _arr(L.ko_name_off(h), nr + 1, np.uint64)
+            raw = _arr(L.ko_names(h), int(off[-1]) if nr else 0, np.uint8).tobytes()
+            self.names = [raw[int(off[i]):int(off[i + 1])].decode("latin-1") for i in range(nr)]
+
+    def close(self):
+        if self._h:
+            lib().ko_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def encode_blocks(self):
+        """-> (bytes of all 4^l blocks back to back, block_off[4^l+1])."""
+        L = lib()
+        nk = 4 ** self.key_len
+        off = np.zeros(nk + 1, dtype=np.uint64)
+        need = L.ko_encode_blocks(self._h, None, 0, off.ctypes.data)
+        out = np.zeros(max(need, 1), dtype=np.uint8)
+        L.ko_encode_blocks(self._h, out.ctypes.data, need, off.ctypes.data)
+        return out[:need].tobytes(), off
+
+    def match(self, ref: "OracleDB", threads: int = 1):
+        hit = np.empty(self.U, dtype=np.int64)
+        n = lib().ko_match(self._h, ref._h, hit.ctypes.data, threads)
+        return hit, n
+
+    def match_lines(self, ref: "OracleDB", hit):
+        L = lib()
+        hit = np.ascontiguousarray(hit, dtype=np.int64)
+        need = L.ko_match_lines(self._h, ref._h, hit.ctypes.data, None, 0)
+        out = np.zeros(max(need, 1), dtype=np.uint8)
+        L.ko_match_lines(self._h, ref._h, hit.ctypes.data, out.ctypes.data, need)
+        return out[:need].tobytes()
+
+    def taxacounts(self):
+        L = lib()
+        cap = max(self.V, 1)
+        t = np.zeros(cap, np.int32)
+        m = np.zeros(cap, np.int64)
+        q = np.zeros(cap, np.int64)
+        n = L.ko_taxacounts(self._h, t.ctypes.data, m.ctypes.data, q.ctypes.data, cap)
+        return t[:n], m[:n], q[:n]

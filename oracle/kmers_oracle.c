@@ -1,0 +1,397 @@
+/* CPU restatement (plain C) of the k-mer hot path of danielmoney/kmers.
+ *
+ * TEST INFRASTRUCTURE ONLY: linked/loaded only by tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg, as the checker / reported baseline -- never by the product path.
+ *
+ * PARITY UNPINNED: the reference has no tests, fixtures or golden vectors and Kmers.jar cannot be
+ * run here (no JVM).  Pinned only by SURVEY.md Appendix B known answers and by byte-for-byte
+ * agreement with the independent literal restatement oracle/slow_ref.py (tests/test_oracle_c.py).
+ *
+ * Follows the reference algorithm step by step (paths relative to /root/reference/src):
+ *   - char-at-a-time ID/KMER/OTHER state machine, sliding maxK-byte window that is shifted per
+ *     base and re-encoded per window           OtherFiles/KmersFromFile.java:84-208,
+ *                                              OtherFiles/KmersFromFileStateChanger.java:46-68
+ *   - base codes A0 C1 T2 G3, 2-bit MSB-first packing   Kmers/Base.java:7-41, Sequence.java:90-115
+ *   - RC record unless palindrome (even k)               Kmers/Kmer.java:142-225, FileCreator.java:77-95
+ *   - bucket by key(keyLength), per bucket sort + dedup + reduce, prefix-delta encode
+ *                                                        KmerFiles/FileCreator.java:65-110,271-406
+ *   - CountDataType / SetCompressor<ReadPos> codecs      Counts/CountDataType.java:31-46, jar
+ *   - per-key two-pointer inner join                     Database/DB.java:76-90,129-137, jar StreamUtils
+ *   - match line text                                    DataTypes/ResultsDataType.java:15-35
+ *   - TaxaCounts default mode                            Utils/TaxaCounts.java:119-150,386-395
+ * Restrictions (documented): minK == maxK, k <= 32, input bytes < 128.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct {
+    uint64_t kmer;  /* cBytes() zero-padded to 8 bytes, read big-endian == left-aligned 2-bit */
+    int32_t a;      /* taxon | read index */
+    int32_t b;      /* (unused) | pos (Java short) */
+} ko_rec;
+
+typedef struct {
+    int k, key_len, kind /*0 ref, 1 read*/, rc;
+    uint64_t n_windows;   /* valid forward windows emitted by the extractor */
+    uint64_t n_records;   /* temp-bucket records (fwd + rc) */
+    uint64_t U, V;
+    uint64_t *keys;       /* U  */
+    uint64_t *val_off;    /* U+1 */
+    int32_t *val_a;       /* V: taxon | read */
+    int32_t *val_b;       /* V: count (unsaturated, clamped to int32) | pos */
+    uint64_t *bucket_off; /* 4^key_len + 1, in units of unique k-mers */
+    /* read DB only: read-name map (ReadIDMapping.java) */
+    uint64_t n_reads;
+    uint64_t *name_off;   /* n_reads+1 offsets into names */
+    char *names;
+} ko_db;
+
+enum { ST_ID = 0, ST_KMER = 1, ST_OTHER = 2 };
+
+static const int8_t *code_table(void) {
+    static int8_t t[256];
+    static int init = 0;
+    if (!init) {
+        memset(t, -1, sizeof t);
+        t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['T'] = t['t'] = 2; t['G'] = t['g'] = 3;
+        init = 1;
+    }
+    return t;
+}
+
+typedef struct { ko_rec *p; size_t n, cap; } recvec;
+static void rv_push(recvec *v, ko_rec r) {
+    if (v->n == v->cap) {
+        v->cap = v->cap ? v->cap * 2 : (1u << 20);
+        v->p = (ko_rec *)realloc(v->p, v->cap * sizeof(ko_rec));
+        if (!v->p) { fprintf(stderr, "ko: out of memory\n"); abort(); }
+    }
+    v->p[v->n++] = r;
+}
+
+static uint64_t rc_packed(uint64_t x, int k) {
+    /* Kmer.inplaceRC: reverse, complement = code ^ 2 */
+    uint64_t r = 0;
+    for (int i = 0; i < k; i++) {
+        uint64_t c = (x >> (62 - 2 * i)) & 3;
+        r |= (c ^ 2) << (62 - 2 * (k - 1 - i));
+    }
+    return r;
+}
+static int is_palindrome(uint64_t x, int k) { /* Kmer.isOwnRC */
+    if (k & 1) return 0;
+    for (int i = 0; i < k / 2; i++)
+        if (((x >> (62 - 2 * i)) & 3) != ((x >> (62 - 2 * (k - 1 - i))) & 3)) return 0;
+    return 1;
+}
+
+static int cmp_rec(const void *pa, const void *pb) {
+    const ko_rec *a = (const ko_rec *)pa, *b = (const ko_rec *)pb;
+    if (a->kmer != b->kmer) return a->kmer < b->kmer ? -1 : 1;   /* Sequence.compareTo, fixed k */
+    if (a->a != b->a) return a->a < b->a ? -1 : 1;               /* TreeCountMap key order / canonical */
+    if (a->b != b->b) return a->b < b->b ? -1 : 1;
+    return 0;
+}
+
+void ko_free(ko_db *d) {
+    if (!d) return;
+    free(d->keys); free(d->val_off); free(d->val_a); free(d->val_b); free(d->bucket_off);
+    free(d->name_off); free(d->names); free(d);
+}
+
+/* mode 0 = FASTA -> reference DB (MakeDatabase -a), 1 = FASTQ -> read DB (MakeDatabase -q). */
+ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, int threads) {
+    if (k < 1 || k > 32 || key_len < 1 || key_len > k || key_len > 12) return NULL;
+    const int8_t *code = code_table();
+    ko_db *d = (ko_db *)calloc(1, sizeof(ko_db));
+    d->k = k; d->key_len = key_len; d->kind = mode; d->rc = (mode == 0);
+    uint32_t nkeys = 1u << (2 * key_len);
+
+    /* ---- transition tables: KmersFromFileStateChanger.java:46-68 */
+    int8_t trans[3][256];
+    memset(trans, -1, sizeof trans);
+    if (mode == 0) {
+        trans[ST_ID][' '] = ST_OTHER; trans[ST_ID]['\n'] = ST_KMER; trans[ST_OTHER]['\n'] = ST_KMER;
+        trans[ST_KMER]['\n'] = ST_OTHER; trans[ST_OTHER]['>'] = ST_ID;
+    } else {
+        trans[ST_OTHER]['@'] = ST_ID; trans[ST_KMER]['@'] = ST_ID; trans[ST_ID]['\n'] = ST_KMER;
+        trans[ST_KMER]['+'] = ST_OTHER;
+    }
+
+    /* ---- HOT LOOP 1: tryAdvance + FileCreator.addKmers, single thread like the reference */
+    recvec recs = {0, 0, 0};
+    uint8_t window[32];
+    memset(window, 0, sizeof window);
+    int state = ST_OTHER;
+    long pos = 0;
+    uint64_t id_start = 0, id_len = 0;           /* current header id = file[id_start .. +id_len) */
+    int32_t taxon = 0; int taxon_valid = 0;
+    /* ReadIDMapping state */
+    uint64_t cur_name_start = 0, cur_name_len = 0; int have_cur = 0; int32_t cur_read = -1;
+    size_t names_cap = 1 << 16, names_len = 0, noff_cap = 1 << 12;
+    if (mode == 1) {
+        d->names = (char *)malloc(names_cap);
+        d->name_off = (uint64_t *)malloc(noff_cap * sizeof(uint64_t));
+        d->name_off[0] = 0;
+    }
+    int have_last = 0; ko_rec last = {0, 0, 0};    /* `kwd` field surviving to EOF (quirk C.7) */
+
+    for (uint64_t ip = 0; ip <= n; ip++) {
+        if (ip == n) {                            /* in.read() == -1 */
+            if (have_last) {                      /* last k-mer emitted a second time */
+                rv_push(&recs, last); d->n_windows++;
+                if (d->rc && !is_palindrome(last.kmer, k)) {
+                    ko_rec r = last; r.kmer = rc_packed(last.kmer, k); rv_push(&recs, r);
+                }
+            }
+            break;
+        }
+        uint8_t c = file[ip];
+        int ns = trans[state][c];
+        if (ns >= 0) {
+            state = ns;
+            if (state == ST_KMER) pos = 0;        /* kwd NOT cleared here (KmersFromFile.java:137-139) */
+            else if (state == ST_ID) { id_start = ip + 1; id_len = 0; taxon_valid = 0; have_last = 0; }
+            else have_last = 0;
+            continue;
+        }
+        if (state == ST_ID) { id_len++; continue; }
+        if (state != ST_KMER) continue;
+        if (c <= 32) { have_last = 0; continue; }
+        pos++;
+        memmove(window, window + 1, (size_t)k - 1); /* System.arraycopy shift, :157 */
+        window[k - 1] = c;
+        if (pos < k) continue;
+        /* new Kmer(newbytes): per-window re-encode, InvalidBaseException => skip window */
+        uint64_t packed = 0; int ok = 1;
+        for (int i = 0; i < k; i++) {
+            int v = window[i] < 128 ? code[window[i]] : -1;
+            if (v < 0) { ok = 0; break; }
+            packed |= (uint64_t)v << (62 - 2 * i);
+        }
+        if (!ok) { have_last = 0; continue; }
+        ko_rec r; r.kmer = packed; r.b = 0;
+        if (mode == 0) {
+            if (!taxon_valid) {                   /* Integer.parseInt(id) */
+                char buf[32]; size_t l = id_len < 31 ? id_len : 31;
+                memcpy(buf, file + id_start, l); buf[l] = 0;
+                taxon = (int32_t)strtol(buf, NULL, 10); taxon_valid = 1;
+            }
+            r.a = taxon;
+        } else {                                  /* ReadIDMapping.geNext: compares with last *emitting* id */
+            if (!have_cur || cur_name_len != id_len ||
+                memcmp(file + cur_name_start, file + id_start, id_len) != 0) {
+                cur_name_start = id_start; cur_name_len = id_len; have_cur = 1; cur_read++;
+                while (names_len + id_len + 1 > names_cap) { names_cap *= 2; d->names = (char *)realloc(d->names, names_cap); }
+                memcpy(d->names + names_len, file + id_start, id_len); names_len += id_len;
+                if ((uint64_t)cur_read + 2 > noff_cap) { noff_cap *= 2; d->name_off = (uint64_t *)realloc(d->name_off, noff_cap * sizeof(uint64_t)); }
+                d->name_off[cur_read + 1] = names_len;
+            }
+            r.a = cur_read;
+            r.b = (int16_t)(pos - k);             /* (short)(pos - maxK) */
+        }
+        rv_push(&recs, r); d->n_windows++;
+        last = r; have_last = 1;
+        if (d->rc && !is_palindrome(packed, k)) { /* FileCreator.java:83-87 */
+            ko_rec q = r; q.kmer = rc_packed(packed, k); rv_push(&recs, q);
+        }
+    }
+    d->n_reads = (uint64_t)(cur_read + 1);
+    d->n_records = recs.n;
+
+    /* ---- temp-bucket scatter by key(keyLength): FileCreator.java:82, jar IntegerIndexedOutputFileCache */
+    uint64_t *boff = (uint64_t *)calloc((size_t)nkeys + 1, sizeof(uint64_t));
+    int sh = 64 - 2 * key_len;
+    for (size_t i = 0; i < recs.n; i++) boff[(recs.p[i].kmer >> sh) + 1]++;
+    for (uint32_t i = 0; i < nkeys; i++) boff[i + 1] += boff[i];
+    ko_rec *sorted = (ko_rec *)malloc((recs.n ? recs.n : 1) * sizeof(ko_rec));
+    {
+        uint64_t *cur = (uint64_t *)malloc((size_t)nkeys * sizeof(uint64_t));
+        memcpy(cur, boff, (size_t)nkeys * sizeof(uint64_t));
+        for (size_t i = 0; i < recs.n; i++) sorted[cur[recs.p[i].kmer >> sh]++] = recs.p[i];
+        free(cur);
+    }
+    free(recs.p);
+
+    /* ---- HOT LOOP 2: MakeAndWriteKey per key on a pool (LimitedQueueExecutor) */
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+    uint64_t *ucount = (uint64_t *)calloc((size_t)nkeys + 1, sizeof(uint64_t));
+    uint64_t *vcount = (uint64_t *)calloc((size_t)nkeys + 1, sizeof(uint64_t));
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t key = 0; key < (int64_t)nkeys; key++) {
+        ko_rec *p = sorted + boff[key]; size_t m = boff[key + 1] - boff[key];
+        qsort(p, m, sizeof(ko_rec), cmp_rec);     /* TreeMap<Kmer,..> + TreeCountMap ordering */
+        uint64_t u = 0, v = 0;
+        for (size_t i = 0; i < m; i++) {
+            int newk = (i == 0) || p[i].kmer != p[i - 1].kmer;
+            if (newk) u++;
+            if (d->kind == 1 || newk || p[i].a != p[i - 1].a) v++;
+        }
+        ucount[key + 1] = u; vcount[key + 1] = v;
+    }
+    for (uint32_t i = 0; i < nkeys; i++) { ucount[i + 1] += ucount[i]; vcount[i + 1] += vcount[i]; }
+    d->U = ucount[nkeys]; d->V = vcount[nkeys];
+    d->keys = (uint64_t *)malloc((d->U + 1) * sizeof(uint64_t));
+    d->val_off = (uint64_t *)malloc((d->U + 1) * sizeof(uint64_t));
+    d->val_a = (int32_t *)malloc((d->V + 1) * sizeof(int32_t));
+    d->val_b = (int32_t *)malloc((d->V + 1) * sizeof(int32_t));
+    d->bucket_off = ucount;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t key = 0; key < (int64_t)nkeys; key++) {
+        ko_rec *p = sorted + boff[key]; size_t m = boff[key + 1] - boff[key];
+        uint64_t u = ucount[key], v = vcount[key];
+        for (size_t i = 0; i < m; i++) {
+            int newk = (i == 0) || p[i].kmer != p[i - 1].kmer;
+            if (newk) { d->keys[u] = p[i].kmer; d->val_off[u] = v; u++; }
+            if (d->kind == 1) { d->val_a[v] = p[i].a; d->val_b[v] = p[i].b; v++; }
+            else if (newk || p[i].a != p[i - 1].a) { d->val_a[v] = p[i].a; d->val_b[v] = 1; v++; }
+            else if (d->val_b[v - 1] < INT32_MAX) d->val_b[v - 1]++;   /* TreeCountMap.add */
+        }
+    }
+    d->val_off[d->U] = d->V;
+    free(vcount); free(boff); free(sorted);
+    return d;
+}
+
+/* accessors for ctypes */
+uint64_t ko_U(const ko_db *d) { return d->U; }
+uint64_t ko_V(const ko_db *d) { return d->V; }
+uint64_t ko_n_windows(const ko_db *d) { return d->n_windows; }
+uint64_t ko_n_records(const ko_db *d) { return d->n_records; }
+uint64_t ko_n_reads(const ko_db *d) { return d->n_reads; }
+const uint64_t *ko_keys(const ko_db *d) { return d->keys; }
+const uint64_t *ko_val_off(const ko_db *d) { return d->val_off; }
+const int32_t *ko_val_a(const ko_db *d) { return d->val_a; }
+const int32_t *ko_val_b(const ko_db *d) { return d->val_b; }
+const uint64_t *ko_bucket_off(const ko_db *d) { return d->bucket_off; }
+const uint64_t *ko_name_off(const ko_db *d) { return d->name_off; }
+const char *ko_names(const ko_db *d) { return d->names; }
+
+/* ---- block encoding: MakeAndWriteKey (FileCreator.java:312-347) + meta (:153-164).
+ * Writes all 4^l blocks back to back into out (cap bytes), block_off[4^l+1]; returns bytes needed. */
+static void be32(uint8_t *p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; }
+static void be16(uint8_t *p, uint16_t v) { p[0] = v >> 8; p[1] = v; }
+
+uint64_t ko_encode_blocks(const ko_db *d, uint8_t *out, uint64_t cap, uint64_t *block_off) {
+    uint32_t nkeys = 1u << (2 * d->key_len);
+    int l = (d->k - 1) / 4 + 1;                   /* packed bytes per k-mer */
+    uint64_t w = 0;
+    uint8_t kc[9], prev[9];
+    for (uint32_t key = 0; key < nkeys; key++) {
+        if (block_off) block_off[key] = w;
+        memset(prev, 0, sizeof prev);             /* byte[] prev = new byte[1] */
+        for (uint64_t u = d->bucket_off[key]; u < d->bucket_off[key + 1]; u++) {
+            kc[0] = (uint8_t)d->k;
+            for (int i = 0; i < 8; i++) kc[1 + i] = (uint8_t)(d->keys[u] >> (56 - 8 * i));
+            int s = 0;
+            if (u > d->bucket_off[key]) while (s < l + 1 && prev[s] == kc[s]) s++;
+            memcpy(prev, kc, 9);
+            uint64_t nv = d->val_off[u + 1] - d->val_off[u];
+            uint64_t need = 1 + (uint64_t)(l + 1 - s) + (d->kind == 0 ? 2 + 5 * nv : 4 + 6 * nv);
+            if (out && w + need <= cap) {
+                uint8_t *p = out + w;
+                *p++ = (uint8_t)s;
+                memcpy(p, kc + s, (size_t)(l + 1 - s)); p += l + 1 - s;
+                if (d->kind == 0) {               /* CountDataType.compress */
+                    be16(p, (uint16_t)nv); p += 2;
+                    for (uint64_t v = d->val_off[u]; v < d->val_off[u + 1]; v++) {
+                        be32(p, (uint32_t)d->val_a[v]); p += 4;
+                        *p++ = (uint8_t)(d->val_b[v] > 255 ? 255 : d->val_b[v]);
+                    }
+                } else {                          /* SetCompressor<ReadPos>, canonical ascending */
+                    be32(p, (uint32_t)nv); p += 4;
+                    for (uint64_t v = d->val_off[u]; v < d->val_off[u + 1]; v++) {
+                        be32(p, (uint32_t)d->val_a[v]); p += 4;
+                        be16(p, (uint16_t)d->val_b[v]); p += 2;
+                    }
+                }
+            }
+            w += need;
+        }
+    }
+    if (block_off) block_off[nkeys] = w;
+    return w;
+}
+
+/* ---- HOT LOOP 3: per-key two-pointer inner join (DB.quickMatchCommonKey + matchTwoStreams).
+ * hit[i] = index of the reference k-mer equal to search k-mer i, or -1.  Returns #hits. */
+uint64_t ko_match(const ko_db *s, const ko_db *r, int64_t *hit, int threads) {
+    if (s->k != r->k || s->key_len != r->key_len) return (uint64_t)-1;
+    uint32_t nkeys = 1u << (2 * s->key_len);
+    uint64_t hits = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : hits)
+    for (int64_t key = 0; key < (int64_t)nkeys; key++) {
+        uint64_t a = s->bucket_off[key], ae = s->bucket_off[key + 1];
+        uint64_t b = r->bucket_off[key], be = r->bucket_off[key + 1];
+        for (uint64_t i = a; i < ae; i++) hit[i] = -1;
+        while (a < ae && b < be) {
+            if (s->keys[a] == r->keys[b]) { hit[a] = (int64_t)b; hits++; a++; b++; }
+            else if (s->keys[a] < r->keys[b]) a++;
+            else b++;
+        }
+    }
+    return hits;
+}
+
+/* Match line text (ResultsDataType.toString) for every hit, ascending; returns bytes needed. */
+uint64_t ko_match_lines(const ko_db *s, const ko_db *r, const int64_t *hit, char *out, uint64_t cap) {
+    static const char B[4] = {'A', 'C', 'T', 'G'};
+    uint64_t w = 0;
+    char tmp[64];
+    for (uint64_t i = 0; i < s->U; i++) {
+        if (hit[i] < 0) continue;
+#define PUT(str, len) do { if (out && w + (len) <= cap) memcpy(out + w, (str), (len)); w += (len); } while (0)
+        for (int j = 0; j < s->k; j++) tmp[j] = B[(s->keys[i] >> (62 - 2 * j)) & 3];
+        PUT(tmp, (uint64_t)s->k); PUT("\t", 1);
+        for (uint64_t v = s->val_off[i]; v < s->val_off[i + 1]; v++) {
+            int n = s->kind == 1 ? snprintf(tmp, sizeof tmp, "%s%d:%d", v > s->val_off[i] ? "|" : "", s->val_a[v], s->val_b[v])
+                                 : snprintf(tmp, sizeof tmp, "%s%dx%d", v > s->val_off[i] ? "|" : "", s->val_a[v], s->val_b[v] > 255 ? 255 : s->val_b[v]);
+            PUT(tmp, (uint64_t)n);
+        }
+        PUT("\t-", 2);
+        uint64_t h = (uint64_t)hit[i];
+        for (uint64_t v = r->val_off[h]; v < r->val_off[h + 1]; v++) {
+            /* counts come back from the DB file, i.e. saturated at 255 (CountDataType.java:40) */
+            int n = snprintf(tmp, sizeof tmp, "|%dx%d", r->val_a[v], r->val_b[v] > 255 ? 255 : r->val_b[v]);
+            PUT(tmp, (uint64_t)n);
+        }
+        PUT("\n", 1);
+#undef PUT
+    }
+    return w;
+}
+
+/* ---- HOT LOOP 4: TaxaCounts default mode.  taxon[] ascending; returns number of taxa (<= cap filled). */
+static int cmp_i32(const void *a, const void *b) {
+    int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return x < y ? -1 : x > y;
+}
+uint64_t ko_taxacounts(const ko_db *r, int32_t *taxon, int64_t *match, int64_t *unique, uint64_t cap) {
+    int32_t *t = (int32_t *)malloc((r->V + 1) * sizeof(int32_t));
+    memcpy(t, r->val_a, r->V * sizeof(int32_t));
+    qsort(t, r->V, sizeof(int32_t), cmp_i32);
+    uint64_t nt = 0;
+    for (uint64_t i = 0; i < r->V; i++) if (i == 0 || t[i] != t[i - 1]) t[nt++] = t[i];
+    int64_t *m = (int64_t *)calloc(nt + 1, sizeof(int64_t)), *q = (int64_t *)calloc(nt + 1, sizeof(int64_t));
+    for (uint64_t u = 0; u < r->U; u++) {
+        uint64_t a = r->val_off[u], b = r->val_off[u + 1];
+        for (uint64_t v = a; v < b; v++) {
+            int32_t *f = (int32_t *)bsearch(&r->val_a[v], t, nt, sizeof(int32_t), cmp_i32);
+            m[f - t]++;
+            if (b - a == 1) q[f - t]++;
+        }
+    }
+    for (uint64_t i = 0; i < nt && i < cap; i++) { taxon[i] = t[i]; match[i] = m[i]; unique[i] = q[i]; }
+    free(t); free(m); free(q);
+    return nt;
+}
