@@ -1,0 +1,147 @@
+/* kmers_gpu.h -- C ABI of the MI355X-native k-mer hot path (libkmers_gpu.so).
+ *
+ * Drop-in boundary for three call sites of danielmoney/kmers (paths relative to the reference's
+ * src/; the reference has no FFI of its own, these are the Java seams a JNI/FFM shim replaces --
+ * see INTEGRATION.md):
+ *   build  : KmerFiles/FileCreator.java:33,65,117,219  (new FileCreator / addKmers / create / close)
+ *            fed by OtherFiles/KmersFromFile.java:28-32 (streamFromFile)
+ *   match  : Database/DB.java:76-90,129-137             (getNearestKmers quick branch)
+ *   counts : Utils/TaxaCounts.java:355-360,386-395      (SingleIndexAll.call / CountDataAll.add)
+ *
+ * Conventions: plain pointers and sizes only.  Every function returns 0 (KMG_OK) or a negative
+ * code and never throws/aborts across the ABI; kmg_last_error() gives the message for the last
+ * nonzero return on that context.  The caller allocates and frees every host buffer; the library
+ * copies inputs before returning and retains no host pointer.  A context is bound to one GPU and is
+ * internally serialised (safe to call from several threads; calls do not overlap on the device).
+ * Supported: 1 <= k <= 32 with minK == maxK, 1 <= key_len <= min(k, 12).  Anything else returns
+ * KMG_EUNSUPPORTED so a shim can fall back to the Java path.
+ *
+ * K-mer representation everywhere: uint64, 2 bits per base, code order A=0 C=1 T=2 G=3
+ * (Kmers/Base.java:7-10), first base in the top bits, low 64-2k bits zero -- i.e. the bytes of
+ * Sequence.cBytes() (Kmers/Sequence.java:90-115) read big-endian.  Unsigned integer order of this
+ * value == Sequence.compareTo order (Kmers/Sequence.java:165-187) for fixed k.
+ */
+#ifndef KMERS_GPU_H
+#define KMERS_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMG_OK            0
+#define KMG_EINVAL       (-1)   /* bad argument / inconsistent parameters (InconsistentDataException) */
+#define KMG_ENOMEM       (-2)   /* host or device allocation failed */
+#define KMG_EDEVICE      (-3)   /* HIP runtime error */
+#define KMG_EUNSUPPORTED (-4)   /* k > 32, minK != maxK, > 2^32-1 records in one build ... */
+#define KMG_ESTATE       (-5)   /* call out of order (add before begin, ...) */
+
+#define KMG_PAYLOAD_TAXON   0   /* reference DB: int32 taxon per sequence  (DataCollector.getCountInstance) */
+#define KMG_PAYLOAD_READPOS 1   /* read DB: (int32 read, int16 pos)        (DataCollector.getReadInstance)  */
+
+typedef struct kmg_ctx kmg_ctx;   /* one per (process, GPU) */
+typedef struct kmg_db  kmg_db;    /* a device-resident sorted, deduplicated k-mer database (CSR) */
+
+/* ---- context -------------------------------------------------------------------------------- */
+int  kmg_create(int device, kmg_ctx **out);
+void kmg_destroy(kmg_ctx *ctx);
+const char *kmg_last_error(kmg_ctx *ctx);
+/* The HIP stream all of this context's kernels run on (a hipStream_t), for callers that time
+ * or order work around the library. */
+void *kmg_stream(kmg_ctx *ctx);
+
+/* ---- stage 1+2: build  (replaces FileCreator.java:33 ctor .. :117 create) -------------------
+ * kmg_build_begin : new FileCreator(temp, keyLength, maxK, cache, collector, rc, ...)
+ *                   (FileCreator.java:33-63).  rc != 0 adds the reverse complement of every k-mer
+ *                   that is not a palindrome (FileCreator.java:83-87, Kmer.java:210-225).
+ * kmg_build_add   : KmersFromFile.streamFromFile + FileCreator.addKmers (KmersFromFile.java:84-208,
+ *                   FileCreator.java:65-110) for a batch of nseq sequences.  The host keeps the
+ *                   ID/KMER/OTHER record splitting; `bases` holds, back to back, exactly the
+ *                   characters > 32 of each sequence (every one of them advances `pos`,
+ *                   KmersFromFile.java:154-158); sequence i is bases[seq_off[i] .. seq_off[i+1]).
+ *                   Every window of k letters from ACGTacgt is a k-mer; a window holding any
+ *                   other character is skipped and the window keeps rolling (:161-177).
+ *                   KMG_PAYLOAD_TAXON  : seq_id[i] = taxon of sequence i; seq_tok unused (NULL).
+ *                   KMG_PAYLOAD_READPOS: seq_tok[i] = any int64 that is equal for two sequences
+ *                     iff their header strings are equal; seq_id unused (NULL).  The library
+ *                     numbers reads as ReadIDMapping.geNext does (ReadIDMapping.java:14-23): a
+ *                     read gets the next index at its first valid k-mer unless its header equals
+ *                     that of the last read that produced a k-mer.  read_index_out (nseq, may be
+ *                     NULL) receives each sequence's index, or -1 if it produced no k-mer, so the
+ *                     host can write the read-name map (MakeDatabase.java:165-185).  Position is
+ *                     the Java (short)(pos - k) (KmersFromFile.java:165).
+ *                   May be called many times; batches are consumed in call order.
+ * kmg_build_add_dev: the same with every pointer a DEVICE pointer on this context's GPU (inputs
+ *                   already resident in HBM); asynchronous on kmg_stream(); the buffers must stay
+ *                   valid until kmg_build_finish returns.  read_index_out is a device pointer.
+ * kmg_build_finish: FileCreator.create's compute (MakeAndWriteKey.call, FileCreator.java:271-347):
+ *                   sort by k-mer, deduplicate, reduce.  Reference DB: per k-mer the ascending
+ *                   taxon list with occurrence counts (TreeCountMap; counts are NOT saturated
+ *                   here, CountDataType.compress saturates at 255 when writing).  Read DB: per
+ *                   k-mer every (read, pos) ascending (the reference's HashSet order is
+ *                   nondeterministic; ascending is the canonical form).  *out owns device memory;
+ *                   release with kmg_db_free.  n_windows (may be NULL) = valid forward windows.
+ */
+int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind);
+int kmg_build_add(kmg_ctx *ctx, const uint8_t *bases, uint64_t nbases, const uint64_t *seq_off,
+                  const int32_t *seq_id, const int64_t *seq_tok, uint64_t nseq,
+                  int32_t *read_index_out);
+int kmg_build_add_dev(kmg_ctx *ctx, const uint8_t *d_bases, uint64_t nbases, const uint64_t *d_seq_off,
+                      const int32_t *d_seq_id, const int64_t *d_seq_tok, uint64_t nseq,
+                      int32_t *d_read_index_out);
+int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows);
+
+/* ---- database handles ----------------------------------------------------------------------- */
+/* kmg_db_info : sizes.  n_unique = distinct k-mers, n_values = total list entries
+ *               ((k-mer, taxon) pairs | (read, pos) occurrences). */
+int kmg_db_info(const kmg_db *db, int *k, int *key_len, int *rc, int *payload_kind,
+                uint64_t *n_unique, uint64_t *n_values);
+/* kmg_db_fetch: copy the CSR to host buffers (any may be NULL to skip):
+ *   keys[n_unique] ascending; val_off[n_unique+1]; val_a[n_values] = taxon | read;
+ *   val_b[n_values] = count | pos; bucket_off[4^key_len + 1] = first k-mer index of each
+ *   Kmer.key(key_len) bucket (Kmer.java:47-55) -- the per-key blocks of the DB file. */
+int kmg_db_fetch(const kmg_db *db, uint64_t *keys, uint64_t *val_off, int32_t *val_a, int32_t *val_b,
+                 uint64_t *bucket_off);
+/* kmg_db_load : upload a decoded database (KmerFile.java:200-250 output) from host CSR arrays. */
+int kmg_db_load(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *keys,
+                uint64_t n_unique, const uint64_t *val_off, const int32_t *val_a, const int32_t *val_b,
+                kmg_db **out);
+void kmg_db_free(kmg_db *db);
+/* kmg_db_encode: the per-key block bytes MakeAndWriteKey writes (FileCreator.java:312-347:
+ *   [shared-prefix byte][rest of compressedBytes][CountDataType | SetCompressor<ReadPos> bytes]),
+ *   all 4^key_len blocks back to back, computed on the GPU.  Two calls: first with out == NULL to
+ *   get *n_bytes, then with a buffer of that size.  block_off[4^key_len + 1] (may be NULL). */
+int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint64_t cap, uint64_t *n_bytes,
+                  uint64_t *block_off);
+
+/* ---- stage 3: match  (replaces DB.getNearestKmers quick branch, DB.java:76-90,129-137) -------
+ * Sorted inner join of the search database's distinct k-mers against the reference database:
+ * hit_index[i] = index (into the reference CSR) of the k-mer equal to search k-mer i, else -1.
+ * Same k and key_len required (DB.java:78-81 -> KMG_EINVAL).  n_hits may be NULL.
+ * kmg_match_dev writes hit_index to a device pointer and does not synchronise. */
+int kmg_match(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *hit_index, uint64_t *n_hits);
+int kmg_match_dev(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *d_hit_index);
+
+/* ---- TaxaCounts default mode (replaces TaxaCounts.java:119-130,355-360,386-395) --------------
+ * Over every stored k-mer: match[t]++ for each taxon of its list, unique[t]++ if the list has
+ * exactly one taxon.  Output ascending by taxon.  In: *n_taxa = capacity; out: taxa found
+ * (if larger than the capacity only the first capacity rows are written). */
+int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, int64_t *match, int64_t *unique,
+                   uint64_t *n_taxa);
+
+/* ---- measurement hook (bench.py) --------------------------------------------------------------
+ * Total device time in ms, measured with HIP events on kmg_stream(), of the launches of one
+ * kernel (ids 0 .. kmg_prof_count()-1, names from kmg_prof_name) since the last kmg_prof_reset,
+ * their launch count and the ALGORITHMIC bytes those launches had to move.
+ * Profiling is off by default (events cost a little): enable with kmg_prof_enable(ctx, 1). */
+int kmg_prof_enable(kmg_ctx *ctx, int on);
+int kmg_prof_reset(kmg_ctx *ctx);
+int kmg_prof_get(kmg_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches, uint64_t *algo_bytes);
+int kmg_prof_count(void);               /* number of kernel ids */
+const char *kmg_prof_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMERS_GPU_H */

@@ -1,0 +1,276 @@
+"""Host-side mirror of the reference's interfaces for the hot path, on top of the C ABI.
+
+Names, argument meaning and error behaviour follow the Java classes they stand in for
+(paths relative to the reference's src/):
+  FileCreator  <- KmerFiles/FileCreator.java        (ctor :33, addKmers :65, create :117, close :219)
+  KmerDatabase <- KmerFiles/KmerFile.java           (decoded DB: meta + per-key k-mers)
+  DB           <- Database/DB.java                  (ctor checks :30-74, getNearestKmers :76-90, kmers :99)
+  taxa_counts  <- Utils/TaxaCounts.java             (default mode :119-150)
+  match_lines  <- DataTypes/ResultsDataType.java    (toString chain, :15-35)
+All compute happens in libkmers_gpu.so; nothing here falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (InconsistentDataException, KmersGpuError, PAYLOAD_READPOS, PAYLOAD_TAXON)
+
+REF_ID = [2048]          # Counts/CountDataType.java:115-121
+READ_ID = [257, 2052]    # jar SetCompressor [257] ++ Reads/ReadPosDataType.java:57-62
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One per (process, GPU): owns the HIP stream and the device-memory pool."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.kmg_create(device, C.byref(h))
+        if rc != 0:
+            raise KmersGpuError(rc, "kmg_create failed (is a GPU visible?)")
+        self.h = h
+
+    def check(self, rc):
+        if rc == 0:
+            return
+        msg = self.lib.kmg_last_error(self.h).decode()
+        if rc == _lib.KMG_EINVAL:
+            raise InconsistentDataException(rc, msg)
+        raise KmersGpuError(rc, msg)
+
+    @property
+    def stream(self):
+        return self.lib.kmg_stream(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.kmg_destroy(self.h)
+            self.h = None
+
+    # ---- measurement hook
+    def prof_enable(self, on=True):
+        self.check(self.lib.kmg_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self.check(self.lib.kmg_prof_reset(self.h))
+
+    def prof(self):
+        out = {}
+        for i in range(self.lib.kmg_prof_count()):
+            ms, n, b = C.c_double(), C.c_uint64(), C.c_uint64()
+            self.check(self.lib.kmg_prof_get(self.h, i, C.byref(ms), C.byref(n), C.byref(b)))
+            out[self.lib.kmg_prof_name(i).decode()] = {"ms": ms.value, "launches": n.value, "bytes": b.value}
+        return out
+
+
+class SequenceBatch:
+    """What the host-side record splitter hands to FileCreator.addKmers: the characters > 32 of each
+    sequence back to back, their offsets and, per sequence, the taxon (reference) or a header token
+    (reads; equal tokens <=> equal header strings)."""
+
+    def __init__(self, bases, seq_off, seq_id=None, seq_tok=None):
+        self.bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        self.seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        self.seq_id = None if seq_id is None else np.ascontiguousarray(seq_id, dtype=np.int32)
+        self.seq_tok = None if seq_tok is None else np.ascontiguousarray(seq_tok, dtype=np.int64)
+        self.nseq = len(self.seq_off) - 1 if len(self.seq_off) else 0
+
+
+class KmerDatabase:
+    """A device-resident database (the decoded content of one KmerFile)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+        k, kl, rc, kind = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        u, v = C.c_uint64(), C.c_uint64()
+        ctx.check(ctx.lib.kmg_db_info(handle, C.byref(k), C.byref(kl), C.byref(rc), C.byref(kind), C.byref(u), C.byref(v)))
+        self.k, self.key_length, self.rc, self.kind = k.value, kl.value, bool(rc.value), kind.value
+        self.n_unique, self.n_values = u.value, v.value
+        self.min_length = self.max_length = self.k
+        self._host = None
+
+    @classmethod
+    def load(cls, ctx, k, key_length, rc, kind, keys, val_off, val_a, val_b):
+        keys = np.ascontiguousarray(keys, np.uint64)
+        val_off = np.ascontiguousarray(val_off, np.uint64)
+        val_a = np.ascontiguousarray(val_a, np.int32)
+        val_b = np.ascontiguousarray(val_b, np.int32)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.kmg_db_load(ctx.h, k, key_length, 1 if rc else 0, kind, _ptr(keys), len(keys), _ptr(val_off),
+                                      _ptr(val_a), _ptr(val_b), C.byref(h)))
+        return cls(ctx, h)
+
+    def data_id(self):
+        return REF_ID if self.kind == PAYLOAD_TAXON else READ_ID
+
+    def meta(self):
+        """The key -1 block, FileCreator.java:153-164."""
+        ids = self.data_id()
+        b = bytes([self.k, self.k, self.key_length]) + len(ids).to_bytes(4, "big")
+        for i in ids:
+            b += i.to_bytes(4, "big")
+        return b + bytes([1 if self.rc else 0])
+
+    def fetch(self):
+        """-> dict of host CSR arrays (cached)."""
+        if self._host is None:
+            U, V = self.n_unique, self.n_values
+            keys = np.empty(U, np.uint64)
+            val_off = np.empty(U + 1, np.uint64)
+            val_a = np.empty(V, np.int32)
+            val_b = np.empty(V, np.int32)
+            boff = np.empty(4 ** self.key_length + 1, np.uint64)
+            self.ctx.check(self.ctx.lib.kmg_db_fetch(self.h, _ptr(keys), _ptr(val_off), _ptr(val_a), _ptr(val_b), _ptr(boff)))
+            self._host = dict(keys=keys, val_off=val_off, val_a=val_a, val_b=val_b, bucket_off=boff)
+        return self._host
+
+    def encode_blocks(self):
+        """Per-key block bytes as MakeAndWriteKey writes them -> (bytes, block_off[4^l+1])."""
+        n = C.c_uint64()
+        boff = np.empty(4 ** self.key_length + 1, np.uint64)
+        self.ctx.check(self.ctx.lib.kmg_db_encode(self.ctx.h, self.h, None, 0, C.byref(n), None))
+        out = np.empty(max(n.value, 1), np.uint8)
+        self.ctx.check(self.ctx.lib.kmg_db_encode(self.ctx.h, self.h, _ptr(out), n.value, C.byref(n), _ptr(boff)))
+        return out[:n.value].tobytes(), boff
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.kmg_db_free(self.h)
+            self.h = None
+
+
+class FileCreator:
+    """KmerFiles/FileCreator.java.  data_kind: 'ref' = DataCollector.getCountInstance (taxon payload,
+    the reference passes rc=True, MakeDatabase.java:130), 'read' = getReadInstance (rc=False, :167)."""
+
+    def __init__(self, ctx, key_length, max_kmer_length, data_kind, rc):
+        self.ctx = ctx
+        self.key_length = key_length
+        self.max_k = max_kmer_length
+        self.kind = PAYLOAD_TAXON if data_kind == "ref" else PAYLOAD_READPOS
+        self.rc = rc
+        self.min_k = -1
+        self.n_windows = 0
+        ctx.check(ctx.lib.kmg_build_begin(ctx.h, max_kmer_length, key_length, 1 if rc else 0, self.kind))
+
+    def add_kmers(self, batch, min_length=None, max_length=None):
+        """addKmers (FileCreator.java:65-110).  Returns, for read DBs, the read index of every sequence
+        (-1 = no k-mer, so no entry in the read-name map)."""
+        min_length = self.max_k if min_length is None else min_length
+        max_length = self.max_k if max_length is None else max_length
+        if self.min_k == -1:
+            self.min_k = min_length
+        if self.min_k != min_length or self.max_k != max_length:
+            raise InconsistentDataException(
+                _lib.KMG_EINVAL, "New stream does not have the same min or max kmer length as a previous stream")
+        if min_length != max_length:
+            raise KmersGpuError(_lib.KMG_EUNSUPPORTED, "minK != maxK is not supported on the GPU path")
+        ridx = None
+        if self.kind == PAYLOAD_READPOS:
+            ridx = np.empty(batch.nseq, np.int32)
+        self.ctx.check(self.ctx.lib.kmg_build_add(self.ctx.h, _ptr(batch.bases), len(batch.bases), _ptr(batch.seq_off),
+                                                  _ptr(batch.seq_id), _ptr(batch.seq_tok), batch.nseq, _ptr(ridx)))
+        return ridx
+
+    def create(self):
+        """FileCreator.create's compute -> KmerDatabase (the caller writes it through the container)."""
+        h = C.c_void_p()
+        nw = C.c_uint64()
+        self.ctx.check(self.ctx.lib.kmg_build_finish(self.ctx.h, C.byref(h), C.byref(nw)))
+        self.n_windows = nw.value
+        return KmerDatabase(self.ctx, h)
+
+
+class DB:
+    """Database/DB.java over device-resident reference databases (one file only for now; the
+    multi-file merge of DB.kmers, DB.java:99-109, is a 'next' row)."""
+
+    def __init__(self, files):
+        if not files:
+            raise ValueError("Empty file list")          # DB.java:44-47
+        f0 = files[0]
+        for f in files:                                   # DB.java:36-42, 57-64
+            if f.data_id() != f0.data_id():
+                raise InconsistentDataException(_lib.KMG_EINVAL, "Files contain different datatypes")
+            if (f.min_length, f.max_length, f.key_length) != (f0.min_length, f0.max_length, f0.key_length) or not f.rc:
+                raise InconsistentDataException(
+                    _lib.KMG_EINVAL, "Files contains different kmer parameters (min/max length, key length or "
+                    "reverse complement included")
+        if len(files) != 1:
+            raise KmersGpuError(_lib.KMG_EUNSUPPORTED, "multi-file reference databases are not supported yet")
+        self.files = list(files)
+        self.ctx = f0.ctx
+        self.min_length, self.max_length, self.key_length = f0.min_length, f0.max_length, f0.key_length
+        self.max_key = 4 ** self.key_length
+
+    def get_max_key(self):
+        return self.max_key
+
+    def get_nearest_kmers(self, search, max_diff=0, just=False):
+        """Quick branch of getNearestKmers (DB.java:76-90): exact matches of a search database.
+        -> hit_index[n_unique(search)] into this DB's k-mers (-1 = no match)."""
+        if search.min_length < self.min_length or search.max_length > self.max_length:
+            raise InconsistentDataException(
+                _lib.KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database")
+        if max_diff != 0:
+            raise KmersGpuError(_lib.KMG_EUNSUPPORTED, "inexact search (-n > 0) is not on the GPU path")
+        hit = np.empty(search.n_unique, np.int64)
+        nh = C.c_uint64()
+        self.ctx.check(self.ctx.lib.kmg_match(self.ctx.h, search.h, self.files[0].h, _ptr(hit), C.byref(nh)))
+        return hit, nh.value
+
+
+def taxa_counts(db):
+    """Utils/TaxaCounts.java default mode -> (taxon[], match[], unique[]) ascending by taxon."""
+    f = db.files[0] if isinstance(db, DB) else db
+    cap = max(f.n_values, 1)
+    t = np.empty(cap, np.int32)
+    m = np.empty(cap, np.int64)
+    q = np.empty(cap, np.int64)
+    n = C.c_uint64(cap)
+    f.ctx.check(f.ctx.lib.kmg_taxacounts(f.ctx.h, f.h, _ptr(t), _ptr(m), _ptr(q), C.byref(n)))
+    return t[:n.value], m[:n.value], q[:n.value]
+
+
+def taxa_count_lines(db):
+    """TaxaCounts.java:142-150: `taxon \\t match \\t unique` per taxon."""
+    t, m, q = taxa_counts(db)
+    return ["%d\t%d\t%d" % x for x in zip(t.tolist(), m.tolist(), q.tolist())]
+
+
+_BASES = np.frombuffer(b"ACTG", dtype=np.uint8)
+
+
+def kmer_strings(keys, k):
+    """Sequence.toString (Sequence.java:117-134) for an array of left-aligned 2-bit k-mers."""
+    keys = np.asarray(keys, np.uint64)
+    shifts = (np.uint64(62) - np.uint64(2) * np.arange(k, dtype=np.uint64))
+    codes = ((keys[:, None] >> shifts[None, :]) & np.uint64(3)).astype(np.intp)
+    return [row.tobytes().decode() for row in _BASES[codes]]
+
+
+def match_lines(search, ref, hit):
+    """One line per matched search k-mer, ascending (Matcher.java:247-249): KMER \\t r:p|r:p \\t -|TxC|TxC
+    (ResultsDataType.java:15-35).  Reference counts are the stored bytes, i.e. saturated at 255
+    (CountDataType.java:40)."""
+    s, r = search.fetch(), ref.fetch()
+    idx = np.nonzero(hit >= 0)[0]
+    names = kmer_strings(s["keys"][idx], search.k)
+    lines = []
+    for name, i in zip(names, idx.tolist()):
+        a, b = int(s["val_off"][i]), int(s["val_off"][i + 1])
+        if search.kind == PAYLOAD_READPOS:
+            left = "|".join("%d:%d" % (x, y) for x, y in zip(s["val_a"][a:b].tolist(), s["val_b"][a:b].tolist()))
+        else:
+            left = "|".join("%dx%d" % (x, min(y, 255)) for x, y in zip(s["val_a"][a:b].tolist(), s["val_b"][a:b].tolist()))
+        h = int(hit[i])
+        c, d = int(r["val_off"][h]), int(r["val_off"][h + 1])
+        right = "|".join("%dx%d" % (x, min(y, 255)) for x, y in zip(r["val_a"][c:d].tolist(), r["val_b"][c:d].tolist()))
+        lines.append("%s\t%s\t-|%s" % (name, left, right))
+    return lines

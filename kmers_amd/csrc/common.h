@@ -1,0 +1,211 @@
+// common.h -- context, device-memory pool, launch timing and error plumbing shared by the stages.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kmers_gpu.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define KMG_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(_e);                 \
+            return _e == hipErrorOutOfMemory ? KMG_ENOMEM : KMG_EDEVICE;                   \
+        }                                                                                  \
+    } while (0)
+
+#define KMG_TRY(expr)                    \
+    do {                                 \
+        int _r = (expr);                 \
+        if (_r != KMG_OK) return _r;     \
+    } while (0)
+
+// Kernel ids for the measurement hook (kmg_prof_get).
+enum {
+    KP_EXTRACT_TILESEQ = 0,
+    KP_EXTRACT_COUNT,
+    KP_EXTRACT_WRITE,
+    KP_NUMBER_READS,
+    KP_SCAN,
+    KP_SORT_HIST,
+    KP_SORT_SCAN,
+    KP_SORT_SCATTER,
+    KP_REDUCE_FLAG,
+    KP_REDUCE_WRITE,
+    KP_BUCKETS,
+    KP_MATCH,
+    KP_TAXA,
+    KP_ENCODE,
+    KP_COUNT_
+};
+
+static const char *const kp_names[KP_COUNT_] = {
+    "extract_tileseq", "extract_count", "extract_write", "number_reads", "scan",
+    "sort_hist",       "sort_scan",     "sort_scatter",  "reduce_flag",  "reduce_write",
+    "bucket_offsets",  "match",         "taxacounts",    "encode"};
+
+// Grow-only caching device allocator: blocks freed to the pool are reused by later requests of a
+// similar size, so a steady-state loop (bench steps, repeated builds) calls hipMalloc only once.
+struct DevPool {
+    std::multimap<size_t, void *> free_blocks;
+    std::map<void *, size_t> live;
+    size_t total = 0;
+
+    int alloc(void **out, size_t bytes) {
+        if (bytes == 0) bytes = 256;
+        bytes = (bytes + 255) & ~(size_t)255;
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
+            *out = it->second;
+            live[it->second] = it->first;
+            free_blocks.erase(it);
+            return KMG_OK;
+        }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            // give everything cached back and retry once
+            trim();
+            e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) return KMG_ENOMEM;
+        }
+        total += bytes;
+        live[p] = bytes;
+        *out = p;
+        return KMG_OK;
+    }
+    void release(void *p) {
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        free_blocks.insert({it->second, p});
+        live.erase(it);
+    }
+    void trim() {
+        for (auto &kv : free_blocks) {
+            (void)hipFree(kv.second);
+            total -= kv.first;
+        }
+        free_blocks.clear();
+    }
+    void destroy() {
+        trim();
+        for (auto &kv : live) (void)hipFree(kv.first);
+        live.clear();
+    }
+};
+
+struct ProfSlot {
+    double ms = 0;
+    u64 launches = 0;
+    u64 bytes = 0;
+};
+
+struct PendingEvent {
+    int id;
+    hipEvent_t a, b;
+};
+
+// Device-resident build state (one 64-bit word each), so that kmg_build_add_dev never has to
+// synchronise with the host.
+enum {
+    ST_NREC = 0,      // records written so far (fwd + rc)
+    ST_NWIN,          // valid forward windows so far
+    ST_READ_BASE,     // reads numbered so far (ReadIDMapping.curReadI + 1)
+    ST_CARRY_TOK,     // token of the last read that produced a k-mer (ReadIDMapping.curReadS)
+    ST_HAVE_CARRY,    // 0 until some read has produced a k-mer
+    ST_ID_OR,         // OR / AND of every (taxon ^ 0x80000000): constant value bits skip sort passes
+    ST_ID_AND,
+    ST_TMP0,          // scratch totals written by scans
+    ST_TMP1,
+    ST_WORDS = 16
+};
+
+struct kmg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+    DevPool pool;
+
+    // build state
+    bool building = false;
+    int k = 0, key_len = 0, rc = 0, kind = 0;
+    u64 *rec_keys = nullptr;     // record keys (left-aligned 2-bit k-mers)
+    void *rec_vals = nullptr;    // u32 taxon | u64 (read << 16 | pos16)
+    u64 rec_cap = 0;             // capacity in records
+    u64 rec_upper = 0;           // host-known upper bound of records added so far
+    u64 *d_state = nullptr;      // ST_WORDS device words
+    std::vector<void *> staged;  // device copies of host batches, released at finish
+
+    // profiling
+    bool prof_on = false;
+    ProfSlot prof[KP_COUNT_];
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+struct kmg_db {
+    kmg_ctx *ctx = nullptr;
+    int k = 0, key_len = 0, rc = 0, kind = 0;
+    u64 U = 0, V = 0;
+    u64 *keys = nullptr;        // U
+    u64 *val_off = nullptr;     // U + 1
+    int32_t *val_a = nullptr;   // V
+    int32_t *val_b = nullptr;   // V
+    u64 *bucket_off = nullptr;  // 4^key_len + 1
+};
+
+static inline int val_bytes(int kind) { return kind == KMG_PAYLOAD_TAXON ? 4 : 8; }
+
+// ---- launch timing ------------------------------------------------------------------------------
+struct ProfScope {
+    kmg_ctx *ctx;
+    int id;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(kmg_ctx *c, int id_, u64 algo_bytes) : ctx(c), id(id_) {
+        if (!ctx->prof_on) return;
+        ctx->prof[id].bytes += algo_bytes;
+        a = get();
+        b = get();
+        if (a && b) (void)hipEventRecord(a, ctx->stream);
+    }
+    ~ProfScope() {
+        if (!ctx->prof_on || !a || !b) return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->pending.push_back({id, a, b});
+    }
+    hipEvent_t get() {
+        if (!ctx->event_pool.empty()) {
+            hipEvent_t e = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
+
+static inline void prof_drain(kmg_ctx *ctx) {
+    for (auto &p : ctx->pending) {
+        float ms = 0;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->prof[p.id].ms += ms;
+            ctx->prof[p.id].launches += 1;
+        }
+        ctx->event_pool.push_back(p.a);
+        ctx->event_pool.push_back(p.b);
+    }
+    ctx->pending.clear();
+}
+
+static inline u32 div_up_u64(u64 a, u64 b) { return (u32)((a + b - 1) / b); }

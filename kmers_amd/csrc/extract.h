@@ -1,0 +1,306 @@
+// extract.h -- stage 1: 2-bit encode + k-mer windows + reverse complement + read numbering.
+//
+// Replaces the per-character loop of KmersFromFileSpliterator.tryAdvance
+// (OtherFiles/KmersFromFile.java:150-178) and the RC branch of FileCreator.addKmers
+// (KmerFiles/FileCreator.java:77-95).  HBM-bound byte work: every base is read once per pass and every
+// record written once; nothing here is a contraction, so no MFMA.
+//
+// A tile is EX_TILE consecutive base positions of the concatenated batch.  The block
+//   1. loads its bytes with 16-B coalesced loads and packs them into LDS: 2 bits per base (A0 C1 T2 G3,
+//      Kmers/Base.java:7-10) plus one "not ACGTacgt" bit per base,
+//   2. counts sequence starts per position in LDS and prefix-scans them, which gives every position its
+//      sequence and a "sequence starts here" bitmask,
+//   3. forms every window with two funnel shifts out of the packed LDS words (no per-base rolling,
+//      no redundant re-encoding): a window is a k-mer iff no bad base in [p, p+k) and no sequence
+//      start in (p, p+k),
+//   4. count pass: per-tile record counts (+ has_kmer flags per sequence);  write pass: records at
+//      exclusive-scanned offsets, in window order (the later stable sort relies on that order).
+#pragma once
+#include "common.h"
+
+#define EX_BLOCK 256
+#define EX_ROUNDS 16
+#define EX_TILE (EX_BLOCK * EX_ROUNDS)   // 4096 window-start positions per tile
+#define EX_EXT 32                        // bases past the tile that its last windows may cover
+
+// tile_seq[t] = largest s in [0, nseq] with seq_off[s] <= t * EX_TILE.
+__global__ void extract_tileseq_kernel(const u64 *__restrict__ seq_off, u64 nseq, u32 *__restrict__ tile_seq,
+                                       u32 ntiles_plus1) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles_plus1) return;
+    u64 pos = (u64)t * EX_TILE;
+    u64 lo = 0, hi = nseq + 1;  // first index with seq_off > pos
+    while (lo < hi) {
+        u64 mid = (lo + hi) >> 1;
+        if (seq_off[mid] <= pos) lo = mid + 1; else hi = mid;
+    }
+    tile_seq[t] = (u32)(lo == 0 ? 0 : lo - 1);
+}
+
+__device__ __forceinline__ u64 revpairs64(u64 x) {
+    // reverse the order of the 32 two-bit groups of x
+    x = __brevll(x);
+    return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+}
+
+struct ExtractArgs {
+    const uint8_t *bases;
+    u64 nbases;
+    const u64 *seq_off;
+    u64 nseq;
+    const int32_t *seq_id;       // taxon per sequence (kind 0)
+    const int32_t *read_index;   // read number per sequence (kind 1, write pass)
+    const u32 *tile_seq;
+    int k;
+    int rc;
+    int kind;
+    // count pass outputs
+    u32 *tile_count;
+    uint8_t *has_kmer;
+    // write pass
+    const u64 *tile_off;         // exclusive scan of tile_count
+    u64 *out_keys;
+    void *out_vals;
+    u64 *state;                  // device build state (ST_*)
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(EX_BLOCK) void extract_kernel(ExtractArgs a) {
+    __shared__ u32 pk[EX_TILE / 16 + 4];          // 2-bit packed bases, base 16w at bits 31:30 of word w
+    __shared__ u32 inv[EX_TILE / 32 + 2];         // 1 = base is not one of ACGTacgt (or past the end)
+    __shared__ u32 stb[EX_TILE / 32 + 2];         // 1 = some sequence starts at this position
+    __shared__ u32 seqrel[EX_TILE + EX_EXT];      // #sequences (beyond the tile's first) starting at or before p
+    __shared__ u32 wave_cnt[EX_ROUNDS][EX_BLOCK / 64];
+    __shared__ u32 scan_smem[4];
+    __shared__ u32 blk_total;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 t0 = (u64)blockIdx.x * EX_TILE;
+    const int k = a.k;
+
+    // ---- 1. load + pack ---------------------------------------------------------------------------
+    const bool aligned = (((uintptr_t)a.bases) & 15) == 0;
+    for (int chunk = tid; chunk < (EX_TILE + EX_EXT) / 16; chunk += EX_BLOCK) {
+        u64 g = t0 + (u64)chunk * 16;
+        u32 q[4];
+        if (aligned && g + 16 <= a.nbases) {
+            uint4 v = *reinterpret_cast<const uint4 *>(a.bases + g);
+            q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                u32 x = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    u64 gi = g + i * 4 + b;
+                    u32 c = gi < a.nbases ? a.bases[gi] : 0u;
+                    x |= c << (8 * b);
+                }
+                q[i] = x;
+            }
+        }
+        u32 word = 0, bad = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            u32 c = (q[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            u32 up = c & 0xDFu;                    // Base.fromCharacterByte accepts both cases
+            u32 ok = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
+            word = (word << 2) | ((c >> 1) & 3u);  // 'A'>>1&3=0 'C'=1 'T'=2 'G'=3
+            bad = (bad << 1) | (ok ^ 1u);
+        }
+        pk[chunk] = word;
+        reinterpret_cast<uint16_t *>(inv)[chunk ^ 1] = (uint16_t)bad;
+    }
+    for (int i = tid; i < EX_TILE + EX_EXT; i += EX_BLOCK) seqrel[i] = 0;
+    __syncthreads();
+
+    // ---- 2. sequence starts -> per-position sequence index ------------------------------------------
+    const u32 s_lo = a.tile_seq[blockIdx.x];
+    for (u64 s = (u64)s_lo + 1 + tid; s <= a.nseq; s += EX_BLOCK) {
+        u64 o = a.seq_off[s];
+        if (o >= t0 + EX_TILE + EX_EXT) break;
+        atomicAdd(&seqrel[(u32)(o - t0)], 1u);
+    }
+    __syncthreads();
+    {
+        // blocked: thread owns positions 16*tid .. 16*tid+15 (threads 0,1 also own the extension)
+        u32 c[16];
+        u32 sum = 0, bits = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            c[i] = seqrel[tid * 16 + i];
+            bits = (bits << 1) | (c[i] != 0);
+            sum += c[i];
+        }
+        reinterpret_cast<uint16_t *>(stb)[tid ^ 1] = (uint16_t)bits;
+        if (tid < EX_EXT / 16) {
+            u32 eb = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) eb = (eb << 1) | (seqrel[EX_TILE + tid * 16 + i] != 0);
+            reinterpret_cast<uint16_t *>(stb)[(EX_TILE / 16 + tid) ^ 1] = (uint16_t)eb;
+        }
+        u32 total;
+        u32 incl = block_scan_inclusive(sum, OpSum(), scan_smem, &total);
+        u32 run = incl - sum;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            run += c[i];
+            seqrel[tid * 16 + i] = run;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. windows -----------------------------------------------------------------------------------
+    const u64 kmask = k == 32 ? ~0ull : ~(~0ull >> (2 * k));
+    u64 fkey[EX_ROUNDS];
+    u32 vmask = 0, rmask = 0;   // bit j: window of round j is a k-mer / also emits its RC
+#pragma unroll
+    for (int j = 0; j < EX_ROUNDS; j++) {
+        const u32 p = j * EX_BLOCK + tid;
+        const u32 w = p >> 4, r = p & 15;
+        u64 hi = ((u64)pk[w] << 32) | pk[w + 1];
+        u64 win = (hi << (2 * r)) | ((u64)pk[w + 2] >> (32 - 2 * r));
+        u64 key = win & kmask;
+        const u32 w2 = p >> 5, r2 = p & 31;
+        u64 bad = (((u64)inv[w2] << 32) | inv[w2 + 1]) << r2;
+        u64 st = (((u64)stb[w2] << 32) | stb[w2 + 1]) << r2;
+        bool ok = (bad >> (64 - k)) == 0;
+        if (k > 1) ok = ok && (((st << 1) >> (65 - k)) == 0);
+        ok = ok && (t0 + p + (u64)k <= a.nbases);
+        fkey[j] = key;
+        bool emit_rc = false;
+        if (a.rc && ok) {
+            // Kmer.isOwnRC (Kmer.java:210-225) is a palindrome test on even lengths
+            u64 rev = revpairs64(key >> (64 - 2 * k));
+            emit_rc = !(((k & 1) == 0) && rev == key);
+        }
+        vmask |= (u32)ok << j;
+        rmask |= (u32)emit_rc << j;
+        u64 bal_v = __ballot(ok), bal_r = __ballot(emit_rc);
+        if (lane == 0) wave_cnt[j][wave] = __popcll(bal_v) + __popcll(bal_r);
+        if (!WRITE && ok && a.has_kmer) a.has_kmer[s_lo + seqrel[p]] = 1;
+    }
+    __syncthreads();
+
+    // ---- 4. counts / offsets --------------------------------------------------------------------------
+    if (tid < 64) {
+        // exclusive scan of the 64 (round, wave) counts in window order
+        u32 v = wave_cnt[tid >> 2][tid & 3];
+        u32 inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            u32 o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        wave_cnt[tid >> 2][tid & 3] = inc - v;
+        if (tid == 63) blk_total = inc;
+    }
+    __syncthreads();
+    if (!WRITE) {
+        if (tid == 0) {
+            a.tile_count[blockIdx.x] = blk_total;
+        }
+        // valid forward windows of this tile -> running total
+        u32 nv = __popc(vmask);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nv += __shfl_down(nv, d, 64);
+        if (lane == 0 && nv) atomicAdd(&a.state[ST_NWIN], (u64)nv);
+        return;
+    }
+
+    const u64 out_base = a.state[ST_NREC] + a.tile_off[blockIdx.x];
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int j = 0; j < EX_ROUNDS; j++) {
+        const bool ok = (vmask >> j) & 1, erc = (rmask >> j) & 1;
+        u64 bal_v = __ballot(ok), bal_r = __ballot(erc);
+        if (ok) {
+        const u32 p = j * EX_BLOCK + tid;
+        const u32 s = s_lo + seqrel[p];
+        u64 slot = out_base + wave_cnt[j][wave] + __popcll(bal_v & lt) + __popcll(bal_r & lt);
+        const u64 key = fkey[j];
+        a.out_keys[slot] = key;
+        u64 rkey = 0;
+        if (erc) {
+            rkey = revpairs64(key >> (64 - 2 * k)) ^ (0xAAAAAAAAAAAAAAAAull & kmask);
+            a.out_keys[slot + 1] = rkey;
+        }
+        if (a.kind == KMG_PAYLOAD_TAXON) {
+            u32 v = (u32)a.seq_id[s];
+            u32 *ov = reinterpret_cast<u32 *>(a.out_vals);
+            ov[slot] = v;
+            if (erc) ov[slot + 1] = v;
+        } else {
+            // ReadPos(read, (short)(pos - maxK)): offset of the window start within its sequence
+            u64 pos16 = (u64)((t0 + p - a.seq_off[s]) & 0xFFFFu);
+            u64 v = ((u64)(u32)a.read_index[s] << 16) | pos16;
+            u64 *ov = reinterpret_cast<u64 *>(a.out_vals);
+            ov[slot] = v;
+            if (erc) ov[slot + 1] = v;
+        }
+        }
+    }
+}
+
+// After a write pass: advance the running record count by this batch's total (tile_off[ntiles]).
+__global__ void extract_advance_kernel(u64 *state, const u64 *tile_off, u32 ntiles) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) state[ST_NREC] += tile_off[ntiles];
+}
+
+// OR / AND of (taxon ^ sign bit) over a batch: value bits that never vary need no sort pass.
+__global__ void id_bits_kernel(const int32_t *__restrict__ ids, u64 n, u64 *state) {
+    u32 o = 0, an = 0xFFFFFFFFu;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        u32 v = (u32)ids[i] ^ 0x80000000u;
+        o |= v;
+        an &= v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        o |= __shfl_down(o, d, 64);
+        an &= __shfl_down(an, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicOr(&state[ST_ID_OR], (u64)o);
+        atomicAnd(&state[ST_ID_AND], (u64)an);
+    }
+}
+
+// ---- read numbering (ReadIDMapping.geNext, OtherFiles/ReadIDMapping.java:14-23) ----------------------
+// emit_idx[i] = i if sequence i produced a k-mer else -1          (input of the exclusive max-scan)
+__global__ void number_emit_kernel(const uint8_t *__restrict__ has_kmer, int32_t *__restrict__ emit_idx, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) emit_idx[i] = has_kmer[i] ? (int32_t)i : -1;
+}
+// is_new[i] = sequence i produced a k-mer and its header differs from the last one that did
+__global__ void number_new_kernel(const uint8_t *__restrict__ has_kmer, const int32_t *__restrict__ prev_emit,
+                                  const int64_t *__restrict__ tok, const u64 *__restrict__ state,
+                                  u32 *__restrict__ is_new, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 nw = 0;
+    if (has_kmer[i]) {
+        int32_t p = prev_emit[i];
+        if (p >= 0) nw = tok[i] != tok[p];
+        else nw = !(state[ST_HAVE_CARRY] && (int64_t)state[ST_CARRY_TOK] == tok[i]);
+    }
+    is_new[i] = nw;
+}
+// read_index[i] = base + (#new up to and including i) - 1, or -1; then advance the carried state.
+__global__ void number_final_kernel(const uint8_t *__restrict__ has_kmer, const u32 *__restrict__ incl_new,
+                                    int32_t *__restrict__ read_index, u64 n, const u64 *__restrict__ state) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    read_index[i] = has_kmer[i] ? (int32_t)(state[ST_READ_BASE] + incl_new[i]) - 1 : -1;
+}
+__global__ void number_carry_kernel(const int32_t *__restrict__ prev_emit, const uint8_t *__restrict__ has_kmer,
+                                    const u32 *__restrict__ incl_new, const int64_t *__restrict__ tok, u64 n,
+                                    u64 *state) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || n == 0) return;
+    int64_t last = has_kmer[n - 1] ? (int64_t)(n - 1) : (int64_t)prev_emit[n - 1];
+    if (last >= 0) {
+        state[ST_CARRY_TOK] = (u64)tok[last];
+        state[ST_HAVE_CARRY] = 1;
+    }
+    state[ST_READ_BASE] += incl_new[n - 1];
+}

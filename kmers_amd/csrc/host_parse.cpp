@@ -1,0 +1,153 @@
+// host_parse.cpp -- host-side record splitting of FASTA/FASTQ text into sequence batches.
+//
+// This is the part of OtherFiles/KmersFromFile.java that stays on the host (north star: parsing stays
+// with the caller): the ID / KMER / OTHER state machine of KmersFromFileStateChanger.java:46-68 run
+// over the file's characters.  It produces what kmg_build_add consumes: for every entry into the KMER
+// state one "sequence" = the characters > 32 seen until the state is left (KmersFromFile.java:154-158:
+// only those advance `pos`), plus the header id current at that time.  Windows, validity, RC and read
+// numbering are the GPU's job.  Plain C++ (no HIP); built into libkmers_host.so.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+enum { S_ID = 0, S_KMER = 1, S_OTHER = 2 };
+
+struct Batch {
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> seq_off;   // nseq + 1
+    std::vector<int32_t> seq_id;     // FASTA: Integer.parseInt(header id); 0 where unparsable
+    std::vector<uint8_t> id_ok;      // FASTA: 1 if the header parsed as a Java int
+    std::vector<int64_t> seq_tok;    // FASTQ: token of the header string (equal <=> equal strings)
+    std::vector<uint64_t> name_off;  // token t's header = names[name_off[t] .. name_off[t+1])
+    std::string names;
+    int eof_in_kmer = 0;             // file ended inside a sequence line whose last char was a base
+    std::string err;
+};
+
+// Integer.parseInt: optional sign, at least one digit, fits in int32.
+bool parse_java_int(const uint8_t *p, size_t n, int32_t *out) {
+    if (n == 0) return false;
+    size_t i = 0;
+    bool neg = false;
+    if (p[0] == '-' || p[0] == '+') { neg = p[0] == '-'; i = 1; }
+    if (i == n) return false;
+    int64_t v = 0;
+    for (; i < n; i++) {
+        if (p[i] < '0' || p[i] > '9') return false;
+        v = v * 10 + (p[i] - '0');
+        if (v > 2147483648LL) return false;
+    }
+    if (neg) v = -v;
+    if (v > 2147483647LL || v < -2147483648LL) return false;
+    *out = (int32_t)v;
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+typedef struct kmh_batch kmh_batch;
+
+// mode 0 = FASTA (KmersFromFileStateChanger.getFAinstance), 1 = FASTQ (getFQinstance).
+// k is only used for the no-trailing-newline quirk, FASTA only: when the file ends
+// inside a sequence line right after a base, the reference emits the last k-mer twice; this appends
+// the last k characters as one more sequence with the same id, which yields exactly that extra k-mer
+// when (and only when) the last window is valid.
+kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
+    Batch *b = new Batch();
+    int8_t trans[3][256];
+    memset(trans, -1, sizeof trans);
+    if (mode == 0) {
+        trans[S_ID][' '] = S_OTHER; trans[S_ID]['\n'] = S_KMER; trans[S_OTHER]['\n'] = S_KMER;
+        trans[S_KMER]['\n'] = S_OTHER; trans[S_OTHER]['>'] = S_ID;
+    } else {
+        trans[S_OTHER]['@'] = S_ID; trans[S_KMER]['@'] = S_ID; trans[S_ID]['\n'] = S_KMER;
+        trans[S_KMER]['+'] = S_OTHER;
+    }
+    std::unordered_map<std::string_view, int64_t> intern;
+    b->name_off.push_back(0);
+    b->bases.reserve(n);
+    int state = S_OTHER;
+    uint64_t id_start = 0, id_len = 0;
+    int32_t cur_id = 0; uint8_t cur_ok = 0; int64_t cur_tok = -1;
+    bool id_done = false, in_seq = false, last_was_base = false;
+    auto finish_id = [&]() {
+        if (id_done) return;
+        id_done = true;
+        if (mode == 0) {
+            cur_ok = parse_java_int(data + id_start, id_len, &cur_id) ? 1 : 0;
+            if (!cur_ok) cur_id = 0;
+        } else {
+            std::string_view sv((const char *)data + id_start, id_len);
+            auto it = intern.find(sv);
+            if (it == intern.end()) {
+                cur_tok = (int64_t)intern.size();
+                intern.emplace(sv, cur_tok);
+                b->names.append(sv);
+                b->name_off.push_back(b->names.size());
+            } else cur_tok = it->second;
+        }
+    };
+    auto close_seq = [&]() {
+        if (in_seq) { b->seq_off.push_back(b->bases.size()); in_seq = false; }
+    };
+    b->seq_off.push_back(0);   // seq_off = [0, end_0, end_1, ...]: a sequence is opened/closed in turn
+    for (uint64_t i = 0; i < n; i++) {
+        uint8_t c = data[i];
+        int ns = trans[state][c];
+        if (ns >= 0) {
+            if (state == S_KMER) close_seq();
+            state = ns;
+            last_was_base = false;
+            if (state == S_ID) { id_start = i + 1; id_len = 0; id_done = false; }
+            else if (state == S_KMER) {
+                finish_id();
+                // open a new sequence (pos = 0, KmersFromFile.java:137-139)
+                in_seq = true;
+                if (mode == 0) { b->seq_id.push_back(cur_id); b->id_ok.push_back(cur_ok); }
+                else b->seq_tok.push_back(cur_tok);
+            }
+            continue;
+        }
+        if (state == S_ID) { id_len++; continue; }
+        if (state != S_KMER) continue;
+        if (c > 32) { b->bases.push_back(c); last_was_base = true; }
+        else last_was_base = false;
+    }
+    const bool ended_in_kmer = state == S_KMER && in_seq && last_was_base;
+    close_seq();
+    const size_t nseq = b->seq_off.size() - 1;
+    if (ended_in_kmer) {
+        b->eof_in_kmer = 1;
+        const uint64_t last_len = b->seq_off[nseq] - b->seq_off[nseq - 1];
+        if (mode == 0 && k > 0 && last_len >= (uint64_t)k) {
+            size_t from = b->bases.size() - (size_t)k;
+            for (int j = 0; j < k; j++) b->bases.push_back(b->bases[from + j]);
+            b->seq_off.push_back(b->bases.size());
+            b->seq_id.push_back(b->seq_id.back());
+            b->id_ok.push_back(b->id_ok.back());
+        }
+    }
+    return (kmh_batch *)b;
+}
+
+void kmh_free(kmh_batch *h) { delete (Batch *)h; }
+uint64_t kmh_nseq(const kmh_batch *h) { return ((const Batch *)h)->seq_off.size() - 1; }
+uint64_t kmh_nbases(const kmh_batch *h) { return ((const Batch *)h)->bases.size(); }
+const uint8_t *kmh_bases(const kmh_batch *h) { return ((const Batch *)h)->bases.data(); }
+const uint64_t *kmh_seq_off(const kmh_batch *h) { return ((const Batch *)h)->seq_off.data(); }
+const int32_t *kmh_seq_id(const kmh_batch *h) { return ((const Batch *)h)->seq_id.data(); }
+const uint8_t *kmh_id_ok(const kmh_batch *h) { return ((const Batch *)h)->id_ok.data(); }
+const int64_t *kmh_seq_tok(const kmh_batch *h) { return ((const Batch *)h)->seq_tok.data(); }
+uint64_t kmh_ntok(const kmh_batch *h) { return ((const Batch *)h)->name_off.size() - 1; }
+const uint64_t *kmh_name_off(const kmh_batch *h) { return ((const Batch *)h)->name_off.data(); }
+const char *kmh_names(const kmh_batch *h) { return ((const Batch *)h)->names.data(); }
+int kmh_eof_in_kmer(const kmh_batch *h) { return ((const Batch *)h)->eof_in_kmer; }
+
+}  // extern "C"

@@ -1,0 +1,658 @@
+// kmers_gpu.hip -- C ABI (include/kmers_gpu.h) and host orchestration of the MI355X k-mer hot path.
+// gfx950 only.  Stages: extract.h (encode + windows + RC + read numbering), radix.h (stable LSD sort),
+// reduce.h (dedup -> CSR, bucket offsets, block encoding), match.h (sorted join, TaxaCounts).
+#include "common.h"
+#include "scan.h"
+#include "extract.h"
+#include "radix.h"
+#include "reduce.h"
+#include "match.h"
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <new>
+
+// ------------------------------------------------------------------------------------------------ utils
+__global__ void set_u64_kernel(u64 *p, u64 v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;
+}
+
+struct PoolBuf {
+    // RAII: device scratch that goes back to the context's pool when the scope ends.  Safe with
+    // asynchronous work because every kernel of a context runs on its one stream, so any later reuse
+    // of the block is ordered after the work that still reads it.
+    kmg_ctx *ctx;
+    void *p = nullptr;
+    explicit PoolBuf(kmg_ctx *c) : ctx(c) {}
+    ~PoolBuf() { ctx->pool.release(p); }
+    int alloc(size_t bytes) { return ctx->pool.alloc(&p, bytes); }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+    void *detach() { void *q = p; p = nullptr; return q; }
+};
+
+static int fail(kmg_ctx *ctx, int code, const char *msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define KMG_ALLOC(buf, bytes)                                                             \
+    do {                                                                                  \
+        if ((buf).alloc(bytes) != KMG_OK) return fail(ctx, KMG_ENOMEM, "device allocation failed"); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ context
+extern "C" int kmg_create(int device, kmg_ctx **out) {
+    if (!out) return KMG_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return KMG_EDEVICE;
+    if (device < 0 || device >= ndev) return KMG_EINVAL;
+    kmg_ctx *ctx = new (std::nothrow) kmg_ctx();
+    if (!ctx) return KMG_ENOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return KMG_EDEVICE;
+    }
+    void *st = nullptr;
+    if (ctx->pool.alloc(&st, ST_WORDS * sizeof(u64)) != KMG_OK) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return KMG_ENOMEM;
+    }
+    ctx->d_state = (u64 *)st;
+    *out = ctx;
+    return KMG_OK;
+}
+
+extern "C" void kmg_destroy(kmg_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_drain(ctx);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    ctx->pool.destroy();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char *kmg_last_error(kmg_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" void *kmg_stream(kmg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------------------ build
+extern "C" int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind) {
+    if (!ctx) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (k < 1 || key_len < 1) return fail(ctx, KMG_EINVAL, "k and key_len must be positive");
+    if (k > 32) return fail(ctx, KMG_EUNSUPPORTED, "k > 32 is not supported on the GPU path");
+    if (key_len > k || key_len > 12) return fail(ctx, KMG_EUNSUPPORTED, "key_len must be <= min(k, 12)");
+    if (payload_kind != KMG_PAYLOAD_TAXON && payload_kind != KMG_PAYLOAD_READPOS)
+        return fail(ctx, KMG_EINVAL, "unknown payload kind");
+    KMG_HIP(hipSetDevice(ctx->device));
+    ctx->k = k; ctx->key_len = key_len; ctx->rc = rc ? 1 : 0; ctx->kind = payload_kind;
+    ctx->rec_upper = 0;
+    u64 init[ST_WORDS];
+    memset(init, 0, sizeof init);
+    init[ST_ID_AND] = 0xFFFFFFFFull;
+    // stream-ordered: the pageable source is consumed before hipMemcpyAsync returns
+    KMG_HIP(hipMemcpyAsync(ctx->d_state, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->building = true;
+    return KMG_OK;
+}
+
+static int ensure_record_capacity(kmg_ctx *ctx, u64 need) {
+    if (need <= ctx->rec_cap && ctx->rec_keys) return KMG_OK;
+    u64 ncap = std::max(need, ctx->rec_cap + ctx->rec_cap / 2);
+    const size_t vb = val_bytes(ctx->kind);
+    void *nk = nullptr, *nv = nullptr;
+    if (ctx->pool.alloc(&nk, ncap * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "record buffer allocation failed");
+    if (ctx->pool.alloc(&nv, ncap * vb) != KMG_OK) {
+        ctx->pool.release(nk);
+        return fail(ctx, KMG_ENOMEM, "record buffer allocation failed");
+    }
+    if (ctx->rec_keys && ctx->rec_upper) {
+        KMG_HIP(hipMemcpyAsync(nk, ctx->rec_keys, ctx->rec_upper * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        KMG_HIP(hipMemcpyAsync(nv, ctx->rec_vals, ctx->rec_upper * vb, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    ctx->pool.release(ctx->rec_keys);
+    ctx->pool.release(ctx->rec_vals);
+    ctx->rec_keys = (u64 *)nk;
+    ctx->rec_vals = nv;
+    ctx->rec_cap = ncap;
+    return KMG_OK;
+}
+
+// All pointers are device pointers.  Caller holds ctx->mu.
+static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, const u64 *d_seq_off,
+                            const int32_t *d_seq_id, const int64_t *d_seq_tok, u64 nseq, int32_t *d_read_index_out) {
+    if (!ctx->building) return fail(ctx, KMG_ESTATE, "kmg_build_add before kmg_build_begin");
+    const bool reads = ctx->kind == KMG_PAYLOAD_READPOS;
+    if (nseq == 0 || nbases == 0) {
+        if (reads && d_read_index_out && nseq)
+            KMG_HIP(hipMemsetAsync(d_read_index_out, 0xFF, nseq * sizeof(int32_t), ctx->stream));
+        return KMG_OK;
+    }
+    if (!d_bases || !d_seq_off) return fail(ctx, KMG_EINVAL, "null bases / seq_off");
+    if (!reads && !d_seq_id) return fail(ctx, KMG_EINVAL, "seq_id required for taxon payload");
+    if (reads && !d_seq_tok) return fail(ctx, KMG_EINVAL, "seq_tok required for read payload");
+    if (nseq >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "too many sequences in one batch");
+    if (nbases >= (u64)0xFFFFFFF0ull * 1024) return fail(ctx, KMG_EUNSUPPORTED, "batch too large");
+
+    const u64 upper = ctx->rec_upper + nbases * (ctx->rc ? 2 : 1);
+    KMG_TRY(ensure_record_capacity(ctx, upper));
+
+    const u32 ntiles = div_up_u64(nbases, EX_TILE);
+    PoolBuf tile_seq(ctx), tile_count(ctx), tile_off(ctx), agg(ctx), has_kmer(ctx), read_index(ctx), tmp_a(ctx), tmp_b(ctx);
+    KMG_ALLOC(tile_seq, (size_t)(ntiles + 1) * 4);
+    KMG_ALLOC(tile_count, (size_t)ntiles * 4);
+    KMG_ALLOC(tile_off, (size_t)(ntiles + 1) * 8);
+    KMG_ALLOC(agg, (size_t)(std::max<u64>(div_up_u64(ntiles, SCAN_TILE), div_up_u64(nseq, SCAN_TILE)) + 1) * 8);
+
+    ExtractArgs a;
+    memset(&a, 0, sizeof a);
+    a.bases = d_bases; a.nbases = nbases; a.seq_off = d_seq_off; a.nseq = nseq; a.seq_id = d_seq_id;
+    a.tile_seq = tile_seq.as<u32>(); a.k = ctx->k; a.rc = ctx->rc; a.kind = ctx->kind;
+    a.tile_count = tile_count.as<u32>(); a.tile_off = tile_off.as<u64>();
+    a.out_keys = ctx->rec_keys; a.out_vals = ctx->rec_vals; a.state = ctx->d_state;
+
+    {
+        ProfScope ps(ctx, KP_EXTRACT_TILESEQ, 0);
+        hipLaunchKernelGGL(extract_tileseq_kernel, dim3(div_up_u64(ntiles + 1, 256)), dim3(256), 0, ctx->stream,
+                           d_seq_off, nseq, tile_seq.as<u32>(), ntiles + 1);
+    }
+    int32_t *ridx = nullptr;
+    if (reads) {
+        KMG_ALLOC(has_kmer, nseq);
+        KMG_HIP(hipMemsetAsync(has_kmer.p, 0, nseq, ctx->stream));
+        a.has_kmer = has_kmer.as<uint8_t>();
+        if (d_read_index_out) ridx = d_read_index_out;
+        else { KMG_ALLOC(read_index, nseq * 4); ridx = read_index.as<int32_t>(); }
+        a.read_index = ridx;
+    }
+    {
+        ProfScope ps(ctx, KP_EXTRACT_COUNT, nbases);
+        hipLaunchKernelGGL((extract_kernel<false>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
+    }
+    if (reads) {
+        // ReadIDMapping.geNext over the batch: two scans and three elementwise kernels
+        KMG_ALLOC(tmp_a, nseq * 4);
+        KMG_ALLOC(tmp_b, nseq * 4);
+        ProfScope ps(ctx, KP_NUMBER_READS, 0);
+        const dim3 g1(div_up_u64(nseq, 256)), b1(256);
+        hipLaunchKernelGGL(number_emit_kernel, g1, b1, 0, ctx->stream, has_kmer.as<uint8_t>(), tmp_a.as<int32_t>(), nseq);
+        KMG_TRY((device_scan<int32_t, int32_t, OpMax, true>(ctx, tmp_a.as<int32_t>(), tmp_a.as<int32_t>(), nseq, OpMax(),
+                                                            (int32_t)-1, agg.as<int32_t>(), nullptr, false, KP_SCAN)));
+        hipLaunchKernelGGL(number_new_kernel, g1, b1, 0, ctx->stream, has_kmer.as<uint8_t>(), tmp_a.as<int32_t>(),
+                           d_seq_tok, ctx->d_state, tmp_b.as<u32>(), nseq);
+        KMG_TRY((device_scan<u32, u32, OpSum, false>(ctx, tmp_b.as<u32>(), tmp_b.as<u32>(), nseq, OpSum(), 0u,
+                                                     agg.as<u32>(), nullptr, false, KP_SCAN)));
+        hipLaunchKernelGGL(number_final_kernel, g1, b1, 0, ctx->stream, has_kmer.as<uint8_t>(), tmp_b.as<u32>(), ridx,
+                           nseq, ctx->d_state);
+        hipLaunchKernelGGL(number_carry_kernel, dim3(1), dim3(64), 0, ctx->stream, tmp_a.as<int32_t>(),
+                           has_kmer.as<uint8_t>(), tmp_b.as<u32>(), d_seq_tok, nseq, ctx->d_state);
+    } else {
+        hipLaunchKernelGGL(id_bits_kernel, dim3(std::min<u32>(div_up_u64(nseq, 256), 1024)), dim3(256), 0, ctx->stream,
+                           d_seq_id, nseq, ctx->d_state);
+    }
+    KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, tile_count.as<u32>(), tile_off.as<u64>(), ntiles, OpSum(), 0ull,
+                                                agg.as<u64>(), nullptr, true, KP_SCAN)));
+    {
+        const u64 rec_b = 8 + val_bytes(ctx->kind);
+        ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases /* + records * rec_b, added at finish when N is known */);
+        (void)rec_b;
+        hipLaunchKernelGGL((extract_kernel<true>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
+        hipLaunchKernelGGL(extract_advance_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, tile_off.as<u64>(), ntiles);
+    }
+    KMG_HIP(hipGetLastError());
+    ctx->rec_upper = upper;
+    return KMG_OK;
+}
+
+extern "C" int kmg_build_add_dev(kmg_ctx *ctx, const uint8_t *d_bases, uint64_t nbases, const uint64_t *d_seq_off,
+                                 const int32_t *d_seq_id, const int64_t *d_seq_tok, uint64_t nseq,
+                                 int32_t *d_read_index_out) {
+    if (!ctx) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    return build_add_locked(ctx, d_bases, nbases, (const u64 *)d_seq_off, d_seq_id, d_seq_tok, nseq, d_read_index_out);
+}
+
+extern "C" int kmg_build_add(kmg_ctx *ctx, const uint8_t *bases, uint64_t nbases, const uint64_t *seq_off,
+                             const int32_t *seq_id, const int64_t *seq_tok, uint64_t nseq, int32_t *read_index_out) {
+    if (!ctx) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!ctx->building) return fail(ctx, KMG_ESTATE, "kmg_build_add before kmg_build_begin");
+    if (nseq == 0) return KMG_OK;
+    if (!seq_off || (nbases && !bases)) return fail(ctx, KMG_EINVAL, "null bases / seq_off");
+    const bool reads = ctx->kind == KMG_PAYLOAD_READPOS;
+    if (!reads && !seq_id) return fail(ctx, KMG_EINVAL, "seq_id required for taxon payload");
+    if (reads && !seq_tok) return fail(ctx, KMG_EINVAL, "seq_tok required for read payload");
+    if (seq_off[0] != 0 || seq_off[nseq] != nbases) return fail(ctx, KMG_EINVAL, "seq_off must run from 0 to nbases");
+    for (u64 i = 0; i < nseq; i++)
+        if (seq_off[i] > seq_off[i + 1]) return fail(ctx, KMG_EINVAL, "seq_off must be non-decreasing");
+    KMG_HIP(hipSetDevice(ctx->device));
+    if (nbases == 0) {
+        if (reads && read_index_out) for (u64 i = 0; i < nseq; i++) read_index_out[i] = -1;
+        return KMG_OK;
+    }
+    PoolBuf d_bases(ctx), d_off(ctx), d_id(ctx), d_tok(ctx), d_ridx(ctx);
+    KMG_ALLOC(d_bases, nbases + 64);
+    KMG_ALLOC(d_off, (nseq + 1) * 8);
+    KMG_HIP(hipMemcpyAsync(d_bases.p, bases, nbases, hipMemcpyHostToDevice, ctx->stream));
+    KMG_HIP(hipMemcpyAsync(d_off.p, seq_off, (nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (reads) {
+        KMG_ALLOC(d_tok, nseq * 8);
+        KMG_HIP(hipMemcpyAsync(d_tok.p, seq_tok, nseq * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (read_index_out) KMG_ALLOC(d_ridx, nseq * 4);
+    } else {
+        KMG_ALLOC(d_id, nseq * 4);
+        KMG_HIP(hipMemcpyAsync(d_id.p, seq_id, nseq * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    KMG_TRY(build_add_locked(ctx, d_bases.as<uint8_t>(), nbases, d_off.as<u64>(), d_id.as<int32_t>(),
+                             d_tok.as<int64_t>(), nseq, d_ridx.as<int32_t>()));
+    if (reads && read_index_out) {
+        KMG_HIP(hipMemcpyAsync(read_index_out, d_ridx.p, nseq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    // the host buffers may be freed or moved by the caller as soon as we return
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    return KMG_OK;
+}
+
+static void db_release(kmg_db *db) {
+    if (!db) return;
+    kmg_ctx *ctx = db->ctx;
+    ctx->pool.release(db->keys);
+    ctx->pool.release(db->val_off);
+    ctx->pool.release(db->val_a);
+    ctx->pool.release(db->val_b);
+    ctx->pool.release(db->bucket_off);
+    delete db;
+}
+
+extern "C" void kmg_db_free(kmg_db *db) {
+    if (!db) return;
+    kmg_ctx *ctx = db->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    db_release(db);
+}
+
+template <typename V, bool IS_REF>
+static int reduce_records(kmg_ctx *ctx, const u64 *keys, const V *vals, u32 n, kmg_db *db, u64 *d_totals) {
+    // allocate the CSR at its upper bound (n) so that no host round trip sits between count and write
+    void *p;
+    if (ctx->pool.alloc(&p, ((size_t)n + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->keys = (u64 *)p;
+    if (ctx->pool.alloc(&p, ((size_t)n + 2) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->val_off = (u64 *)p;
+    if (ctx->pool.alloc(&p, ((size_t)n + 1) * 4) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->val_a = (int32_t *)p;
+    if (ctx->pool.alloc(&p, ((size_t)n + 1) * 4) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->val_b = (int32_t *)p;
+    const u32 nbuckets = 1u << (2 * db->key_len);
+    if (ctx->pool.alloc(&p, ((size_t)nbuckets + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->bucket_off = (u64 *)p;
+
+    const u32 ntiles = div_up_u64(n, RD_TILE);
+    PoolBuf cnt_k(ctx), cnt_v(ctx), off_k(ctx), off_v(ctx), agg(ctx), vstart(ctx);
+    KMG_ALLOC(cnt_k, (size_t)(ntiles + 1) * 4);
+    KMG_ALLOC(cnt_v, (size_t)(ntiles + 1) * 4);
+    KMG_ALLOC(off_k, (size_t)(ntiles + 1) * 8);
+    KMG_ALLOC(off_v, (size_t)(ntiles + 1) * 8);
+    KMG_ALLOC(agg, (size_t)(div_up_u64(ntiles, SCAN_TILE) + 1) * 8);
+    if (IS_REF) KMG_ALLOC(vstart, ((size_t)n + 1) * 4);
+    const u64 rec_b = 8 + sizeof(V);
+    if (n > 0) {
+        {
+            ProfScope ps(ctx, KP_REDUCE_FLAG, (u64)n * rec_b);
+            hipLaunchKernelGGL((rd_count_kernel<V, IS_REF>), dim3(ntiles), dim3(RD_BLOCK), 0, ctx->stream, keys, vals, n,
+                               cnt_k.as<u32>(), cnt_v.as<u32>());
+        }
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt_k.as<u32>(), off_k.as<u64>(), ntiles, OpSum(), 0ull,
+                                                    agg.as<u64>(), d_totals + 0, false, KP_SCAN)));
+        if (IS_REF) {
+            KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt_v.as<u32>(), off_v.as<u64>(), ntiles, OpSum(), 0ull,
+                                                        agg.as<u64>(), d_totals + 1, false, KP_SCAN)));
+        } else {
+            hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, d_totals + 1, (u64)n);
+        }
+        {
+            ProfScope ps(ctx, KP_REDUCE_WRITE, (u64)n * rec_b /* + CSR bytes, added when U,V are known */);
+            hipLaunchKernelGGL((rd_write_kernel<V, IS_REF>), dim3(ntiles), dim3(RD_BLOCK), 0, ctx->stream, keys, vals, n,
+                               off_k.as<u64>(), off_v.as<u64>(), db->keys, db->val_off, db->val_a, db->val_b,
+                               vstart.as<u32>());
+            if (IS_REF)
+                hipLaunchKernelGGL(rd_counts_kernel, dim3(std::min<u32>(div_up_u64(n, 256), 4096)), dim3(256), 0,
+                                   ctx->stream, vstart.as<u32>(), d_totals, n, db->val_b);
+        }
+    } else {
+        KMG_HIP(hipMemsetAsync(d_totals, 0, 16, ctx->stream));
+    }
+    {
+        ProfScope ps(ctx, KP_BUCKETS, 0);
+        hipLaunchKernelGGL(rd_buckets_kernel, dim3(div_up_u64(nbuckets + 1, 256)), dim3(256), 0, ctx->stream, db->keys,
+                           d_totals, db->val_off, db->bucket_off, nbuckets, db->key_len);
+    }
+    KMG_HIP(hipGetLastError());
+    return KMG_OK;
+}
+
+extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows) {
+    if (!ctx || !out) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *out = nullptr;
+    if (!ctx->building) return fail(ctx, KMG_ESTATE, "kmg_build_finish before kmg_build_begin");
+    KMG_HIP(hipSetDevice(ctx->device));
+    ctx->building = false;
+
+    u64 st[ST_WORDS];
+    KMG_HIP(hipMemcpyAsync(st, ctx->d_state, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    const u64 N = st[ST_NREC];
+    if (n_windows) *n_windows = st[ST_NWIN];
+    if (N >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 records in one build");
+    if (ctx->prof_on) ctx->prof[KP_EXTRACT_WRITE].bytes += N * (8 + val_bytes(ctx->kind));
+    const u32 n = (u32)N;
+    const bool reads = ctx->kind == KMG_PAYLOAD_READPOS;
+
+    kmg_db *db = new (std::nothrow) kmg_db();
+    if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+    std::unique_ptr<kmg_db, void (*)(kmg_db *)> db_guard(db, db_release);
+    db->ctx = ctx; db->k = ctx->k; db->key_len = ctx->key_len; db->rc = ctx->rc; db->kind = ctx->kind;
+
+    // sort passes: payload bits that vary (taxa order inside a k-mer), then the 2k key bits
+    std::vector<SortPass> passes;
+    if (!reads) {
+        const u32 varying = (u32)st[ST_ID_OR] ^ (u32)st[ST_ID_AND];
+        for (int b = 0; b < 4; b++)
+            if ((varying >> (8 * b)) & 0xFFu) passes.push_back({8 * b, 8, true});
+    }
+    for (int shift = 64 - 2 * ctx->k; shift < 64; shift += RS_BITS) passes.push_back({shift, std::min(RS_BITS, 64 - shift), false});
+
+    PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx);
+    const size_t vb = val_bytes(ctx->kind);
+    const u32 ntiles = n ? div_up_u64(n, RS_TILE) : 1;
+    KMG_ALLOC(totals, 64);
+    int r = KMG_OK;
+    bool in1 = false;
+    if (n > 0) {
+        if (!ctx->rec_keys) return fail(ctx, KMG_ESTATE, "no record buffer");
+        KMG_ALLOC(k1, (size_t)n * 8);
+        KMG_ALLOC(v1, (size_t)n * vb);
+        KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
+        KMG_ALLOC(agg, (size_t)(div_up_u64((u64)RS_DIGITS * ntiles, SCAN_TILE) + 1) * 8);
+        if (reads) r = radix_sort_records<u64>(ctx, ctx->rec_keys, (u64 *)ctx->rec_vals, k1.as<u64>(), v1.as<u64>(), n, passes, table.as<u32>(), agg.as<u32>(), &in1);
+        else r = radix_sort_records<u32>(ctx, ctx->rec_keys, (u32 *)ctx->rec_vals, k1.as<u64>(), v1.as<u32>(), n, passes, table.as<u32>(), agg.as<u32>(), &in1);
+    }
+    if (r == KMG_OK) {
+        const u64 *sk = in1 ? k1.as<u64>() : ctx->rec_keys;
+        const void *sv = in1 ? v1.p : ctx->rec_vals;
+        if (reads) r = reduce_records<u64, false>(ctx, sk, (const u64 *)sv, n, db, totals.as<u64>());
+        else r = reduce_records<u32, true>(ctx, sk, (const u32 *)sv, n, db, totals.as<u64>());
+    }
+    u64 tot[2] = {0, 0};
+    if (r == KMG_OK) {
+        hipError_t e = hipMemcpyAsync(tot, totals.p, 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { ctx->err = hipGetErrorString(e); r = KMG_EDEVICE; }
+    }
+    // the record buffers go back to the pool: the next build (or the DB arrays of this one) reuses them
+    ctx->pool.release(ctx->rec_keys);
+    ctx->pool.release(ctx->rec_vals);
+    ctx->rec_keys = nullptr; ctx->rec_vals = nullptr; ctx->rec_cap = 0; ctx->rec_upper = 0;
+    if (r != KMG_OK) return r;
+    db->U = tot[0];
+    db->V = tot[1];
+    if (ctx->prof_on)
+        ctx->prof[KP_REDUCE_WRITE].bytes += db->U * 16 + db->V * (reads ? 6 : 8);
+    *out = db_guard.release();
+    return KMG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ db
+extern "C" int kmg_db_info(const kmg_db *db, int *k, int *key_len, int *rc, int *payload_kind, uint64_t *n_unique,
+                           uint64_t *n_values) {
+    if (!db) return KMG_EINVAL;
+    if (k) *k = db->k;
+    if (key_len) *key_len = db->key_len;
+    if (rc) *rc = db->rc;
+    if (payload_kind) *payload_kind = db->kind;
+    if (n_unique) *n_unique = db->U;
+    if (n_values) *n_values = db->V;
+    return KMG_OK;
+}
+
+extern "C" int kmg_db_fetch(const kmg_db *db, uint64_t *keys, uint64_t *val_off, int32_t *val_a, int32_t *val_b,
+                            uint64_t *bucket_off) {
+    if (!db) return KMG_EINVAL;
+    kmg_ctx *ctx = db->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    if (keys && db->U) KMG_HIP(hipMemcpyAsync(keys, db->keys, db->U * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (val_off) KMG_HIP(hipMemcpyAsync(val_off, db->val_off, (db->U + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (val_a && db->V) KMG_HIP(hipMemcpyAsync(val_a, db->val_a, db->V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (val_b && db->V) KMG_HIP(hipMemcpyAsync(val_b, db->val_b, db->V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (bucket_off)
+        KMG_HIP(hipMemcpyAsync(bucket_off, db->bucket_off, (((size_t)1 << (2 * db->key_len)) + 1) * 8,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    return KMG_OK;
+}
+
+extern "C" int kmg_db_load(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *keys,
+                           uint64_t n_unique, const uint64_t *val_off, const int32_t *val_a, const int32_t *val_b,
+                           kmg_db **out) {
+    if (!ctx || !out) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *out = nullptr;
+    if (k < 1 || key_len < 1) return fail(ctx, KMG_EINVAL, "k and key_len must be positive");
+    if (k > 32 || key_len > k || key_len > 12) return fail(ctx, KMG_EUNSUPPORTED, "k > 32 or key_len > min(k, 12)");
+    if (!val_off || (n_unique && !keys)) return fail(ctx, KMG_EINVAL, "null keys / val_off");
+    const u64 V = val_off[n_unique];
+    if (V && (!val_a || !val_b)) return fail(ctx, KMG_EINVAL, "null values");
+    for (u64 i = 1; i < n_unique; i++)
+        if (keys[i - 1] >= keys[i]) return fail(ctx, KMG_EINVAL, "keys must be strictly ascending");
+    KMG_HIP(hipSetDevice(ctx->device));
+    kmg_db *db = new (std::nothrow) kmg_db();
+    if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+    db->ctx = ctx; db->k = k; db->key_len = key_len; db->rc = rc ? 1 : 0; db->kind = payload_kind;
+    db->U = n_unique; db->V = V;
+    const u32 nbuckets = 1u << (2 * key_len);
+    void *p;
+    int r = KMG_OK;
+    if (ctx->pool.alloc(&p, (n_unique + 1) * 8) == KMG_OK) db->keys = (u64 *)p; else r = KMG_ENOMEM;
+    if (r == KMG_OK && ctx->pool.alloc(&p, (n_unique + 2) * 8) == KMG_OK) db->val_off = (u64 *)p; else r = KMG_ENOMEM;
+    if (r == KMG_OK && ctx->pool.alloc(&p, (V + 1) * 4) == KMG_OK) db->val_a = (int32_t *)p; else r = KMG_ENOMEM;
+    if (r == KMG_OK && ctx->pool.alloc(&p, (V + 1) * 4) == KMG_OK) db->val_b = (int32_t *)p; else r = KMG_ENOMEM;
+    if (r == KMG_OK && ctx->pool.alloc(&p, ((size_t)nbuckets + 1) * 8) == KMG_OK) db->bucket_off = (u64 *)p; else r = KMG_ENOMEM;
+    PoolBuf totals(ctx);
+    if (r == KMG_OK && totals.alloc(64) != KMG_OK) r = KMG_ENOMEM;
+    if (r != KMG_OK) { db_release(db); return fail(ctx, KMG_ENOMEM, "device allocation failed"); }
+    hipError_t e = hipSuccess;
+    if (n_unique) e = hipMemcpyAsync(db->keys, keys, n_unique * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db->val_off, val_off, (n_unique + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && V) e = hipMemcpyAsync(db->val_a, val_a, V * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && V) e = hipMemcpyAsync(db->val_b, val_b, V * 4, hipMemcpyHostToDevice, ctx->stream);
+    u64 tot[2] = {n_unique, V};
+    if (e == hipSuccess) e = hipMemcpyAsync(totals.p, tot, 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rd_buckets_kernel, dim3(div_up_u64(nbuckets + 1, 256)), dim3(256), 0, ctx->stream, db->keys,
+                           totals.as<u64>(), db->val_off, db->bucket_off, nbuckets, key_len);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); db_release(db); return KMG_EDEVICE; }
+    *out = db;
+    return KMG_OK;
+}
+
+extern "C" int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint64_t cap, uint64_t *n_bytes,
+                             uint64_t *block_off) {
+    if (!ctx || !db || !n_bytes) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    const u64 U = db->U;
+    const u32 nbuckets = 1u << (2 * db->key_len);
+    PoolBuf sizes(ctx), enc_off(ctx), agg(ctx), d_out(ctx), d_boff(ctx);
+    KMG_ALLOC(sizes, (U + 1) * 4);
+    KMG_ALLOC(enc_off, (U + 2) * 8);
+    KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
+    ProfScope ps(ctx, KP_ENCODE, 0);
+    if (U) {
+        hipLaunchKernelGGL(enc_size_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys, db->val_off, U,
+                           db->k, db->key_len, db->kind, sizes.as<u32>());
+    }
+    KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, sizes.as<u32>(), enc_off.as<u64>(), U, OpSum(), 0ull, agg.as<u64>(),
+                                                nullptr, true, KP_SCAN)));
+    u64 total = 0;
+    KMG_HIP(hipMemcpyAsync(&total, enc_off.as<u64>() + U, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    *n_bytes = total;
+    if (block_off) {
+        KMG_ALLOC(d_boff, ((size_t)nbuckets + 1) * 8);
+        hipLaunchKernelGGL(enc_blockoff_kernel, dim3(div_up_u64(nbuckets + 1, 256)), dim3(256), 0, ctx->stream,
+                           db->bucket_off, enc_off.as<u64>(), nbuckets, d_boff.as<u64>());
+        KMG_HIP(hipMemcpyAsync(block_off, d_boff.p, ((size_t)nbuckets + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (out) {
+        if (cap < total) return fail(ctx, KMG_EINVAL, "encode buffer too small");
+        if (total) {
+            KMG_ALLOC(d_out, total);
+            hipLaunchKernelGGL(enc_write_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys,
+                               db->val_off, db->val_a, db->val_b, U, db->k, db->key_len, db->kind, enc_off.as<u64>(),
+                               d_out.as<uint8_t>());
+            KMG_HIP(hipMemcpyAsync(out, d_out.p, total, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    KMG_HIP(hipGetLastError());
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    return KMG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ match
+static int match_locked(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, long long *d_hit, u64 *d_nhits) {
+    if (search->ctx != ctx || ref->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
+    // DB.java:78-81: search k-mers must have the database's length; keys are compared per key bucket
+    if (search->k != ref->k || search->key_len != ref->key_len)
+        return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
+    if (search->U == 0) return KMG_OK;
+    ProfScope ps(ctx, KP_MATCH, 8 * (search->U + ref->U) + 8 * search->U);
+    hipLaunchKernelGGL(match_kernel, dim3(div_up_u64(search->U, MT_BLOCK)), dim3(MT_BLOCK), 0, ctx->stream, search->keys,
+                       search->U, ref->keys, ref->bucket_off, ref->key_len, d_hit, d_nhits);
+    KMG_HIP(hipGetLastError());
+    return KMG_OK;
+}
+
+extern "C" int kmg_match_dev(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *d_hit_index) {
+    if (!ctx || !search || !ref || !d_hit_index) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    return match_locked(ctx, search, ref, (long long *)d_hit_index, nullptr);
+}
+
+extern "C" int kmg_match(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *hit_index, uint64_t *n_hits) {
+    if (!ctx || !search || !ref || !hit_index) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    PoolBuf d_hit(ctx), d_n(ctx);
+    KMG_ALLOC(d_hit, (search->U + 1) * 8);
+    KMG_ALLOC(d_n, 64);
+    KMG_HIP(hipMemsetAsync(d_n.p, 0, 8, ctx->stream));
+    KMG_TRY(match_locked(ctx, search, ref, d_hit.as<long long>(), d_n.as<u64>()));
+    u64 nh = 0;
+    if (search->U) KMG_HIP(hipMemcpyAsync(hit_index, d_hit.p, search->U * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(hipMemcpyAsync(&nh, d_n.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_hits) *n_hits = nh;
+    return KMG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ taxa counts
+extern "C" int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, int64_t *match, int64_t *unique,
+                              uint64_t *n_taxa) {
+    if (!ctx || !db || !n_taxa) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (db->kind != KMG_PAYLOAD_TAXON) return fail(ctx, KMG_EINVAL, "TaxaCounts needs a reference (taxon) database");
+    KMG_HIP(hipSetDevice(ctx->device));
+    const u64 cap = *n_taxa;
+    *n_taxa = 0;
+    const u64 V = db->V;
+    if (V == 0 || db->U == 0) return KMG_OK;
+    if (V >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 values");
+    ProfScope ps(ctx, KP_TAXA, 8 * (db->U + 1) + 4 * V);
+
+    // distinct taxa: sort a copy of val_a (sign-flipped so that int order == unsigned order), keep run heads
+    PoolBuf k0(ctx), v0(ctx), k1(ctx), v1(ctx), table(ctx), agg(ctx), flag(ctx), total(ctx), taxa(ctx), cm(ctx), cu(ctx);
+    const u32 n = (u32)V;
+    const u32 ntiles = div_up_u64(n, RS_TILE);
+    KMG_ALLOC(k0, (size_t)n * 8); KMG_ALLOC(v0, (size_t)n * 4); KMG_ALLOC(k1, (size_t)n * 8); KMG_ALLOC(v1, (size_t)n * 4);
+    KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
+    KMG_ALLOC(agg, (size_t)(div_up_u64((u64)RS_DIGITS * ntiles, SCAN_TILE) + 1) * 8);
+    KMG_ALLOC(flag, (size_t)n * 4);
+    KMG_ALLOC(total, 64);
+    hipLaunchKernelGGL(taxa_expand_kernel, dim3(div_up_u64(n, 256)), dim3(256), 0, ctx->stream, db->val_a, V, k0.as<u64>(), v0.as<u32>());
+    std::vector<SortPass> passes;
+    for (int b = 0; b < 4; b++) passes.push_back({8 * b, 8, false});
+    bool in1 = false;
+    KMG_TRY(radix_sort_records<u32>(ctx, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), n, passes, table.as<u32>(), agg.as<u32>(), &in1));
+    const u64 *sk = in1 ? k1.as<u64>() : k0.as<u64>();
+    u32 *pos = in1 ? v0.as<u32>() : v1.as<u32>();   // the idle value buffer holds the scan output
+    hipLaunchKernelGGL(taxa_headflag_kernel, dim3(div_up_u64(n, 256)), dim3(256), 0, ctx->stream, sk, V, flag.as<u32>());
+    KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, flag.as<u32>(), pos, V, OpSum(), 0u, agg.as<u32>(), total.as<u32>(), false, KP_SCAN)));
+    u32 nt = 0;
+    KMG_HIP(hipMemcpyAsync(&nt, total.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    KMG_ALLOC(taxa, (size_t)nt * 4);
+    KMG_ALLOC(cm, (size_t)nt * 8);
+    KMG_ALLOC(cu, (size_t)nt * 8);
+    KMG_HIP(hipMemsetAsync(cm.p, 0, (size_t)nt * 8, ctx->stream));
+    KMG_HIP(hipMemsetAsync(cu.p, 0, (size_t)nt * 8, ctx->stream));
+    hipLaunchKernelGGL(taxa_compact_kernel, dim3(div_up_u64(n, 256)), dim3(256), 0, ctx->stream, sk, flag.as<u32>(), pos, V, taxa.as<int32_t>());
+    const u32 grid = std::min<u32>(div_up_u64(db->U, 256), 2048);
+    if (nt <= TX_LDS_MAX)
+        hipLaunchKernelGGL((taxa_count_kernel<true>), dim3(grid), dim3(256), 0, ctx->stream, db->val_off, db->val_a, db->U, taxa.as<int32_t>(), nt, cm.as<u64>(), cu.as<u64>());
+    else
+        hipLaunchKernelGGL((taxa_count_kernel<false>), dim3(grid), dim3(256), 0, ctx->stream, db->val_off, db->val_a, db->U, taxa.as<int32_t>(), nt, cm.as<u64>(), cu.as<u64>());
+    KMG_HIP(hipGetLastError());
+    const u64 w = std::min<u64>(nt, cap);
+    if (w) {
+        if (taxon) KMG_HIP(hipMemcpyAsync(taxon, taxa.p, w * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (match) KMG_HIP(hipMemcpyAsync(match, cm.p, w * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (unique) KMG_HIP(hipMemcpyAsync(unique, cu.p, w * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    *n_taxa = nt;
+    return KMG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+extern "C" int kmg_prof_enable(kmg_ctx *ctx, int on) {
+    if (!ctx) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->prof_on = on != 0;
+    return KMG_OK;
+}
+extern "C" int kmg_prof_reset(kmg_ctx *ctx) {
+    if (!ctx) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_drain(ctx);
+    for (int i = 0; i < KP_COUNT_; i++) ctx->prof[i] = ProfSlot();
+    return KMG_OK;
+}
+extern "C" int kmg_prof_get(kmg_ctx *ctx, int id, double *total_ms, uint64_t *launches, uint64_t *algo_bytes) {
+    if (!ctx || id < 0 || id >= KP_COUNT_) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_drain(ctx);
+    if (total_ms) *total_ms = ctx->prof[id].ms;
+    if (launches) *launches = ctx->prof[id].launches;
+    if (algo_bytes) *algo_bytes = ctx->prof[id].bytes;
+    return KMG_OK;
+}
+extern "C" const char *kmg_prof_name(int id) { return (id >= 0 && id < KP_COUNT_) ? kp_names[id] : ""; }
+extern "C" int kmg_prof_count(void) { return KP_COUNT_; }

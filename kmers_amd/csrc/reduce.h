@@ -1,0 +1,210 @@
+// reduce.h -- stage 2b: deduplicate the sorted records into a CSR database, bucket offsets, block encoding.
+//
+// Replaces the reducer half of MakeAndWriteKey.call (KmerFiles/FileCreator.java:294-301: TreeCountMap.add
+// per taxon | HashSet<ReadPos>.add) and its prefix-delta encoder (:312-347).  One read of the sorted
+// records, one write of the CSR: HBM-bound streaming with a two-level prefix sum for the output slots.
+#pragma once
+#include "common.h"
+#include "scan.h"
+
+#define RD_BLOCK 256
+#define RD_ITEMS 8
+#define RD_TILE (RD_BLOCK * RD_ITEMS)
+
+// A record starts a new k-mer run if its key differs from its predecessor's; a new (k-mer, taxon) run if
+// additionally / alternatively the payload differs.  For read DBs every record is its own value.
+template <typename V, bool IS_REF>
+__global__ __launch_bounds__(RD_BLOCK) void rd_count_kernel(const u64 *__restrict__ keys, const V *__restrict__ vals,
+                                                             u32 n, u32 *__restrict__ cnt_k, u32 *__restrict__ cnt_v) {
+    __shared__ u32 smem[4];
+    const u32 base = blockIdx.x * RD_TILE + threadIdx.x * RD_ITEMS;
+    u32 ck = 0, cv = 0;
+    u64 pk = 0;
+    V pv = 0;
+    if (base > 0 && base < n) { pk = keys[base - 1]; if (IS_REF) pv = vals[base - 1]; }
+#pragma unroll
+    for (int i = 0; i < RD_ITEMS; i++) {
+        u32 idx = base + i;
+        if (idx < n) {
+            u64 kk = keys[idx];
+            bool hk = idx == 0 || kk != pk;
+            ck += hk;
+            if (IS_REF) {
+                V vv = vals[idx];
+                cv += hk || vv != pv;
+                pv = vv;
+            }
+            pk = kk;
+        }
+    }
+    u32 tk, tv = 0;
+    block_scan_inclusive(ck, OpSum(), smem, &tk);
+    if (IS_REF) block_scan_inclusive(cv, OpSum(), smem, &tv);
+    if (threadIdx.x == 0) {
+        cnt_k[blockIdx.x] = tk;
+        if (IS_REF) cnt_v[blockIdx.x] = tv;
+    }
+}
+
+template <typename V, bool IS_REF>
+__global__ __launch_bounds__(RD_BLOCK) void rd_write_kernel(const u64 *__restrict__ keys, const V *__restrict__ vals,
+                                                             u32 n, const u64 *__restrict__ off_k,
+                                                             const u64 *__restrict__ off_v, u64 *__restrict__ ukeys,
+                                                             u64 *__restrict__ val_off, int32_t *__restrict__ val_a,
+                                                             int32_t *__restrict__ val_b, u32 *__restrict__ vstart) {
+    __shared__ u32 smem[4];
+    const u32 base = blockIdx.x * RD_TILE + threadIdx.x * RD_ITEMS;
+    u64 kk[RD_ITEMS];
+    V vv[RD_ITEMS];
+    u32 hk = 0, hv = 0, ck = 0, cv = 0;
+    u64 pk = 0;
+    V pv = 0;
+    if (base > 0 && base < n) { pk = keys[base - 1]; if (IS_REF) pv = vals[base - 1]; }
+#pragma unroll
+    for (int i = 0; i < RD_ITEMS; i++) {
+        u32 idx = base + i;
+        kk[i] = 0; vv[i] = 0;
+        if (idx < n) {
+            kk[i] = keys[idx];
+            vv[i] = vals[idx];
+            bool h = idx == 0 || kk[i] != pk;
+            hk |= (u32)h << i;
+            ck += h;
+            if (IS_REF) {
+                bool h2 = h || vv[i] != pv;
+                hv |= (u32)h2 << i;
+                cv += h2;
+                pv = vv[i];
+            }
+            pk = kk[i];
+        }
+    }
+    u32 tk, tv;
+    u32 ik = block_scan_inclusive(ck, OpSum(), smem, &tk);
+    u64 u = off_k[blockIdx.x] + (ik - ck);
+    u64 v = 0;
+    if (IS_REF) {
+        u32 iv = block_scan_inclusive(cv, OpSum(), smem, &tv);
+        v = off_v[blockIdx.x] + (iv - cv);
+    }
+#pragma unroll
+    for (int i = 0; i < RD_ITEMS; i++) {
+        u32 idx = base + i;
+        if (idx >= n) break;
+        if (IS_REF) {
+            if ((hv >> i) & 1) {
+                if ((hk >> i) & 1) { ukeys[u] = kk[i]; val_off[u] = v; u++; }
+                val_a[v] = (int32_t)vv[i];
+                vstart[v] = idx;
+                v++;
+            }
+        } else {
+            if ((hk >> i) & 1) { ukeys[u] = kk[i]; val_off[u] = idx; u++; }
+            // payload = read << 16 | pos16  ->  ReadPos(int read, short pos)
+            u64 p = (u64)vv[i];
+            val_a[idx] = (int32_t)(p >> 16);
+            val_b[idx] = (int32_t)(int16_t)(p & 0xFFFFu);
+        }
+    }
+}
+
+// counts of a reference DB: occurrences of each (k-mer, taxon) = distance to the next run start
+__global__ void rd_counts_kernel(const u32 *__restrict__ vstart, const u64 *__restrict__ totals /*[0]=U,[1]=V*/,
+                                 u32 n, int32_t *__restrict__ val_b) {
+    u64 V = totals[1];
+    for (u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (u64)gridDim.x * blockDim.x) {
+        u32 next = v + 1 < V ? vstart[v + 1] : n;
+        u32 c = next - vstart[v];
+        val_b[v] = c > 0x7FFFFFFFu ? 0x7FFFFFFF : (int32_t)c;
+    }
+}
+
+// val_off[U] = V ; bucket_off[b] = first k-mer whose Kmer.key(key_len) (Kmers/Kmer.java:47-55) is >= b
+__global__ void rd_buckets_kernel(const u64 *__restrict__ ukeys, const u64 *__restrict__ totals,
+                                  u64 *__restrict__ val_off, u64 *__restrict__ bucket_off, u32 nbuckets, int key_len) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 U = totals[0];
+    if (b == 0) val_off[U] = totals[1];
+    if (b > nbuckets) return;
+    if (b == nbuckets) { bucket_off[b] = U; return; }
+    const u64 target = (u64)b << (64 - 2 * key_len);
+    u64 lo = 0, hi = U;
+    while (lo < hi) {
+        u64 mid = (lo + hi) >> 1;
+        if (ukeys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    bucket_off[b] = lo;
+}
+
+// ---- block encoding (FileCreator.java:312-347) -----------------------------------------------------------
+// Per k-mer: [s = bytes shared with the previous compressedBytes in this bucket][compressedBytes[s:]]
+// then CountDataType.compress (Counts/CountDataType.java:31-46) or SetCompressor<ReadPos> (jar, A.4).
+__device__ __forceinline__ int enc_shared(u64 prev, u64 cur, int l) {
+    // compressedBytes = [len][packed bytes]; the length byte always matches inside a bucket
+    u64 x = prev ^ cur;
+    int same = x == 0 ? 8 : (__clzll((long long)x) >> 3);
+    if (same > l) same = l;
+    return 1 + same;
+}
+
+__global__ void enc_size_kernel(const u64 *__restrict__ ukeys, const u64 *__restrict__ val_off, u64 U, int k, int key_len,
+                                int kind, u32 *__restrict__ sizes) {
+    u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const int l = (k - 1) / 4 + 1;
+    const int sh = 64 - 2 * key_len;
+    u64 cur = ukeys[u];
+    int s = 0;
+    if (u > 0) {
+        u64 prev = ukeys[u - 1];
+        if ((prev >> sh) == (cur >> sh)) s = enc_shared(prev, cur, l);
+    }
+    u64 nv = val_off[u + 1] - val_off[u];
+    u64 sz = 1 + (u64)(l + 1 - s) + (kind == KMG_PAYLOAD_TAXON ? 2 + 5 * nv : 4 + 6 * nv);
+    sizes[u] = (u32)sz;
+}
+
+__global__ void enc_write_kernel(const u64 *__restrict__ ukeys, const u64 *__restrict__ val_off,
+                                 const int32_t *__restrict__ val_a, const int32_t *__restrict__ val_b, u64 U, int k,
+                                 int key_len, int kind, const u64 *__restrict__ enc_off, uint8_t *__restrict__ out) {
+    u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const int l = (k - 1) / 4 + 1;
+    const int sh = 64 - 2 * key_len;
+    u64 cur = ukeys[u];
+    int s = 0;
+    if (u > 0) {
+        u64 prev = ukeys[u - 1];
+        if ((prev >> sh) == (cur >> sh)) s = enc_shared(prev, cur, l);
+    }
+    uint8_t *p = out + enc_off[u];
+    *p++ = (uint8_t)s;
+    if (s == 0) *p++ = (uint8_t)k;
+    for (int i = (s == 0 ? 0 : s - 1); i < l; i++) *p++ = (uint8_t)(cur >> (56 - 8 * i));
+    const u64 a = val_off[u], b = val_off[u + 1];
+    const u64 nv = b - a;
+    if (kind == KMG_PAYLOAD_TAXON) {
+        *p++ = (uint8_t)(nv >> 8);
+        *p++ = (uint8_t)nv;
+        for (u64 v = a; v < b; v++) {
+            u32 t = (u32)val_a[v];
+            int32_t c = val_b[v];
+            *p++ = (uint8_t)(t >> 24); *p++ = (uint8_t)(t >> 16); *p++ = (uint8_t)(t >> 8); *p++ = (uint8_t)t;
+            *p++ = (uint8_t)(c > 255 ? 255 : c);   // CountDataType.java:40
+        }
+    } else {
+        *p++ = (uint8_t)(nv >> 24); *p++ = (uint8_t)(nv >> 16); *p++ = (uint8_t)(nv >> 8); *p++ = (uint8_t)nv;
+        for (u64 v = a; v < b; v++) {
+            u32 r = (u32)val_a[v];
+            u32 q = (u32)val_b[v];
+            *p++ = (uint8_t)(r >> 24); *p++ = (uint8_t)(r >> 16); *p++ = (uint8_t)(r >> 8); *p++ = (uint8_t)r;
+            *p++ = (uint8_t)(q >> 8); *p++ = (uint8_t)q;
+        }
+    }
+}
+
+__global__ void enc_blockoff_kernel(const u64 *__restrict__ bucket_off, const u64 *__restrict__ enc_off, u32 nbuckets,
+                                    u64 *__restrict__ block_off) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= nbuckets) block_off[b] = enc_off[bucket_off[b]];
+}

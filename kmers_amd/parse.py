@@ -1,0 +1,80 @@
+"""Host-side FASTA/FASTQ record splitting (libkmers_host.so, csrc/host_parse.cpp): the ID/KMER/OTHER
+state machine of OtherFiles/KmersFromFileStateChanger.java:46-68 -> SequenceBatch for FileCreator."""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+
+from .api import SequenceBatch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkmers_host.so")
+_lib = None
+
+FASTA, FASTQ = 0, 1
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not found: run __graft_entry__.build()" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        vp, u64 = C.c_void_p, C.c_uint64
+        lib.kmh_parse.restype = vp
+        lib.kmh_parse.argtypes = [C.c_char_p, u64, C.c_int, C.c_int]
+        lib.kmh_free.argtypes = [vp]
+        lib.kmh_free.restype = None
+        for n in ("nseq", "nbases", "ntok"):
+            f = getattr(lib, "kmh_" + n)
+            f.restype, f.argtypes = u64, [vp]
+        for n in ("bases", "seq_off", "seq_id", "id_ok", "seq_tok", "name_off", "names"):
+            f = getattr(lib, "kmh_" + n)
+            f.restype, f.argtypes = vp, [vp]
+        lib.kmh_eof_in_kmer.restype = C.c_int
+        lib.kmh_eof_in_kmer.argtypes = [vp]
+        _lib = lib
+    return _lib
+
+
+def _arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+def maybe_gunzip(data: bytes) -> bytes:
+    """jar Zip.ZipOrNot.isGZipped: first two bytes 1f 8b."""
+    return gzip.decompress(data) if data[:2] == b"\x1f\x8b" else data
+
+
+class ParsedFile:
+    def __init__(self, batch, names, id_ok, eof_in_kmer):
+        self.batch = batch
+        self.names = names            # FASTQ: header string of every token
+        self.id_ok = id_ok            # FASTA: header parsed as a Java int
+        self.eof_in_kmer = eof_in_kmer
+
+
+def parse(data: bytes, mode: int, k: int) -> ParsedFile:
+    lib = _load()
+    data = maybe_gunzip(data)
+    h = lib.kmh_parse(data, len(data), mode, k)
+    try:
+        nseq, nb = lib.kmh_nseq(h), lib.kmh_nbases(h)
+        bases = _arr(lib.kmh_bases(h), nb, np.uint8)
+        off = _arr(lib.kmh_seq_off(h), nseq + 1, np.uint64)
+        if mode == FASTA:
+            ids = _arr(lib.kmh_seq_id(h), nseq, np.int32)
+            ok = _arr(lib.kmh_id_ok(h), nseq, np.uint8)
+            return ParsedFile(SequenceBatch(bases, off, seq_id=ids), None, ok, lib.kmh_eof_in_kmer(h))
+        tok = _arr(lib.kmh_seq_tok(h), nseq, np.int64)
+        nt = lib.kmh_ntok(h)
+        noff = _arr(lib.kmh_name_off(h), nt + 1, np.uint64)
+        raw = _arr(lib.kmh_names(h), int(noff[-1]) if nt else 0, np.uint8).tobytes()
+        names = [raw[int(noff[i]):int(noff[i + 1])].decode("latin-1") for i in range(nt)]
+        return ParsedFile(SequenceBatch(bases, off, seq_tok=tok), names, None, lib.kmh_eof_in_kmer(h))
+    finally:
+        lib.kmh_free(h)

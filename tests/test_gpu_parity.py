@@ -1,0 +1,241 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
+
+Bar: bit-exact (integer / byte / index work).  The oracle is the C restatement (oracle/kmers_oracle.c),
+itself checked byte for byte against the literal Python restatement and the Appendix-B known answers
+(tests/test_oracle_*.py); parity with Kmers.jar itself is UNPINNED (no JVM, no reference fixtures).
+Read-position lists are compared in the canonical ascending order (the Java HashSet order is
+nondeterministic).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import kmers_amd as km
+    c = km.Context(0)
+    yield c
+    c.close()
+
+
+def _same_db(got, want):
+    h = got.fetch()
+    assert got.n_unique == want.U and got.n_values == want.V
+    assert np.array_equal(h["keys"], want.keys)
+    assert np.array_equal(h["val_off"], want.val_off)
+    assert np.array_equal(h["val_a"], want.val_a)
+    assert np.array_equal(h["val_b"], want.val_b)
+    assert np.array_equal(h["bucket_off"], want.bucket_off)
+
+
+def _rand_fasta(rng, n_seq, max_len, alphabet, taxa):
+    parts = []
+    for _ in range(n_seq):
+        L = int(rng.integers(0, max_len))
+        s = bytes(rng.choice(np.frombuffer(alphabet, np.uint8), size=L).tolist())
+        parts.append(b">%d d\n%s\n" % (taxa[int(rng.integers(0, len(taxa)))], s))
+    return b"".join(parts)
+
+
+def _rand_fastq(rng, n_seq, max_len, alphabet):
+    parts = []
+    for i in range(n_seq):
+        L = int(rng.integers(0, max_len))
+        s = bytes(rng.choice(np.frombuffer(alphabet, np.uint8), size=L).tolist())
+        name = b"r%d" % (i - 1 if i % 7 == 3 else i)      # some neighbours share a header
+        parts.append(b"@%s\n%s\n+\n%s\n" % (name, s, b"I" * L))
+    return b"".join(parts)
+
+
+# ---------------------------------------------------------------------------- known answers (App. B)
+def test_kat_b12_b15(ctx):
+    import kmers_amd as km
+    ref = km.make_reference_db(ctx, b">7\nACGTNACGTA\n", 4, 2)
+    blocks, off = ref.encode_blocks()
+    blk = lambda k: blocks[int(off[k]):int(off[k + 1])]
+    assert ref.meta() == bytes.fromhex("040402000000010000080001")
+    assert blk(1) == bytes.fromhex("00041E00010000000704")
+    assert blk(7) == bytes.fromhex("00047800010000000701")
+    assert blk(8) == bytes.fromhex("00048700010000000701")
+    assert all(blk(k) == b"" for k in range(16) if k not in (1, 7, 8))
+    fq = b"@r1\nACGTA\n+\nIIIII\n@r2\nNNNNN\n+\nIIIII\n@r3\nTTTTT\n+\nIIIII\n"
+    rdb, names = km.make_read_db(ctx, fq, 4, 2)
+    assert names == ["r1", "r3"]
+    assert rdb.meta() == bytes.fromhex("04040200000002000001010000080400")
+    rb, roff = rdb.encode_blocks()
+    assert rb[int(roff[10]):int(roff[11])] == bytes.fromhex("0004AA00000002000000010000000000010001")
+    hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
+    assert km.match_lines(rdb, ref, hit) == ["ACGT\t0:0\t-|7x4", "CGTA\t0:1\t-|7x1"]
+    assert km.taxa_count_lines(ref) == ["7\t3\t3"]
+
+
+# ---------------------------------------------------------------------------- build parity
+@pytest.mark.parametrize("k,key_len,seed,alphabet", [
+    (4, 2, 1, b"AACCGTN"), (5, 2, 2, b"ACGTN"), (6, 3, 3, b"ACGT"), (8, 4, 4, b"ACGTacgtN"),
+    (21, 6, 5, b"ACGT"), (31, 6, 6, b"ACGTN"), (32, 6, 7, b"ACGT"), (1, 1, 8, b"ACGTN"), (16, 8, 9, b"AC"),
+])
+def test_reference_build_matches_oracle(ctx, k, key_len, seed, alphabet):
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(seed)
+    fa = _rand_fasta(rng, 40, 700, alphabet, (5, 7, 11, -3, 70000, 2 ** 31 - 1))
+    got = km.make_reference_db(ctx, fa, k, key_len)
+    want = OracleDB(fa, 0, k, key_len)
+    _same_db(got, want)
+    assert got.n_windows == want.n_windows
+    gb, goff = got.encode_blocks()
+    wb, woff = want.encode_blocks()
+    assert gb == wb and np.array_equal(goff, woff)
+    got.close()
+
+
+@pytest.mark.parametrize("k,key_len,seed,alphabet", [
+    (4, 2, 11, b"AACGTN"), (7, 3, 12, b"ACGTN"), (31, 6, 13, b"ACGTN"), (32, 5, 14, b"ACGT"), (12, 6, 15, b"AC"),
+])
+def test_read_build_matches_oracle(ctx, k, key_len, seed, alphabet):
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(seed)
+    fq = _rand_fastq(rng, 300, 260, alphabet)
+    got, names = km.make_read_db(ctx, fq, k, key_len)
+    want = OracleDB(fq, 1, k, key_len)
+    _same_db(got, want)
+    assert names == want.names
+    gb, goff = got.encode_blocks()
+    wb, woff = want.encode_blocks()
+    assert gb == wb and np.array_equal(goff, woff)
+    got.close()
+
+
+def test_edge_cases(ctx):
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    for fa in (b"", b">1\n\n", b">1\nACG\n>2\nAC\n", b">1\n" + b"N" * 100 + b"\n", b">1\nACGTACGTAC",
+               b">4\n" + b"A" * 5000 + b"\n", b">1\nACGT\n" * 3000):
+        got = km.make_reference_db(ctx, fa, 5, 2)
+        want = OracleDB(fa, 0, 5, 2)
+        _same_db(got, want)
+        got.close()
+    for fq in (b"", b"@a\n\n+\n\n", b"@a\nACG\n+\nIII\n", b"@a\nNNNNNNN\n+\nIIIIIII\n"):
+        got, names = km.make_read_db(ctx, fq, 5, 2)
+        want = OracleDB(fq, 1, 5, 2)
+        _same_db(got, want)
+        assert names == want.names
+        got.close()
+
+
+def test_long_read_position_wraps_like_java_short(ctx):
+    """(short)(pos - maxK), KmersFromFile.java:165: offsets past 32767 wrap negative."""
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(5)
+    s = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=40000).tolist())
+    fq = b"@long\n%s\n+\n%s\n" % (s, b"I" * len(s))
+    got, _ = km.make_read_db(ctx, fq, 31, 6)
+    want = OracleDB(fq, 1, 31, 6)
+    _same_db(got, want)
+    assert got.fetch()["val_b"].min() < 0
+    got.close()
+
+
+def test_many_batches_equal_one_batch(ctx):
+    """addKmers may be called many times (FileCreator.java:65); read numbering carries across calls."""
+    import kmers_amd as km
+    from kmers_amd import parse
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(21)
+    fq = _rand_fastq(rng, 500, 200, b"ACGTN")
+    pf = parse.parse(fq, parse.FASTQ, 9)
+    b = pf.batch
+    fc = km.FileCreator(ctx, 3, 9, "read", rc=False)
+    cuts = [0, 1, 2, 150, 151, 333, b.nseq]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        a0, a1 = int(b.seq_off[lo]), int(b.seq_off[hi])
+        fc.add_kmers(km.SequenceBatch(b.bases[a0:a1], b.seq_off[lo:hi + 1] - b.seq_off[lo], seq_tok=b.seq_tok[lo:hi]))
+    got = fc.create()
+    _same_db(got, OracleDB(fq, 1, 9, 3))
+    got.close()
+
+
+# ---------------------------------------------------------------------------- match + counts parity
+@pytest.mark.parametrize("k,key_len,seed", [(5, 2, 31), (9, 3, 32), (31, 6, 33)])
+def test_match_and_taxacounts_match_oracle(ctx, k, key_len, seed):
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(seed, 6, 3000, first_taxon=900, shared_frac=0.3)
+    reads = synth.random_reads(seed + 1, genomes, 400, 100, 0.02, n_rate=0.003)
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    ref = km.make_reference_db(ctx, fa, k, key_len)
+    rdb, _ = km.make_read_db(ctx, fq, k, key_len)
+    o_ref, o_reads = OracleDB(fa, 0, k, key_len), OracleDB(fq, 1, k, key_len)
+    hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
+    o_hit, o_nh = o_reads.match(o_ref)
+    assert nh == o_nh and np.array_equal(hit, o_hit)
+    assert "\n".join(km.match_lines(rdb, ref, hit)) + "\n" == o_reads.match_lines(o_ref, o_hit).decode()
+    t, m, q = km.taxa_counts(ref)
+    ot, om, oq = o_ref.taxacounts()
+    assert np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
+    # reference-vs-reference search (Matcher.java:182-210): every k-mer finds itself
+    hit2, nh2 = km.DB([ref]).get_nearest_kmers(ref)
+    assert nh2 == ref.n_unique and np.array_equal(hit2, np.arange(ref.n_unique))
+    ref.close()
+    rdb.close()
+
+
+def test_db_load_roundtrip_and_errors(ctx):
+    import kmers_amd as km
+    from kmers_amd import synth
+    taxa, genomes = synth.random_genomes(41, 3, 2000)
+    ref = km.make_reference_db(ctx, synth.fasta_bytes(taxa, genomes), 15, 4)
+    h = ref.fetch()
+    again = km.KmerDatabase.load(ctx, 15, 4, True, 0, h["keys"], h["val_off"], h["val_a"], h["val_b"])
+    g = again.fetch()
+    for name in ("keys", "val_off", "val_a", "val_b", "bucket_off"):
+        assert np.array_equal(g[name], h[name])
+    other = km.make_reference_db(ctx, synth.fasta_bytes(taxa, genomes), 14, 4)
+    with pytest.raises(km.InconsistentDataException):       # DB.java:78-81
+        km.DB([ref]).get_nearest_kmers(other)
+    with pytest.raises(km.KmersGpuError):                   # k > 32 -> shim falls back to Java
+        km.FileCreator(ctx, 6, 33, "ref", True)
+    for d in (ref, again, other):
+        d.close()
+
+
+# ---------------------------------------------------------------------------- full-size properties
+def test_cfg1_scale_properties(ctx):
+    """BASELINE config 1 at full size (5 Mbp, 1M x 150 bp, k=31): size-independent properties, plus
+    exact equality with the C oracle (multi-threaded, finishes in seconds)."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes, reads = synth.cfg1(1.0)
+    fa = synth.fasta_bytes(taxa, genomes)
+    ref = km.make_reference_db(ctx, fa, 31, 6)
+    h = ref.fetch()
+    keys = h["keys"]
+    assert np.all(keys[1:] > keys[:-1])                                  # strictly ascending, unique
+    assert int(h["val_b"].sum()) == 2 * ref.n_windows                    # odd k: every window + its RC
+    assert ref.n_windows == sum(len(g) - 30 for g in genomes)
+    # the stored set is closed under reverse complement: re-running the join on itself finds all
+    hit, nh = km.DB([ref]).get_nearest_kmers(ref)
+    assert nh == ref.n_unique
+    want = OracleDB(fa, 0, 31, 6, threads=8)
+    _same_db(ref, want)
+    nreads = 200_000                                                     # oracle-sized slice of the reads
+    fq = synth.fastq_bytes(reads[:nreads])
+    rdb, names = km.make_read_db(ctx, fq, 31, 6)
+    assert rdb.n_values == nreads * 120 == rdb.n_windows
+    o_reads = OracleDB(fq, 1, 31, 6, threads=8)
+    _same_db(rdb, o_reads)
+    hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
+    o_hit, o_nh = o_reads.match(want, threads=8)
+    assert nh == o_nh and np.array_equal(hit, o_hit)
+    assert 0.5 < nh / rdb.n_unique < 0.9                                 # ~0.99^31 of read k-mers hit
+    t, m, q = km.taxa_counts(ref)
+    ot, om, oq = want.taxacounts()
+    assert np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
+    ref.close()
+    rdb.close()

@@ -1,0 +1,89 @@
+"""Host record splitting (kmers_amd/csrc/host_parse.cpp) must hand the GPU exactly the sequences whose
+windows the reference's extractor emits.  Checked on CPU against the literal oracle: windows derived
+from the parsed batch with a few lines of Python == KmersFromFile stream of oracle/slow_ref.py."""
+import numpy as np
+import pytest
+
+from kmers_amd import parse
+from oracle import slow_ref as R
+
+VALID = set(b"ACGTacgt")
+
+
+def windows_from_batch(batch, k, reads, names=None):
+    """Boundary contract of kmg_build_add restated in Python (tiny inputs only)."""
+    out = []
+    cur_s, cur_i = None, -1
+    map_names = []
+    for s in range(batch.nseq):
+        a, b = int(batch.seq_off[s]), int(batch.seq_off[s + 1])
+        seq = batch.bases[a:b].tobytes()
+        for p in range(0, len(seq) - k + 1):
+            w = seq[p:p + k]
+            if all(c in VALID for c in w):
+                if reads:
+                    tok = int(batch.seq_tok[s])
+                    if tok != cur_s:
+                        cur_s = tok
+                        cur_i += 1
+                        map_names.append(names[tok])
+                    pos = (p + 0x8000) % 0x10000 - 0x8000
+                    out.append((w.decode().upper(), (cur_i, pos)))
+                else:
+                    out.append((w.decode().upper(), int(batch.seq_id[s])))
+    return out, map_names
+
+
+CASES_FA = [
+    b">7\nACGTNACGTA\n",
+    b">7\nACGTA",                                   # no trailing newline: last k-mer twice
+    b">7 desc here\nACGTA\nCCCCC\nGGGGG\n",          # wrapped: every other line swallowed
+    b"\n>5\nacgtacgt\n>6\n\n>8\nAC GT\tACG\n",       # leading newline, empty seq, blanks inside a line
+    b">-12\nACGTACGT\n>13\nAC\n>14\nNNNNNNNN\n",
+    b"junk\n>9\nACGTACGTAC\n",
+]
+
+
+@pytest.mark.parametrize("fa", CASES_FA)
+@pytest.mark.parametrize("k", [3, 4, 5])
+def test_fasta_split_matches_oracle(fa, k):
+    want = []
+    try:
+        want = [(str(km), d) for km, d in R.kmers_from_file(fa, R.fa_state_changer(), k, k, R.fa_to_refdb_mapper)]
+    except ValueError:
+        pytest.skip("header does not parse as int (NumberFormatException in the reference)")
+    pf = parse.parse(fa, parse.FASTA, k)
+    got, _ = windows_from_batch(pf.batch, k, False)
+    assert got == want
+
+
+CASES_FQ = [
+    b"@r1\nACGTA\n+\nIIIII\n@r2\nNNNNN\n+\nIIIII\n@r3\nTTTTT\n+\nIIIII\n",
+    b"@a\nACGTA\n+\nIIIII\n@b\nNN\n+\nII\n@a\nCCCCC\n+\nIIIII\n",       # index reuse across a silent read
+    b"@a x\nACG\nTAC\n+\nIIIIII\n@a x\nGGGGG\n+\nIIIII\n",              # multi-line sequence, equal neighbours
+    b"@q\nACGTACGT\n+\nII@IIIII\n@z\nCCCCCC\n+\nIIIIII\n",              # '@' inside the quality line
+    b"@t\nACGTAC",                                                      # truncated file
+]
+
+
+@pytest.mark.parametrize("fq", CASES_FQ)
+@pytest.mark.parametrize("k", [3, 4])
+def test_fastq_split_matches_oracle(fq, k):
+    rm = R.ReadIDMapping()
+    want = [(str(km), d) for km, d in R.kmers_from_file(fq, R.fq_state_changer(), k, k, R.make_fq_mapper(rm))]
+    pf = parse.parse(fq, parse.FASTQ, k)
+    got, names = windows_from_batch(pf.batch, k, True, pf.names)
+    if pf.eof_in_kmer:
+        # documented divergence: the duplicated last k-mer of a truncated FASTQ is not reproduced
+        assert want[:-1] == got or want == got
+    else:
+        assert got == want
+    assert names == rm.names
+
+
+def test_gzip_input_is_sniffed():
+    import gzip
+    fa = b">3\nACGTACGT\n"
+    a = parse.parse(gzip.compress(fa), parse.FASTA, 4)
+    b = parse.parse(fa, parse.FASTA, 4)
+    assert np.array_equal(a.batch.bases, b.batch.bases) and np.array_equal(a.batch.seq_off, b.batch.seq_off)
