@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the k-mer hot path on MI355X.
+
+One step = BASELINE config 2 on one GPU, inputs already resident in HBM:
+    build the reference DB (10 taxa x 500 kbp, both strands)      kmg_build_add_dev + kmg_build_finish
+  + build the read DB (1M x 150 bp reads, 1 % substitutions)      kmg_build_add_dev + kmg_build_finish
+  + match the read DB against the reference DB                    kmg_match_dev
+at k = 31, key length 6.  value = (reference windows + read windows) / step time, whole job.
+N > 1: one process per GPU, every rank builds the (small) reference and its own shard of 1M reads
+(weak scaling, no data-path collective -- see DESIGN.md "Multi-GPU"); value sums over ranks.
+
+Adds "roofline" (dominant kernel, algorithmic bytes / HIP-event time measured live on the library's
+stream) and, on rank 0 at N = 1, "cpu_baseline" (the C restatement of the reference's algorithm timed
+on a bounded sample on this box's host cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+K, KEY_LEN = 31, 6
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scale", type=float, default=1.0, help="scale factor on config sizes (1.0 = BASELINE config 2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import kmers_amd as km
+    from kmers_amd import synth
+
+    # ---- synthetic inputs, resident in HBM before anything is timed ------------------------------
+    glen = max(1000, int(500_000 * args.scale))
+    nreads = max(100, int(1_000_000 * args.scale))
+    taxa, genomes = synth.random_genomes(1, 10, glen)
+    reads = synth.random_reads(2 + rank, genomes, nreads, 150, 0.01)
+    ref_bases, ref_off = synth.batch_from_seqs(genomes)
+    read_off = np.arange(nreads + 1, dtype=np.uint64) * np.uint64(150)
+    d_ref_bases = torch.from_numpy(ref_bases).to(dev)
+    d_ref_off = torch.from_numpy(ref_off.view(np.int64)).to(dev)
+    d_ref_id = torch.tensor(taxa, dtype=torch.int32, device=dev)
+    d_read_bases = torch.from_numpy(np.ascontiguousarray(reads).reshape(-1)).to(dev)
+    d_read_off = torch.from_numpy(read_off.view(np.int64)).to(dev)
+    d_read_tok = torch.arange(nreads, dtype=torch.int64, device=dev)
+    n_ref_win = sum(len(g) - K + 1 for g in genomes)
+    n_read_win = nreads * (150 - K + 1)
+    d_hit = torch.empty(n_read_win + 16, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    ctx = km.Context(local_rank)
+    lib, h = ctx.lib, ctx.h
+
+    def build(bases, off, ids, toks, nseq, kind, rc):
+        ctx.check(lib.kmg_build_begin(h, K, KEY_LEN, rc, kind))
+        ctx.check(lib.kmg_build_add_dev(h, bases.data_ptr(), bases.numel(), off.data_ptr(),
+                                        ids.data_ptr() if ids is not None else None,
+                                        toks.data_ptr() if toks is not None else None, nseq, None))
+        db = C.c_void_p()
+        nw = C.c_uint64()
+        ctx.check(lib.kmg_build_finish(h, C.byref(db), C.byref(nw)))
+        return db, nw.value
+
+    stage_s = {"ref_build": 0.0, "read_build": 0.0, "match": 0.0}
+
+    def step(timed_stages=False):
+        t0 = time.perf_counter()
+        ref, nw_ref = build(d_ref_bases, d_ref_off, d_ref_id, None, len(genomes), 0, 1)
+        t1 = time.perf_counter()
+        rdb, nw_reads = build(d_read_bases, d_read_off, None, d_read_tok, nreads, 1, 0)
+        t2 = time.perf_counter()
+        ctx.check(lib.kmg_match_dev(h, rdb, ref, d_hit.data_ptr()))
+        if timed_stages:
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            stage_s["ref_build"] += t1 - t0
+            stage_s["read_build"] += t2 - t1
+            stage_s["match"] += t3 - t2
+        info = (nw_ref, nw_reads)
+        lib.kmg_db_free(rdb)
+        lib.kmg_db_free(ref)
+        return info
+
+    for _ in range(args.warmup):
+        info = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert info == (n_ref_win, n_read_win), (info, n_ref_win, n_read_win)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-stage rates and the roofline of the dominant kernel (extra, untimed steps) -----------
+    prof_steps = 3
+    for _ in range(prof_steps):
+        step(timed_stages=True)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    prof = ctx.prof()
+    ctx.prof_enable(False)
+    cand = {k: v for k, v in prof.items() if v["launches"] and v["bytes"]}
+    dom = max(cand, key=lambda k: cand[k]["ms"])
+    d = cand[dom]
+    avg_ms = d["ms"] / d["launches"]
+    bytes_per_launch = d["bytes"] / d["launches"]
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": int(bytes_per_launch),
+                "launches_per_step": d["launches"] // prof_steps}
+    kernels = {k: {"ms_per_step": round(v["ms"] / prof_steps, 4), "launches_per_step": v["launches"] // prof_steps,
+                   "algo_GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) if v["bytes"] else None}
+               for k, v in prof.items() if v["launches"]}
+
+    if rank == 0:
+        total_windows = (n_ref_win + n_read_win) * world
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "k-mers/sec built + matched (reference build + read build + match, node)",
+            "value": total_windows * args.steps / elapsed,
+            "unit": "k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: 5 Mbp reference (10 taxa) + 1M x 150 bp reads per GPU, k=31, "
+                                   "key length 6; build both DBs + exact match; inputs resident in HBM",
+                       "k": K, "key_len": KEY_LEN, "scale": args.scale,
+                       "ref_windows": n_ref_win, "read_windows_per_gpu": n_read_win},
+            "stages": {"ref_kmers_built_per_s": n_ref_win * prof_steps / stage_s["ref_build"],
+                       "read_kmers_built_per_s": n_read_win * prof_steps / stage_s["read_build"],
+                       "read_kmers_matched_per_s": n_read_win * prof_steps / stage_s["match"]},
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(synth, taxa, genomes, reads)
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(synth, taxa, genomes, reads):
+    """The C restatement of the reference's algorithm (oracle/kmers_oracle.c: char-at-a-time extractor,
+    per-key-bucket sort + reduce on a thread pool, two-pointer join) on a bounded sample of the same
+    workload: the full reference + the first 100k reads.  kind = "port": Kmers.jar needs a JVM."""
+    from oracle.c_oracle import OracleDB
+    threads = min(16, os.cpu_count() or 1)
+    sample_reads = min(100_000, reads.shape[0])
+    fa = synth.fasta_bytes(taxa, genomes)
+    fq = synth.fastq_bytes(reads[:sample_reads])
+    t0 = time.perf_counter()
+    ref = OracleDB(fa, 0, K, KEY_LEN, threads=threads)
+    rdb = OracleDB(fq, 1, K, KEY_LEN, threads=threads)
+    rdb.match(ref, threads=threads)
+    dt = time.perf_counter() - t0
+    windows = ref.n_windows + rdb.n_windows
+    return {"value": windows / dt, "unit": "k-mers/s", "cores": threads, "kind": "port",
+            "sample": "full 5 Mbp reference + first %d of the reads (%d windows) in %.1f s; extraction is "
+                      "single-threaded as in the reference, sort/join use %d threads" % (sample_reads, windows, dt, threads)}
+
+
+if __name__ == "__main__":
+    main()

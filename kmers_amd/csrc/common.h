@@ -124,6 +124,7 @@ enum {
     ST_HAVE_CARRY,    // 0 until some read has produced a k-mer
     ST_ID_OR,         // OR / AND of every (taxon ^ 0x80000000): constant value bits skip sort passes
     ST_ID_AND,
+    ST_DUP_READS,     // 1 once two sequences shared a read index (equal neighbouring headers)
     ST_TMP0,          // scratch totals written by scans
     ST_TMP1,
     ST_WORDS = 16

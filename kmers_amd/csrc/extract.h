@@ -274,7 +274,7 @@ __global__ void number_emit_kernel(const uint8_t *__restrict__ has_kmer, int32_t
 }
 // is_new[i] = sequence i produced a k-mer and its header differs from the last one that did
 __global__ void number_new_kernel(const uint8_t *__restrict__ has_kmer, const int32_t *__restrict__ prev_emit,
-                                  const int64_t *__restrict__ tok, const u64 *__restrict__ state,
+                                  const int64_t *__restrict__ tok, u64 *__restrict__ state,
                                   u32 *__restrict__ is_new, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -283,6 +283,9 @@ __global__ void number_new_kernel(const uint8_t *__restrict__ has_kmer, const in
         int32_t p = prev_emit[i];
         if (p >= 0) nw = tok[i] != tok[p];
         else nw = !(state[ST_HAVE_CARRY] && (int64_t)state[ST_CARRY_TOK] == tok[i]);
+        // two sequences now share a read index: their (read, pos) pairs are no longer generated in
+        // ascending order, so the sort must also order the payload (rare; costs extra passes)
+        if (!nw) state[ST_DUP_READS] = 1;
     }
     is_new[i] = nw;
 }

@@ -367,9 +367,14 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     if (!reads) {
         const u32 varying = (u32)st[ST_ID_OR] ^ (u32)st[ST_ID_AND];
         for (int b = 0; b < 4; b++)
-            if ((varying >> (8 * b)) & 0xFFu) passes.push_back({8 * b, 8, true});
+            if ((varying >> (8 * b)) & 0xFFu) passes.push_back({8 * b, 8, RS_SRC_VAL32});
+    } else if (st[ST_DUP_READS]) {
+        // canonical (read, pos) order inside a k-mer when sequences shared a read index
+        int bits = 16;
+        while (bits < 48 && (st[ST_READ_BASE] >> (bits - 16)) != 0) bits++;
+        for (int shift = 0; shift < bits; shift += RS_BITS) passes.push_back({shift, std::min(RS_BITS, bits - shift), RS_SRC_VAL64});
     }
-    for (int shift = 64 - 2 * ctx->k; shift < 64; shift += RS_BITS) passes.push_back({shift, std::min(RS_BITS, 64 - shift), false});
+    for (int shift = 64 - 2 * ctx->k; shift < 64; shift += RS_BITS) passes.push_back({shift, std::min(RS_BITS, 64 - shift), RS_SRC_KEY});
 
     PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx);
     const size_t vb = val_bytes(ctx->kind);
@@ -594,7 +599,7 @@ extern "C" int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, in
     KMG_ALLOC(total, 64);
     hipLaunchKernelGGL(taxa_expand_kernel, dim3(div_up_u64(n, 256)), dim3(256), 0, ctx->stream, db->val_a, V, k0.as<u64>(), v0.as<u32>());
     std::vector<SortPass> passes;
-    for (int b = 0; b < 4; b++) passes.push_back({8 * b, 8, false});
+    for (int b = 0; b < 4; b++) passes.push_back({8 * b, 8, RS_SRC_KEY});
     bool in1 = false;
     KMG_TRY(radix_sort_records<u32>(ctx, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), n, passes, table.as<u32>(), agg.as<u32>(), &in1));
     const u64 *sk = in1 ? k1.as<u64>() : k0.as<u64>();

@@ -23,17 +23,22 @@
 #define RS_ITEMS 16
 #define RS_TILE (RS_BLOCK * RS_ITEMS)  // 4096 records per tile
 
-// Digit of a record for this pass.  from_val: digit comes from the (sign-flipped) 32-bit payload,
-// used to order taxa inside equal k-mers (TreeCountMap<Integer> key order).
+// Digit of a record for this pass.  src 0: from the k-mer key.  src 1: from the sign-flipped 32-bit
+// payload, used to order taxa inside equal k-mers (TreeCountMap<Integer> key order).  src 2: from the raw
+// 64-bit payload (read << 16 | pos), only needed when two sequences share a read index.
+#define RS_SRC_KEY 0
+#define RS_SRC_VAL32 1
+#define RS_SRC_VAL64 2
 template <typename V>
-__device__ __forceinline__ u32 rs_digit(u64 key, V val, int shift, u32 mask, bool from_val) {
-    if (from_val) return (u32)((((u32)val) ^ 0x80000000u) >> shift) & mask;
+__device__ __forceinline__ u32 rs_digit(u64 key, V val, int shift, u32 mask, int src) {
+    if (src == RS_SRC_VAL32) return (u32)((((u32)val) ^ 0x80000000u) >> shift) & mask;
+    if (src == RS_SRC_VAL64) return (u32)(((u64)val) >> shift) & mask;
     return (u32)(key >> shift) & mask;
 }
 
 template <typename V>
 __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict__ keys, const V *__restrict__ vals,
-                                                            u32 n, int shift, u32 mask, bool from_val,
+                                                            u32 n, int shift, u32 mask, int src,
                                                             u32 *__restrict__ table, u32 ntiles) {
     __shared__ u32 h[RS_DIGITS];
     h[threadIdx.x] = 0;
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict
     for (int i = 0; i < RS_ITEMS; i++) {
         u32 idx = base + i * RS_BLOCK + threadIdx.x;
         if (idx < n) {
-            u32 d = from_val ? rs_digit<V>(0, vals[idx], shift, mask, true) : rs_digit<V>(keys[idx], (V)0, shift, mask, false);
+            u32 d = src ? rs_digit<V>(0, vals[idx], shift, mask, src) : rs_digit<V>(keys[idx], (V)0, shift, mask, 0);
             atomicAdd(&h[d], 1u);
         }
     }
@@ -55,7 +60,7 @@ template <typename V>
 __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restrict__ keys_in,
                                                                const V *__restrict__ vals_in,
                                                                u64 *__restrict__ keys_out, V *__restrict__ vals_out,
-                                                               u32 n, int shift, u32 mask, bool from_val,
+                                                               u32 n, int shift, u32 mask, int src,
                                                                const u32 *__restrict__ table, u32 ntiles) {
     __shared__ u32 wcnt[RS_WAVES][RS_DIGITS];   // per-wave digit counts -> exclusive prefix over waves
     __shared__ u32 dstart[RS_DIGITS];           // tile-local start of each digit's run
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restr
     for (int j = 0; j < RS_ITEMS; j++) {
         const u32 li = wave_base + j * 64 + lane;
         const bool valid = li < tile_n;
-        const u32 d = rs_digit<V>(key[j], val[j], shift, mask, from_val);
+        const u32 d = rs_digit<V>(key[j], val[j], shift, mask, src);
         u64 m = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < RS_BITS; b++) {
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restr
         if (lp < tile_n) {
             const u64 kk = skeys[lp];
             const V vv = svals[lp];
-            const u32 d = rs_digit<V>(kk, vv, shift, mask, from_val);
+            const u32 d = rs_digit<V>(kk, vv, shift, mask, src);
             const u32 gp = lp + (u32)gdelta[d];
             keys_out[gp] = kk;
             vals_out[gp] = vv;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restr
 struct SortPass {
     int shift;
     int bits;
-    bool from_val;
+    int src;
 };
 
 // Sorts n records.  Buffers ping-pong between (k0,v0) and (k1,v1); *result_in_1 tells where the
@@ -173,16 +178,16 @@ static int radix_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 
         V *vo = flip ? v0 : v1;
         const u32 mask = (1u << p.bits) - 1u;
         {
-            ProfScope ps(ctx, KP_SORT_HIST, (u64)n * (p.from_val ? sizeof(V) : 8));
+            ProfScope ps(ctx, KP_SORT_HIST, (u64)n * (p.src ? sizeof(V) : 8));
             hipLaunchKernelGGL((rs_hist_kernel<V>), dim3(ntiles), dim3(RS_BLOCK), 0, ctx->stream, ki, vi, n, p.shift,
-                               mask, p.from_val, table, ntiles);
+                               mask, p.src, table, ntiles);
         }
         KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, table, table, (u64)RS_DIGITS * ntiles, OpSum(), 0u, agg,
                                                     nullptr, false, KP_SORT_SCAN)));
         {
             ProfScope ps(ctx, KP_SORT_SCATTER, (u64)n * (8 + sizeof(V)) * 2);
             hipLaunchKernelGGL((rs_scatter_kernel<V>), dim3(ntiles), dim3(RS_BLOCK), 0, ctx->stream, ki, vi, ko, vo, n,
-                               p.shift, mask, p.from_val, table, ntiles);
+                               p.shift, mask, p.src, table, ntiles);
         }
         KMG_HIP(hipGetLastError());
         flip = !flip;
