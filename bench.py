@@ -180,10 +180,11 @@ def main():
 def cpu_baseline(synth, taxa, genomes, reads):
     """The C restatement of the reference's algorithm (oracle/kmers_oracle.c: char-at-a-time extractor,
     per-key-bucket sort + reduce on a thread pool, two-pointer join) on a bounded sample of the same
-    workload: the full reference + the first 100k reads.  kind = "port": Kmers.jar needs a JVM."""
+    workload (the full reference + the first 400k reads, a few seconds to a few tens of seconds of CPU
+    work depending on the host).  kind = "port": Kmers.jar needs a JVM, which neither box has."""
     from oracle.c_oracle import OracleDB
     threads = min(16, os.cpu_count() or 1)
-    sample_reads = min(100_000, reads.shape[0])
+    sample_reads = min(400_000, reads.shape[0])
     fa = synth.fasta_bytes(taxa, genomes)
     fq = synth.fastq_bytes(reads[:sample_reads])
     t0 = time.perf_counter()

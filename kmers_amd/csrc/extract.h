@@ -56,6 +56,7 @@ struct ExtractArgs {
     int kind;
     // count pass outputs
     u32 *tile_count;
+    u32 *tile_fwd;               // valid forward windows per tile
     uint8_t *has_kmer;
     // write pass
     const u64 *tile_off;         // exclusive scan of tile_count
@@ -197,14 +198,15 @@ __global__ __launch_bounds__(EX_BLOCK) void extract_kernel(ExtractArgs a) {
     }
     __syncthreads();
     if (!WRITE) {
+        // valid forward windows of this tile (summed into ST_NWIN by sum_u32_kernel: one atomic per
+        // 2048 tiles instead of one per wave, which serialised on a single address)
+        u32 nv = __popc(vmask);
+        u32 tot;
+        block_scan_inclusive(nv, OpSum(), scan_smem, &tot);
         if (tid == 0) {
             a.tile_count[blockIdx.x] = blk_total;
+            a.tile_fwd[blockIdx.x] = tot;
         }
-        // valid forward windows of this tile -> running total
-        u32 nv = __popc(vmask);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) nv += __shfl_down(nv, d, 64);
-        if (lane == 0 && nv) atomicAdd(&a.state[ST_NWIN], (u64)nv);
         return;
     }
 
@@ -245,6 +247,21 @@ __global__ __launch_bounds__(EX_BLOCK) void extract_kernel(ExtractArgs a) {
 // After a write pass: advance the running record count by this batch's total (tile_off[ntiles]).
 __global__ void extract_advance_kernel(u64 *state, const u64 *tile_off, u32 ntiles) {
     if (threadIdx.x == 0 && blockIdx.x == 0) state[ST_NREC] += tile_off[ntiles];
+}
+
+// out += sum(in[0..n)): one 64-bit atomic per block of 2048 elements.
+__global__ __launch_bounds__(256) void sum_u32_kernel(const u32 *__restrict__ in, u32 n, u64 *out) {
+    __shared__ u64 smem[4];
+    u64 acc = 0;
+    u32 base = blockIdx.x * 2048 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 idx = base + i * 256;
+        if (idx < n) acc += in[idx];
+    }
+    u64 total;
+    block_scan_inclusive(acc, OpSum(), smem, &total);
+    if (threadIdx.x == 0 && total) atomicAdd(out, total);
 }
 
 // OR / AND of (taxon ^ sign bit) over a batch: value bits that never vary need no sort pass.

@@ -144,9 +144,10 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     KMG_TRY(ensure_record_capacity(ctx, upper));
 
     const u32 ntiles = div_up_u64(nbases, EX_TILE);
-    PoolBuf tile_seq(ctx), tile_count(ctx), tile_off(ctx), agg(ctx), has_kmer(ctx), read_index(ctx), tmp_a(ctx), tmp_b(ctx);
+    PoolBuf tile_seq(ctx), tile_count(ctx), tile_fwd(ctx), tile_off(ctx), agg(ctx), has_kmer(ctx), read_index(ctx), tmp_a(ctx), tmp_b(ctx);
     KMG_ALLOC(tile_seq, (size_t)(ntiles + 1) * 4);
     KMG_ALLOC(tile_count, (size_t)ntiles * 4);
+    KMG_ALLOC(tile_fwd, (size_t)ntiles * 4);
     KMG_ALLOC(tile_off, (size_t)(ntiles + 1) * 8);
     KMG_ALLOC(agg, (size_t)(std::max<u64>(div_up_u64(ntiles, SCAN_TILE), div_up_u64(nseq, SCAN_TILE)) + 1) * 8);
 
@@ -154,7 +155,7 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     memset(&a, 0, sizeof a);
     a.bases = d_bases; a.nbases = nbases; a.seq_off = d_seq_off; a.nseq = nseq; a.seq_id = d_seq_id;
     a.tile_seq = tile_seq.as<u32>(); a.k = ctx->k; a.rc = ctx->rc; a.kind = ctx->kind;
-    a.tile_count = tile_count.as<u32>(); a.tile_off = tile_off.as<u64>();
+    a.tile_count = tile_count.as<u32>(); a.tile_fwd = tile_fwd.as<u32>(); a.tile_off = tile_off.as<u64>();
     a.out_keys = ctx->rec_keys; a.out_vals = ctx->rec_vals; a.state = ctx->d_state;
 
     {
@@ -174,6 +175,8 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     {
         ProfScope ps(ctx, KP_EXTRACT_COUNT, nbases);
         hipLaunchKernelGGL((extract_kernel<false>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
+        hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_fwd.as<u32>(),
+                           ntiles, ctx->d_state + ST_NWIN);
     }
     if (reads) {
         // ReadIDMapping.geNext over the batch: two scans and three elementwise kernels
