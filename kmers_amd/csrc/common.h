@@ -35,9 +35,14 @@ enum {
     KP_EXTRACT_WRITE,
     KP_NUMBER_READS,
     KP_SCAN,
-    KP_SORT_HIST,
+    KP_SORT_HIST_V32,
+    KP_SORT_HIST_V64,
     KP_SORT_SCAN,
-    KP_SORT_SCATTER,
+    KP_SORT_SCATTER_V32,
+    KP_SORT_SCATTER_V64,
+    KP_SORT_SEGMENTS,
+    KP_SORT_LOCAL_V32,
+    KP_SORT_LOCAL_V64,
     KP_REDUCE_FLAG,
     KP_REDUCE_WRITE,
     KP_BUCKETS,
@@ -49,7 +54,8 @@ enum {
 
 static const char *const kp_names[KP_COUNT_] = {
     "extract_tileseq", "extract_count", "extract_write", "number_reads", "scan",
-    "sort_hist",       "sort_scan",     "sort_scatter",  "reduce_flag",  "reduce_write",
+    "sort_hist_ref",   "sort_hist_reads", "sort_scan", "sort_scatter_ref", "sort_scatter_reads",
+    "sort_segments",   "sort_local_ref", "sort_local_reads", "reduce_flag",  "reduce_write",
     "bucket_offsets",  "match",         "taxacounts",    "encode"};
 
 // Grow-only caching device allocator: blocks freed to the pool are reused by later requests of a

@@ -365,21 +365,23 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     std::unique_ptr<kmg_db, void (*)(kmg_db *)> db_guard(db, db_release);
     db->ctx = ctx; db->k = ctx->k; db->key_len = ctx->key_len; db->rc = ctx->rc; db->kind = ctx->kind;
 
-    // sort passes: payload bits that vary (taxa order inside a k-mer), then the 2k key bits
-    std::vector<SortPass> passes;
+    // payload digits (least significant): taxa order inside a k-mer / shared read indices
+    std::vector<SortPass> payload;
     if (!reads) {
         const u32 varying = (u32)st[ST_ID_OR] ^ (u32)st[ST_ID_AND];
         for (int b = 0; b < 4; b++)
-            if ((varying >> (8 * b)) & 0xFFu) passes.push_back({8 * b, 8, RS_SRC_VAL32});
+            if ((varying >> (8 * b)) & 0xFFu) payload.push_back({8 * b, 8, RS_SRC_VAL32});
     } else if (st[ST_DUP_READS]) {
         // canonical (read, pos) order inside a k-mer when sequences shared a read index
         int bits = 16;
         while (bits < 48 && (st[ST_READ_BASE] >> (bits - 16)) != 0) bits++;
-        for (int shift = 0; shift < bits; shift += RS_BITS) passes.push_back({shift, std::min(RS_BITS, bits - shift), RS_SRC_VAL64});
+        for (int shift = 0; shift < bits; shift += RS_BITS) payload.push_back({shift, std::min(RS_BITS, bits - shift), RS_SRC_VAL64});
     }
-    for (int shift = 64 - 2 * ctx->k; shift < 64; shift += RS_BITS) passes.push_back({shift, std::min(RS_BITS, 64 - shift), RS_SRC_KEY});
+    // prefix bits for the global passes: segments of ~1-2 K records on uniform data
+    int pbits = 0;
+    while (pbits < 2 * ctx->k && pbits < 24 && ((u64)n >> pbits) > 2048) pbits++;
 
-    PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx);
+    PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx), seg(ctx);
     const size_t vb = val_bytes(ctx->kind);
     const u32 ntiles = n ? div_up_u64(n, RS_TILE) : 1;
     KMG_ALLOC(totals, 64);
@@ -391,8 +393,10 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
         KMG_ALLOC(v1, (size_t)n * vb);
         KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
         KMG_ALLOC(agg, (size_t)(div_up_u64((u64)RS_DIGITS * ntiles, SCAN_TILE) + 1) * 8);
-        if (reads) r = radix_sort_records<u64>(ctx, ctx->rec_keys, (u64 *)ctx->rec_vals, k1.as<u64>(), v1.as<u64>(), n, passes, table.as<u32>(), agg.as<u32>(), &in1);
-        else r = radix_sort_records<u32>(ctx, ctx->rec_keys, (u32 *)ctx->rec_vals, k1.as<u64>(), v1.as<u32>(), n, passes, table.as<u32>(), agg.as<u32>(), &in1);
+        KMG_ALLOC(seg, (((size_t)1 << pbits) + 4) * 4);
+        const int low_bit = 64 - 2 * ctx->k;
+        if (reads) r = hybrid_sort_records<u64>(ctx, ctx->rec_keys, (u64 *)ctx->rec_vals, k1.as<u64>(), v1.as<u64>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, &in1);
+        else r = hybrid_sort_records<u32>(ctx, ctx->rec_keys, (u32 *)ctx->rec_vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, &in1);
     }
     if (r == KMG_OK) {
         const u64 *sk = in1 ? k1.as<u64>() : ctx->rec_keys;

@@ -178,14 +178,14 @@ static int radix_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 
         V *vo = flip ? v0 : v1;
         const u32 mask = (1u << p.bits) - 1u;
         {
-            ProfScope ps(ctx, KP_SORT_HIST, (u64)n * (p.src ? sizeof(V) : 8));
+            ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_HIST_V64 : KP_SORT_HIST_V32, (u64)n * (p.src ? sizeof(V) : 8));
             hipLaunchKernelGGL((rs_hist_kernel<V>), dim3(ntiles), dim3(RS_BLOCK), 0, ctx->stream, ki, vi, n, p.shift,
                                mask, p.src, table, ntiles);
         }
         KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, table, table, (u64)RS_DIGITS * ntiles, OpSum(), 0u, agg,
                                                     nullptr, false, KP_SORT_SCAN)));
         {
-            ProfScope ps(ctx, KP_SORT_SCATTER, (u64)n * (8 + sizeof(V)) * 2);
+            ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_SCATTER_V64 : KP_SORT_SCATTER_V32, (u64)n * (8 + sizeof(V)) * 2);
             hipLaunchKernelGGL((rs_scatter_kernel<V>), dim3(ntiles), dim3(RS_BLOCK), 0, ctx->stream, ki, vi, ko, vo, n,
                                p.shift, mask, p.src, table, ntiles);
         }
@@ -193,5 +193,222 @@ static int radix_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 
         flip = !flip;
     }
     *result_in_1 = flip;
+    return KMG_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// Hybrid sort: a few global LSD passes over the TOP prefix bits of the key, then every segment of equal
+// prefix (a few thousand records) is sorted on all remaining digits inside LDS by one workgroup.
+// For n records this moves each record through HBM ceil(P/8) + 1 times instead of once per key byte.
+// Correctness: the prefix passes are a stable sort by prefix; a stable sort of each equal-prefix segment
+// by (payload digits, low key bits) then yields the same order as the full LSD sort.
+// ------------------------------------------------------------------------------------------------------
+#define LS_ITEMS 12
+#define LS_MAX (RS_BLOCK * LS_ITEMS)   // 3072 records per segment at most
+#define LS_MAX_PASSES 16
+
+struct LocalPasses {
+    int n;
+    int shift[LS_MAX_PASSES];
+    int bits[LS_MAX_PASSES];
+    int src[LS_MAX_PASSES];
+};
+
+// seg_off[s] = first record whose top `pbits` key bits are >= s (s = 0 .. 2^pbits); also the largest
+// segment size (atomicMax into *max_seg).  keys must be sorted by that prefix.
+__global__ void ls_segments_kernel(const u64 *__restrict__ keys, u32 n, int pbits, u32 *__restrict__ seg_off,
+                                   u32 nseg, u32 *max_seg) {
+    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > nseg) return;
+    u32 lo = 0, hi = n;
+    if (s == nseg) lo = n;
+    else if (pbits > 0) {
+        while (lo < hi) {
+            u32 mid = lo + ((hi - lo) >> 1);
+            if ((u32)(keys[mid] >> (64 - pbits)) < s) lo = mid + 1; else hi = mid;
+        }
+    }
+    seg_off[s] = lo;
+}
+__global__ void ls_maxseg_kernel(const u32 *__restrict__ seg_off, u32 nseg, u32 *max_seg) {
+    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 m = s < nseg ? seg_off[s + 1] - seg_off[s] : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (u32)__shfl_down(m, d, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(max_seg, m);
+}
+
+template <typename V>
+__global__ __launch_bounds__(RS_BLOCK) void ls_sort_kernel(const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
+                                                            u64 *__restrict__ keys_out, V *__restrict__ vals_out,
+                                                            const u32 *__restrict__ seg_off, LocalPasses lp) {
+    __shared__ u32 wcnt[RS_WAVES][RS_DIGITS];
+    __shared__ u32 dstart[RS_DIGITS];
+    __shared__ u64 skeys[LS_MAX];
+    __shared__ V svals[LS_MAX];
+    __shared__ u32 scan_smem[4];
+
+    const u32 s0 = seg_off[blockIdx.x];
+    const u32 m = seg_off[blockIdx.x + 1] - s0;
+    if (m == 0 || m > LS_MAX) return;   // oversize segments: the host falls back to full LSD passes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int rounds = (int)((m + RS_BLOCK - 1) / RS_BLOCK);          // wave-uniform
+    const u32 wave_base = wave * 64 * rounds;
+
+    u64 key[LS_ITEMS];
+    V val[LS_ITEMS];
+    u32 rank[LS_ITEMS], dig[LS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < LS_ITEMS; j++) {
+        const u32 li = wave_base + j * 64 + lane;
+        const bool valid = j < rounds && li < m;
+        key[j] = valid ? keys_in[s0 + li] : 0;
+        val[j] = valid ? vals_in[s0 + li] : (V)0;
+    }
+    if (lp.n == 0) {
+#pragma unroll
+        for (int j = 0; j < LS_ITEMS; j++) {
+            const u32 li = wave_base + j * 64 + lane;
+            if (j < rounds && li < m) { keys_out[s0 + li] = key[j]; vals_out[s0 + li] = val[j]; }
+        }
+        return;
+    }
+    for (int p = 0; p < lp.n; p++) {
+        const int shift = lp.shift[p], src = lp.src[p];
+        const u32 mask = (1u << lp.bits[p]) - 1u;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) wcnt[w][tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < LS_ITEMS; j++) {
+            if (j < rounds) {
+                const u32 li = wave_base + j * 64 + lane;
+                const bool valid = li < m;
+                const u32 d = rs_digit<V>(key[j], val[j], shift, mask, src);
+                u64 mm = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < RS_BITS; b++) {
+                    const bool bit = (d >> b) & 1;
+                    const u64 bal = __ballot(bit);
+                    mm &= bit ? bal : ~bal;
+                }
+                const u32 before = wcnt[wave][d];
+                rank[j] = before + __popcll(mm & lt);
+                dig[j] = d;
+                if (valid && (mm & lt) == 0) wcnt[wave][d] = before + __popcll(mm);
+            }
+        }
+        __syncthreads();
+        {
+            u32 run = 0;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; w++) {
+                u32 c = wcnt[w][tid];
+                wcnt[w][tid] = run;
+                run += c;
+            }
+            u32 total;
+            u32 incl = block_scan_inclusive(run, OpSum(), scan_smem, &total);
+            dstart[tid] = incl - run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < LS_ITEMS; j++) {
+            const u32 li = wave_base + j * 64 + lane;
+            if (j < rounds && li < m) {
+                const u32 pos = dstart[dig[j]] + wcnt[wave][dig[j]] + rank[j];
+                skeys[pos] = key[j];
+                svals[pos] = val[j];
+            }
+        }
+        __syncthreads();
+        if (p + 1 < lp.n) {
+#pragma unroll
+            for (int j = 0; j < LS_ITEMS; j++) {
+                const u32 li = wave_base + j * 64 + lane;
+                if (j < rounds && li < m) { key[j] = skeys[li]; val[j] = svals[li]; }
+            }
+            // the next pass's first barrier orders these reads before its LDS writes
+        }
+    }
+    for (u32 i = tid; i < m; i += RS_BLOCK) {
+        keys_out[s0 + i] = skeys[i];
+        vals_out[s0 + i] = svals[i];
+    }
+}
+
+// Sorts n records by (key bits [low_bit, 64), then payload passes).  `payload_passes` are the least
+// significant digits (taxa inside a k-mer / shared read indices).  Result location in *result_in_1.
+// scratch: table (RS_DIGITS * ntiles u32), agg (scan), seg (2^pbits + 2 u32 + 1 for the max).
+template <typename V>
+static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 n, int low_bit,
+                               const std::vector<SortPass> &payload_passes, u32 *table, u32 *agg, u32 *seg,
+                               int pbits, bool *result_in_1) {
+    *result_in_1 = false;
+    if (n == 0) return KMG_OK;
+    // global LSD passes over the top pbits of the key
+    std::vector<SortPass> prefix;
+    if (pbits > 0) {
+        const int np = (pbits + RS_BITS - 1) / RS_BITS;
+        int shift = 64 - pbits;
+        for (int i = 0; i < np; i++) {
+            int bits = pbits / np + (i < pbits % np ? 1 : 0);
+            prefix.push_back({shift, bits, RS_SRC_KEY});
+            shift += bits;
+        }
+    }
+    bool in1 = false;
+    KMG_TRY(radix_sort_records<V>(ctx, k0, v0, k1, v1, n, prefix, table, agg, &in1));
+    u64 *ka = in1 ? k1 : k0, *kb = in1 ? k0 : k1;
+    V *va = in1 ? v1 : v0, *vb = in1 ? v0 : v1;
+
+    const u32 nseg = 1u << pbits;
+    u32 *max_seg = seg + nseg + 1;
+    KMG_HIP(hipMemsetAsync(max_seg, 0, 4, ctx->stream));
+    {
+        ProfScope ps(ctx, KP_SORT_SEGMENTS, 0);
+        hipLaunchKernelGGL(ls_segments_kernel, dim3(div_up_u64(nseg + 1, 256)), dim3(256), 0, ctx->stream, ka, n, pbits,
+                           seg, nseg, max_seg);
+        hipLaunchKernelGGL(ls_maxseg_kernel, dim3(div_up_u64(nseg, 256)), dim3(256), 0, ctx->stream, seg, nseg, max_seg);
+    }
+    u32 h_max = 0;
+    KMG_HIP(hipMemcpyAsync(&h_max, max_seg, 4, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+
+    // remaining digits, least significant first: payload, then key bits [low_bit, 64 - pbits)
+    std::vector<SortPass> rest = payload_passes;
+    {
+        const int lbits = 64 - pbits - low_bit;
+        if (lbits > 0) {
+            const int np = (lbits + RS_BITS - 1) / RS_BITS;
+            int shift = low_bit;
+            for (int i = 0; i < np; i++) {
+                int bits = lbits / np + (i < lbits % np ? 1 : 0);
+                rest.push_back({shift, bits, RS_SRC_KEY});
+                shift += bits;
+            }
+        }
+    }
+    if (h_max <= LS_MAX && rest.size() <= LS_MAX_PASSES) {
+        LocalPasses lp;
+        lp.n = (int)rest.size();
+        for (int i = 0; i < lp.n; i++) { lp.shift[i] = rest[i].shift; lp.bits[i] = rest[i].bits; lp.src[i] = rest[i].src; }
+        if (lp.n == 0) { *result_in_1 = in1; return KMG_OK; }
+        ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_LOCAL_V64 : KP_SORT_LOCAL_V32, (u64)n * (8 + sizeof(V)) * 2);
+        hipLaunchKernelGGL((ls_sort_kernel<V>), dim3(nseg), dim3(RS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp);
+        KMG_HIP(hipGetLastError());
+        *result_in_1 = !in1;
+        return KMG_OK;
+    }
+    // Skewed input (a segment does not fit one workgroup's LDS): finish with plain LSD passes.  Starting
+    // from the prefix-sorted array is fine -- those passes were stable -- but the prefix digits must be
+    // redone after the low digits.
+    std::vector<SortPass> all = rest;
+    for (const SortPass &p : prefix) all.push_back(p);
+    bool in1b = false;
+    KMG_TRY(radix_sort_records<V>(ctx, ka, va, kb, vb, n, all, table, agg, &in1b));
+    *result_in_1 = in1b ? !in1 : in1;
     return KMG_OK;
 }

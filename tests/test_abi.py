@@ -28,7 +28,7 @@ def test_binding_loads_and_names_kernels():
     n = lib.kmg_prof_count()
     assert n > 5
     names = [lib.kmg_prof_name(i).decode() for i in range(n)]
-    assert "sort_scatter" in names and "extract_write" in names
+    assert "sort_scatter_reads" in names and "extract_write" in names
 
 
 def test_product_never_imports_oracle():
