@@ -56,42 +56,55 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict
     table[(u64)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
+// Scatter geometry: 512 threads x 8 records.  Eight waves per block and a 32-KB staging buffer that is
+// used for the keys first and the payloads second keep three blocks (24 waves) resident per CU, so one
+// block's loads/stores overlap another's ranking.
+#define RSC_BLOCK 512
+#define RSC_WAVES (RSC_BLOCK / 64)
+#define RSC_ITEMS (RS_TILE / RSC_BLOCK)
+
 template <typename V>
-__global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restrict__ keys_in,
-                                                               const V *__restrict__ vals_in,
-                                                               u64 *__restrict__ keys_out, V *__restrict__ vals_out,
-                                                               u32 n, int shift, u32 mask, int src,
-                                                               const u32 *__restrict__ table, u32 ntiles) {
-    __shared__ u32 wcnt[RS_WAVES][RS_DIGITS];   // per-wave digit counts -> exclusive prefix over waves
+__global__ __launch_bounds__(RSC_BLOCK) void rs_scatter_kernel(const u64 *__restrict__ keys_in,
+                                                                const V *__restrict__ vals_in,
+                                                                u64 *__restrict__ keys_out, V *__restrict__ vals_out,
+                                                                u32 n, int shift, u32 mask, int src,
+                                                                const u32 *__restrict__ table, u32 ntiles) {
+    __shared__ u32 wcnt[RSC_WAVES][RS_DIGITS];  // per-wave digit counts -> exclusive prefix over waves
     __shared__ u32 dstart[RS_DIGITS];           // tile-local start of each digit's run
-    __shared__ int32_t gdelta[RS_DIGITS];       // global position = local position + gdelta[digit] (mod 2^32)
-    __shared__ u64 skeys[RS_TILE];
-    __shared__ V svals[RS_TILE];
-    __shared__ u32 scan_smem[4];
+    __shared__ u32 gdelta[RS_DIGITS];           // global position = local position + gdelta[digit] (mod 2^32)
+    __shared__ u64 stage[RS_TILE];              // keys, then payloads, in digit order
+    __shared__ uint8_t sdig[RS_TILE];           // digit of each staged slot
+    __shared__ u32 scan_smem[RSC_WAVES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 tile_base = blockIdx.x * RS_TILE;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so block b and b+8 share an
+    // L2.  Giving each XCD a contiguous range of tiles puts neighbouring tiles -- whose runs of one digit
+    // are adjacent in the output -- behind the same L2, where their partial cache lines merge.
+    const u32 per_xcd = (ntiles + 7) / 8;
+    const u32 tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;
+    const u32 tile_base = tile * RS_TILE;
     const u32 tile_n = min((u32)RS_TILE, n - tile_base);
     const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
+    if (tid < RS_DIGITS) {
 #pragma unroll
-    for (int w = 0; w < RS_WAVES; w++) wcnt[w][tid] = 0;
-    __syncthreads();
-
-    u64 key[RS_ITEMS];
-    V val[RS_ITEMS];
-    u32 rank[RS_ITEMS];   // rank of the record among its wave's records with the same digit
-    u32 dig[RS_ITEMS];
-    const u32 wave_base = wave * (64 * RS_ITEMS);
+        for (int w = 0; w < RSC_WAVES; w++) wcnt[w][tid] = 0;
+    }
+    u64 key[RSC_ITEMS];
+    V val[RSC_ITEMS];
+    u32 lpos[RSC_ITEMS];   // rank among the wave's records of the same digit, later the staged slot
+    const u32 wave_base = wave * (64 * RSC_ITEMS);
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; j++) {
+    for (int j = 0; j < RSC_ITEMS; j++) {
         const u32 li = wave_base + j * 64 + lane;
         const bool valid = li < tile_n;
         key[j] = valid ? keys_in[tile_base + li] : 0;
         val[j] = valid ? vals_in[tile_base + li] : (V)0;
     }
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; j++) {
+    for (int j = 0; j < RSC_ITEMS; j++) {
         const u32 li = wave_base + j * 64 + lane;
         const bool valid = li < tile_n;
         const u32 d = rs_digit<V>(key[j], val[j], shift, mask, src);
@@ -104,8 +117,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restr
         }
         // m = lanes (valid) holding the same digit as this lane
         const u32 before = wcnt[wave][d];
-        rank[j] = before + __popcll(m & lt);
-        dig[j] = d;
+        lpos[j] = before + __popcll(m & lt);
         // the lowest lane of each digit group publishes the group's size; a wave's LDS operations
         // execute in program order, so the read above precedes this write for every lane
         if (valid && (m & lt) == 0) wcnt[wave][d] = before + __popcll(m);
@@ -115,42 +127,51 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const u64 *__restr
     // per digit (thread == digit): exclusive prefix over waves, tile-local run start, global delta
     {
         u32 run = 0;
+        if (tid < RS_DIGITS) {
 #pragma unroll
-        for (int w = 0; w < RS_WAVES; w++) {
-            u32 c = wcnt[w][tid];
-            wcnt[w][tid] = run;
-            run += c;
+            for (int w = 0; w < RSC_WAVES; w++) {
+                u32 c = wcnt[w][tid];
+                wcnt[w][tid] = run;
+                run += c;
+            }
         }
         u32 total;
-        u32 incl = block_scan_inclusive(run, OpSum(), scan_smem, &total);
-        u32 start = incl - run;
-        dstart[tid] = start;
-        gdelta[tid] = (int32_t)(table[(u64)tid * ntiles + blockIdx.x] - start);
+        u32 incl = block_scan_inclusive<u32, OpSum, RSC_WAVES>(run, OpSum(), scan_smem, &total);
+        if (tid < RS_DIGITS) {
+            u32 start = incl - run;
+            dstart[tid] = start;
+            gdelta[tid] = table[(u64)tid * ntiles + tile] - start;
+        }
     }
     __syncthreads();
 
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; j++) {
+    for (int j = 0; j < RSC_ITEMS; j++) {
         const u32 li = wave_base + j * 64 + lane;
         if (li < tile_n) {
-            const u32 lp = dstart[dig[j]] + wcnt[wave][dig[j]] + rank[j];
-            skeys[lp] = key[j];
-            svals[lp] = val[j];
+            const u32 d = rs_digit<V>(key[j], val[j], shift, mask, src);
+            lpos[j] += dstart[d] + wcnt[wave][d];
+            stage[lpos[j]] = key[j];
+            sdig[lpos[j]] = (uint8_t)d;
         }
     }
     __syncthreads();
-
-#pragma unroll 4
-    for (int i = 0; i < RS_ITEMS; i++) {
-        const u32 lp = i * RS_BLOCK + tid;
-        if (lp < tile_n) {
-            const u64 kk = skeys[lp];
-            const V vv = svals[lp];
-            const u32 d = rs_digit<V>(kk, vv, shift, mask, src);
-            const u32 gp = lp + (u32)gdelta[d];
-            keys_out[gp] = kk;
-            vals_out[gp] = vv;
-        }
+#pragma unroll
+    for (int i = 0; i < RSC_ITEMS; i++) {
+        const u32 lp = i * RSC_BLOCK + tid;
+        if (lp < tile_n) keys_out[lp + gdelta[sdig[lp]]] = stage[lp];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RSC_ITEMS; j++) {
+        const u32 li = wave_base + j * 64 + lane;
+        if (li < tile_n) reinterpret_cast<V *>(stage)[lpos[j]] = val[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RSC_ITEMS; i++) {
+        const u32 lp = i * RSC_BLOCK + tid;
+        if (lp < tile_n) vals_out[lp + gdelta[sdig[lp]]] = reinterpret_cast<V *>(stage)[lp];
     }
 }
 
@@ -186,7 +207,7 @@ static int radix_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 
                                                     nullptr, false, KP_SORT_SCAN)));
         {
             ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_SCATTER_V64 : KP_SORT_SCATTER_V32, (u64)n * (8 + sizeof(V)) * 2);
-            hipLaunchKernelGGL((rs_scatter_kernel<V>), dim3(ntiles), dim3(RS_BLOCK), 0, ctx->stream, ki, vi, ko, vo, n,
+            hipLaunchKernelGGL((rs_scatter_kernel<V>), dim3(((ntiles + 7) / 8) * 8), dim3(RSC_BLOCK), 0, ctx->stream, ki, vi, ko, vo, n,
                                p.shift, mask, p.src, table, ntiles);
         }
         KMG_HIP(hipGetLastError());
@@ -204,8 +225,10 @@ static int radix_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 
 // Correctness: the prefix passes are a stable sort by prefix; a stable sort of each equal-prefix segment
 // by (payload digits, low key bits) then yields the same order as the full LSD sort.
 // ------------------------------------------------------------------------------------------------------
-#define LS_ITEMS 12
-#define LS_MAX (RS_BLOCK * LS_ITEMS)   // 3072 records per segment at most
+#define LS_BLOCK 512
+#define LS_WAVES (LS_BLOCK / 64)
+#define LS_ITEMS 6
+#define LS_MAX (LS_BLOCK * LS_ITEMS)   // 3072 records per segment at most
 #define LS_MAX_PASSES 16
 
 struct LocalPasses {
@@ -240,26 +263,26 @@ __global__ void ls_maxseg_kernel(const u32 *__restrict__ seg_off, u32 nseg, u32 
 }
 
 template <typename V>
-__global__ __launch_bounds__(RS_BLOCK) void ls_sort_kernel(const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
+__global__ __launch_bounds__(LS_BLOCK) void ls_sort_kernel(const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
                                                             u64 *__restrict__ keys_out, V *__restrict__ vals_out,
                                                             const u32 *__restrict__ seg_off, LocalPasses lp) {
-    __shared__ u32 wcnt[RS_WAVES][RS_DIGITS];
+    __shared__ u32 wcnt[LS_WAVES][RS_DIGITS];
     __shared__ u32 dstart[RS_DIGITS];
     __shared__ u64 skeys[LS_MAX];
     __shared__ V svals[LS_MAX];
-    __shared__ u32 scan_smem[4];
+    __shared__ u32 scan_smem[LS_WAVES];
 
     const u32 s0 = seg_off[blockIdx.x];
     const u32 m = seg_off[blockIdx.x + 1] - s0;
     if (m == 0 || m > LS_MAX) return;   // oversize segments: the host falls back to full LSD passes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    const int rounds = (int)((m + RS_BLOCK - 1) / RS_BLOCK);          // wave-uniform
+    const int rounds = (int)((m + LS_BLOCK - 1) / LS_BLOCK);          // block-uniform
     const u32 wave_base = wave * 64 * rounds;
 
     u64 key[LS_ITEMS];
     V val[LS_ITEMS];
-    u32 rank[LS_ITEMS], dig[LS_ITEMS];
+    u32 rank[LS_ITEMS];
 #pragma unroll
     for (int j = 0; j < LS_ITEMS; j++) {
         const u32 li = wave_base + j * 64 + lane;
@@ -278,8 +301,10 @@ __global__ __launch_bounds__(RS_BLOCK) void ls_sort_kernel(const u64 *__restrict
     for (int p = 0; p < lp.n; p++) {
         const int shift = lp.shift[p], src = lp.src[p];
         const u32 mask = (1u << lp.bits[p]) - 1u;
+        if (tid < RS_DIGITS) {
 #pragma unroll
-        for (int w = 0; w < RS_WAVES; w++) wcnt[w][tid] = 0;
+            for (int w = 0; w < LS_WAVES; w++) wcnt[w][tid] = 0;
+        }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < LS_ITEMS; j++) {
@@ -296,29 +321,31 @@ __global__ __launch_bounds__(RS_BLOCK) void ls_sort_kernel(const u64 *__restrict
                 }
                 const u32 before = wcnt[wave][d];
                 rank[j] = before + __popcll(mm & lt);
-                dig[j] = d;
                 if (valid && (mm & lt) == 0) wcnt[wave][d] = before + __popcll(mm);
             }
         }
         __syncthreads();
         {
             u32 run = 0;
+            if (tid < RS_DIGITS) {
 #pragma unroll
-            for (int w = 0; w < RS_WAVES; w++) {
-                u32 c = wcnt[w][tid];
-                wcnt[w][tid] = run;
-                run += c;
+                for (int w = 0; w < LS_WAVES; w++) {
+                    u32 c = wcnt[w][tid];
+                    wcnt[w][tid] = run;
+                    run += c;
+                }
             }
             u32 total;
-            u32 incl = block_scan_inclusive(run, OpSum(), scan_smem, &total);
-            dstart[tid] = incl - run;
+            u32 incl = block_scan_inclusive<u32, OpSum, LS_WAVES>(run, OpSum(), scan_smem, &total);
+            if (tid < RS_DIGITS) dstart[tid] = incl - run;
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < LS_ITEMS; j++) {
             const u32 li = wave_base + j * 64 + lane;
             if (j < rounds && li < m) {
-                const u32 pos = dstart[dig[j]] + wcnt[wave][dig[j]] + rank[j];
+                const u32 d = rs_digit<V>(key[j], val[j], shift, mask, src);
+                const u32 pos = dstart[d] + wcnt[wave][d] + rank[j];
                 skeys[pos] = key[j];
                 svals[pos] = val[j];
             }
@@ -333,7 +360,7 @@ __global__ __launch_bounds__(RS_BLOCK) void ls_sort_kernel(const u64 *__restrict
             // the next pass's first barrier orders these reads before its LDS writes
         }
     }
-    for (u32 i = tid; i < m; i += RS_BLOCK) {
+    for (u32 i = tid; i < m; i += LS_BLOCK) {
         keys_out[s0 + i] = skeys[i];
         vals_out[s0 + i] = svals[i];
     }
@@ -397,7 +424,7 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
         for (int i = 0; i < lp.n; i++) { lp.shift[i] = rest[i].shift; lp.bits[i] = rest[i].bits; lp.src[i] = rest[i].src; }
         if (lp.n == 0) { *result_in_1 = in1; return KMG_OK; }
         ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_LOCAL_V64 : KP_SORT_LOCAL_V32, (u64)n * (8 + sizeof(V)) * 2);
-        hipLaunchKernelGGL((ls_sort_kernel<V>), dim3(nseg), dim3(RS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp);
+        hipLaunchKernelGGL((ls_sort_kernel<V>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp);
         KMG_HIP(hipGetLastError());
         *result_in_1 = !in1;
         return KMG_OK;

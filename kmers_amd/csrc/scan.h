@@ -17,8 +17,8 @@ struct OpMax {
 };
 
 // Inclusive scan of one value per thread across a 256-thread block.  Returns the inclusive prefix;
-// *block_total = aggregate of the whole block.  `smem` must hold 4 T's.
-template <typename T, typename Op>
+// *block_total = aggregate of the whole block.  `smem` must hold WAVES T's.
+template <typename T, typename Op, int WAVES = SCAN_BLOCK / 64>
 __device__ __forceinline__ T block_scan_inclusive(T v, Op op, T *smem, T *block_total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -32,7 +32,7 @@ __device__ __forceinline__ T block_scan_inclusive(T v, Op op, T *smem, T *block_
     T carry = smem[0];
     bool have = false;
 #pragma unroll
-    for (int w = 1; w < SCAN_BLOCK / 64; w++) {
+    for (int w = 1; w < WAVES; w++) {
         if (w == wave) { carry = total; have = true; }
         total = op(total, smem[w]);
     }
