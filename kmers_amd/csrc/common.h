@@ -168,6 +168,7 @@ struct kmg_db {
     u64 *val_off = nullptr;     // U + 1
     int32_t *val_a = nullptr;   // V
     int32_t *val_b = nullptr;   // V
+    u64 *vals_packed = nullptr; // read DBs built here: V x (read << 16 | pos16); val_a/val_b unpacked on demand
     u64 *bucket_off = nullptr;  // 4^key_len + 1
 };
 

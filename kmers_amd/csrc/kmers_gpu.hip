@@ -270,6 +270,7 @@ static void db_release(kmg_db *db) {
     ctx->pool.release(db->val_off);
     ctx->pool.release(db->val_a);
     ctx->pool.release(db->val_b);
+    ctx->pool.release(db->vals_packed);
     ctx->pool.release(db->bucket_off);
     delete db;
 }
@@ -342,6 +343,61 @@ static int reduce_records(kmg_ctx *ctx, const u64 *keys, const V *vals, u32 n, k
     return KMG_OK;
 }
 
+// Read DB: k-mer runs from the sorted keys alone; the sorted payload array becomes the value array.
+static int reduce_read_keys(kmg_ctx *ctx, const u64 *keys, u32 n, kmg_db *db, u64 *d_totals) {
+    void *p;
+    if (ctx->pool.alloc(&p, ((size_t)n + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->keys = (u64 *)p;
+    if (ctx->pool.alloc(&p, ((size_t)n + 2) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->val_off = (u64 *)p;
+    const u32 nbuckets = 1u << (2 * db->key_len);
+    if (ctx->pool.alloc(&p, ((size_t)nbuckets + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->bucket_off = (u64 *)p;
+    const u32 ntiles = div_up_u64(n, RDK_TILE);
+    PoolBuf cnt_k(ctx), off_k(ctx), agg(ctx);
+    KMG_ALLOC(cnt_k, (size_t)(ntiles + 1) * 4);
+    KMG_ALLOC(off_k, (size_t)(ntiles + 1) * 8);
+    KMG_ALLOC(agg, (size_t)(div_up_u64(ntiles, SCAN_TILE) + 1) * 8);
+    if (n > 0) {
+        {
+            ProfScope ps(ctx, KP_REDUCE_FLAG, (u64)n * 8);
+            hipLaunchKernelGGL(rdk_count_kernel, dim3(ntiles), dim3(RD_BLOCK), 0, ctx->stream, keys, n, cnt_k.as<u32>());
+        }
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt_k.as<u32>(), off_k.as<u64>(), ntiles, OpSum(), 0ull,
+                                                    agg.as<u64>(), d_totals + 0, false, KP_SCAN)));
+        hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, d_totals + 1, (u64)n);
+        {
+            ProfScope ps(ctx, KP_REDUCE_WRITE, (u64)n * 8 /* + 16 B per unique k-mer, added when U is known */);
+            hipLaunchKernelGGL(rdk_write_kernel, dim3(ntiles), dim3(RD_BLOCK), 0, ctx->stream, keys, n, off_k.as<u64>(),
+                               db->keys, db->val_off);
+        }
+    } else {
+        KMG_HIP(hipMemsetAsync(d_totals, 0, 16, ctx->stream));
+    }
+    {
+        ProfScope ps(ctx, KP_BUCKETS, 0);
+        hipLaunchKernelGGL(rd_buckets_kernel, dim3(div_up_u64(nbuckets + 1, 256)), dim3(256), 0, ctx->stream, db->keys,
+                           d_totals, db->val_off, db->bucket_off, nbuckets, db->key_len);
+    }
+    KMG_HIP(hipGetLastError());
+    return KMG_OK;
+}
+
+// val_a / val_b of a read DB are materialised from the packed payloads the first time they are needed.
+static int ensure_vals(kmg_ctx *ctx, kmg_db *db) {
+    if (db->val_a || !db->vals_packed) return KMG_OK;
+    void *a = nullptr, *b = nullptr;
+    if (ctx->pool.alloc(&a, (db->V + 1) * 4) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    if (ctx->pool.alloc(&b, (db->V + 1) * 4) != KMG_OK) { ctx->pool.release(a); return fail(ctx, KMG_ENOMEM, "db allocation failed"); }
+    db->val_a = (int32_t *)a;
+    db->val_b = (int32_t *)b;
+    if (db->V)
+        hipLaunchKernelGGL(rd_unpack_kernel, dim3(div_up_u64(db->V, 256)), dim3(256), 0, ctx->stream, db->vals_packed, db->V,
+                           db->val_a, db->val_b);
+    KMG_HIP(hipGetLastError());
+    return KMG_OK;
+}
+
 extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows) {
     if (!ctx || !out) return KMG_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
@@ -401,8 +457,12 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     if (r == KMG_OK) {
         const u64 *sk = in1 ? k1.as<u64>() : ctx->rec_keys;
         const void *sv = in1 ? v1.p : ctx->rec_vals;
-        if (reads) r = reduce_records<u64, false>(ctx, sk, (const u64 *)sv, n, db, totals.as<u64>());
-        else r = reduce_records<u32, true>(ctx, sk, (const u32 *)sv, n, db, totals.as<u64>());
+        if (reads) {
+            r = reduce_read_keys(ctx, sk, n, db, totals.as<u64>());
+            // the sorted payload buffer changes owner: it is the DB's value array now
+            if (in1) db->vals_packed = (u64 *)v1.detach();
+            else { db->vals_packed = (u64 *)ctx->rec_vals; ctx->rec_vals = nullptr; }
+        } else r = reduce_records<u32, true>(ctx, sk, (const u32 *)sv, n, db, totals.as<u64>());
     }
     u64 tot[2] = {0, 0};
     if (r == KMG_OK) {
@@ -418,7 +478,7 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     db->U = tot[0];
     db->V = tot[1];
     if (ctx->prof_on)
-        ctx->prof[KP_REDUCE_WRITE].bytes += db->U * 16 + db->V * (reads ? 6 : 8);
+        ctx->prof[KP_REDUCE_WRITE].bytes += db->U * 16 + (reads ? 0 : db->V * 8);
     *out = db_guard.release();
     return KMG_OK;
 }
@@ -442,6 +502,7 @@ extern "C" int kmg_db_fetch(const kmg_db *db, uint64_t *keys, uint64_t *val_off,
     kmg_ctx *ctx = db->ctx;
     std::lock_guard<std::mutex> g(ctx->mu);
     KMG_HIP(hipSetDevice(ctx->device));
+    if (val_a || val_b) KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(db)));
     if (keys && db->U) KMG_HIP(hipMemcpyAsync(keys, db->keys, db->U * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (val_off) KMG_HIP(hipMemcpyAsync(val_off, db->val_off, (db->U + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (val_a && db->V) KMG_HIP(hipMemcpyAsync(val_a, db->val_a, db->V * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -507,6 +568,7 @@ extern "C" int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint6
     KMG_HIP(hipSetDevice(ctx->device));
     const u64 U = db->U;
     const u32 nbuckets = 1u << (2 * db->key_len);
+    KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(db)));
     PoolBuf sizes(ctx), enc_off(ctx), agg(ctx), d_out(ctx), d_boff(ctx);
     KMG_ALLOC(sizes, (U + 1) * 4);
     KMG_ALLOC(enc_off, (U + 2) * 8);

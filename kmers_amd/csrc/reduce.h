@@ -108,6 +108,80 @@ __global__ __launch_bounds__(RD_BLOCK) void rd_write_kernel(const u64 *__restric
     }
 }
 
+// ---- read DBs: only the keys are needed to find the k-mer runs; every record is its own value and the
+// sorted payload array (read << 16 | pos16) IS the value array (unpacked on demand by rd_unpack_kernel).
+// Coalesced: lane i of a round reads key base + i (and its predecessor), heads are ranked with ballots.
+#define RDK_ROUNDS 8
+#define RDK_TILE (RD_BLOCK * RDK_ROUNDS)
+
+__global__ __launch_bounds__(RD_BLOCK) void rdk_count_kernel(const u64 *__restrict__ keys, u32 n, u32 *__restrict__ cnt_k) {
+    __shared__ u32 smem[4];
+    const u32 base = blockIdx.x * RDK_TILE;
+    u32 c = 0;
+#pragma unroll
+    for (int r = 0; r < RDK_ROUNDS; r++) {
+        const u32 idx = base + r * RD_BLOCK + threadIdx.x;
+        bool h = false;
+        if (idx < n) h = idx == 0 || keys[idx] != keys[idx - 1];
+        c += __popcll(__ballot(h));       // wave-uniform count
+    }
+    u32 total;
+    block_scan_inclusive((threadIdx.x & 63) == 0 ? c : 0u, OpSum(), smem, &total);
+    if (threadIdx.x == 0) cnt_k[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(RD_BLOCK) void rdk_write_kernel(const u64 *__restrict__ keys, u32 n,
+                                                              const u64 *__restrict__ off_k, u64 *__restrict__ ukeys,
+                                                              u64 *__restrict__ val_off) {
+    __shared__ u32 wc[RDK_ROUNDS][RD_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 base = blockIdx.x * RDK_TILE;
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    u64 kk[RDK_ROUNDS];
+    u32 hmask = 0, pre[RDK_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < RDK_ROUNDS; r++) {
+        const u32 idx = base + r * RD_BLOCK + tid;
+        bool h = false;
+        kk[r] = 0;
+        if (idx < n) { kk[r] = keys[idx]; h = idx == 0 || kk[r] != keys[idx - 1]; }
+        const u64 bal = __ballot(h);
+        pre[r] = __popcll(bal & lt);
+        hmask |= (u32)h << r;
+        if (lane == 0) wc[r][wave] = __popcll(bal);
+    }
+    __syncthreads();
+    if (tid < RDK_ROUNDS * (RD_BLOCK / 64)) {     // 32 (round, wave) counts in record order
+        u32 v = wc[tid >> 2][tid & 3], inc = v;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            u32 o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        wc[tid >> 2][tid & 3] = inc - v;
+    }
+    __syncthreads();
+    const u64 ubase = off_k[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < RDK_ROUNDS; r++) {
+        if ((hmask >> r) & 1) {
+            const u64 u = ubase + wc[r][wave] + pre[r];
+            ukeys[u] = kk[r];
+            val_off[u] = base + r * RD_BLOCK + tid;
+        }
+    }
+}
+
+// ReadPos(int read, short pos) from the packed payload
+__global__ void rd_unpack_kernel(const u64 *__restrict__ packed, u64 V, int32_t *__restrict__ val_a, int32_t *__restrict__ val_b) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < V) {
+        u64 p = packed[i];
+        val_a[i] = (int32_t)(p >> 16);
+        val_b[i] = (int32_t)(int16_t)(p & 0xFFFFu);
+    }
+}
+
 // counts of a reference DB: occurrences of each (k-mer, taxon) = distance to the next run start
 __global__ void rd_counts_kernel(const u32 *__restrict__ vstart, const u64 *__restrict__ totals /*[0]=U,[1]=V*/,
                                  u32 n, int32_t *__restrict__ val_b) {
