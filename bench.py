@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale", type=float, default=1.0, help="scale factor on config sizes (1.0 = BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--calib", action="store_true", help="also launch the known-traffic copy kernel (PMC calibration)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,6 +104,8 @@ def main():
         lib.kmg_db_free(ref)
         return info
 
+    if args.calib:
+        ctx.check(lib.kmg_calib_copy(h, 1 << 27))   # 1 GiB read + 1 GiB written, known exactly
     for _ in range(args.warmup):
         info = step()
     torch.cuda.synchronize()
@@ -140,8 +143,9 @@ def main():
     avg_ms = d["ms"] / d["launches"]
     bytes_per_launch = d["bytes"] / d["launches"]
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    traffic = pmc_traffic(dom)
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": int(bytes_per_launch),
                 "launches_per_step": d["launches"] // prof_steps}
     kernels = {k: {"ms_per_step": round(v["ms"] / prof_steps, 4), "launches_per_step": v["launches"] // prof_steps,
@@ -175,6 +179,34 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+# kernel id of the measurement hook -> kernel symbol in the rocprofv3 traces
+KERNEL_SYMBOL = {
+    "sort_scatter_reads": "rs_scatter_kernel<unsigned long long>", "sort_scatter_ref": "rs_scatter_kernel<unsigned int>",
+    "sort_local_reads": "ls_sort_kernel<unsigned long long>", "sort_local_ref": "ls_sort_kernel<unsigned int>",
+    "sort_hist_reads": "rs_hist_kernel<unsigned long long>", "sort_hist_ref": "rs_hist_kernel<unsigned int>",
+    "extract_write": "extract_kernel<true>", "extract_count": "extract_kernel<false>", "match": "match_kernel",
+}
+
+
+def pmc_traffic(kernel_id):
+    """HBM bytes per launch of the dominant kernel from the committed PMC measurement
+    (profiles/*_pmc_traffic.json, produced by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE
+    passes, calibrated on a copy of known size).  None when no measurement covers the kernel."""
+    import glob
+    sym = KERNEL_SYMBOL.get(kernel_id)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not sym or not files:
+        return None
+    try:
+        data = json.load(open(files[-1]))
+        for name, v in data["kernels"].items():
+            if sym in name:
+                return int(v["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+    return None
 
 
 def cpu_baseline(synth, taxa, genomes, reads):

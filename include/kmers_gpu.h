@@ -138,6 +138,10 @@ int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, int64_t *matc
 int kmg_prof_enable(kmg_ctx *ctx, int on);
 int kmg_prof_reset(kmg_ctx *ctx);
 int kmg_prof_get(kmg_ctx *ctx, int kernel_id, double *total_ms, uint64_t *launches, uint64_t *algo_bytes);
+/* Launches calib_copy_kernel: an 8-byte-per-lane streaming copy of n_words words whose HBM traffic is
+ * known exactly (8n read + 8n written) -- the calibration launch for the rocprofv3 FETCH_SIZE /
+ * WRITE_SIZE counters (tools/pmc_traffic.py). */
+int kmg_calib_copy(kmg_ctx *ctx, uint64_t n_words);
 int kmg_prof_count(void);               /* number of kernel ids */
 const char *kmg_prof_name(int kernel_id);
 

@@ -21,7 +21,7 @@ SYMBOLS = [
     "kmg_build_begin", "kmg_build_add", "kmg_build_add_dev", "kmg_build_finish",
     "kmg_db_info", "kmg_db_fetch", "kmg_db_load", "kmg_db_free", "kmg_db_encode",
     "kmg_match", "kmg_match_dev", "kmg_taxacounts",
-    "kmg_prof_enable", "kmg_prof_reset", "kmg_prof_get", "kmg_prof_count", "kmg_prof_name",
+    "kmg_prof_enable", "kmg_prof_reset", "kmg_prof_get", "kmg_prof_count", "kmg_prof_name", "kmg_calib_copy",
 ]
 
 
@@ -72,6 +72,7 @@ def load():
     lib.kmg_prof_enable.argtypes = [vp, i32]
     lib.kmg_prof_reset.argtypes = [vp]
     lib.kmg_prof_get.argtypes = [vp, i32, P(C.c_double), P(u64), P(u64)]
+    lib.kmg_calib_copy.argtypes = [vp, u64]
     lib.kmg_prof_count.argtypes = []
     lib.kmg_prof_name.argtypes = [i32]
     lib.kmg_prof_name.restype = C.c_char_p

@@ -728,5 +728,25 @@ extern "C" int kmg_prof_get(kmg_ctx *ctx, int id, double *total_ms, uint64_t *la
     if (algo_bytes) *algo_bytes = ctx->prof[id].bytes;
     return KMG_OK;
 }
+// 8-byte-per-lane streaming copy of n words: a launch whose HBM bytes are known exactly (8n read, 8n
+// written), used to calibrate the FETCH_SIZE / WRITE_SIZE counters for this library's access width.
+__global__ __launch_bounds__(256) void calib_copy_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, u64 n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) out[i] = in[i];
+}
+extern "C" int kmg_calib_copy(kmg_ctx *ctx, uint64_t n_words) {
+    if (!ctx || n_words == 0) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    PoolBuf a(ctx), b(ctx);
+    KMG_ALLOC(a, n_words * 8);
+    KMG_ALLOC(b, n_words * 8);
+    KMG_HIP(hipMemsetAsync(a.p, 0x5A, n_words * 8, ctx->stream));
+    hipLaunchKernelGGL(calib_copy_kernel, dim3(div_up_u64(n_words, 256 * 8)), dim3(256), 0, ctx->stream, a.as<u64>(),
+                       b.as<u64>(), (u64)n_words);
+    KMG_HIP(hipGetLastError());
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    return KMG_OK;
+}
+
 extern "C" const char *kmg_prof_name(int id) { return (id >= 0 && id < KP_COUNT_) ? kp_names[id] : ""; }
 extern "C" int kmg_prof_count(void) { return KP_COUNT_; }

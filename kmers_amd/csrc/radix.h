@@ -36,24 +36,34 @@ __device__ __forceinline__ u32 rs_digit(u64 key, V val, int shift, u32 mask, int
     return (u32)(key >> shift) & mask;
 }
 
+// One block histograms RSH_TILES consecutive tiles, so that each digit's RSH_TILES counters -- adjacent in
+// the digit-major table -- leave as one 64-byte store instead of sixteen stray 4-byte ones (measured with
+// WRITE_SIZE: the one-tile-per-block version wrote 8x the table's size).
+#define RSH_TILES 16
 template <typename V>
 __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict__ keys, const V *__restrict__ vals,
                                                             u32 n, int shift, u32 mask, int src,
-                                                            u32 *__restrict__ table, u32 ntiles) {
-    __shared__ u32 h[RS_DIGITS];
-    h[threadIdx.x] = 0;
+                                                            u32 *__restrict__ table, u32 ntiles, int tpb) {
+    __shared__ u32 h[RS_DIGITS][RSH_TILES + 1];
+    for (int t = 0; t < tpb; t++) h[threadIdx.x][t] = 0;
     __syncthreads();
-    const u32 base = blockIdx.x * RS_TILE;
+    const u32 tile0 = blockIdx.x * tpb;
+    for (int t = 0; t < tpb; t++) {
+        const u32 base = (tile0 + t) * RS_TILE;
+        if (base >= n) break;
 #pragma unroll 4
-    for (int i = 0; i < RS_ITEMS; i++) {
-        u32 idx = base + i * RS_BLOCK + threadIdx.x;
-        if (idx < n) {
-            u32 d = src ? rs_digit<V>(0, vals[idx], shift, mask, src) : rs_digit<V>(keys[idx], (V)0, shift, mask, 0);
-            atomicAdd(&h[d], 1u);
+        for (int i = 0; i < RS_ITEMS; i++) {
+            u32 idx = base + i * RS_BLOCK + threadIdx.x;
+            if (idx < n) {
+                u32 d = src ? rs_digit<V>(0, vals[idx], shift, mask, src) : rs_digit<V>(keys[idx], (V)0, shift, mask, 0);
+                atomicAdd(&h[d][t], 1u);
+            }
         }
     }
     __syncthreads();
-    table[(u64)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+    u32 *row = table + (u64)threadIdx.x * ntiles + tile0;
+    for (int t = 0; t < tpb; t++)
+        if (tile0 + t < ntiles) row[t] = h[threadIdx.x][t];
 }
 
 // Scatter geometry: 512 threads x 8 records.  Eight waves per block and a 32-KB staging buffer that is
@@ -200,8 +210,11 @@ static int radix_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 
         const u32 mask = (1u << p.bits) - 1u;
         {
             ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_HIST_V64 : KP_SORT_HIST_V32, (u64)n * (p.src ? sizeof(V) : 8));
-            hipLaunchKernelGGL((rs_hist_kernel<V>), dim3(ntiles), dim3(RS_BLOCK), 0, ctx->stream, ki, vi, n, p.shift,
-                               mask, p.src, table, ntiles);
+            // tiles per block: as many as keep >= ~2048 blocks in flight (small inputs: one tile per block)
+            int tpb = 1;
+            while (tpb < RSH_TILES && ntiles / (tpb * 2) >= 2048) tpb *= 2;
+            hipLaunchKernelGGL((rs_hist_kernel<V>), dim3(div_up_u64(ntiles, tpb)), dim3(RS_BLOCK), 0, ctx->stream, ki, vi, n, p.shift,
+                               mask, p.src, table, ntiles, tpb);
         }
         KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, table, table, (u64)RS_DIGITS * ntiles, OpSum(), 0u, agg,
                                                     nullptr, false, KP_SORT_SCAN)));
@@ -388,7 +401,6 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_sort_kernel(const u64 *__restrict
                     bad |= ls_greater<V>(skeys[i], svals[i], skeys[i + 1], svals[i + 1], lp.pay_mode);
                 unsorted = __syncthreads_or(bad);
                 if (!unsorted || it == LS_BUBBLE) break;
-#pragma unroll
                 for (int phase = 0; phase < 2; phase++) {
                     for (u32 i = 2 * tid + phase; i + 1 < m; i += 2 * LS_BLOCK) {
                         const u64 ka = skeys[i], kb = skeys[i + 1];

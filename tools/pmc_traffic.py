@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""HBM traffic per kernel launch from rocprofv3 PMC counters (run ON the GPU box, from the repo root).
+
+Two separate --pmc passes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2: they do not fit one pass) over a
+short bench.py run that also launches calib_copy_kernel, whose traffic is known exactly (8-byte-per-lane
+streaming copy: 1 GiB read, 1 GiB written).  gfx950's FETCH_SIZE under-reports wide coalesced reads
+(MI355X_MICROARCH.md, HBM section), so every kernel's counters are scaled by the factor that makes the
+calibration launch come out right for this library's access width.  Output: profiles/<tag>_pmc_traffic.json.
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r1"
+CALIB_BYTES = (1 << 27) * 8
+
+
+def run_pass(counter):
+    out = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (TAG, counter))
+    cmd = ["timeout", "-s", "KILL", "240", "rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--calib"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    per = {}
+    for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            name = row["Kernel_Name"]
+            s = per.setdefault(name, [0.0, 0])
+            s[0] += float(row["Counter_Value"])
+            s[1] += 1
+    return per
+
+
+def main():
+    fetch, write = run_pass("FETCH_SIZE"), run_pass("WRITE_SIZE")
+    cal = [k for k in fetch if "calib_copy_kernel" in k][0]
+    # counters are reported in KiB
+    f_fac = CALIB_BYTES / (fetch[cal][0] / fetch[cal][1] * 1024.0)
+    w_fac = CALIB_BYTES / (write[cal][0] / write[cal][1] * 1024.0)
+    res = {"calibration": {"kernel": cal, "known_bytes_each_way": CALIB_BYTES, "fetch_factor": f_fac, "write_factor": w_fac,
+                           "note": "traffic = FETCH_SIZE*1024*fetch_factor + WRITE_SIZE*1024*write_factor, averaged per launch"},
+           "kernels": {}}
+    for k in sorted(fetch):
+        if k not in write:
+            continue
+        fb = fetch[k][0] / fetch[k][1] * 1024.0 * f_fac
+        wb = write[k][0] / write[k][1] * 1024.0 * w_fac
+        res["kernels"][k] = {"launches": fetch[k][1], "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                             "traffic_bytes_per_launch": fb + wb}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    path = os.path.join(ROOT, "gpurun_out", "%s_pmc_traffic.json" % TAG)
+    json.dump(res, open(path, "w"), indent=1)
+    print("calibration factors: fetch %.3f write %.3f" % (f_fac, w_fac))
+    for k, v in sorted(res["kernels"].items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"])[:12]:
+        print("%-60s x%-4d %8.1f MB fetched %8.1f MB written" % (k[:60], v["launches"], v["fetch_bytes_per_launch"] / 1e6,
+                                                               v["write_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
