@@ -240,16 +240,17 @@ static int radix_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 
 // ------------------------------------------------------------------------------------------------------
 #define LS_BLOCK 512
 #define LS_WAVES (LS_BLOCK / 64)
-#define LS_ITEMS 6
-#define LS_MAX (LS_BLOCK * LS_ITEMS)   // 3072 records per segment at most
+#define LS_ITEMS 5
+#define LS_MAX (LS_BLOCK * LS_ITEMS)   // 2560 records per segment at most (48 KB of LDS: 3 blocks per CU)
 #define LS_MAX_PASSES 16
 
-#define LS_TOP 3      // key digits sorted on the fast path before the order is verified
-#define LS_BUBBLE 3   // odd-even transposition rounds tried before falling back to the full digit list
+#define LS_TOP 2        // key digits sorted by counting passes before the comparison finish
+#define LS_RUNCAP 384   // longest equal-prefix run the comparison finish accepts
 
 struct LocalPasses {
     int n;
-    int fast_from;   // > 0: first run only passes [fast_from, n) and verify (see ls_sort_kernel)
+    int fast_from;   // > 0: run only passes [fast_from, n), then finish by comparison (see ls_sort_kernel)
+    int cmp_shift;   // lowest key bit covered by those passes
     int pay_mode;    // payload ordering inside equal keys: 0 none (stable), 1 signed 32-bit, 2 raw 64-bit
     int shift[LS_MAX_PASSES];
     int bits[LS_MAX_PASSES];
@@ -291,21 +292,18 @@ __device__ __forceinline__ bool ls_greater(u64 ka, V va, u64 kb, V vb, int mode)
     return mode != 0 && ls_pay_ord<V>(va, mode) > ls_pay_ord<V>(vb, mode);
 }
 
-// One workgroup sorts one equal-prefix segment (<= LS_MAX records) entirely in LDS.
-// Fast path: sort by the top LS_TOP digits only, then verify the full order with one pass of neighbour
-// compares (+ a few odd-even transposition rounds).  On genomic data almost every run of records that
-// agree on prefix + 3 digits is a run of identical k-mers, which is already in its final (stable) order,
-// so half of the digit passes are skipped.  A segment that is still unordered afterwards is re-sorted
-// with the complete digit list; that is correct from any arrangement the stable steps above produce.
+// One workgroup sorts one equal-prefix segment (<= LS_MAX records) entirely in LDS: stable counting passes
+// on the top LS_TOP digits of the remaining key bits, then a comparison finish inside the short runs that
+// still agree on those digits.  A segment with an over-long run is sorted with the complete digit list
+// (payload digits, then every key digit), which is correct from any arrangement the stable steps produce.
 template <typename V>
-__global__ __launch_bounds__(LS_BLOCK) void ls_sort_kernel(const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
+__global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
                                                             u64 *__restrict__ keys_out, V *__restrict__ vals_out,
                                                             const u32 *__restrict__ seg_off, LocalPasses lp) {
-    __shared__ u32 wcnt[LS_WAVES][RS_DIGITS];
-    __shared__ u32 dstart[RS_DIGITS];
+    __shared__ uint16_t wcnt[LS_WAVES][RS_DIGITS];    // per-wave digit counts of the current pass (<= LS_MAX)
+    __shared__ uint16_t wbase[LS_WAVES][RS_DIGITS];   // per-wave first LDS slot of each digit
     __shared__ u64 skeys[LS_MAX];
     __shared__ V svals[LS_MAX];
-    __shared__ u32 scan_smem[LS_WAVES];
 
     const u32 s0 = seg_off[blockIdx.x];
     const u32 m = seg_off[blockIdx.x + 1] - s0;
@@ -335,15 +333,13 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_sort_kernel(const u64 *__restrict
     }
     int p = lp.fast_from, p_end = lp.n;
     bool fast = lp.fast_from > 0;
+    *reinterpret_cast<uint2 *>(&wcnt[wave][4 * lane]) = make_uint2(0, 0);   // own row; only this wave writes it
     for (;;) {
-        // ---- one stable counting pass: registers -> LDS in digit order
-        const int shift = lp.shift[p], src = lp.src[p];
-        const u32 mask = (1u << lp.bits[p]) - 1u;
-        if (tid < RS_DIGITS) {
-#pragma unroll
-            for (int w = 0; w < LS_WAVES; w++) wcnt[w][tid] = 0;
-        }
-        __syncthreads();
+        // ---- one stable counting pass: registers -> LDS in digit order.  Two barriers per pass: every wave
+        // derives its own slot bases from all waves' counts (redundantly, 4 digits per lane) instead of
+        // waiting for a block-wide scan, and clears its own counter row for the next pass.
+        const int shift = lp.shift[p], src = lp.src[p], nbits = lp.bits[p];
+        const u32 mask = (1u << nbits) - 1u;
 #pragma unroll
         for (int j = 0; j < LS_ITEMS; j++) {
             if (j < rounds) {
@@ -353,6 +349,7 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_sort_kernel(const u64 *__restrict
                 u64 mm = __ballot(valid);
 #pragma unroll
                 for (int b = 0; b < RS_BITS; b++) {
+
                     const bool bit = (d >> b) & 1;
                     const u64 bal = __ballot(bit);
                     mm &= bit ? bal : ~bal;
@@ -364,56 +361,97 @@ __global__ __launch_bounds__(LS_BLOCK) void ls_sort_kernel(const u64 *__restrict
         }
         __syncthreads();
         {
-            u32 run = 0;
-            if (tid < RS_DIGITS) {
+            // lane owns digits 4*lane .. 4*lane+3
+            u32 tot[4] = {0, 0, 0, 0}, mine[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int w = 0; w < LS_WAVES; w++) {
-                    u32 c = wcnt[w][tid];
-                    wcnt[w][tid] = run;
-                    run += c;
-                }
+            for (int w = 0; w < LS_WAVES; w++) {
+                const uint2 c = *reinterpret_cast<const uint2 *>(&wcnt[w][4 * lane]);   // 4 x u16
+                if (w == wave) { mine[0] = tot[0]; mine[1] = tot[1]; mine[2] = tot[2]; mine[3] = tot[3]; }
+                tot[0] += c.x & 0xFFFFu; tot[1] += c.x >> 16; tot[2] += c.y & 0xFFFFu; tot[3] += c.y >> 16;
             }
-            u32 total;
-            u32 incl = block_scan_inclusive<u32, OpSum, LS_WAVES>(run, OpSum(), scan_smem, &total);
-            if (tid < RS_DIGITS) dstart[tid] = incl - run;
+            const u32 s4 = tot[0] + tot[1] + tot[2] + tot[3];
+            u32 inc = s4;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const u32 o = __shfl_up(inc, dd, 64);
+                if (lane >= dd) inc += o;
+            }
+            u32 start = inc - s4;
+            u32 b0 = start + mine[0]; start += tot[0];
+            u32 b1 = start + mine[1]; start += tot[1];
+            u32 b2 = start + mine[2]; start += tot[2];
+            u32 b3 = start + mine[3];
+            *reinterpret_cast<uint2 *>(&wbase[wave][4 * lane]) = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
         }
-        __syncthreads();
+        // same-wave LDS accesses execute in order: wbase is complete for this wave's reads below
 #pragma unroll
         for (int j = 0; j < LS_ITEMS; j++) {
             const u32 li = wave_base + j * 64 + lane;
             if (j < rounds && li < m) {
                 const u32 d = rs_digit<V>(key[j], val[j], shift, mask, src);
-                const u32 pos = dstart[d] + wcnt[wave][d] + rank[j];
+                const u32 pos = wbase[wave][d] + rank[j];
                 skeys[pos] = key[j];
                 svals[pos] = val[j];
             }
         }
         __syncthreads();
+        // every wave has read all counter rows (before the barrier above): clear the own row for the next pass
+        *reinterpret_cast<uint2 *>(&wcnt[wave][4 * lane]) = make_uint2(0, 0);
         p++;
         if (p == p_end) {
             if (!fast) break;
-            // ---- verify the full order; repair small disorder by odd-even transposition
+            // ---- finish by comparison: the segment is now sorted on the bits >= lp.cmp_shift.  Inside every
+            // run of records that agree on those bits, a record's final slot is
+            //   run start + #(records of the run that are smaller) + #(equal records that precede it),
+            // found by walking the run in LDS.  Runs are short (a k-mer's copies plus the few k-mers that
+            // share its top digits), lanes of a wave sit in the same or neighbouring runs, and no further
+            // counting pass over the low digits (or the payload digits) is needed.  Runs longer than
+            // LS_RUNCAP would make this quadratic: such segments take the complete digit list instead.
             fast = false;
-            bool unsorted = true;
-            for (int it = 0; it <= LS_BUBBLE; it++) {
-                bool bad = false;
-                for (u32 i = tid; i + 1 < m; i += LS_BLOCK)
-                    bad |= ls_greater<V>(skeys[i], svals[i], skeys[i + 1], svals[i + 1], lp.pay_mode);
-                unsorted = __syncthreads_or(bad);
-                if (!unsorted || it == LS_BUBBLE) break;
-                for (int phase = 0; phase < 2; phase++) {
-                    for (u32 i = 2 * tid + phase; i + 1 < m; i += 2 * LS_BLOCK) {
-                        const u64 ka = skeys[i], kb = skeys[i + 1];
-                        const V va = svals[i], vb = svals[i + 1];
-                        if (ls_greater<V>(ka, va, kb, vb, lp.pay_mode)) {   // strict: equal records never swap
-                            skeys[i] = kb; skeys[i + 1] = ka;
-                            svals[i] = vb; svals[i + 1] = va;
-                        }
+            bool toolong = false;
+            u32 npos[LS_ITEMS];
+#pragma unroll
+            for (int j = 0; j < LS_ITEMS; j++) {
+                const u32 li = wave_base + j * 64 + lane;
+                npos[j] = li;
+                if (j < rounds && li < m) {
+                    const u64 x = skeys[li];
+                    const V xv = svals[li];
+                    const u64 px = x >> lp.cmp_shift;
+                    u32 less = 0, eq = 0, t = li, steps = 0;
+                    while (t > 0) {
+                        const u64 y = skeys[t - 1];
+                        if ((y >> lp.cmp_shift) != px) break;
+                        t--;
+                        const V yv = svals[t];
+                        if (ls_greater<V>(x, xv, y, yv, lp.pay_mode)) less++;
+                        else if (!ls_greater<V>(y, yv, x, xv, lp.pay_mode)) eq++;
+                        if (++steps > LS_RUNCAP) { toolong = true; break; }
                     }
-                    __syncthreads();
+                    const u32 run_start = t;
+                    t = li + 1;
+                    while (t < m) {
+                        const u64 y = skeys[t];
+                        if ((y >> lp.cmp_shift) != px) break;
+                        if (ls_greater<V>(x, xv, y, svals[t], lp.pay_mode)) less++;
+                        t++;
+                        if (++steps > LS_RUNCAP) { toolong = true; break; }
+                    }
+                    npos[j] = run_start + less + eq;
+                    key[j] = x;
+                    val[j] = xv;
                 }
             }
-            if (!unsorted) break;
+            const bool fallback = __syncthreads_or(toolong);   // also: every LDS read above is done
+            if (!fallback) {
+#pragma unroll
+                for (int j = 0; j < LS_ITEMS; j++) {
+                    const u32 li = wave_base + j * 64 + lane;
+                    if (j < rounds && li < m) { skeys[npos[j]] = key[j]; svals[npos[j]] = val[j]; }
+                }
+                __syncthreads();
+                break;
+            }
             p = 0;   // complete digit list, starting from the (stably permuted) current arrangement
         }
 #pragma unroll
@@ -484,11 +522,13 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
     if (h_max <= LS_MAX && rest.size() <= LS_MAX_PASSES) {
         LocalPasses lp;
         lp.n = (int)rest.size();
-        // The verify-after-3-digits fast path pays off when runs that agree on prefix + 3 digits are runs of
-        // identical k-mers (reference DBs: measured 0.32 -> 0.19 ms).  Deep read sets carry, next to every
-        // k-mer's ~9 copies, its sequencing-error variants that differ only in the low digits, so nearly every
-        // segment would fail verification (measured 2.9 -> 5.3 ms): read DBs always run the full digit list.
-        lp.fast_from = (sizeof(V) == 4 && lp.n > LS_TOP) ? lp.n - LS_TOP : 0;
+        // Reference DBs: counting passes on the top LS_TOP key digits only, the rest is finished by comparison
+        // in LDS (measured 0.32 -> 0.14 ms on config 2, and the taxon digits need no pass at all).
+        // Read DBs always run the full digit list: deep read sets hold ~9 copies of every k-mer plus its
+        // sequencing-error variants, so every run is ~10-20 records long and walking it is a chain of
+        // dependent LDS reads (measured 2.6 -> 5.9 ms).
+        lp.fast_from = (sizeof(V) == 4 && lp.n > LS_TOP && (lp.n - (int)payload_passes.size()) >= LS_TOP) ? lp.n - LS_TOP : 0;
+        lp.cmp_shift = lp.fast_from > 0 ? rest[lp.fast_from].shift : 0;
         lp.pay_mode = payload_passes.empty() ? 0 : (payload_passes[0].src == RS_SRC_VAL32 ? 1 : 2);
         for (int i = 0; i < lp.n; i++) { lp.shift[i] = rest[i].shift; lp.bits[i] = rest[i].bits; lp.src[i] = rest[i].src; }
         if (lp.n == 0) { *result_in_1 = in1; return KMG_OK; }
