@@ -519,7 +519,24 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
             }
         }
     }
-    if (h_max <= LS_MAX && rest.size() <= LS_MAX_PASSES) {
+    // Segments that do not fit one workgroup's LDS (skew: poly-A, low-complexity repeats pile into a few
+    // prefixes).  A handful of them are sorted one by one with global passes restricted to the segment's
+    // slice (its records already agree on the prefix, so only the remaining digits are needed); if there
+    // are many, or they hold most of the data, the whole array takes the plain LSD path below.
+    std::vector<std::pair<u32, u32>> big;   // (first record, size)
+    bool local_ok = rest.size() <= LS_MAX_PASSES;
+    if (local_ok && h_max > LS_MAX) {
+        std::vector<u32> h_seg((size_t)nseg + 1);
+        KMG_HIP(hipMemcpyAsync(h_seg.data(), seg, ((size_t)nseg + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        KMG_HIP(hipStreamSynchronize(ctx->stream));
+        u64 total_big = 0;
+        for (u32 sgi = 0; sgi < nseg; sgi++) {
+            const u32 sz = h_seg[sgi + 1] - h_seg[sgi];
+            if (sz > LS_MAX) { big.push_back({h_seg[sgi], sz}); total_big += sz; }
+        }
+        if (big.size() > 64 || total_big > (u64)n / 2) local_ok = false;
+    }
+    if (local_ok) {
         LocalPasses lp;
         lp.n = (int)rest.size();
         // Reference DBs: counting passes on the top LS_TOP key digits only, the rest is finished by comparison
@@ -532,9 +549,20 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
         lp.pay_mode = payload_passes.empty() ? 0 : (payload_passes[0].src == RS_SRC_VAL32 ? 1 : 2);
         for (int i = 0; i < lp.n; i++) { lp.shift[i] = rest[i].shift; lp.bits[i] = rest[i].bits; lp.src[i] = rest[i].src; }
         if (lp.n == 0) { *result_in_1 = in1; return KMG_OK; }
-        ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_LOCAL_V64 : KP_SORT_LOCAL_V32, (u64)n * (8 + sizeof(V)) * 2);
-        hipLaunchKernelGGL((ls_sort_kernel<V>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp);
-        KMG_HIP(hipGetLastError());
+        {
+            ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_LOCAL_V64 : KP_SORT_LOCAL_V32, (u64)n * (8 + sizeof(V)) * 2);
+            hipLaunchKernelGGL((ls_sort_kernel<V>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp);
+            KMG_HIP(hipGetLastError());
+        }
+        for (const auto &bs : big) {
+            bool slice_in_b = false;
+            KMG_TRY(radix_sort_records<V>(ctx, ka + bs.first, va + bs.first, kb + bs.first, vb + bs.first, bs.second, rest,
+                                          table, agg, &slice_in_b));
+            if (!slice_in_b) {   // even number of passes: the slice ended up in the source buffer
+                KMG_HIP(hipMemcpyAsync(kb + bs.first, ka + bs.first, (size_t)bs.second * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                KMG_HIP(hipMemcpyAsync(vb + bs.first, va + bs.first, (size_t)bs.second * sizeof(V), hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
         *result_in_1 = !in1;
         return KMG_OK;
     }

@@ -239,3 +239,41 @@ def test_cfg1_scale_properties(ctx):
     assert np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
     ref.close()
     rdb.close()
+
+
+# ---------------------------------------------------------------------------- skew (config 5 flavour)
+def _skewed_reads(rng, n_reads, read_len):
+    """Reads with homopolymer / dinucleotide tracts: a few key prefixes hold most of the k-mers."""
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    out = acgt[rng.integers(0, 4, size=(n_reads, read_len))]
+    for i in range(n_reads):
+        r = rng.random()
+        if r < 0.25:
+            out[i, :] = ord("A")                                   # poly-A: every window is the same k-mer
+        elif r < 0.40:
+            out[i, ::2], out[i, 1::2] = ord("A"), ord("C")         # (AC)n
+        elif r < 0.55:
+            s = int(rng.integers(0, read_len // 2))
+            out[i, s:s + read_len // 2] = ord("T")                 # poly-T tract inside a random read
+    return out
+
+
+@pytest.mark.parametrize("k,n_reads", [(21, 3000), (31, 20000)])
+def test_skewed_reads_match_oracle(ctx, k, n_reads):
+    """Oversize sort segments (some sorted slice by slice, or the whole-array LSD path) stay bit-exact."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(k)
+    reads = _skewed_reads(rng, n_reads, 120)
+    fq = synth.fastq_bytes(reads)
+    got, names = km.make_read_db(ctx, fq, k, 6)
+    want = OracleDB(fq, 1, k, 6, threads=8)
+    _same_db(got, want)
+    assert names == want.names
+    got.close()
+    # the same sequences as a reference (taxon payload, both strands)
+    fa = b"".join(b">%d\n%s\n" % (100 + i % 7, reads[i].tobytes()) for i in range(min(n_reads, 4000)))
+    ref = km.make_reference_db(ctx, fa, k, 6)
+    _same_db(ref, OracleDB(fa, 0, k, 6, threads=8))
+    ref.close()
