@@ -84,6 +84,13 @@ void *kmg_stream(kmg_ctx *ctx);
  *                   release with kmg_db_free.  n_windows (may be NULL) = valid forward windows.
  */
 int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind);
+/* kmg_build_set_filters: MakeDatabase -D <threshold> / -R <length> (MakeDatabase.java:279-291): the
+ *                   per-k-mer predicates Kmers/Dust.java:12-30 (keep iff sum c(c-1) over the triplet
+ *                   counts < threshold*k*2) and Kmers/RunOfSame.java:12-36 (drop iff a run of equal
+ *                   bases reaches length), applied to the forward k-mer before FileCreator.addKmers
+ *                   (its RC goes with it); reads are numbered before the filters.  -1 = off.  Call
+ *                   between kmg_build_begin and the first kmg_build_add. */
+int kmg_build_set_filters(kmg_ctx *ctx, int dust_threshold, int runofsame_length);
 int kmg_build_add(kmg_ctx *ctx, const uint8_t *bases, uint64_t nbases, const uint64_t *seq_off,
                   const int32_t *seq_id, const int64_t *seq_tok, uint64_t nseq,
                   int32_t *read_index_out);

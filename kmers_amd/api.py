@@ -149,7 +149,9 @@ class FileCreator:
     """KmerFiles/FileCreator.java.  data_kind: 'ref' = DataCollector.getCountInstance (taxon payload,
     the reference passes rc=True, MakeDatabase.java:130), 'read' = getReadInstance (rc=False, :167)."""
 
-    def __init__(self, ctx, key_length, max_kmer_length, data_kind, rc):
+    def __init__(self, ctx, key_length, max_kmer_length, data_kind, rc, dust=None, runofsame=None):
+        """dust / runofsame: the -D / -R stream filters of MakeDatabase.filterAndAdd (MakeDatabase.java:279-291),
+        fused into the extraction kernel."""
         self.ctx = ctx
         self.key_length = key_length
         self.max_k = max_kmer_length
@@ -158,6 +160,9 @@ class FileCreator:
         self.min_k = -1
         self.n_windows = 0
         ctx.check(ctx.lib.kmg_build_begin(ctx.h, max_kmer_length, key_length, 1 if rc else 0, self.kind))
+        if dust is not None or runofsame is not None:
+            ctx.check(ctx.lib.kmg_build_set_filters(ctx.h, -1 if dust is None else dust,
+                                                    -1 if runofsame is None else runofsame))
 
     def add_kmers(self, batch, min_length=None, max_length=None):
         """addKmers (FileCreator.java:65-110).  Returns, for read DBs, the read index of every sequence

@@ -43,6 +43,38 @@ __device__ __forceinline__ u64 revpairs64(u64 x) {
     return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
 }
 
+// Kmers/RunOfSame.java:12-36 on the packed k-mer: drop the k-mer iff some run of equal bases reaches
+// `length` (the reference only checks after an increment, so length < 2 never drops anything).
+__device__ __forceinline__ bool runofsame_keep(u64 key, int k, int length) {
+    const int R = length - 1;                          // consecutive equal neighbour pairs needed
+    if (R < 1 || R > k - 1) return true;
+    const u64 x = key ^ (key << 2);                    // group i (from the top): base_i ^ base_{i+1}
+    const u64 lowbits = 0x5555555555555555ull;
+    u64 eq = ~(x | (x >> 1)) & lowbits;                // 1 per group whose two bases are equal
+    eq &= (k - 1) >= 32 ? ~0ull : ~(~0ull >> (2 * (k - 1)));   // pairs 0 .. k-2 only
+    u64 t = eq;
+    int s = 1;
+    while (s * 2 <= R) { t &= t << (2 * s); s *= 2; }  // t[i] = eq[i .. i+s-1] all set
+    if (R > s) t &= t << (2 * (R - s));
+    return t == 0;
+}
+
+// Kmers/Dust.java:12-30 on the packed k-mer.  score = sum c(c-1) over the triplet counts = twice the
+// number of unordered pairs of equal triplets, so "score < threshold * k * 2" is "pairs < threshold * k".
+__device__ __forceinline__ bool dust_keep(u64 key, int k, int threshold) {
+    const int nt = k - 2;                              // triplets at positions 0 .. nt-1
+    int pairs = 0;
+    const u64 lowbits = 0x5555555555555555ull;
+    for (int d = 1; d < nt; d++) {
+        const u64 y = key ^ (key << (2 * d));          // group i: base_i ^ base_{i+d}
+        const u64 e = ~(y | (y >> 1)) & lowbits;       // base_i == base_{i+d}
+        u64 t3 = e & (e << 2) & (e << 4);              // ... and the next two bases as well
+        t3 &= ~(~0ull >> (2 * (nt - d)));              // i = 0 .. nt-1-d
+        pairs += __popcll(t3);
+    }
+    return pairs < threshold * k;
+}
+
 struct ExtractArgs {
     const uint8_t *bases;
     u64 nbases;
@@ -54,6 +86,8 @@ struct ExtractArgs {
     int k;
     int rc;
     int kind;
+    int dust;                    // MakeDatabase -D threshold, -1 = off
+    int runofsame;               // MakeDatabase -R length, -1 = off
     // count pass outputs
     u32 *tile_count;
     u32 *tile_fwd;               // valid forward windows per tile
@@ -168,6 +202,10 @@ __global__ __launch_bounds__(EX_BLOCK) void extract_kernel(ExtractArgs a) {
         bool ok = (bad >> (64 - k)) == 0;
         if (k > 1) ok = ok && (((st << 1) >> (65 - k)) == 0);
         ok = ok && (t0 + p + (u64)k <= a.nbases);
+        // reads are numbered by the extractor's mapper, i.e. before the -D / -R filters see the k-mer
+        if (!WRITE && ok && a.has_kmer) a.has_kmer[s_lo + seqrel[p]] = 1;
+        if (ok && a.runofsame >= 0) ok = runofsame_keep(key, k, a.runofsame);
+        if (ok && a.dust >= 0) ok = dust_keep(key, k, a.dust);
         fkey[j] = key;
         bool emit_rc = false;
         if (a.rc && ok) {
@@ -179,7 +217,6 @@ __global__ __launch_bounds__(EX_BLOCK) void extract_kernel(ExtractArgs a) {
         rmask |= (u32)emit_rc << j;
         u64 bal_v = __ballot(ok), bal_r = __ballot(emit_rc);
         if (lane == 0) wave_cnt[j][wave] = __popcll(bal_v) + __popcll(bal_r);
-        if (!WRITE && ok && a.has_kmer) a.has_kmer[s_lo + seqrel[p]] = 1;
     }
     __syncthreads();
 

@@ -91,6 +91,7 @@ extern "C" int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int pay
         return fail(ctx, KMG_EINVAL, "unknown payload kind");
     KMG_HIP(hipSetDevice(ctx->device));
     ctx->k = k; ctx->key_len = key_len; ctx->rc = rc ? 1 : 0; ctx->kind = payload_kind;
+    ctx->dust = -1; ctx->runofsame = -1;
     ctx->rec_upper = 0;
     u64 init[ST_WORDS];
     memset(init, 0, sizeof init);
@@ -99,6 +100,16 @@ extern "C" int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int pay
     KMG_HIP(hipMemcpyAsync(ctx->d_state, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     KMG_HIP(hipStreamSynchronize(ctx->stream));
     ctx->building = true;
+    return KMG_OK;
+}
+
+extern "C" int kmg_build_set_filters(kmg_ctx *ctx, int dust_threshold, int runofsame_length) {
+    if (!ctx) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!ctx->building) return fail(ctx, KMG_ESTATE, "kmg_build_set_filters before kmg_build_begin");
+    if (ctx->rec_upper) return fail(ctx, KMG_ESTATE, "filters must be set before the first kmg_build_add");
+    ctx->dust = dust_threshold < 0 ? -1 : dust_threshold;
+    ctx->runofsame = runofsame_length < 0 ? -1 : runofsame_length;
     return KMG_OK;
 }
 
@@ -155,6 +166,7 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     memset(&a, 0, sizeof a);
     a.bases = d_bases; a.nbases = nbases; a.seq_off = d_seq_off; a.nseq = nseq; a.seq_id = d_seq_id;
     a.tile_seq = tile_seq.as<u32>(); a.k = ctx->k; a.rc = ctx->rc; a.kind = ctx->kind;
+    a.dust = ctx->dust; a.runofsame = ctx->runofsame;
     a.tile_count = tile_count.as<u32>(); a.tile_fwd = tile_fwd.as<u32>(); a.tile_off = tile_off.as<u64>();
     a.out_keys = ctx->rec_keys; a.out_vals = ctx->rec_vals; a.state = ctx->d_state;
 

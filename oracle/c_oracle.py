@@ -21,6 +21,8 @@ def _load():
     lib.ko_build.restype = vp
     lib.ko_build.argtypes = [C.c_char_p, u64, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.ko_free.argtypes = [vp]
+    lib.ko_set_filters.argtypes = [C.c_int, C.c_int]
+    lib.ko_set_filters.restype = None
     for n in ("U", "V", "n_windows", "n_records", "n_reads"):
         f = getattr(lib, "ko_" + n)
         f.restype, f.argtypes = u64, [vp]
@@ -58,9 +60,14 @@ def _arr(ptr, n, dtype):
 class OracleDB:
     """Result of MakeDatabase (-a: mode 0, -q: mode 1) as CSR arrays."""
 
-    def __init__(self, data: bytes, mode: int, k: int, key_len: int, threads: int = 1):
+    def __init__(self, data: bytes, mode: int, k: int, key_len: int, threads: int = 1, dust: int = -1,
+                 runofsame: int = -1):
         L = lib()
-        self._h = L.ko_build(data, len(data), mode, k, key_len, threads)
+        L.ko_set_filters(dust, runofsame)          # MakeDatabase -D / -R
+        try:
+            self._h = L.ko_build(data, len(data), mode, k, key_len, threads)
+        finally:
+            L.ko_set_filters(-1, -1)
         if not self._h:
             raise ValueError("ko_build rejected the parameters")
         h = self._h

@@ -104,6 +104,35 @@ void ko_free(ko_db *d) {
     free(d->name_off); free(d->names); free(d);
 }
 
+/* Kmers/Dust.java:12-30: keep iff sum c(c-1) over the 64 triplet counts < threshold * k * 2 */
+static int dust_keep(uint64_t packed, int k, int threshold) {
+    int counts[64];
+    memset(counts, 0, sizeof counts);
+    for (int i = 0; i < k - 2; i++) {
+        int a = (packed >> (62 - 2 * i)) & 3, b = (packed >> (62 - 2 * (i + 1))) & 3, c = (packed >> (62 - 2 * (i + 2))) & 3;
+        counts[a * 16 + b * 4 + c]++;
+    }
+    int score = 0;
+    for (int i = 0; i < 64; i++) score += counts[i] * (counts[i] - 1);
+    return score < threshold * k * 2;
+}
+/* Kmers/RunOfSame.java:12-36: drop iff some run of equal bases reaches `length` (checked on increments only) */
+static int runofsame_keep(uint64_t packed, int k, int length) {
+    int c = (packed >> 62) & 3;
+    int l = 1;
+    for (int i = 1; i < k; i++) {
+        int b = (packed >> (62 - 2 * i)) & 3;
+        if (b == c) { l++; if (l == length) return 0; }
+        else { c = b; l = 1; }
+    }
+    return 1;
+}
+
+static int g_dust = -1, g_runofsame = -1;
+/* MakeDatabase -D / -R (MakeDatabase.java:279-291): filters applied to the forward k-mer stream of the
+ * NEXT ko_build call(s); -1 = off.  (Test infrastructure: a process-wide setting is good enough.) */
+void ko_set_filters(int dust_threshold, int runofsame_length) { g_dust = dust_threshold; g_runofsame = runofsame_length; }
+
 /* mode 0 = FASTA -> reference DB (MakeDatabase -a), 1 = FASTQ -> read DB (MakeDatabase -q). */
 ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, int threads) {
     if (k < 1 || k > 32 || key_len < 1 || key_len > k || key_len > 12) return NULL;
@@ -143,7 +172,8 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
 
     for (uint64_t ip = 0; ip <= n; ip++) {
         if (ip == n) {                            /* in.read() == -1 */
-            if (have_last) {                      /* last k-mer emitted a second time */
+            if (have_last && (g_dust < 0 || dust_keep(last.kmer, k, g_dust)) &&
+                (g_runofsame < 0 || runofsame_keep(last.kmer, k, g_runofsame))) { /* last k-mer emitted a second time */
                 rv_push(&recs, last); d->n_windows++;
                 if (d->rc && !is_palindrome(last.kmer, k)) {
                     ko_rec r = last; r.kmer = rc_packed(last.kmer, k); rv_push(&recs, r);
@@ -195,8 +225,11 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
             r.a = cur_read;
             r.b = (int16_t)(pos - k);             /* (short)(pos - maxK) */
         }
-        rv_push(&recs, r); d->n_windows++;
         last = r; have_last = 1;
+        /* kstream.filter(Dust).filter(RunOfSame) sits between the extractor and addKmers */
+        if (g_dust >= 0 && !dust_keep(packed, k, g_dust)) continue;
+        if (g_runofsame >= 0 && !runofsame_keep(packed, k, g_runofsame)) continue;
+        rv_push(&recs, r); d->n_windows++;
         if (d->rc && !is_palindrome(packed, k)) { /* FileCreator.java:83-87 */
             ko_rec q = r; q.kmer = rc_packed(packed, k); rv_push(&recs, q);
         }

@@ -590,21 +590,45 @@ def dust_test(kmer, threshold):  # Dust.java:12-30
     return score < threshold * len(ch) * 2
 
 
+def run_of_same_test(kmer, length):  # RunOfSame.java:12-36
+    ch = kmer.chars
+    c = ch[0]
+    l = 1
+    for i in range(1, len(ch)):
+        if ch[i] == c:
+            l += 1
+            if l == length:
+                return False
+        else:
+            c = ch[i]
+            l = 1
+    return True
+
+
+def filter_stream(kwds, dust=None, runofsame=None):
+    """MakeDatabase.filterAndAdd (MakeDatabase.java:279-291)."""
+    if dust is not None:
+        kwds = [kw for kw in kwds if dust_test(kw[0], dust)]
+    if runofsame is not None:
+        kwds = [kw for kw in kwds if run_of_same_test(kw[0], runofsame)]
+    return kwds
+
+
 # --------------------------------------------------------------------- convenience pipelines
-def build_ref_db(fasta_bytes, k, key_length, min_k=None, rc=True):
+def build_ref_db(fasta_bytes, k, key_length, min_k=None, rc=True, dust=None, runofsame=None):
     """MakeDatabase -a (MakeDatabase.java:127-163): FASTA -> reference DB blocks."""
     min_k = k if min_k is None else min_k
     fc = FileCreator(key_length, "ref", rc)
-    fc.add_kmers(kmers_from_file(fasta_bytes, fa_state_changer(), min_k, k, fa_to_refdb_mapper),
-                 min_k, k)
+    kw = kmers_from_file(fasta_bytes, fa_state_changer(), min_k, k, fa_to_refdb_mapper)
+    fc.add_kmers(filter_stream(kw, dust, runofsame), min_k, k)
     return fc.create()
 
 
-def build_read_db(fastq_bytes, k, key_length, min_k=None):
+def build_read_db(fastq_bytes, k, key_length, min_k=None, dust=None, runofsame=None):
     """MakeDatabase -q (MakeDatabase.java:165-185): FASTQ -> read DB blocks + read-name map."""
     min_k = k if min_k is None else min_k
     rm = ReadIDMapping()
     fc = FileCreator(key_length, "read", False)
-    fc.add_kmers(kmers_from_file(fastq_bytes, fq_state_changer(), min_k, k, make_fq_mapper(rm)),
-                 min_k, k)
+    kw = kmers_from_file(fastq_bytes, fq_state_changer(), min_k, k, make_fq_mapper(rm))
+    fc.add_kmers(filter_stream(kw, dust, runofsame), min_k, k)
     return fc.create(), rm.names

@@ -277,3 +277,26 @@ def test_skewed_reads_match_oracle(ctx, k, n_reads):
     ref = km.make_reference_db(ctx, fa, k, 6)
     _same_db(ref, OracleDB(fa, 0, k, 6, threads=8))
     ref.close()
+
+
+# ---------------------------------------------------------------------------- -D / -R filters
+@pytest.mark.parametrize("k,dust,run", [(9, 2, None), (9, None, 4), (12, 1, 3), (31, 14, 5), (31, None, 2), (5, 0, 1),
+                                        (32, 3, 32), (4, 1, None)])
+def test_dust_and_runofsame_filters_match_oracle(ctx, k, dust, run):
+    """MakeDatabase -D / -R fused into the extraction kernel (Dust.java:12-30, RunOfSame.java:12-36)."""
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(200 + k)
+    fa = _rand_fasta(rng, 30, 600, b"AAAACGT", (3, 4, 9))
+    fq = _rand_fastq(rng, 200, 200, b"AAACCGTN")
+    od, orr = (-1 if dust is None else dust), (-1 if run is None else run)
+    ref = km.make_reference_db(ctx, fa, k, 3, dust=dust, runofsame=run)
+    want = OracleDB(fa, 0, k, 3, dust=od, runofsame=orr)
+    _same_db(ref, want)
+    assert ref.n_windows == want.n_windows
+    rdb, names = km.make_read_db(ctx, fq, k, 3, dust=dust, runofsame=run)
+    wr = OracleDB(fq, 1, k, 3, dust=od, runofsame=orr)
+    _same_db(rdb, wr)
+    assert names == wr.names          # reads are numbered before the filters
+    ref.close()
+    rdb.close()

@@ -90,3 +90,20 @@ def test_multithreaded_build_is_identical():
     b = OracleDB(fa, 0, 21, 4, threads=4)
     assert np.array_equal(a.keys, b.keys) and np.array_equal(a.val_a, b.val_a)
     assert np.array_equal(a.val_b, b.val_b) and np.array_equal(a.val_off, b.val_off)
+
+
+@pytest.mark.parametrize("k,dust,run", [(9, 2, None), (9, None, 4), (12, 1, 3), (31, 14, 5)])
+def test_dust_and_runofsame_filters_agree(k, dust, run):
+    """MakeDatabase -D / -R (MakeDatabase.java:279-291, Dust.java, RunOfSame.java)."""
+    rng = np.random.default_rng(100 + k)
+    fa = _rand_fasta(rng, 12, 300, alphabet=b"AAAACGT")
+    fq = _rand_fastq(rng, 30, 120, alphabet=b"AAACCGT")
+    py = R.build_ref_db(fa, k, 3, dust=dust, runofsame=run)
+    c = OracleDB(fa, 0, k, 3, dust=-1 if dust is None else dust, runofsame=-1 if run is None else run)
+    assert c.encode_blocks()[0] == _py_blocks_concat(py, 3)
+    unfiltered = OracleDB(fa, 0, k, 3)
+    assert c.V < unfiltered.V                       # the filters did drop something
+    pyr, names = R.build_read_db(fq, k, 3, dust=dust, runofsame=run)
+    cr = OracleDB(fq, 1, k, 3, dust=-1 if dust is None else dust, runofsame=-1 if run is None else run)
+    assert cr.encode_blocks()[0] == _py_blocks_concat(pyr, 3)
+    assert cr.names == names                        # reads are numbered before the filter sees their k-mers
