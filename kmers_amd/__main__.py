@@ -1,0 +1,44 @@
+"""python -m kmers_amd <Database.MakeDatabase | Database.Matcher | Utils.TaxaCounts> <options>
+-- the reference's option letters for the hot path (README.md:9-12 `java -cp Kmers.jar <Class> <opts>`)."""
+import argparse
+import sys
+
+from . import Context, programs
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    if not argv:
+        print(__doc__)
+        return 1
+    prog, rest = argv[0].split(".")[-1], argv[1:]
+    ap = argparse.ArgumentParser(prog=prog, add_help=False)
+    if prog == "MakeDatabase":
+        for f in "ioKklzrDR":
+            ap.add_argument("-" + f)
+        for f in "aqZv":
+            ap.add_argument("-" + f, action="store_true")
+        a = ap.parse_args(rest)
+        ctx = Context(0)
+        programs.make_database(ctx, a.i, a.o, "a" if a.a else "q", int(a.K or 32), int(a.k or 24), int(a.l or 6),
+                               None if a.Z else int(a.z or 5), a.r, None if a.D is None else int(a.D),
+                               None if a.R is None else int(a.R))
+    elif prog == "Matcher":
+        for f in "idozZn":
+            ap.add_argument("-" + f)
+        a = ap.parse_args(rest)
+        if int(a.n or 0) != 0:
+            raise SystemExit("inexact search (-n > 0) stays on the Java path")
+        programs.matcher(Context(0), a.i, a.d, a.o, plain=a.Z is not None)
+    elif prog == "TaxaCounts":
+        for f in "do":
+            ap.add_argument("-" + f)
+        a = ap.parse_args(rest)
+        programs.taxa_counts(Context(0), a.d, a.o)
+    else:
+        raise SystemExit("unknown program %s" % argv[0])
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

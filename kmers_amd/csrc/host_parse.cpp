@@ -150,4 +150,81 @@ const uint64_t *kmh_name_off(const kmh_batch *h) { return ((const Batch *)h)->na
 const char *kmh_names(const kmh_batch *h) { return ((const Batch *)h)->names.data(); }
 int kmh_eof_in_kmer(const kmh_batch *h) { return ((const Batch *)h)->eof_in_kmer; }
 
+
+// ---- KmerFile decode (KmerFiles/KmerFile.java:200-250, CompressedKmerSpliterator.tryAdvance) ----------
+// `data` = the bytes of every key block in ascending key order, back to back (each block's first record
+// has copy == 0, so the prefix state needs no reset between blocks).  kind 0: CountDataType values
+// ([short n][n x (int taxon, byte count)], Counts/CountDataType.java:83-95); kind 1: SetCompressor<ReadPos>
+// ([int n][n x (int read, short pos)], jar + Reads/ReadPosDataType.java:41-44).  k-mers longer than 32
+// bases cannot be represented on the GPU path: returns NULL.
+struct Decoded {
+    std::vector<uint64_t> keys, val_off;
+    std::vector<int32_t> val_a, val_b;
+};
+
+kmh_batch *kmh_decode_blocks(const uint8_t *data, uint64_t n, int kind) {
+    Decoded *d = new Decoded();
+    d->val_off.push_back(0);
+    uint8_t prev[10] = {0}, kb[10];
+    uint64_t off = 0;
+    auto fail = [&]() -> kmh_batch * { delete d; return nullptr; };
+    while (off < n) {
+        int copy = (int8_t)data[off++];
+        int len;
+        if (copy == 0) { if (off >= n) return fail(); len = (int8_t)data[off++]; }
+        else len = (int8_t)prev[0];
+        if (len < 1 || len > 32 || copy < 0) return fail();
+        const int l = (len - 1) / 4 + 1;
+        if (copy > l + 1) return fail();
+        if (copy > 0) {
+            memcpy(kb, prev, (size_t)copy);
+            const int need = l - copy + 1;
+            if (off + need > n) return fail();
+            memcpy(kb + copy, data + off, (size_t)need);
+            off += need;
+        } else {
+            kb[0] = (uint8_t)len;
+            if (off + l > n) return fail();
+            memcpy(kb + 1, data + off, (size_t)l);
+            off += l;
+        }
+        memcpy(prev, kb, (size_t)l + 1);
+        uint64_t key = 0;
+        for (int i = 0; i < l; i++) key |= (uint64_t)kb[1 + i] << (56 - 8 * i);
+        d->keys.push_back(key);
+        if (kind == 0) {
+            if (off + 2 > n) return fail();
+            const int cnt = (int16_t)((data[off] << 8) | data[off + 1]);
+            off += 2;
+            if (cnt < 0 || off + 5ull * cnt > n) return fail();
+            for (int i = 0; i < cnt; i++) {
+                const uint8_t *p = data + off;
+                d->val_a.push_back((int32_t)(((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]));
+                d->val_b.push_back((int32_t)p[4]);       // stored byte, 0..255 (CountDataType.java:57-62)
+                off += 5;
+            }
+        } else {
+            if (off + 4 > n) return fail();
+            const int64_t cnt = (int32_t)(((uint32_t)data[off] << 24) | (data[off + 1] << 16) | (data[off + 2] << 8) | data[off + 3]);
+            off += 4;
+            if (cnt < 0 || off + 6ull * cnt > n) return fail();
+            for (int64_t i = 0; i < cnt; i++) {
+                const uint8_t *p = data + off;
+                d->val_a.push_back((int32_t)(((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]));
+                d->val_b.push_back((int32_t)(int16_t)((p[4] << 8) | p[5]));
+                off += 6;
+            }
+        }
+        d->val_off.push_back(d->val_a.size());
+    }
+    return (kmh_batch *)d;
+}
+void kmh_decoded_free(kmh_batch *h) { delete (Decoded *)h; }
+uint64_t kmh_decoded_nkeys(const kmh_batch *h) { return ((const Decoded *)h)->keys.size(); }
+uint64_t kmh_decoded_nvals(const kmh_batch *h) { return ((const Decoded *)h)->val_a.size(); }
+const uint64_t *kmh_decoded_keys(const kmh_batch *h) { return ((const Decoded *)h)->keys.data(); }
+const uint64_t *kmh_decoded_val_off(const kmh_batch *h) { return ((const Decoded *)h)->val_off.data(); }
+const int32_t *kmh_decoded_val_a(const kmh_batch *h) { return ((const Decoded *)h)->val_a.data(); }
+const int32_t *kmh_decoded_val_b(const kmh_batch *h) { return ((const Decoded *)h)->val_b.data(); }
+
 }  // extern "C"

@@ -34,6 +34,16 @@ def _load():
             f.restype, f.argtypes = vp, [vp]
         lib.kmh_eof_in_kmer.restype = C.c_int
         lib.kmh_eof_in_kmer.argtypes = [vp]
+        lib.kmh_decode_blocks.restype = vp
+        lib.kmh_decode_blocks.argtypes = [C.c_char_p, u64, C.c_int]
+        lib.kmh_decoded_free.argtypes = [vp]
+        lib.kmh_decoded_free.restype = None
+        for n in ("nkeys", "nvals"):
+            f = getattr(lib, "kmh_decoded_" + n)
+            f.restype, f.argtypes = u64, [vp]
+        for n in ("keys", "val_off", "val_a", "val_b"):
+            f = getattr(lib, "kmh_decoded_" + n)
+            f.restype, f.argtypes = vp, [vp]
         _lib = lib
     return _lib
 
@@ -78,3 +88,18 @@ def parse(data: bytes, mode: int, k: int) -> ParsedFile:
         return ParsedFile(SequenceBatch(bases, off, seq_tok=tok), names, None, lib.kmh_eof_in_kmer(h))
     finally:
         lib.kmh_free(h)
+
+
+def decode_blocks(data: bytes, kind: int):
+    """KmerFile's prefix-delta decode (KmerFile.java:200-250) of all key blocks back to back
+    -> (keys u64, val_off u64, val_a i32, val_b i32).  kind 0 = reference (counts), 1 = reads."""
+    lib = _load()
+    h = lib.kmh_decode_blocks(data, len(data), kind)
+    if not h:
+        raise ValueError("malformed k-mer blocks, or k-mers longer than 32 bases (not supported on the GPU path)")
+    try:
+        nk, nv = lib.kmh_decoded_nkeys(h), lib.kmh_decoded_nvals(h)
+        return (_arr(lib.kmh_decoded_keys(h), nk, np.uint64), _arr(lib.kmh_decoded_val_off(h), nk + 1, np.uint64),
+                _arr(lib.kmh_decoded_val_a(h), nv, np.int32), _arr(lib.kmh_decoded_val_b(h), nv, np.int32))
+    finally:
+        lib.kmh_decoded_free(h)

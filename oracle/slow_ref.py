@@ -580,6 +580,75 @@ def taxa_counts(db):
     return ["%d\t%d\t%d" % (t, match[t], unique.get(t, 0)) for t in sorted(match)]
 
 
+# ------------------------------------------------ jar IndexedFiles.* 
+def _gz_member(data, level):
+    """jar GzipCompressorOutputStream + GzipParameters (A.2): mtime 0, XFL 2/4/0, OS 255, raw deflate."""
+    import zlib
+    xfl = 2 if level == 9 else (4 if level == 1 else 0)
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = co.compress(data) + co.flush()
+    return bytes([0x1F, 0x8B, 8, 0, 0, 0, 0, 0, xfl, 0xFF]) + body + \
+        struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+
+
+def write_indexed_file(path, blocks, zip_level=5):
+    """jar IndexedOutputFile (A.1): `blocks` = {key: bytes} as FileCreator.create writes them (key -1 first,
+    then 0 .. 4^l-1, one block each).  zip_level None = unzipped (41-byte header), else zipped (64-byte)."""
+    z = zip_level is not None
+    body = bytearray(b"\0" * (64 if z else 41))
+    index = []
+    for key in [-1] + [k for k in sorted(blocks) if k >= 0]:
+        blob = _gz_member(blocks[key], zip_level) if z else blocks[key]
+        index.append((key, len(body), len(blob)))
+        body += blob
+    idx = struct.pack(">i", len(index))
+    for key, pos, ln in sorted(index):                       # TreeMap order: -1 first
+        idx += struct.pack(">ii", key, 1) + struct.pack(">qq", pos, ln)
+    iblob = _gz_member(idx, zip_level) if z else idx
+    ipos = len(body)
+    body += iblob
+    footer = ("%-19d\n%-19d\n%s\n%1d\n" % (ipos, len(iblob), "1", 0)).encode()
+    fblob = _gz_member(footer, 0) if z else footer
+    fpos = len(body)
+    body += fblob
+    header = ("%-19d %-19d%s" % (fpos, len(fblob), " \n")).encode()
+    hblob = _gz_member(header, 0) if z else header
+    body[0:len(hblob)] = hblob
+    with open(path, "wb") as f:
+        f.write(bytes(body))
+
+
+def read_indexed_file(path):
+    """jar IndexedInputFile.<init> + getInputStream(key) (A.1) -> {key: bytes}."""
+    import zlib
+    data = open(path, "rb").read()
+    z = data[:2] == b"\x1f\x8b"
+
+    def blk(pos, ln):
+        raw = data[pos:pos + ln]
+        if not z:
+            return raw
+        d = zlib.decompressobj(31)
+        return d.decompress(raw) + d.flush()
+    import re
+    fpos, flen = [int(x) for x in re.split(" +", blk(0, 100)[:41].decode().strip())[:2]]
+    lines = blk(fpos, flen).decode().split("\n")
+    raw = blk(int(lines[0].strip()), int(lines[1].strip()))
+    assert lines[3].strip() == "0", "hr files not handled by the oracle"
+    (n,) = struct.unpack_from(">i", raw, 0)
+    off, out = 4, {}
+    for _ in range(n):
+        key, nb = struct.unpack_from(">ii", raw, off)
+        off += 8
+        parts = []
+        for _ in range(nb):
+            pos, ln = struct.unpack_from(">qq", raw, off)
+            off += 16
+            parts.append(blk(pos, ln))
+        out[key] = b"".join(parts)
+    return out
+
+
 # ----------------------------------------------------------------- Kmers/Dust.java, RunOfSame
 def dust_test(kmer, threshold):  # Dust.java:12-30
     counts = [0] * 64

@@ -1,0 +1,68 @@
+"""End to end through files, the way the reference's programs are used (README.md:14-30):
+MakeDatabase -a / -q  ->  DB files  ->  Matcher  ->  match file;  TaxaCounts -> counts file.
+Unzipped database files are compared byte for byte with files the oracle writes (tier T2); zipped ones by
+payload (tier T1: gzip bytes depend on the zlib build).  Parity vs Kmers.jar itself is UNPINNED."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_blocks(odb):
+    from oracle import slow_ref as R  # noqa: F401
+    blob, off = odb.encode_blocks()
+    ids = [2048] if odb.kind == 0 else [257, 2052]
+    meta = bytes([odb.k, odb.k, odb.key_len]) + len(ids).to_bytes(4, "big") + b"".join(i.to_bytes(4, "big") for i in ids) + \
+        bytes([1 if odb.kind == 0 else 0])
+    blocks = {-1: meta}
+    for key in range(4 ** odb.key_len):
+        blocks[key] = blob[int(off[key]):int(off[key + 1])]
+    return blocks
+
+
+def test_programs_end_to_end(tmp_path):
+    import kmers_amd as km
+    from kmers_amd import programs, synth
+    from kmers_amd.__main__ import main as cli
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(71, 5, 8000, first_taxon=300, shared_frac=0.25)
+    reads = synth.random_reads(72, genomes, 1500, 120, 0.01, n_rate=0.002)
+    fa, fq = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fq.gz")
+    open(fa, "wb").write(synth.fasta_bytes(taxa, genomes))
+    open(fq, "wb").write(gzip.compress(synth.fastq_bytes(reads)))          # inputs may be gzipped (ZipOrNot)
+    k, l = 25, 5
+    o_ref = OracleDB(synth.fasta_bytes(taxa, genomes), 0, k, l)
+    o_reads = OracleDB(synth.fastq_bytes(reads), 1, k, l)
+
+    ctx = km.Context(0)
+    refdb, readdb = str(tmp_path / "ref.db"), str(tmp_path / "reads.db")
+    programs.make_database(ctx, fa, refdb, "a", k, k, l, zip_level=None)                       # -Z
+    programs.make_database(ctx, fq, readdb, "q", k, k, l, zip_level=5, read_map_path=str(tmp_path / "map.gz"))
+    want_ref, want_reads = str(tmp_path / "ref.oracle.db"), str(tmp_path / "reads.oracle.db")
+    R.write_indexed_file(want_ref, _oracle_blocks(o_ref), None)
+    R.write_indexed_file(want_reads, _oracle_blocks(o_reads), 5)
+    assert open(refdb, "rb").read() == open(want_ref, "rb").read()           # T2: unzipped file, byte for byte
+    assert R.read_indexed_file(readdb) == R.read_indexed_file(want_reads)    # T1: every block's payload
+    assert gzip.open(str(tmp_path / "map.gz"), "rt").read().splitlines() == o_reads.names
+
+    lines = programs.matcher(ctx, readdb, refdb, str(tmp_path / "matches.gz"))
+    hit, _ = o_reads.match(o_ref)
+    assert gzip.open(str(tmp_path / "matches.gz"), "rb").read() == o_reads.match_lines(o_ref, hit)
+    assert len(lines) > 1000
+    counts = programs.taxa_counts(ctx, refdb, str(tmp_path / "counts.tsv"))
+    t, m, q = o_ref.taxacounts()
+    assert open(str(tmp_path / "counts.tsv")).read().splitlines() == ["%d\t%d\t%d" % x for x in zip(t, m, q)] == counts
+    ctx.close()
+
+    # the same through the reference's command lines
+    assert cli(["Database.MakeDatabase", "-a", "-i", fa, "-o", str(tmp_path / "cli.db"), "-K", str(k), "-k", str(k),
+                "-l", str(l), "-Z"]) == 0
+    assert open(str(tmp_path / "cli.db"), "rb").read() == open(want_ref, "rb").read()
+    assert cli(["Utils.TaxaCounts", "-d", str(tmp_path / "cli.db"), "-o", str(tmp_path / "cli.tsv")]) == 0
+    assert open(str(tmp_path / "cli.tsv")).read() == open(str(tmp_path / "counts.tsv")).read()
+    assert cli(["Database.Matcher", "-i", readdb, "-d", str(tmp_path / "cli.db"), "-o", str(tmp_path / "cli.txt"), "-Z", "x"]) == 0
+    assert open(str(tmp_path / "cli.txt"), "rb").read() == o_reads.match_lines(o_ref, hit)
