@@ -151,6 +151,11 @@ struct kmg_ctx {
     void *rec_vals = nullptr;    // u32 taxon | u64 (read << 16 | pos16)
     u64 rec_cap = 0;             // capacity in records
     u64 rec_upper = 0;           // host-known upper bound of records added so far
+    // first batch of a build: records are written already partitioned by the first prefix digit
+    // (extract_part.h); a second batch voids that and finish() runs every pass
+    int n_adds = 0;
+    bool prepart = false;
+    int plan_pbits = 0;          // prefix bits the partition digit was planned for
     u64 *d_state = nullptr;      // ST_WORDS device words
     std::vector<void *> staged;  // device copies of host batches, released at finish
 

@@ -4,6 +4,7 @@
 #include "common.h"
 #include "scan.h"
 #include "extract.h"
+#include "extract_part.h"
 #include "radix.h"
 #include "reduce.h"
 #include "match.h"
@@ -93,6 +94,7 @@ extern "C" int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int pay
     ctx->k = k; ctx->key_len = key_len; ctx->rc = rc ? 1 : 0; ctx->kind = payload_kind;
     ctx->dust = -1; ctx->runofsame = -1;
     ctx->rec_upper = 0;
+    ctx->n_adds = 0; ctx->prepart = false; ctx->plan_pbits = 0;
     u64 init[ST_WORDS];
     memset(init, 0, sizeof init);
     init[ST_ID_AND] = 0xFFFFFFFFull;
@@ -184,9 +186,34 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         else { KMG_ALLOC(read_index, nseq * 4); ridx = read_index.as<int32_t>(); }
         a.read_index = ridx;
     }
+    // First batch: plan the sort's prefix bits from the record upper bound and let the extractor write the
+    // records partitioned by the first prefix digit.  Later batches append in window order (and void it).
+    const int plan = ctx->n_adds == 0 ? choose_pbits(upper, 2 * ctx->k) : 0;
+    const bool part = plan > 0 && nbases < 0xFFFFFFF0ull / 2;
+    ctx->prepart = part;
+    ctx->plan_pbits = plan;
+    ctx->n_adds++;
+    PartArgs pa;
+    PoolBuf table(ctx), tagg(ctx);
+    if (part) {
+        const SortPass d0 = prefix_digits(plan)[0];
+        pa.dshift = d0.shift; pa.dmask = (1u << d0.bits) - 1u;
+        pa.ntiles = ntiles; pa.ncols = ntiles * (ctx->rc ? 2 : 1);
+        KMG_ALLOC(table, (size_t)RS_DIGITS * pa.ncols * 4);
+        KMG_ALLOC(tagg, (size_t)(div_up_u64((u64)RS_DIGITS * pa.ncols, SCAN_TILE) + 1) * 8);
+        pa.table = table.as<u32>();
+        // forward and RC records of a tile are written as two runs: (read, pos) order inside a k-mer is
+        // restored by the payload passes
+        if (reads && ctx->rc) KMG_HIP(hipMemsetAsync((char *)(ctx->d_state + ST_DUP_READS), 1, 1, ctx->stream));
+    }
+    const dim3 pgrid(((ntiles + 7) / 8) * 8);
     {
         ProfScope ps(ctx, KP_EXTRACT_COUNT, nbases);
-        hipLaunchKernelGGL((extract_kernel<false>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
+        if (part) {
+            pa.e = a;
+            if (reads) hipLaunchKernelGGL((extract_part_kernel<false, u64>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+            else hipLaunchKernelGGL((extract_part_kernel<false, u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+        } else hipLaunchKernelGGL((extract_kernel<false>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
         hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_fwd.as<u32>(),
                            ntiles, ctx->d_state + ST_NWIN);
     }
@@ -211,12 +238,19 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         hipLaunchKernelGGL(id_bits_kernel, dim3(std::min<u32>(div_up_u64(nseq, 256), 1024)), dim3(256), 0, ctx->stream,
                            d_seq_id, nseq, ctx->d_state);
     }
-    KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, tile_count.as<u32>(), tile_off.as<u64>(), ntiles, OpSum(), 0ull,
-                                                agg.as<u64>(), nullptr, true, KP_SCAN)));
-    {
-        const u64 rec_b = 8 + val_bytes(ctx->kind);
+    if (part) {
+        KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, table.as<u32>(), table.as<u32>(), (u64)RS_DIGITS * pa.ncols, OpSum(),
+                                                    0u, tagg.as<u32>(), nullptr, false, KP_SCAN)));
         ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases /* + records * rec_b, added at finish when N is known */);
-        (void)rec_b;
+        pa.e = a;
+        if (reads) hipLaunchKernelGGL((extract_part_kernel<true, u64>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+        else hipLaunchKernelGGL((extract_part_kernel<true, u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+        hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_count.as<u32>(),
+                           ntiles, ctx->d_state + ST_NREC);
+    } else {
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, tile_count.as<u32>(), tile_off.as<u64>(), ntiles, OpSum(), 0ull,
+                                                    agg.as<u64>(), nullptr, true, KP_SCAN)));
+        ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases /* + records * rec_b, added at finish when N is known */);
         hipLaunchKernelGGL((extract_kernel<true>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
         hipLaunchKernelGGL(extract_advance_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, tile_off.as<u64>(), ntiles);
     }
@@ -446,8 +480,9 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
         for (int shift = 0; shift < bits; shift += RS_BITS) payload.push_back({shift, std::min(RS_BITS, bits - shift), RS_SRC_VAL64});
     }
     // prefix bits for the global passes: segments of ~1-2 K records on uniform data
-    int pbits = 0;
-    while (pbits < 2 * ctx->k && pbits < 24 && ((u64)n >> pbits) > 2048) pbits++;
+    // (a single-batch build keeps the bits its extractor already partitioned the records by)
+    const bool prepart = ctx->prepart && ctx->n_adds == 1;
+    const int pbits = prepart ? ctx->plan_pbits : choose_pbits(n, 2 * ctx->k);
 
     PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx), seg(ctx);
     const size_t vb = val_bytes(ctx->kind);
@@ -463,8 +498,8 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
         KMG_ALLOC(agg, (size_t)(div_up_u64((u64)RS_DIGITS * ntiles, SCAN_TILE) + 1) * 8);
         KMG_ALLOC(seg, (((size_t)1 << pbits) + 4) * 4);
         const int low_bit = 64 - 2 * ctx->k;
-        if (reads) r = hybrid_sort_records<u64>(ctx, ctx->rec_keys, (u64 *)ctx->rec_vals, k1.as<u64>(), v1.as<u64>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, &in1);
-        else r = hybrid_sort_records<u32>(ctx, ctx->rec_keys, (u32 *)ctx->rec_vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, &in1);
+        if (reads) r = hybrid_sort_records<u64>(ctx, ctx->rec_keys, (u64 *)ctx->rec_vals, k1.as<u64>(), v1.as<u64>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1);
+        else r = hybrid_sort_records<u32>(ctx, ctx->rec_keys, (u32 *)ctx->rec_vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1);
     }
     if (r == KMG_OK) {
         const u64 *sk = in1 ? k1.as<u64>() : ctx->rec_keys;
@@ -675,7 +710,8 @@ extern "C" int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, in
     const u32 ntiles = div_up_u64(n, RS_TILE);
     KMG_ALLOC(k0, (size_t)n * 8); KMG_ALLOC(v0, (size_t)n * 4); KMG_ALLOC(k1, (size_t)n * 8); KMG_ALLOC(v1, (size_t)n * 4);
     KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
-    KMG_ALLOC(agg, (size_t)(div_up_u64((u64)RS_DIGITS * ntiles, SCAN_TILE) + 1) * 8);
+    // scan scratch: shared by the sort's table scans and the head-flag scan over all n values
+    KMG_ALLOC(agg, (size_t)(div_up_u64(std::max<u64>((u64)RS_DIGITS * ntiles, n), SCAN_TILE) + 1) * 8);
     KMG_ALLOC(flag, (size_t)n * 4);
     KMG_ALLOC(total, 64);
     hipLaunchKernelGGL(taxa_expand_kernel, dim3(div_up_u64(n, 256)), dim3(256), 0, ctx->stream, db->val_a, V, k0.as<u64>(), v0.as<u32>());

@@ -191,6 +191,30 @@ struct SortPass {
     int src;
 };
 
+// number of prefix bits sorted by global passes for n records of `kbits` key bits: segments of ~1-2 K
+// records, and one pass fewer when that still keeps the average segment under ~2.3 K.
+static inline int choose_pbits(u64 n, int kbits) {
+    int p = 0;
+    while (p < kbits && p < 24 && (n >> p) > 2048) p++;
+    if (p > 1 && (p % RS_BITS) == 1 && (n >> (p - 1)) <= 2300) p--;
+    return p;
+}
+
+// the global passes' digits, lowest first
+static inline std::vector<SortPass> prefix_digits(int pbits) {
+    std::vector<SortPass> prefix;
+    if (pbits > 0) {
+        const int np = (pbits + RS_BITS - 1) / RS_BITS;
+        int shift = 64 - pbits;
+        for (int i = 0; i < np; i++) {
+            int bits = pbits / np + (i < pbits % np ? 1 : 0);
+            prefix.push_back({shift, bits, RS_SRC_KEY});
+            shift += bits;
+        }
+    }
+    return prefix;
+}
+
 // Sorts n records.  Buffers ping-pong between (k0,v0) and (k1,v1); *result_in_1 tells where the
 // sorted records ended up.  `table` must hold RS_DIGITS * ntiles u32 and `agg` the scan scratch.
 template <typename V>
@@ -473,22 +497,15 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
 template <typename V>
 static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 n, int low_bit,
                                const std::vector<SortPass> &payload_passes, u32 *table, u32 *agg, u32 *seg,
-                               int pbits, bool *result_in_1) {
+                               int pbits, bool skip_first, bool *result_in_1) {
     *result_in_1 = false;
     if (n == 0) return KMG_OK;
     // global LSD passes over the top pbits of the key
-    std::vector<SortPass> prefix;
-    if (pbits > 0) {
-        const int np = (pbits + RS_BITS - 1) / RS_BITS;
-        int shift = 64 - pbits;
-        for (int i = 0; i < np; i++) {
-            int bits = pbits / np + (i < pbits % np ? 1 : 0);
-            prefix.push_back({shift, bits, RS_SRC_KEY});
-            shift += bits;
-        }
-    }
+    const std::vector<SortPass> prefix = prefix_digits(pbits);
+    // `skip_first`: the records already arrive partitioned by the first prefix digit (extract_part.h)
+    std::vector<SortPass> todo(prefix.begin() + (skip_first && !prefix.empty() ? 1 : 0), prefix.end());
     bool in1 = false;
-    KMG_TRY(radix_sort_records<V>(ctx, k0, v0, k1, v1, n, prefix, table, agg, &in1));
+    KMG_TRY(radix_sort_records<V>(ctx, k0, v0, k1, v1, n, todo, table, agg, &in1));
     u64 *ka = in1 ? k1 : k0, *kb = in1 ? k0 : k1;
     V *va = in1 ? v1 : v0, *vb = in1 ? v0 : v1;
 
