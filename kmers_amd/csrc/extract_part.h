@@ -9,7 +9,7 @@
 //                staged through LDS in digit order, runs stored contiguously at the scanned offsets.
 // Forward and RC records of a tile form two table columns (2t, 2t+1), so a sub-pass never stages more than
 // EX_TILE records; both are emitted in window order, which keeps the partition stable.
-// Same window logic as extract_kernel (extract.h), 512 threads: a wave owns 512 consecutive positions.
+// Same window logic as extract_kernel (extract.h); a wave owns 64 * windows-per-thread consecutive positions.
 #pragma once
 #include "common.h"
 #include "extract.h"
@@ -28,19 +28,32 @@ struct PartArgs {
     u32 ntiles;
 };
 
+// the k-mer starting at tile position p, from the packed LDS image (3 words that the whole wave shares)
+__device__ __forceinline__ u64 ep_window(const u32 *pk, u32 p, u64 kmask) {
+    const u32 w = p >> 4, r = p & 15;
+    const u64 hi = ((u64)pk[w] << 32) | pk[w + 1];
+    return ((hi << (2 * r)) | ((u64)pk[w + 2] >> (32 - 2 * r))) & kmask;
+}
+
+// Register budget: the write pass keeps only validity masks and ranks per window and re-reads the k-mer
+// from the LDS image where it needs it (broadcast reads), which fits 3 workgroups per CU (<= 80 VGPRs,
+// ~52 KB of LDS).
 template <bool WRITE, typename V>
-__global__ __launch_bounds__(EP_BLOCK, 4) void extract_part_kernel(PartArgs pa) {
+__global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(PartArgs pa) {
     const ExtractArgs &a = pa.e;
     __shared__ u32 pk[EX_TILE / 16 + 4];
     __shared__ u32 inv[EX_TILE / 32 + 2];
     __shared__ u32 stb[EX_TILE / 32 + 2];
-    __shared__ u32 seqrel[EX_TILE + EX_EXT];
-    __shared__ u32 wcnt[EP_WAVES][RS_DIGITS];          // count pass: rows 0/1 = forward / RC histograms
+    __shared__ uint16_t seqrel[EX_TILE + EX_EXT];      // #sequences (beyond the tile's first) starting at or before p
+    __shared__ u32 cnt32[WRITE ? 1 : EX_TILE + EX_EXT]; // sequence starts per position (write pass: inside `stage`)
+    __shared__ u32 hist[WRITE ? 1 : 2][RS_DIGITS];     // count pass: forward / RC digit histograms
+    __shared__ uint16_t wcnt[WRITE ? EP_WAVES : 1][RS_DIGITS];
     __shared__ u32 dstart[RS_DIGITS];
     __shared__ u32 gdelta[RS_DIGITS];
     __shared__ u64 stage[WRITE ? EX_TILE : 1];
     __shared__ uint8_t sdig[WRITE ? EX_TILE : 1];
     __shared__ u32 scan_smem[EP_WAVES];
+    u32 *starts = WRITE ? reinterpret_cast<u32 *>(stage) : cnt32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order (see rs_scatter_kernel): neighbouring tiles' runs are adjacent in the output
@@ -83,10 +96,15 @@ __global__ __launch_bounds__(EP_BLOCK, 4) void extract_part_kernel(PartArgs pa) 
         pk[chunk] = word;
         reinterpret_cast<uint16_t *>(inv)[chunk ^ 1] = (uint16_t)bad;
     }
-    for (int i = tid; i < EX_TILE + EX_EXT; i += EP_BLOCK) seqrel[i] = 0;
+    for (int i = tid; i < EX_TILE + EX_EXT; i += EP_BLOCK) starts[i] = 0;
     if (tid < RS_DIGITS) {
+        if (WRITE) {
 #pragma unroll
-        for (int w = 0; w < EP_WAVES; w++) wcnt[w][tid] = 0;
+            for (int w = 0; w < EP_WAVES; w++) wcnt[w][tid] = 0;
+        } else {
+            hist[0][tid] = 0;
+            hist[1][tid] = 0;
+        }
     }
     __syncthreads();
 
@@ -95,7 +113,7 @@ __global__ __launch_bounds__(EP_BLOCK, 4) void extract_part_kernel(PartArgs pa) 
     for (u64 s = (u64)s_lo + 1 + tid; s <= a.nseq; s += EP_BLOCK) {
         u64 o = a.seq_off[s];
         if (o >= t0 + EX_TILE + EX_EXT) break;
-        atomicAdd(&seqrel[(u32)(o - t0)], 1u);
+        atomicAdd(&starts[(u32)(o - t0)], 1u);
     }
     __syncthreads();
     {
@@ -104,7 +122,7 @@ __global__ __launch_bounds__(EP_BLOCK, 4) void extract_part_kernel(PartArgs pa) 
         u32 sum = 0, bits = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            c[i] = seqrel[tid * 8 + i];
+            c[i] = starts[tid * 8 + i];
             bits = (bits << 1) | (c[i] != 0);
             sum += c[i];
         }
@@ -112,7 +130,7 @@ __global__ __launch_bounds__(EP_BLOCK, 4) void extract_part_kernel(PartArgs pa) 
         if (tid < EX_EXT / 8) {
             u32 eb = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) eb = (eb << 1) | (seqrel[EX_TILE + tid * 8 + i] != 0);
+            for (int i = 0; i < 8; i++) eb = (eb << 1) | (starts[EX_TILE + tid * 8 + i] != 0);
             const int bn = EX_TILE / 8 + tid;
             reinterpret_cast<uint8_t *>(stb)[(bn & ~3) + (3 - (bn & 3))] = (uint8_t)eb;
         }
@@ -122,7 +140,7 @@ __global__ __launch_bounds__(EP_BLOCK, 4) void extract_part_kernel(PartArgs pa) 
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             run += c[i];
-            seqrel[tid * 8 + i] = run;
+            seqrel[tid * 8 + i] = (uint16_t)run;   // <= EX_TILE + EX_EXT starts
         }
     }
     __syncthreads();
@@ -130,16 +148,12 @@ __global__ __launch_bounds__(EP_BLOCK, 4) void extract_part_kernel(PartArgs pa) 
     // ---- 3. windows: a wave owns positions wave*512 .. +511, round j covers 64 consecutive ones ------
     const u64 kmask = k == 32 ? ~0ull : ~(~0ull >> (2 * k));
     const u64 rcx = 0xAAAAAAAAAAAAAAAAull & kmask;
-    u64 fkey[EP_ROUNDS];
-    V val[EP_ROUNDS];
+    const u32 pbase = wave * (64 * EP_ROUNDS) + lane;
     u32 vmask = 0, rmask = 0;
 #pragma unroll
     for (int j = 0; j < EP_ROUNDS; j++) {
-        const u32 p = wave * (64 * EP_ROUNDS) + j * 64 + lane;
-        const u32 w = p >> 4, r = p & 15;
-        u64 hi = ((u64)pk[w] << 32) | pk[w + 1];
-        u64 win = (hi << (2 * r)) | ((u64)pk[w + 2] >> (32 - 2 * r));
-        u64 key = win & kmask;
+        const u32 p = pbase + j * 64;
+        const u64 key = ep_window(pk, p, kmask);
         const u32 w2 = p >> 5, r2 = p & 31;
         u64 bad = (((u64)inv[w2] << 32) | inv[w2 + 1]) << r2;
         u64 st = (((u64)stb[w2] << 32) | stb[w2 + 1]) << r2;
@@ -149,38 +163,30 @@ __global__ __launch_bounds__(EP_BLOCK, 4) void extract_part_kernel(PartArgs pa) 
         if (!WRITE && ok && a.has_kmer) a.has_kmer[s_lo + seqrel[p]] = 1;
         if (ok && a.runofsame >= 0) ok = runofsame_keep(key, k, a.runofsame);
         if (ok && a.dust >= 0) ok = dust_keep(key, k, a.dust);
-        fkey[j] = key;
         bool emit_rc = false;
+        u64 rk = 0;
         if (a.rc && ok) {
-            u64 rev = revpairs64(key >> (64 - 2 * k));
+            const u64 rev = revpairs64(key >> (64 - 2 * k));
             emit_rc = !(((k & 1) == 0) && rev == key);
+            rk = rev ^ rcx;
         }
         vmask |= (u32)ok << j;
         rmask |= (u32)emit_rc << j;
-        val[j] = 0;
-        if (WRITE && ok) {
-            const u32 s = s_lo + seqrel[p];
-            if (a.kind == KMG_PAYLOAD_TAXON) val[j] = (V)(u32)a.seq_id[s];
-            else val[j] = (V)(((u64)(u32)a.read_index[s] << 16) | (u64)((t0 + p - a.seq_off[s]) & 0xFFFFu));
-        }
         if (!WRITE) {
-            if (ok) atomicAdd(&wcnt[0][(u32)(key >> pa.dshift) & pa.dmask], 1u);
-            if (emit_rc) {
-                const u64 rk = revpairs64(key >> (64 - 2 * k)) ^ rcx;
-                atomicAdd(&wcnt[1][(u32)(rk >> pa.dshift) & pa.dmask], 1u);
-            }
+            if (ok) atomicAdd(&hist[0][(u32)(key >> pa.dshift) & pa.dmask], 1u);
+            if (emit_rc) atomicAdd(&hist[1][(u32)(rk >> pa.dshift) & pa.dmask], 1u);
         }
+        if (WRITE && (j & 1)) __builtin_amdgcn_sched_barrier(0);   // two windows in flight: bounds live registers
     }
     __syncthreads();
-    const u32 ncol_per_tile = a.rc ? 2u : 1u;
-    const u32 col0 = tile * ncol_per_tile;
+    const u32 col0 = tile * (a.rc ? 2u : 1u);
 
     if (!WRITE) {
         // histogram columns + the tile's record / forward-window totals
         u32 hf = 0, hr = 0;
         if (tid < RS_DIGITS) {
-            hf = wcnt[0][tid];
-            hr = wcnt[1][tid];
+            hf = hist[0][tid];
+            hr = hist[1][tid];
             pa.table[(u64)tid * pa.ncols + col0] = hf;
             if (a.rc) pa.table[(u64)tid * pa.ncols + col0 + 1] = hr;
         }
@@ -194,28 +200,28 @@ __global__ __launch_bounds__(EP_BLOCK, 4) void extract_part_kernel(PartArgs pa) 
         return;
     }
 
-    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const u32 out_base = (u32)a.state[ST_NREC];
     V *out_vals = reinterpret_cast<V *>(a.out_vals);
     for (int sp = 0; sp < (a.rc ? 2 : 1); sp++) {
         const u32 imask = sp == 0 ? vmask : rmask;
-        u32 lpos[EP_ROUNDS];
+        // opaque copy of the position base: keeps per-window address arithmetic inside the loop body
+        // (hoisted out of the sub-pass loop it would sit in 16+ registers across every barrier)
+        u32 pb = pbase;
+        asm volatile("" : "+v"(pb));
+        u32 lpos[EP_ROUNDS];   // digit << 16 | slot
         // ---- stable rank of every record among the tile's records with the same digit
 #pragma unroll
         for (int j = 0; j < EP_ROUNDS; j++) {
             const bool valid = (imask >> j) & 1;
-            const u64 key = sp == 0 ? fkey[j] : (revpairs64(fkey[j] >> (64 - 2 * k)) ^ rcx);
+            u64 key = ep_window(pk, pb + j * 64, kmask);
+            if (sp) key = revpairs64(key >> (64 - 2 * k)) ^ rcx;
             const u32 d = (u32)(key >> pa.dshift) & pa.dmask;
-            u64 m = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < RS_BITS; b++) {
-                const bool bit = (d >> b) & 1;
-                const u64 bal = __ballot(bit);
-                m &= bit ? bal : ~bal;
-            }
+            u32 below, total;
+            wave_match(d, valid, below, total);
             const u32 before = wcnt[wave][d];
-            lpos[j] = before + __popcll(m & lt);
-            if (valid && (m & lt) == 0) wcnt[wave][d] = before + __popcll(m);
+            lpos[j] = (d << 16) | (before + below);
+            if (valid && below == 0) wcnt[wave][d] = (uint16_t)(before + total);
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         u32 tile_n;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(EP_BLOCK, 4) void extract_part_kernel(PartArgs pa) 
 #pragma unroll
                 for (int w = 0; w < EP_WAVES; w++) {
                     u32 c = wcnt[w][tid];
-                    wcnt[w][tid] = run;
+                    wcnt[w][tid] = (uint16_t)run;
                     run += c;
                 }
             }
@@ -240,11 +246,13 @@ __global__ __launch_bounds__(EP_BLOCK, 4) void extract_part_kernel(PartArgs pa) 
 #pragma unroll
         for (int j = 0; j < EP_ROUNDS; j++) {
             if ((imask >> j) & 1) {
-                const u64 key = sp == 0 ? fkey[j] : (revpairs64(fkey[j] >> (64 - 2 * k)) ^ rcx);
-                const u32 d = (u32)(key >> pa.dshift) & pa.dmask;
-                lpos[j] += dstart[d] + wcnt[wave][d];
-                stage[lpos[j]] = key;
-                sdig[lpos[j]] = (uint8_t)d;
+                u64 key = ep_window(pk, pb + j * 64, kmask);
+                if (sp) key = revpairs64(key >> (64 - 2 * k)) ^ rcx;
+                const u32 d = lpos[j] >> 16;
+                const u32 slot = (lpos[j] & 0xFFFFu) + dstart[d] + wcnt[wave][d];
+                lpos[j] = slot;
+                stage[slot] = key;
+                sdig[slot] = (uint8_t)d;
             }
         }
         __syncthreads();
@@ -255,8 +263,17 @@ __global__ __launch_bounds__(EP_BLOCK, 4) void extract_part_kernel(PartArgs pa) 
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < EP_ROUNDS; j++)
-            if ((imask >> j) & 1) reinterpret_cast<V *>(stage)[lpos[j]] = val[j];
+        for (int j = 0; j < EP_ROUNDS; j++) {
+            if ((imask >> j) & 1) {
+                // payload of the window (the sequence tables are tiny and cached: a tile spans few sequences)
+                const u32 p = pb + j * 64;
+                const u32 sq = s_lo + seqrel[p];
+                V v;
+                if (a.kind == KMG_PAYLOAD_TAXON) v = (V)(u32)a.seq_id[sq];
+                else v = (V)(((u64)(u32)a.read_index[sq] << 16) | (u64)(((u32)t0 + p - (u32)a.seq_off[sq]) & 0xFFFFu));
+                reinterpret_cast<V *>(stage)[lpos[j]] = v;
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < EP_ROUNDS; i++) {

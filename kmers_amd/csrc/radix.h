@@ -18,6 +18,26 @@
 
 #define RS_BITS 8
 #define RS_DIGITS (1 << RS_BITS)
+
+// Wave-level digit matching: for this lane's digit d, `below` = number of lower lanes (with `valid`) holding
+// the same digit and `total` = number of such lanes in the whole wave.  Per digit bit: the bit sign-extended
+// to a 0 / ~0 word B (one v_bfe_i32), its ballot, and "keep the lanes whose bit equals mine" folded into the
+// running mask as m & ~(ballot ^ B) (one three-input bit-op per half).
+__device__ __forceinline__ void wave_match(u32 d, bool valid, u32 &below, u32 &total) {
+    const u64 v = __ballot(valid);
+    u32 mlo = (u32)v, mhi = (u32)(v >> 32);
+#pragma unroll
+    for (int b = 0; b < RS_BITS; b++) {
+        int B = ((int)(d << (31 - b))) >> 31;
+        asm("" : "+v"(B));                     // keep B a value of its own: the ballot is one compare of it
+        const u64 bal = __ballot(B != 0);
+        mlo &= ~((u32)bal ^ (u32)B);
+        mhi &= ~((u32)(bal >> 32) ^ (u32)B);
+        asm("" : "+v"(mlo), "+v"(mhi));        // one three-input op per half and bit, not a re-associated chain
+    }
+    below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+    total = __popc(mlo) + __popc(mhi);
+}
 #define RS_BLOCK 256
 #define RS_WAVES (RS_BLOCK / 64)
 #define RS_ITEMS 16
@@ -118,19 +138,13 @@ __global__ __launch_bounds__(RSC_BLOCK) void rs_scatter_kernel(const u64 *__rest
         const u32 li = wave_base + j * 64 + lane;
         const bool valid = li < tile_n;
         const u32 d = rs_digit<V>(key[j], val[j], shift, mask, src);
-        u64 m = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < RS_BITS; b++) {
-            const bool bit = (d >> b) & 1;
-            const u64 bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
-        }
-        // m = lanes (valid) holding the same digit as this lane
+        u32 below, total;
+        wave_match(d, valid, below, total);
         const u32 before = wcnt[wave][d];
-        lpos[j] = before + __popcll(m & lt);
+        lpos[j] = before + below;
         // the lowest lane of each digit group publishes the group's size; a wave's LDS operations
         // execute in program order, so the read above precedes this write for every lane
-        if (valid && (m & lt) == 0) wcnt[wave][d] = before + __popcll(m);
+        if (valid && below == 0) wcnt[wave][d] = before + total;
     }
     __syncthreads();
 
@@ -370,17 +384,11 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
                 const u32 li = wave_base + j * 64 + lane;
                 const bool valid = li < m;
                 const u32 d = rs_digit<V>(key[j], val[j], shift, mask, src);
-                u64 mm = __ballot(valid);
-#pragma unroll
-                for (int b = 0; b < RS_BITS; b++) {
-
-                    const bool bit = (d >> b) & 1;
-                    const u64 bal = __ballot(bit);
-                    mm &= bit ? bal : ~bal;
-                }
+                u32 below, total;
+                wave_match(d, valid, below, total);
                 const u32 before = wcnt[wave][d];
-                rank[j] = before + __popcll(mm & lt);
-                if (valid && (mm & lt) == 0) wcnt[wave][d] = before + __popcll(mm);
+                rank[j] = before + below;
+                if (valid && below == 0) wcnt[wave][d] = before + total;
             }
         }
         __syncthreads();
@@ -491,6 +499,100 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
     }
 }
 
+// Key-digit-only variant (no payload passes): what moves through LDS in every pass is one 64-bit word per
+// record -- the key shifted left by pbits (its top pbits are the segment number, the same for the whole
+// segment) with the record's load index in the freed low 12 bits -- instead of key + payload.  The payload
+// is stored to LDS once and gathered through the index when the segment is written out.  Half the LDS
+// traffic of ls_sort_kernel per pass and no payload registers.  Needs pbits + low_bit >= 12.
+template <typename V>
+__global__ __launch_bounds__(LS_BLOCK, 6) void ls_sortidx_kernel(const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
+                                                               u64 *__restrict__ keys_out, V *__restrict__ vals_out,
+                                                               const u32 *__restrict__ seg_off, LocalPasses lp, int pbits) {
+    __shared__ uint16_t wcnt[LS_WAVES][RS_DIGITS];
+    __shared__ uint16_t wbase[LS_WAVES][RS_DIGITS];
+    __shared__ u64 swords[LS_MAX];
+    __shared__ V svals[LS_MAX];
+
+    const u32 s0 = seg_off[blockIdx.x];
+    const u32 m = seg_off[blockIdx.x + 1] - s0;
+    if (m == 0 || m > LS_MAX) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int rounds = (int)((m + LS_BLOCK - 1) / LS_BLOCK);
+    const u32 wave_base = wave * 64 * rounds;
+
+    // Slots [m, rounds * 512) hold all-ones sentinels: they sort behind every record (stably, they are
+    // loaded last), so no step below needs a per-lane validity branch.
+    u64 sw[LS_ITEMS];
+    u32 rank[LS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < LS_ITEMS; j++) {
+        const u32 li = wave_base + j * 64 + lane;
+        const bool valid = j < rounds && li < m;
+        sw[j] = valid ? ((keys_in[s0 + li] << pbits) | li) : ~0ull;
+        if (valid) svals[li] = vals_in[s0 + li];
+    }
+    *reinterpret_cast<uint2 *>(&wcnt[wave][4 * lane]) = make_uint2(0, 0);
+    for (int p = 0; p < lp.n; p++) {
+        const int shift = lp.shift[p] + pbits;
+        const u32 mask = (1u << lp.bits[p]) - 1u;
+#pragma unroll
+        for (int j = 0; j < LS_ITEMS; j++) {
+            if (j < rounds) {
+                const u32 d = (u32)(sw[j] >> shift) & mask;
+                u32 below, total;
+                wave_match(d, true, below, total);
+                const u32 before = wcnt[wave][d];
+                rank[j] = before + below;
+                if (below == 0) wcnt[wave][d] = before + total;
+            }
+        }
+        __syncthreads();
+        {
+            u32 tot[4] = {0, 0, 0, 0}, mine[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int w = 0; w < LS_WAVES; w++) {
+                const uint2 c = *reinterpret_cast<const uint2 *>(&wcnt[w][4 * lane]);
+                if (w == wave) { mine[0] = tot[0]; mine[1] = tot[1]; mine[2] = tot[2]; mine[3] = tot[3]; }
+                tot[0] += c.x & 0xFFFFu; tot[1] += c.x >> 16; tot[2] += c.y & 0xFFFFu; tot[3] += c.y >> 16;
+            }
+            const u32 s4 = tot[0] + tot[1] + tot[2] + tot[3];
+            u32 inc = s4;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const u32 o = __shfl_up(inc, dd, 64);
+                if (lane >= dd) inc += o;
+            }
+            u32 start = inc - s4;
+            u32 b0 = start + mine[0]; start += tot[0];
+            u32 b1 = start + mine[1]; start += tot[1];
+            u32 b2 = start + mine[2]; start += tot[2];
+            u32 b3 = start + mine[3];
+            *reinterpret_cast<uint2 *>(&wbase[wave][4 * lane]) = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+        }
+        u32 pos[LS_ITEMS];
+#pragma unroll
+        for (int j = 0; j < LS_ITEMS; j++)
+            if (j < rounds) pos[j] = wbase[wave][(u32)(sw[j] >> shift) & mask] + rank[j];
+#pragma unroll
+        for (int j = 0; j < LS_ITEMS; j++)
+            if (j < rounds) swords[pos[j]] = sw[j];
+        __syncthreads();
+        *reinterpret_cast<uint2 *>(&wcnt[wave][4 * lane]) = make_uint2(0, 0);
+        if (p + 1 < lp.n) {
+#pragma unroll
+            for (int j = 0; j < LS_ITEMS; j++)
+                if (j < rounds) sw[j] = swords[wave_base + j * 64 + lane];
+        }
+    }
+    const u64 seg_prefix = pbits > 0 ? ((u64)blockIdx.x << (64 - pbits)) : 0ull;
+    for (u32 i = tid; i < m; i += LS_BLOCK) {
+        const u64 w = swords[i];
+        keys_out[s0 + i] = seg_prefix | ((w & ~0xFFFull) >> pbits);
+        vals_out[s0 + i] = svals[(u32)w & 0xFFFu];
+    }
+}
+
 // Sorts n records by (key bits [low_bit, 64), then payload passes).  `payload_passes` are the least
 // significant digits (taxa inside a k-mer / shared read indices).  Result location in *result_in_1.
 // scratch: table (RS_DIGITS * ntiles u32), agg (scan), seg (2^pbits + 2 u32 + 1 for the max).
@@ -568,7 +670,11 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
         if (lp.n == 0) { *result_in_1 = in1; return KMG_OK; }
         {
             ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_LOCAL_V64 : KP_SORT_LOCAL_V32, (u64)n * (8 + sizeof(V)) * 2);
-            hipLaunchKernelGGL((ls_sort_kernel<V>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp);
+            // key digits only and room for a 12-bit index under the key: the one-word-per-record kernel
+            if (lp.fast_from == 0 && payload_passes.empty() && pbits + low_bit >= 12 && pbits < 64)
+                hipLaunchKernelGGL((ls_sortidx_kernel<V>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp, pbits);
+            else
+                hipLaunchKernelGGL((ls_sort_kernel<V>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp);
             KMG_HIP(hipGetLastError());
         }
         for (const auto &bs : big) {
