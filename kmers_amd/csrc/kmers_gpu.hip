@@ -429,6 +429,37 @@ static int reduce_read_keys(kmg_ctx *ctx, const u64 *keys, u32 n, kmg_db *db, u6
     return KMG_OK;
 }
 
+// Read DB whose k-mer runs were already found by the local sort (SortHeads): scan the per-segment counts and
+// gather the distinct k-mers and their first-record indices into the DB arrays.
+static int reduce_read_heads(kmg_ctx *ctx, const SortHeads &h, u32 n, kmg_db *db, u64 *d_totals) {
+    void *p;
+    if (ctx->pool.alloc(&p, ((size_t)n + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->keys = (u64 *)p;
+    if (ctx->pool.alloc(&p, ((size_t)n + 2) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->val_off = (u64 *)p;
+    const u32 nbuckets = 1u << (2 * db->key_len);
+    if (ctx->pool.alloc(&p, ((size_t)nbuckets + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->bucket_off = (u64 *)p;
+    PoolBuf ubase(ctx), agg(ctx);
+    KMG_ALLOC(ubase, ((size_t)h.nseg + 1) * 8);
+    KMG_ALLOC(agg, (size_t)(div_up_u64(h.nseg, SCAN_TILE) + 1) * 8);
+    KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, h.ucount, ubase.as<u64>(), h.nseg, OpSum(), 0ull, agg.as<u64>(),
+                                                d_totals + 0, false, KP_SCAN)));
+    hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, d_totals + 1, (u64)n);
+    {
+        ProfScope ps(ctx, KP_REDUCE_WRITE, 0 /* 32 B per unique k-mer, added when U is known */);
+        hipLaunchKernelGGL(ls_heads_gather_kernel, dim3(h.nseg), dim3(256), 0, ctx->stream, h.head_keys, h.head_first,
+                           h.seg_off, h.ucount, ubase.as<u64>(), db->keys, db->val_off);
+    }
+    {
+        ProfScope ps(ctx, KP_BUCKETS, 0);
+        hipLaunchKernelGGL(rd_buckets_kernel, dim3(div_up_u64(nbuckets + 1, 256)), dim3(256), 0, ctx->stream, db->keys,
+                           d_totals, db->val_off, db->bucket_off, nbuckets, db->key_len);
+    }
+    KMG_HIP(hipGetLastError());
+    return KMG_OK;
+}
+
 // val_a / val_b of a read DB are materialised from the packed payloads the first time they are needed.
 static int ensure_vals(kmg_ctx *ctx, kmg_db *db) {
     if (db->val_a || !db->vals_packed) return KMG_OK;
@@ -484,7 +515,9 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     const bool prepart = ctx->prepart && ctx->n_adds == 1;
     const int pbits = prepart ? ctx->plan_pbits : choose_pbits(n, 2 * ctx->k);
 
-    PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx), seg(ctx);
+    PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx), seg(ctx), ucount(ctx);
+    SortHeads heads;
+    memset(&heads, 0, sizeof heads);
     const size_t vb = val_bytes(ctx->kind);
     const u32 ntiles = n ? div_up_u64(n, RS_TILE) : 1;
     KMG_ALLOC(totals, 64);
@@ -498,14 +531,19 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
         KMG_ALLOC(agg, (size_t)(div_up_u64((u64)RS_DIGITS * ntiles, SCAN_TILE) + 1) * 8);
         KMG_ALLOC(seg, (((size_t)1 << pbits) + 4) * 4);
         const int low_bit = 64 - 2 * ctx->k;
-        if (reads) r = hybrid_sort_records<u64>(ctx, ctx->rec_keys, (u64 *)ctx->rec_vals, k1.as<u64>(), v1.as<u64>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1);
+        if (reads) {
+            KMG_ALLOC(ucount, (((size_t)1 << pbits) + 1) * 4);
+            heads.ucount = ucount.as<u32>();
+            r = hybrid_sort_records<u64>(ctx, ctx->rec_keys, (u64 *)ctx->rec_vals, k1.as<u64>(), v1.as<u64>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1, &heads);
+        }
         else r = hybrid_sort_records<u32>(ctx, ctx->rec_keys, (u32 *)ctx->rec_vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1);
     }
     if (r == KMG_OK) {
         const u64 *sk = in1 ? k1.as<u64>() : ctx->rec_keys;
         const void *sv = in1 ? v1.p : ctx->rec_vals;
         if (reads) {
-            r = reduce_read_keys(ctx, sk, n, db, totals.as<u64>());
+            r = heads.done ? reduce_read_heads(ctx, heads, n, db, totals.as<u64>())
+                           : reduce_read_keys(ctx, sk, n, db, totals.as<u64>());
             // the sorted payload buffer changes owner: it is the DB's value array now
             if (in1) db->vals_packed = (u64 *)v1.detach();
             else { db->vals_packed = (u64 *)ctx->rec_vals; ctx->rec_vals = nullptr; }
@@ -525,7 +563,7 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     db->U = tot[0];
     db->V = tot[1];
     if (ctx->prof_on)
-        ctx->prof[KP_REDUCE_WRITE].bytes += db->U * 16 + (reads ? 0 : db->V * 8);
+        ctx->prof[KP_REDUCE_WRITE].bytes += db->U * (heads.done ? 32 : 16) + (reads ? 0 : db->V * 8);
     *out = db_guard.release();
     return KMG_OK;
 }

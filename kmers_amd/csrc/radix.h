@@ -115,7 +115,6 @@ __global__ __launch_bounds__(RSC_BLOCK) void rs_scatter_kernel(const u64 *__rest
     if (tile >= ntiles) return;
     const u32 tile_base = tile * RS_TILE;
     const u32 tile_n = min((u32)RS_TILE, n - tile_base);
-    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
     if (tid < RS_DIGITS) {
 #pragma unroll
@@ -347,7 +346,6 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
     const u32 m = seg_off[blockIdx.x + 1] - s0;
     if (m == 0 || m > LS_MAX) return;   // oversize segments: the host falls back to full LSD passes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const int rounds = (int)((m + LS_BLOCK - 1) / LS_BLOCK);          // block-uniform
     const u32 wave_base = wave * 64 * rounds;
 
@@ -504,10 +502,16 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
 // segment) with the record's load index in the freed low 12 bits -- instead of key + payload.  The payload
 // is stored to LDS once and gathered through the index when the segment is written out.  Half the LDS
 // traffic of ls_sort_kernel per pass and no payload registers.  Needs pbits + low_bit >= 12.
-template <typename V>
-__global__ __launch_bounds__(LS_BLOCK, 6) void ls_sortidx_kernel(const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
-                                                               u64 *__restrict__ keys_out, V *__restrict__ vals_out,
-                                                               const u32 *__restrict__ seg_off, LocalPasses lp, int pbits) {
+//
+// HEADS (read DBs): the k-mer runs are found while the sorted segment is still in LDS, so no later pass has
+// to read the sorted keys again.  The block writes, compacted at the start of its own slice of the INPUT
+// buffers (whose records it holds in LDS by then), the segment's distinct k-mers (keys_in[s0 ..]) and the
+// index of each one's first record (vals_in[s0 ..], as 64-bit words), their number to ucount[segment], and
+// only the payloads to vals_out: the per-record sorted keys are never needed again.
+template <typename V, bool HEADS>
+__global__ __launch_bounds__(LS_BLOCK, 6) void ls_sortidx_kernel(u64 *keys_in, V *vals_in, u64 *__restrict__ keys_out,
+                                                               V *__restrict__ vals_out, const u32 *__restrict__ seg_off,
+                                                               LocalPasses lp, int pbits, u32 *__restrict__ ucount) {
     __shared__ uint16_t wcnt[LS_WAVES][RS_DIGITS];
     __shared__ uint16_t wbase[LS_WAVES][RS_DIGITS];
     __shared__ u64 swords[LS_MAX];
@@ -515,9 +519,11 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sortidx_kernel(const u64 *__re
 
     const u32 s0 = seg_off[blockIdx.x];
     const u32 m = seg_off[blockIdx.x + 1] - s0;
-    if (m == 0 || m > LS_MAX) return;
+    if (m == 0 || m > LS_MAX) {
+        if (HEADS && threadIdx.x == 0) ucount[blockIdx.x] = 0;   // (the host never asks for HEADS with oversize segments)
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const int rounds = (int)((m + LS_BLOCK - 1) / LS_BLOCK);
     const u32 wave_base = wave * 64 * rounds;
 
@@ -586,12 +592,85 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sortidx_kernel(const u64 *__re
         }
     }
     const u64 seg_prefix = pbits > 0 ? ((u64)blockIdx.x << (64 - pbits)) : 0ull;
-    for (u32 i = tid; i < m; i += LS_BLOCK) {
-        const u64 w = swords[i];
-        keys_out[s0 + i] = seg_prefix | ((w & ~0xFFFull) >> pbits);
-        vals_out[s0 + i] = svals[(u32)w & 0xFFFu];
+    if (!HEADS) {
+        for (u32 i = tid; i < m; i += LS_BLOCK) {
+            const u64 w = swords[i];
+            keys_out[s0 + i] = seg_prefix | ((w & ~0xFFFull) >> pbits);
+            vals_out[s0 + i] = svals[(u32)w & 0xFFFu];
+        }
+        return;
+    }
+    // the last pass's closing barrier ordered every load of this block's input slice before these stores
+    u32 *wtot = reinterpret_cast<u32 *>(&wbase[0][0]);   // head counts per (round, wave), in record order
+    const u64 below_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    u64 hw[LS_ITEMS];
+    u32 hbelow[LS_ITEMS];
+    u32 hmask = 0;
+#pragma unroll
+    for (int r = 0; r < LS_ITEMS; r++) {
+        if (r < rounds) {
+            const u32 i = r * LS_BLOCK + tid;
+            const bool inb = i < m;
+            const u64 w = inb ? swords[i] : 0ull;
+            const bool head = inb && (i == 0 || ((swords[i - 1] ^ w) >> 12) != 0);
+            const u64 hb = __ballot(head);
+            if (lane == 0) wtot[r * LS_WAVES + wave] = __popcll(hb);
+            if (inb) vals_out[s0 + i] = svals[(u32)w & 0xFFFu];
+            hw[r] = w;
+            hbelow[r] = __popcll(hb & below_mask);
+            hmask |= (u32)head << r;
+        }
+    }
+    __syncthreads();
+    // every wave scans the (at most 40) counts itself: lane = round * 8 + wave
+    const u32 c = lane < rounds * LS_WAVES ? wtot[lane] : 0u;
+    u32 inc = c;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const u32 o = __shfl_up(inc, dd, 64);
+        if (lane >= dd) inc += o;
+    }
+    const u32 exc = inc - c;
+#pragma unroll
+    for (int r = 0; r < LS_ITEMS; r++) {
+        if (r < rounds) {
+            const u32 base = __shfl(exc, r * LS_WAVES + wave, 64);
+            if ((hmask >> r) & 1) {
+                const u32 slot = s0 + base + hbelow[r];
+                keys_in[slot] = seg_prefix | ((hw[r] & ~0xFFFull) >> pbits);
+                reinterpret_cast<u64 *>(vals_in)[slot] = (u64)(s0 + r * LS_BLOCK + tid);
+            }
+        }
+    }
+    const u32 nheads = __shfl(inc, 63, 64);
+    if (tid == 0) ucount[blockIdx.x] = nheads;
+}
+
+// Gathers what ls_sortidx_kernel<.., true> left per segment into the DB arrays: one block per segment.
+__global__ __launch_bounds__(256) void ls_heads_gather_kernel(const u64 *__restrict__ head_keys, const u64 *__restrict__ head_first,
+                                                             const u32 *__restrict__ seg_off, const u32 *__restrict__ ucount,
+                                                             const u64 *__restrict__ ubase, u64 *__restrict__ ukeys,
+                                                             u64 *__restrict__ val_off) {
+    const u32 seg = blockIdx.x;
+    const u32 u = ucount[seg], s0 = seg_off[seg];
+    const u64 b = ubase[seg];
+    for (u32 i = threadIdx.x; i < u; i += 256) {
+        ukeys[b + i] = head_keys[s0 + i];
+        val_off[b + i] = head_first[s0 + i];
     }
 }
+
+// Optional by-product of the local sort for read DBs (see ls_sortidx_kernel): the caller provides ucount
+// (2^pbits u32); when `done` comes back true the sorted KEYS were not written at all -- the distinct k-mers
+// and their first-record indices sit per segment in the sort's other buffer pair instead.
+struct SortHeads {
+    u32 *ucount;
+    bool done;
+    const u64 *head_keys;
+    const u64 *head_first;
+    const u32 *seg_off;
+    u32 nseg;
+};
 
 // Sorts n records by (key bits [low_bit, 64), then payload passes).  `payload_passes` are the least
 // significant digits (taxa inside a k-mer / shared read indices).  Result location in *result_in_1.
@@ -599,8 +678,9 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sortidx_kernel(const u64 *__re
 template <typename V>
 static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 n, int low_bit,
                                const std::vector<SortPass> &payload_passes, u32 *table, u32 *agg, u32 *seg,
-                               int pbits, bool skip_first, bool *result_in_1) {
+                               int pbits, bool skip_first, bool *result_in_1, SortHeads *heads = nullptr) {
     *result_in_1 = false;
+    if (heads) heads->done = false;
     if (n == 0) return KMG_OK;
     // global LSD passes over the top pbits of the key
     const std::vector<SortPass> prefix = prefix_digits(pbits);
@@ -671,9 +751,19 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
         {
             ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_LOCAL_V64 : KP_SORT_LOCAL_V32, (u64)n * (8 + sizeof(V)) * 2);
             // key digits only and room for a 12-bit index under the key: the one-word-per-record kernel
-            if (lp.fast_from == 0 && payload_passes.empty() && pbits + low_bit >= 12 && pbits < 64)
-                hipLaunchKernelGGL((ls_sortidx_kernel<V>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp, pbits);
-            else
+            if (lp.fast_from == 0 && payload_passes.empty() && pbits + low_bit >= 12 && pbits < 64) {
+                if (heads && sizeof(V) == 8 && big.empty()) {
+                    hipLaunchKernelGGL((ls_sortidx_kernel<V, true>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg,
+                                       lp, pbits, heads->ucount);
+                    heads->done = true;
+                    heads->head_keys = ka;
+                    heads->head_first = reinterpret_cast<u64 *>(va);
+                    heads->seg_off = seg;
+                    heads->nseg = nseg;
+                } else
+                    hipLaunchKernelGGL((ls_sortidx_kernel<V, false>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg,
+                                       lp, pbits, (u32 *)nullptr);
+            } else
                 hipLaunchKernelGGL((ls_sort_kernel<V>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp);
             KMG_HIP(hipGetLastError());
         }
