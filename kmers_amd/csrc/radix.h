@@ -554,28 +554,32 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sortidx_kernel(u64 *keys_in, V
             }
         }
         __syncthreads();
-        {
-            u32 tot[4] = {0, 0, 0, 0}, mine[4] = {0, 0, 0, 0};
+        if (wave == 0) {
+            // One wave turns the 8 x 256 per-wave counts into per-wave slot bases; lane owns digits 4*lane .. +3.
+            // Counts are 16-bit and every partial sum stays <= LS_MAX, so four of them are added at once as two
+            // 32-bit words without carries between the halves.
+            uint2 run = make_uint2(0, 0), pre[LS_WAVES];
 #pragma unroll
             for (int w = 0; w < LS_WAVES; w++) {
                 const uint2 c = *reinterpret_cast<const uint2 *>(&wcnt[w][4 * lane]);
-                if (w == wave) { mine[0] = tot[0]; mine[1] = tot[1]; mine[2] = tot[2]; mine[3] = tot[3]; }
-                tot[0] += c.x & 0xFFFFu; tot[1] += c.x >> 16; tot[2] += c.y & 0xFFFFu; tot[3] += c.y >> 16;
+                pre[w] = run;
+                run.x += c.x; run.y += c.y;
             }
-            const u32 s4 = tot[0] + tot[1] + tot[2] + tot[3];
+            const u32 t0 = run.x & 0xFFFFu, t1 = run.x >> 16, t2 = run.y & 0xFFFFu, t3 = run.y >> 16;
+            const u32 s4 = t0 + t1 + t2 + t3;
             u32 inc = s4;
 #pragma unroll
             for (int dd = 1; dd < 64; dd <<= 1) {
                 const u32 o = __shfl_up(inc, dd, 64);
                 if (lane >= dd) inc += o;
             }
-            u32 start = inc - s4;
-            u32 b0 = start + mine[0]; start += tot[0];
-            u32 b1 = start + mine[1]; start += tot[1];
-            u32 b2 = start + mine[2]; start += tot[2];
-            u32 b3 = start + mine[3];
-            *reinterpret_cast<uint2 *>(&wbase[wave][4 * lane]) = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+            const u32 b0 = inc - s4, b1 = b0 + t0, b2 = b1 + t1, b3 = b2 + t2;
+            const uint2 start = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+#pragma unroll
+            for (int w = 0; w < LS_WAVES; w++)
+                *reinterpret_cast<uint2 *>(&wbase[w][4 * lane]) = make_uint2(start.x + pre[w].x, start.y + pre[w].y);
         }
+        __syncthreads();
         u32 pos[LS_ITEMS];
 #pragma unroll
         for (int j = 0; j < LS_ITEMS; j++)
