@@ -8,30 +8,94 @@
 #include "common.h"
 
 #define MT_BLOCK 256
+#define MT_ITEMS 8
+#define MT_TILE (MT_BLOCK * MT_ITEMS)   // search k-mers per workgroup
+#define MT_RMAX 3072                    // reference k-mers staged in LDS per tile (24 KB)
 
-// One thread per search k-mer: binary search inside the reference's bucket for the k-mer's
-// Kmer.key(key_len) prefix.  Neighbouring threads hold neighbouring (sorted) keys, so their probes walk
-// the same cache lines of the reference array.
-__global__ __launch_bounds__(MT_BLOCK) void match_kernel(const u64 *__restrict__ skeys, u64 ns,
-                                                          const u64 *__restrict__ rkeys,
-                                                          const u64 *__restrict__ rbucket, int key_len,
-                                                          long long *__restrict__ hit, u64 *__restrict__ nhits) {
-    u64 i = (u64)blockIdx.x * MT_BLOCK + threadIdx.x;
-    bool found = false;
-    if (i < ns) {
-        const u64 key = skeys[i];
-        const u64 b = key >> (64 - 2 * key_len);
-        u64 lo = rbucket[b], hi = rbucket[b + 1];
-        while (lo < hi) {
-            u64 mid = (lo + hi) >> 1;
-            if (rkeys[mid] < key) lo = mid + 1; else hi = mid;
+// number of threads of the block for which pred holds (all threads must call)
+__device__ __forceinline__ u32 mt_block_count(bool pred, u32 *smem) {
+    const u64 bal = __ballot(pred);
+    __syncthreads();                       // previous readers of smem are done
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    return smem[0] + smem[1] + smem[2] + smem[3];
+}
+
+// The whole block searches [lo, hi) of the ascending array a for the first element that is not `less`
+// than key (STRICT: first element > key).  256-ary: every round each thread probes one position.
+template <bool STRICT>
+__device__ __forceinline__ u64 mt_block_bound(const u64 *__restrict__ a, u64 lo, u64 hi, u64 key, u32 *smem) {
+    const u32 t = threadIdx.x;
+    while (hi > lo) {
+        const u64 n = hi - lo;
+        if (n <= MT_BLOCK) {
+            bool before = false;
+            if (t < n) { const u64 v = a[lo + t]; before = STRICT ? v <= key : v < key; }
+            return lo + mt_block_count(before, smem);
         }
-        found = lo < rbucket[b + 1] && rkeys[lo] == key;
-        hit[i] = found ? (long long)lo : -1ll;
+        // probes split [lo, hi) into 257 parts; predicates are 1..1 0..0 along t
+        const u64 p = lo + (n * (u64)(t + 1)) / (MT_BLOCK + 1);
+        const u64 v = a[p];
+        const bool before = STRICT ? v <= key : v < key;
+        const u32 c = mt_block_count(before, smem);
+        const u64 nlo = c == 0 ? lo : lo + (n * (u64)c) / (MT_BLOCK + 1) + 1;
+        const u64 nhi = c == MT_BLOCK ? hi : lo + (n * (u64)(c + 1)) / (MT_BLOCK + 1);
+        lo = nlo; hi = nhi;
     }
-    if (nhits) {
-        u64 bal = __ballot(found);
-        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(nhits, (u64)__popcll(bal));
+    return lo;
+}
+
+// One workgroup joins MT_TILE consecutive search k-mers.  Both sides are ascending, so the reference
+// k-mers that can match them form one contiguous range [lower_bound(first), upper_bound(last)); the block
+// finds it cooperatively, stages it in LDS (it is a few hundred k-mers when the two sets are of similar
+// density) and every search k-mer is then binary-searched in LDS instead of through L2.  Ranges that do not
+// fit are searched in place.  hit[i] = index of the k-mer in the reference, or -1.
+__global__ __launch_bounds__(MT_BLOCK) void match_kernel(const u64 *__restrict__ skeys, u64 ns,
+                                                          const u64 *__restrict__ rkeys, u64 nr,
+                                                          long long *__restrict__ hit, u64 *__restrict__ nhits) {
+    __shared__ u64 sref[MT_RMAX];
+    __shared__ u32 smem[4];
+    const u64 q0 = (u64)blockIdx.x * MT_TILE;
+    const u64 q1 = q0 + MT_TILE < ns ? q0 + MT_TILE : ns;
+    const u64 r_lo = mt_block_bound<false>(rkeys, 0, nr, skeys[q0], smem);
+    const u64 r_hi = mt_block_bound<true>(rkeys, r_lo, nr, skeys[q1 - 1], smem);
+    const u32 cnt = (u32)(r_hi - r_lo < MT_RMAX ? r_hi - r_lo : MT_RMAX);
+    const bool staged = r_hi - r_lo <= MT_RMAX;
+    if (staged)
+        for (u32 i = threadIdx.x; i < cnt; i += MT_BLOCK) sref[i] = rkeys[r_lo + i];
+    __syncthreads();
+    u32 nfound = 0;
+#pragma unroll
+    for (int j = 0; j < MT_ITEMS; j++) {
+        const u64 i = q0 + (u64)j * MT_BLOCK + threadIdx.x;
+        if (i < q1) {
+            const u64 key = skeys[i];
+            long long res = -1;
+            if (staged) {
+                u32 lo = 0, hi = cnt;
+                while (lo < hi) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (sref[mid] < key) lo = mid + 1; else hi = mid;
+                }
+                if (lo < cnt && sref[lo] == key) res = (long long)(r_lo + lo);
+            } else {
+                u64 lo = r_lo, hi = r_hi;
+                while (lo < hi) {
+                    const u64 mid = (lo + hi) >> 1;
+                    if (rkeys[mid] < key) lo = mid + 1; else hi = mid;
+                }
+                if (lo < r_hi && rkeys[lo] == key) res = (long long)lo;
+            }
+            hit[i] = res;
+            nfound += res >= 0;
+        }
+    }
+    if (nhits) {   // uniform
+        // per-thread counts <= MT_ITEMS: sum the block with one more counting round per bit
+        u32 total = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) total += mt_block_count((nfound >> b) & 1, smem) << b;
+        if (threadIdx.x == 0 && total) atomicAdd(nhits, (u64)total);
     }
 }
 
