@@ -185,6 +185,33 @@ def test_match_and_taxacounts_match_oracle(ctx, k, key_len, seed):
     rdb.close()
 
 
+@pytest.mark.parametrize("n_reads,genome_len", [(40, 150_000), (6000, 3_000)])
+def test_match_sparse_and_dense_search(ctx, n_reads, genome_len):
+    """The join kernel stages the reference range of a search tile in LDS when it fits: few reads against a
+    large reference (range >> stage: searched in place) and many reads against a small one (range << stage)."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(77, 3, genome_len, first_taxon=5)
+    reads = synth.random_reads(78, genomes, n_reads, 120, 0.01)
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    ref = km.make_reference_db(ctx, fa, 21, 5)
+    rdb, _ = km.make_read_db(ctx, fq, 21, 5)
+    o_ref, o_reads = OracleDB(fa, 0, 21, 5, threads=8), OracleDB(fq, 1, 21, 5, threads=8)
+    hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
+    o_hit, o_nh = o_reads.match(o_ref, threads=8)
+    assert nh == o_nh and nh > 0 and np.array_equal(hit, o_hit)
+    # and the other way round (reference k-mers searched in the read set)
+    rh = rdb.fetch()
+    as_ref = km.KmerDatabase.load(ctx, 21, 5, True, 1, rh["keys"], rh["val_off"], rh["val_a"], rh["val_b"])
+    hit2, nh2 = km.DB([as_ref]).get_nearest_kmers(ref)
+    want = np.searchsorted(rh["keys"], ref.fetch()["keys"])
+    found = (want < len(rh["keys"])) & (rh["keys"][np.minimum(want, len(rh["keys"]) - 1)] == ref.fetch()["keys"])
+    assert nh2 == int(found.sum()) and np.array_equal(hit2, np.where(found, want, -1))
+    for d in (ref, rdb, as_ref):
+        d.close()
+
+
 def test_db_load_roundtrip_and_errors(ctx):
     import kmers_amd as km
     from kmers_amd import synth
