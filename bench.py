@@ -184,9 +184,10 @@ def main():
 # kernel id of the measurement hook -> kernel symbol in the rocprofv3 traces
 KERNEL_SYMBOL = {
     "sort_scatter_reads": "rs_scatter_kernel<unsigned long long>", "sort_scatter_ref": "rs_scatter_kernel<unsigned int>",
-    "sort_local_reads": "ls_sort_kernel<unsigned long long>", "sort_local_ref": "ls_sort_kernel<unsigned int>",
+    "sort_local_reads": "ls_sortidx_kernel<unsigned long long", "sort_local_ref": "ls_sort_kernel<unsigned int>",
     "sort_hist_reads": "rs_hist_kernel<unsigned long long>", "sort_hist_ref": "rs_hist_kernel<unsigned int>",
-    "extract_write": "extract_kernel<true>", "extract_count": "extract_kernel<false>", "match": "match_kernel",
+    "extract_write": "extract_part_kernel<true, unsigned long long>",
+    "extract_count": "extract_part_kernel<false, unsigned long long>", "match": "match_kernel",
 }
 
 

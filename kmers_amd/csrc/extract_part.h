@@ -46,7 +46,7 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
     __shared__ u32 stb[EX_TILE / 32 + 2];
     __shared__ uint16_t seqrel[EX_TILE + EX_EXT];      // #sequences (beyond the tile's first) starting at or before p
     __shared__ u32 cnt32[WRITE ? 1 : EX_TILE + EX_EXT]; // sequence starts per position (write pass: inside `stage`)
-    __shared__ u32 hist[WRITE ? 1 : 2][RS_DIGITS];     // count pass: forward / RC digit histograms
+    __shared__ u32 hist[2][WRITE ? 1 : RS_DIGITS];     // count pass: forward / RC digit histograms
     __shared__ uint16_t wcnt[WRITE ? EP_WAVES : 1][RS_DIGITS];
     __shared__ u32 dstart[RS_DIGITS];
     __shared__ u32 gdelta[RS_DIGITS];
@@ -150,7 +150,9 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
     const u64 rcx = 0xAAAAAAAAAAAAAAAAull & kmask;
     const u32 pbase = wave * (64 * EP_ROUNDS) + lane;
     u32 vmask = 0, rmask = 0;
-#pragma unroll
+    // (not unrolled in the write pass: the eight copies of the window logic with both filters inlined cost
+    // registers the rank and staging steps need -- spills there are real memory traffic)
+#pragma unroll WRITE ? 1 : EP_ROUNDS
     for (int j = 0; j < EP_ROUNDS; j++) {
         const u32 p = pbase + j * 64;
         const u64 key = ep_window(pk, p, kmask);
@@ -176,7 +178,6 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
             if (ok) atomicAdd(&hist[0][(u32)(key >> pa.dshift) & pa.dmask], 1u);
             if (emit_rc) atomicAdd(&hist[1][(u32)(rk >> pa.dshift) & pa.dmask], 1u);
         }
-        if (WRITE && (j & 1)) __builtin_amdgcn_sched_barrier(0);   // two windows in flight: bounds live registers
     }
     __syncthreads();
     const u32 col0 = tile * (a.rc ? 2u : 1u);
@@ -225,21 +226,23 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
         }
         __syncthreads();
         u32 tile_n;
+        u32 tdx = tid;                      // opaque copy, as pb: no addresses hoisted out of the loop
+        asm volatile("" : "+v"(tdx));
         {
             u32 run = 0;
-            if (tid < RS_DIGITS) {
+            if (tdx < RS_DIGITS) {
 #pragma unroll
                 for (int w = 0; w < EP_WAVES; w++) {
-                    u32 c = wcnt[w][tid];
-                    wcnt[w][tid] = (uint16_t)run;
+                    u32 c = wcnt[w][tdx];
+                    wcnt[w][tdx] = (uint16_t)run;
                     run += c;
                 }
             }
             u32 incl = block_scan_inclusive<u32, OpSum, EP_WAVES>(run, OpSum(), scan_smem, &tile_n);
-            if (tid < RS_DIGITS) {
+            if (tdx < RS_DIGITS) {
                 const u32 start = incl - run;
-                dstart[tid] = start;
-                gdelta[tid] = out_base + pa.table[(u64)tid * pa.ncols + col0 + sp] - start;
+                dstart[tdx] = start;
+                gdelta[tdx] = out_base + pa.table[(u64)tdx * pa.ncols + col0 + sp] - start;
             }
         }
         __syncthreads();
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
             }
         }
         __syncthreads();
-#pragma unroll
+#pragma unroll 4
         for (int i = 0; i < EP_ROUNDS; i++) {
             const u32 lp = i * EP_BLOCK + tid;
             if (lp < tile_n) a.out_keys[lp + gdelta[sdig[lp]]] = stage[lp];
@@ -273,9 +276,10 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
                 else v = (V)(((u64)(u32)a.read_index[sq] << 16) | (u64)(((u32)t0 + p - (u32)a.seq_off[sq]) & 0xFFFFu));
                 reinterpret_cast<V *>(stage)[lpos[j]] = v;
             }
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four payload gathers in flight
         }
         __syncthreads();
-#pragma unroll
+#pragma unroll 4
         for (int i = 0; i < EP_ROUNDS; i++) {
             const u32 lp = i * EP_BLOCK + tid;
             if (lp < tile_n) out_vals[lp + gdelta[sdig[lp]]] = reinterpret_cast<V *>(stage)[lp];

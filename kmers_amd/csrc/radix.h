@@ -753,10 +753,15 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
         for (int i = 0; i < lp.n; i++) { lp.shift[i] = rest[i].shift; lp.bits[i] = rest[i].bits; lp.src[i] = rest[i].src; }
         if (lp.n == 0) { *result_in_1 = in1; return KMG_OK; }
         {
-            ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_LOCAL_V64 : KP_SORT_LOCAL_V32, (u64)n * (8 + sizeof(V)) * 2);
+            const bool idx_kernel = lp.fast_from == 0 && payload_passes.empty() && pbits + low_bit >= 12 && pbits < 64;
+            const bool with_heads = idx_kernel && heads && sizeof(V) == 8 && big.empty();
+            // algorithmic bytes: records in, records out -- with heads only the payloads go out (+ 16 B per distinct
+            // k-mer, added by the caller once their number is known)
+            ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_LOCAL_V64 : KP_SORT_LOCAL_V32,
+                         (u64)n * (8 + sizeof(V)) + (u64)n * (with_heads ? sizeof(V) : 8 + sizeof(V)));
             // key digits only and room for a 12-bit index under the key: the one-word-per-record kernel
-            if (lp.fast_from == 0 && payload_passes.empty() && pbits + low_bit >= 12 && pbits < 64) {
-                if (heads && sizeof(V) == 8 && big.empty()) {
+            if (idx_kernel) {
+                if (with_heads) {
                     hipLaunchKernelGGL((ls_sortidx_kernel<V, true>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg,
                                        lp, pbits, heads->ucount);
                     heads->done = true;
