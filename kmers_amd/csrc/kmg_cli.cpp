@@ -1,0 +1,560 @@
+// kmg_cli.cpp -- native (C++) host side of the hot path: the three reference programs that sit on it, driven
+// through the C ABI of libkmers_gpu.so, plus the on-disk container they read and write.
+//
+//   kmg Database.MakeDatabase -a|-q -i in -o out [-K k -k k] [-l keylen] [-z level | -Z] [-r readmap] [-D n] [-R n] [-t threads]
+//   kmg Database.Matcher      -i search.db -d ref.db -o out [-Z x] [-t threads]
+//   kmg Utils.TaxaCounts      -d ref.db -o out
+//
+// Mirrors Database/MakeDatabase.java:100-185 (option letters and defaults), Database/Matcher.java:60-250
+// (-n 0 only), Utils/TaxaCounts.java:100-150 (default mode).  The container is jar IndexedFiles.* (SURVEY.md
+// Appendix A.1-A.3): header | gzip-member blocks | index block | footer; every key's block is its own gzip
+// member, so blocks are deflated / inflated on a thread pool and written in key order
+// (FileCreator.java:385-391 enforces that order with OrderedLatches).  Options outside the GPU path
+// (minK != maxK, k > 32, -n > 0, -h, -p, -x, multi-file sets) exit with status 3 so that a wrapper can fall
+// back to the Java program.  Plain C++17 + zlib; no HIP in this file.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/kmers_gpu.h"
+
+extern "C" {
+typedef struct kmh_batch kmh_batch;
+kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k);
+void kmh_free(kmh_batch *);
+uint64_t kmh_nseq(const kmh_batch *);
+uint64_t kmh_nbases(const kmh_batch *);
+const uint8_t *kmh_bases(const kmh_batch *);
+const uint64_t *kmh_seq_off(const kmh_batch *);
+const int32_t *kmh_seq_id(const kmh_batch *);
+const uint8_t *kmh_id_ok(const kmh_batch *);
+const int64_t *kmh_seq_tok(const kmh_batch *);
+uint64_t kmh_ntok(const kmh_batch *);
+const uint64_t *kmh_name_off(const kmh_batch *);
+const char *kmh_names(const kmh_batch *);
+kmh_batch *kmh_decode_blocks(const uint8_t *data, uint64_t n, int kind);
+void kmh_decoded_free(kmh_batch *);
+uint64_t kmh_decoded_nkeys(const kmh_batch *);
+uint64_t kmh_decoded_nvals(const kmh_batch *);
+const uint64_t *kmh_decoded_keys(const kmh_batch *);
+const uint64_t *kmh_decoded_val_off(const kmh_batch *);
+const int32_t *kmh_decoded_val_a(const kmh_batch *);
+const int32_t *kmh_decoded_val_b(const kmh_batch *);
+}
+
+namespace {
+
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
+
+int g_threads = 8;
+
+// ---------------------------------------------------------------------------------------------- helpers
+std::string read_file(const std::string &path) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::string s;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+    fclose(f);
+    return s;
+}
+
+// sequence input, gzipped or not (jar Zip.ZipOrNot: sniffed from the first two bytes; gzread does the same)
+std::string read_input(const std::string &path) {
+    gzFile z = gzopen(path.c_str(), "rb");
+    if (!z) throw std::runtime_error("cannot open " + path);
+    gzbuffer(z, 1 << 20);
+    std::string s;
+    std::vector<char> buf(1 << 20);
+    int n;
+    while ((n = gzread(z, buf.data(), (unsigned)buf.size())) > 0) s.append(buf.data(), (size_t)n);
+    const bool bad = n < 0;
+    gzclose(z);
+    if (bad) throw std::runtime_error("read error in " + path);
+    return s;
+}
+
+template <typename F>
+void parallel_for(size_t n, F f) {
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)g_threads, n));
+    std::atomic<size_t> next(0);
+    std::vector<std::thread> pool;
+    std::atomic<bool> failed(false);
+    std::string err;
+    for (int t = 0; t < nt; t++)
+        pool.emplace_back([&]() {
+            try {
+                for (size_t i; (i = next.fetch_add(1)) < n;) f(i);
+            } catch (const std::exception &e) {
+                if (!failed.exchange(true)) err = e.what();
+            }
+        });
+    for (auto &th : pool) th.join();
+    if (failed) throw std::runtime_error("Exception in thread: " + err);   // jar LimitedQueueExecutor.shutdownAndCheck
+}
+
+void put_be32(std::string &s, uint32_t v) { for (int i = 3; i >= 0; i--) s.push_back((char)(v >> (8 * i))); }
+void put_be64(std::string &s, uint64_t v) { for (int i = 7; i >= 0; i--) s.push_back((char)(v >> (8 * i))); }
+uint32_t get_be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
+uint64_t get_be64(const uint8_t *p) { return ((uint64_t)get_be32(p) << 32) | get_be32(p + 4); }
+
+// commons-compress GzipCompressorOutputStream with GzipParameters(level): header 1f 8b 08 00 | mtime 0 |
+// XFL (2 at level 9, 4 at level 1, else 0) | OS 255; raw deflate; CRC32, ISIZE  
+std::string gzip_member(const uint8_t *data, size_t n, int level) {
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2");
+    std::string out("\x1f\x8b\x08\x00\x00\x00\x00\x00", 8);
+    out.push_back((char)(level == 9 ? 2 : (level == 1 ? 4 : 0)));
+    out.push_back((char)0xFF);
+    const size_t head = out.size();
+    out.resize(head + deflateBound(&z, n) + 16);
+    z.next_in = const_cast<Bytef *>(data);
+    z.avail_in = (uInt)n;
+    z.next_out = (Bytef *)&out[head];
+    z.avail_out = (uInt)(out.size() - head);
+    if (n > 0xFFFFFFF0ull || deflate(&z, Z_FINISH) != Z_STREAM_END) { deflateEnd(&z); throw std::runtime_error("deflate"); }
+    out.resize(head + z.total_out);
+    deflateEnd(&z);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)n), isz = (uint32_t)n;
+    for (int i = 0; i < 4; i++) out.push_back((char)(crc >> (8 * i)));
+    for (int i = 0; i < 4; i++) out.push_back((char)(isz >> (8 * i)));
+    return out;
+}
+
+// one gzip member starting at data (trailing bytes are ignored)
+std::string gunzip_member(const uint8_t *data, size_t n) {
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, 15 + 16) != Z_OK) throw std::runtime_error("inflateInit2");
+    std::string out;
+    std::vector<uint8_t> buf(1 << 16);
+    z.next_in = const_cast<Bytef *>(data);
+    z.avail_in = (uInt)std::min<size_t>(n, 0xFFFFFFF0u);
+    int rc;
+    do {
+        z.next_out = buf.data();
+        z.avail_out = (uInt)buf.size();
+        rc = inflate(&z, Z_NO_FLUSH);
+        if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&z); throw std::runtime_error("corrupt gzip block"); }
+        out.append((const char *)buf.data(), buf.size() - z.avail_out);
+    } while (rc != Z_STREAM_END && (z.avail_in || z.avail_out == 0));
+    inflateEnd(&z);
+    if (rc != Z_STREAM_END) throw std::runtime_error("truncated gzip block");
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------- container
+const int HEADER_ZIPPED = 64, HEADER_RAW = 41;
+
+// jar IndexedFiles.IndexedOutputFile<Integer> with an IntCompressor key (A.1).  level < 0 = unzipped (-Z).
+struct IndexedOutputFile {
+    FILE *f;
+    int level;
+    std::map<int, std::vector<std::pair<uint64_t, uint64_t>>> index;
+    uint64_t pos;
+
+    IndexedOutputFile(const std::string &path, int zip_level) : level(zip_level) {
+        f = fopen(path.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot create " + path);
+        std::string zeros(level < 0 ? HEADER_RAW : HEADER_ZIPPED, '\0');
+        fwrite(zeros.data(), 1, zeros.size(), f);
+        pos = zeros.size();
+    }
+    std::string pack(const std::string &raw, int lvl) const {
+        return level < 0 ? raw : gzip_member((const uint8_t *)raw.data(), raw.size(), lvl);
+    }
+    // a finished block (already deflated when the file is zipped) of `key`
+    void add_block(int key, const std::string &blob) {
+        if (fwrite(blob.data(), 1, blob.size(), f) != blob.size()) throw std::runtime_error("write failed");
+        index[key].push_back({pos, blob.size()});
+        pos += blob.size();
+    }
+    void close() {
+        std::string idx;
+        put_be32(idx, (uint32_t)index.size());
+        for (auto &kv : index) {
+            put_be32(idx, (uint32_t)kv.first);
+            put_be32(idx, (uint32_t)kv.second.size());
+            for (auto &b : kv.second) { put_be64(idx, b.first); put_be64(idx, b.second); }
+        }
+        const std::string iblob = pack(idx, level);
+        const uint64_t ipos = pos;
+        fwrite(iblob.data(), 1, iblob.size(), f);
+        pos += iblob.size();
+        char buf[128];
+        snprintf(buf, sizeof buf, "%-19llu\n%-19llu\n%s\n%1d\n", (unsigned long long)ipos, (unsigned long long)iblob.size(), "1", 0);
+        const std::string fblob = pack(buf, 0);          // footer and header: always level 0
+        const uint64_t fpos = pos;
+        fwrite(fblob.data(), 1, fblob.size(), f);
+        snprintf(buf, sizeof buf, "%-19llu %-19llu \n", (unsigned long long)fpos, (unsigned long long)fblob.size());
+        const std::string hblob = pack(buf, 0);
+        if ((int)hblob.size() != (level < 0 ? HEADER_RAW : HEADER_ZIPPED)) throw std::runtime_error("header size");
+        fseek(f, 0, SEEK_SET);
+        fwrite(hblob.data(), 1, hblob.size(), f);
+        if (fclose(f) != 0) throw std::runtime_error("close failed");
+        f = nullptr;
+    }
+};
+
+// jar IndexedFiles.IndexedInputFile<Integer>: header -> footer -> index -> blocks by key
+struct IndexedInputFile {
+    std::string data;
+    bool zipped, hr;
+    std::map<int, std::vector<std::pair<uint64_t, uint64_t>>> index;
+
+    std::string block(uint64_t p, uint64_t len) const {
+        if (p > data.size()) throw std::runtime_error("block outside the file");
+        len = std::min<uint64_t>(len, data.size() - p);
+        if (!zipped) return data.substr(p, len);
+        return gunzip_member((const uint8_t *)data.data() + p, len);
+    }
+    explicit IndexedInputFile(const std::string &path) : data(read_file(path)) {
+        zipped = data.size() >= 2 && (uint8_t)data[0] == 0x1f && (uint8_t)data[1] == 0x8b;   // Zip.ZipOrNot.isGZipped
+        const std::string head = block(0, 100).substr(0, HEADER_RAW);
+        unsigned long long fpos, flen, ipos, ilen;
+        if (sscanf(head.c_str(), "%llu %llu", &fpos, &flen) != 2) throw std::runtime_error("bad container header: " + path);
+        const std::string foot = block(fpos, flen);
+        int hrflag = 0;
+        char cid[32];
+        if (sscanf(foot.c_str(), "%llu %llu %31s %d", &ipos, &ilen, cid, &hrflag) != 4) throw std::runtime_error("bad container footer: " + path);
+        hr = hrflag == 1;
+        const std::string raw = block(ipos, ilen);
+        if (hr) return;   // the caller refuses -h files before touching the index
+        const uint8_t *p = (const uint8_t *)raw.data();
+        if (raw.size() < 4) throw std::runtime_error("bad index block");
+        const uint32_t n = get_be32(p);
+        size_t off = 4;
+        for (uint32_t i = 0; i < n; i++) {
+            if (off + 8 > raw.size()) throw std::runtime_error("bad index block");
+            const int key = (int)get_be32(p + off);
+            const uint32_t nb = get_be32(p + off + 4);
+            off += 8;
+            auto &v = index[key];
+            for (uint32_t b = 0; b < nb; b++) {
+                if (off + 16 > raw.size()) throw std::runtime_error("bad index block");
+                v.push_back({get_be64(p + off), get_be64(p + off + 8)});
+                off += 16;
+            }
+        }
+    }
+    std::string read_key(int key) const {
+        std::string out;
+        auto it = index.find(key);
+        if (it != index.end()) for (auto &b : it->second) out += block(b.first, b.second);
+        return out;
+    }
+};
+
+// path if it exists, else path.1, path.2, ... (Matcher.java:70-95,111-128)
+std::vector<std::string> file_set(const std::string &path) {
+    std::vector<std::string> out;
+    if (FILE *f = fopen(path.c_str(), "rb")) { fclose(f); out.push_back(path); return out; }
+    for (int i = 1;; i++) {
+        const std::string p = path + "." + std::to_string(i);
+        FILE *f = fopen(p.c_str(), "rb");
+        if (!f) break;
+        fclose(f);
+        out.push_back(p);
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------- GPU side
+struct Gpu {
+    kmg_ctx *ctx = nullptr;
+    Gpu() { if (kmg_create(0, &ctx) != KMG_OK) throw std::runtime_error("no usable GPU (kmg_create failed)"); }
+    ~Gpu() { kmg_destroy(ctx); }
+    void check(int rc) const {
+        if (rc == KMG_OK) return;
+        const std::string msg = kmg_last_error(ctx);
+        if (rc == KMG_EUNSUPPORTED) throw Unsupported(msg);
+        if (rc == KMG_EINVAL) throw std::runtime_error("InconsistentDataException: " + msg);
+        throw std::runtime_error("kmers_gpu error " + std::to_string(rc) + ": " + msg);
+    }
+};
+
+struct DbInfo { int k, key_len, rc, kind; uint64_t U, V; };
+DbInfo db_info(const kmg_db *db) {
+    DbInfo d;
+    kmg_db_info(db, &d.k, &d.key_len, &d.rc, &d.kind, &d.U, &d.V);
+    return d;
+}
+
+// FileCreator.create (FileCreator.java:117-217): meta under key -1, then every key 0..4^l-1 in order (each
+// gets a block, empty ones included)
+void write_database(const Gpu &g, const kmg_db *db, const std::string &path, int level) {
+    const DbInfo d = db_info(db);
+    const size_t nkeys = (size_t)1 << (2 * d.key_len);
+    uint64_t nbytes = 0;
+    g.check(kmg_db_encode(g.ctx, db, nullptr, 0, &nbytes, nullptr));
+    std::vector<uint8_t> bytes(std::max<uint64_t>(nbytes, 1));
+    std::vector<uint64_t> off(nkeys + 1);
+    g.check(kmg_db_encode(g.ctx, db, bytes.data(), nbytes, &nbytes, off.data()));
+    std::string meta;                                            // FileCreator.java:153-164
+    meta.push_back((char)d.k); meta.push_back((char)d.k); meta.push_back((char)d.key_len);
+    if (d.kind == KMG_PAYLOAD_TAXON) { put_be32(meta, 1); put_be32(meta, 2048); }                 // CountDataType.java:115-121
+    else { put_be32(meta, 2); put_be32(meta, 257); put_be32(meta, 2052); }                        // SetCompressor ++ ReadPosDataType
+    meta.push_back((char)(d.rc ? 1 : 0));
+    std::vector<std::string> blobs(nkeys);
+    if (level >= 0)
+        parallel_for(nkeys, [&](size_t key) { blobs[key] = gzip_member(bytes.data() + off[key], off[key + 1] - off[key], level); });
+    IndexedOutputFile out(path, level);
+    out.add_block(-1, out.pack(meta, level));
+    for (size_t key = 0; key < nkeys; key++) {
+        if (level >= 0) out.add_block((int)key, blobs[key]);
+        else out.add_block((int)key, std::string((const char *)bytes.data() + off[key], off[key + 1] - off[key]));
+    }
+    out.close();
+}
+
+// new KmerFile(file, dataType) + its decoded content uploaded to the GPU
+kmg_db *open_database(const Gpu &g, const std::string &path) {
+    IndexedInputFile f(path);
+    if (f.hr) throw Unsupported("human-readable (-h) databases are read by the Java path");
+    const std::string m = f.read_key(-1);                                   // KmerFile.getMetaData, KmerFile.java:284-288
+    if (m.size() < 8) throw std::runtime_error("bad meta block: " + path);
+    const int min_k = (uint8_t)m[0], max_k = (uint8_t)m[1], key_len = (uint8_t)m[2];
+    const uint32_t nid = get_be32((const uint8_t *)m.data() + 3);
+    if (m.size() < 8 + 4ull * nid) throw std::runtime_error("bad meta block: " + path);
+    std::vector<uint32_t> ids(nid);
+    for (uint32_t i = 0; i < nid; i++) ids[i] = get_be32((const uint8_t *)m.data() + 7 + 4 * i);
+    const int rc = m[7 + 4 * nid] == 1;
+    if (min_k != max_k || max_k > 32) throw Unsupported("minK != maxK or k > 32: use the Java path");
+    int kind;
+    if (ids == std::vector<uint32_t>{2048}) kind = KMG_PAYLOAD_TAXON;
+    else if (ids == std::vector<uint32_t>{257, 2052}) kind = KMG_PAYLOAD_READPOS;
+    else throw std::runtime_error("UnexpectedDataTypeException: " + path);   // KmerFile.java:30-33
+    // blocks of every key >= 0, inflated in parallel, concatenated in key order
+    std::vector<std::pair<uint64_t, uint64_t>> blocks;
+    for (auto &kv : f.index) if (kv.first >= 0) for (auto &b : kv.second) blocks.push_back(b);
+    std::vector<std::string> parts(blocks.size());
+    parallel_for(blocks.size(), [&](size_t i) { parts[i] = f.block(blocks[i].first, blocks[i].second); });
+    std::string all;
+    size_t total = 0;
+    for (auto &p : parts) total += p.size();
+    all.reserve(total);
+    for (auto &p : parts) { all += p; std::string().swap(p); }
+    kmh_batch *dec = kmh_decode_blocks((const uint8_t *)all.data(), all.size(), kind);
+    if (!dec) throw std::runtime_error("corrupt k-mer blocks (or k > 32): " + path);
+    kmg_db *db = nullptr;
+    const int r = kmg_db_load(g.ctx, max_k, key_len, rc, kind, kmh_decoded_keys(dec), kmh_decoded_nkeys(dec),
+                              kmh_decoded_val_off(dec), kmh_decoded_val_a(dec), kmh_decoded_val_b(dec), &db);
+    kmh_decoded_free(dec);
+    g.check(r);
+    return db;
+}
+
+// ---------------------------------------------------------------------------------------------- programs
+struct Args {
+    std::map<char, std::string> val;
+    std::map<char, bool> flag;
+    bool has(char c) const { return val.count(c) || flag.count(c); }
+    std::string get(char c, const std::string &dflt = "") const { auto it = val.find(c); return it == val.end() ? dflt : it->second; }
+    int geti(char c, int dflt) const { auto it = val.find(c); return it == val.end() ? dflt : atoi(it->second.c_str()); }
+};
+Args parse_args(int argc, char **argv, int from, const std::string &with_value, const std::string &flags) {
+    Args a;
+    for (int i = from; i < argc; i++) {
+        const std::string s = argv[i];
+        if (s.size() != 2 || s[0] != '-') throw std::runtime_error("unexpected argument " + s);
+        if (flags.find(s[1]) != std::string::npos) a.flag[s[1]] = true;
+        else if (with_value.find(s[1]) != std::string::npos) {
+            if (i + 1 >= argc) throw std::runtime_error("option " + s + " needs a value");
+            a.val[s[1]] = argv[++i];
+        } else throw Unsupported("option " + s + " is not on the GPU path");
+    }
+    return a;
+}
+
+int make_database(int argc, char **argv) {
+    const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmN", "aqZv");
+    for (char c : std::string("SmN")) if (a.has(c)) throw Unsupported(std::string("option -") + c + " is not on the GPU path");
+    const int k = a.geti('K', 32), min_k = a.geti('k', 24), key_len = a.geti('l', 6);     // MakeDatabase.java:106-109
+    const int level = a.has('Z') ? -1 : a.geti('z', 5);
+    g_threads = std::max(1, a.geti('t', g_threads));
+    if (min_k != k) throw Unsupported("minK != maxK is not supported on the GPU path");
+    if (a.has('a') == a.has('q')) throw std::runtime_error("exactly one of -a (FASTA reference) / -q (FASTQ reads) is required");
+    if (!a.has('i') || !a.has('o')) throw std::runtime_error("-i and -o are required");
+    const bool reads = a.has('q');
+    if (reads && !a.has('r')) throw std::runtime_error("-r <read map file> is required with -q");   // MakeDatabase.java:172-173
+    const std::string data = read_input(a.get('i'));
+    kmh_batch *b = kmh_parse((const uint8_t *)data.data(), data.size(), reads ? 1 : 0, k);
+    const uint64_t nseq = kmh_nseq(b);
+    const uint64_t *off = kmh_seq_off(b);
+    if (!reads) {
+        const uint8_t *ok = kmh_id_ok(b);
+        for (uint64_t s = 0; s < nseq; s++)   // Integer.parseInt throws at the sequence's first k-mer
+            if (!ok[s] && off[s + 1] - off[s] >= (uint64_t)k) {
+                kmh_free(b);
+                throw std::runtime_error("NumberFormatException: FASTA header of sequence " + std::to_string(s) + " is not an int");
+            }
+    }
+    Gpu g;
+    g.check(kmg_build_begin(g.ctx, k, key_len, reads ? 0 : 1, reads ? KMG_PAYLOAD_READPOS : KMG_PAYLOAD_TAXON));
+    if (a.has('D') || a.has('R')) g.check(kmg_build_set_filters(g.ctx, a.geti('D', -1), a.geti('R', -1)));
+    std::vector<int32_t> ridx(reads ? nseq : 0);
+    g.check(kmg_build_add(g.ctx, kmh_bases(b), kmh_nbases(b), off, reads ? nullptr : kmh_seq_id(b),
+                          reads ? kmh_seq_tok(b) : nullptr, nseq, reads ? ridx.data() : nullptr));
+    kmg_db *db = nullptr;
+    uint64_t nwin = 0;
+    g.check(kmg_build_finish(g.ctx, &db, &nwin));
+    if (reads) {
+        // ReadIDMapping.geNext prints a header each time a new index is handed out (gzip text, one per line)
+        gzFile z = gzopen(a.get('r').c_str(), "wb");
+        if (!z) throw std::runtime_error("cannot create " + a.get('r'));
+        const int64_t *tok = kmh_seq_tok(b);
+        const uint64_t *noff = kmh_name_off(b);
+        const char *names = kmh_names(b);
+        int32_t last = -1;
+        for (uint64_t s = 0; s < nseq; s++)
+            if (ridx[s] >= 0 && ridx[s] != last) {
+                gzwrite(z, names + noff[tok[s]], (unsigned)(noff[tok[s] + 1] - noff[tok[s]]));
+                gzwrite(z, "\n", 1);
+                last = ridx[s];
+            }
+        gzclose(z);
+    }
+    kmh_free(b);
+    write_database(g, db, a.get('o'), level);
+    if (a.has('v')) {
+        const DbInfo d = db_info(db);
+        fprintf(stderr, "%llu k-mer windows, %llu distinct k-mers, %llu values\n", (unsigned long long)nwin,
+                (unsigned long long)d.U, (unsigned long long)d.V);
+    }
+    kmg_db_free(db);
+    return 0;
+}
+
+struct HostDb {
+    DbInfo d;
+    std::vector<uint64_t> keys, val_off;
+    std::vector<int32_t> a, b;
+};
+HostDb fetch(const Gpu &g, const kmg_db *db) {
+    HostDb h;
+    h.d = db_info(db);
+    h.keys.resize(h.d.U + 1); h.val_off.resize(h.d.U + 1); h.a.resize(h.d.V + 1); h.b.resize(h.d.V + 1);
+    g.check(kmg_db_fetch(db, h.keys.data(), h.val_off.data(), h.a.data(), h.b.data(), nullptr));
+    return h;
+}
+
+// "r:p|r:p" (SetCompressor.toString over ReadPosDataType.java:46-49) or "TxC|TxC" (CountDataType.java:109-113;
+// counts print as the stored byte, i.e. saturated at 255, CountDataType.java:40)
+void append_values(std::string &s, const HostDb &h, uint64_t i) {
+    char buf[48];
+    for (uint64_t v = h.val_off[i]; v < h.val_off[i + 1]; v++) {
+        if (v != h.val_off[i]) s.push_back('|');
+        if (h.d.kind == KMG_PAYLOAD_READPOS) snprintf(buf, sizeof buf, "%d:%d", h.a[v], h.b[v]);
+        else snprintf(buf, sizeof buf, "%dx%d", h.a[v], std::min(h.b[v], 255));
+        s += buf;
+    }
+}
+
+int matcher(int argc, char **argv) {
+    const Args a = parse_args(argc, argv, 2, "idozZnt", "");
+    if (a.geti('n', 0) != 0) throw Unsupported("inexact search (-n > 0) stays on the Java path");
+    if (!a.has('i') || !a.has('d') || !a.has('o')) throw std::runtime_error("-i, -d and -o are required");
+    g_threads = std::max(1, a.geti('t', g_threads));
+    const auto dbf = file_set(a.get('d')), sf = file_set(a.get('i'));
+    if (dbf.size() != 1 || sf.size() != 1) throw Unsupported("multi-file databases: use the Java path");
+    Gpu g;
+    kmg_db *ref = open_database(g, dbf[0]), *search = open_database(g, sf[0]);
+    const DbInfo rd = db_info(ref), sd = db_info(search);
+    if (!rd.rc)   // DB.java:57-64
+        throw std::runtime_error("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included");
+    std::vector<int64_t> hit(sd.U + 1);
+    uint64_t nh = 0;
+    g.check(kmg_match(g.ctx, search, ref, hit.data(), &nh));
+    const HostDb hs = fetch(g, search), hr = fetch(g, ref);
+    // one line per matched search k-mer, ascending (Matcher.java:247-249, ResultsDataType.java:15-35):
+    //   KMER \t values of the search k-mer \t -|values of the reference k-mer       ("-" = empty KmerDiff)
+    std::vector<uint64_t> rows;
+    rows.reserve(nh);
+    for (uint64_t i = 0; i < sd.U; i++) if (hit[i] >= 0) rows.push_back(i);
+    const size_t nchunk = (rows.size() + 65535) / 65536;
+    std::vector<std::string> text(nchunk);
+    parallel_for(nchunk, [&](size_t c) {
+        std::string &s = text[c];
+        const size_t lo = c * 65536, hi = std::min(rows.size(), lo + 65536);
+        for (size_t r = lo; r < hi; r++) {
+            const uint64_t i = rows[r], key = hs.keys[i];
+            for (int p = 0; p < sd.k; p++) s.push_back("ACTG"[(key >> (62 - 2 * p)) & 3]);   // Sequence.java:117-134
+            s.push_back('\t');
+            append_values(s, hs, i);
+            s += "\t-|";
+            append_values(s, hr, (uint64_t)hit[i]);
+            s.push_back('\n');
+        }
+    });
+    if (a.has('Z')) {
+        FILE *f = fopen(a.get('o').c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot create " + a.get('o'));
+        for (auto &s : text) fwrite(s.data(), 1, s.size(), f);
+        fclose(f);
+    } else {
+        gzFile z = gzopen(a.get('o').c_str(), "wb");    // default level, Matcher.java:138-139
+        if (!z) throw std::runtime_error("cannot create " + a.get('o'));
+        for (auto &s : text) if (!s.empty()) gzwrite(z, s.data(), (unsigned)s.size());
+        gzclose(z);
+    }
+    kmg_db_free(ref);
+    kmg_db_free(search);
+    return 0;
+}
+
+int taxa_counts(int argc, char **argv) {
+    const Args a = parse_args(argc, argv, 2, "dot", "");
+    if (!a.has('d') || !a.has('o')) throw std::runtime_error("-d and -o are required");
+    const auto dbf = file_set(a.get('d'));
+    if (dbf.size() != 1) throw Unsupported("multi-file databases: use the Java path");
+    Gpu g;
+    kmg_db *ref = open_database(g, dbf[0]);
+    const DbInfo d = db_info(ref);
+    uint64_t n = std::max<uint64_t>(d.V, 1);
+    std::vector<int32_t> t(n);
+    std::vector<int64_t> m(n), q(n);
+    g.check(kmg_taxacounts(g.ctx, ref, t.data(), m.data(), q.data(), &n));
+    FILE *f = fopen(a.get('o').c_str(), "w");
+    if (!f) throw std::runtime_error("cannot create " + a.get('o'));
+    for (uint64_t i = 0; i < n; i++) fprintf(f, "%d\t%lld\t%lld\n", t[i], (long long)m[i], (long long)q[i]);   // TaxaCounts.java:142-150
+    fclose(f);
+    kmg_db_free(ref);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 2) {
+        fprintf(stderr, "usage: kmg Database.MakeDatabase|Database.Matcher|Utils.TaxaCounts <options>\n");
+        return 1;
+    }
+    std::string prog = argv[1];
+    const size_t dot = prog.rfind('.');
+    if (dot != std::string::npos) prog = prog.substr(dot + 1);
+    try {
+        if (prog == "MakeDatabase") return make_database(argc, argv);
+        if (prog == "Matcher") return matcher(argc, argv);
+        if (prog == "TaxaCounts") return taxa_counts(argc, argv);
+        fprintf(stderr, "unknown program %s\n", argv[1]);
+        return 1;
+    } catch (const Unsupported &e) {
+        fprintf(stderr, "kmg: not on the GPU path: %s\n", e.what());
+        return 3;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "kmg: %s\n", e.what());
+        return 1;
+    }
+}

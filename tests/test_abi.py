@@ -40,3 +40,20 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in src.replace("oracle/", "oracle/") or "import oracle" not in src, f
                 assert "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_native_cli_builds_and_refuses_what_is_off_the_gpu_path():
+    """kmers_amd/kmg (C++ drivers + container codec): argument handling needs no GPU; options the GPU path does
+    not cover exit with status 3 so that a wrapper can fall back to the Java program."""
+    import os
+    import subprocess
+    import kmers_amd
+    kmg = os.path.join(os.path.dirname(kmers_amd.__file__), "kmg")
+    assert os.path.exists(kmg)
+    run = lambda *a: subprocess.run([kmg] + list(a), capture_output=True, text=True, timeout=60)
+    assert run().returncode == 1
+    assert run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y").returncode == 3          # default -k 24 != -K 32
+    assert run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y", "-K", "31", "-k", "31", "-S", "5").returncode == 3
+    assert run("Database.Matcher", "-i", "a", "-d", "b", "-o", "c", "-n", "1").returncode == 3
+    r = run("Database.MakeDatabase", "-a", "-q", "-i", "x", "-o", "y", "-K", "31", "-k", "31")
+    assert r.returncode == 1 and "exactly one of" in r.stderr

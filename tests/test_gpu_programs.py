@@ -66,3 +66,62 @@ def test_programs_end_to_end(tmp_path):
     assert open(str(tmp_path / "cli.tsv")).read() == open(str(tmp_path / "counts.tsv")).read()
     assert cli(["Database.Matcher", "-i", readdb, "-d", str(tmp_path / "cli.db"), "-o", str(tmp_path / "cli.txt"), "-Z", "x"]) == 0
     assert open(str(tmp_path / "cli.txt"), "rb").read() == o_reads.match_lines(o_ref, hit)
+
+
+def test_native_cli_matches_python_drivers(tmp_path):
+    """kmers_amd/kmg (C++: container codec with threaded zlib + drivers over the C ABI) against the Python
+    drivers and the oracle: unzipped DB files byte for byte, zipped ones by payload, texts byte for byte."""
+    import subprocess
+    import kmers_amd as km
+    from kmers_amd import programs, synth
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    kmg = os.path.join(os.path.dirname(km.__file__), "kmg")
+    assert os.path.exists(kmg), "build() must have produced kmers_amd/kmg"
+    taxa, genomes = synth.random_genomes(81, 4, 9000, first_taxon=40, shared_frac=0.2)
+    reads = synth.random_reads(82, genomes, 1200, 110, 0.01, n_rate=0.003)
+    fa, fq = str(tmp_path / "ref.fa.gz"), str(tmp_path / "reads.fq")
+    open(fa, "wb").write(gzip.compress(synth.fasta_bytes(taxa, genomes)))
+    open(fq, "wb").write(synth.fastq_bytes(reads))
+    k, l = 27, 4
+    o_ref = OracleDB(synth.fasta_bytes(taxa, genomes), 0, k, l)
+    o_reads = OracleDB(synth.fastq_bytes(reads), 1, k, l)
+    p = lambda n: str(tmp_path / n)
+
+    def run(*args, rc=0):
+        r = subprocess.run([kmg] + list(args), capture_output=True, text=True, timeout=110)
+        assert r.returncode == rc, r.stderr
+        return r
+
+    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("ref.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z")
+    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("refz.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-z", "9")
+    run("Database.MakeDatabase", "-q", "-i", fq, "-o", p("reads.db"), "-r", p("map.gz"), "-K", str(k), "-k", str(k), "-l", str(l))
+    R.write_indexed_file(p("ref.want"), _oracle_blocks(o_ref), None)
+    assert open(p("ref.db"), "rb").read() == open(p("ref.want"), "rb").read()
+    assert R.read_indexed_file(p("refz.db")) == R.read_indexed_file(p("ref.want"))
+    R.write_indexed_file(p("reads.want"), _oracle_blocks(o_reads), 5)
+    assert R.read_indexed_file(p("reads.db")) == R.read_indexed_file(p("reads.want"))
+    assert gzip.open(p("map.gz"), "rt").read().splitlines() == o_reads.names
+    # files written by either side are read by the other
+    ctx = km.Context(0)
+    again = programs.open_database(ctx, p("refz.db"))
+    assert np.array_equal(again.fetch()["keys"], o_ref.keys) and np.array_equal(again.fetch()["val_b"], o_ref.val_b)
+    programs.make_database(ctx, fq, p("reads.py.db"), "q", k, k, l, zip_level=1, read_map_path=p("map.py.gz"))
+    ctx.close()
+    hit, _ = o_reads.match(o_ref)
+    want = o_reads.match_lines(o_ref, hit)
+    run("Database.Matcher", "-i", p("reads.py.db"), "-d", p("refz.db"), "-o", p("m.txt"), "-Z", "x")
+    assert open(p("m.txt"), "rb").read() == want
+    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("m.gz"))
+    assert gzip.open(p("m.gz"), "rb").read() == want
+    run("Utils.TaxaCounts", "-d", p("refz.db"), "-o", p("c.tsv"))
+    t, m, q = o_ref.taxacounts()
+    assert open(p("c.tsv")).read().splitlines() == ["%d\t%d\t%d" % x for x in zip(t, m, q)]
+    # -D / -R filters reach the kernel
+    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("f.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z", "-D", "2", "-R", "5")
+    o_f = OracleDB(synth.fasta_bytes(taxa, genomes), 0, k, l, dust=2, runofsame=5)
+    R.write_indexed_file(p("f.want"), _oracle_blocks(o_f), None)
+    assert open(p("f.db"), "rb").read() == open(p("f.want"), "rb").read()
+    # what is not on the GPU path exits with status 3 (wrapper falls back to Java)
+    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("x.db"), "-K", "32", "-k", "24", rc=3)
+    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-n", "2", rc=3)
