@@ -122,6 +122,13 @@ void kmg_db_free(kmg_db *db);
 int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint64_t cap, uint64_t *n_bytes,
                   uint64_t *block_off);
 
+/* kmg_db_merge: one database from several (replaces DB.kmers over a multi-file database, Database/DB.java:99-109
+ *   + jar StreamUtils.mergeSortedStreams / groupAndReduceStream: k-way merge of the files' ascending k-mer
+ *   streams, equal k-mers reduced with addAll -- per-taxon counts add (as long in Java; here int32, saturating),
+ *   read-position sets unite).  Inputs must agree in datatype, k and key_len (DB.java:36-42,57-64 ->
+ *   KMG_EINVAL); they stay valid.  Also the local step after a key-range exchange between GPUs. */
+int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, kmg_db **out);
+
 /* ---- stage 3: match  (replaces DB.getNearestKmers quick branch, DB.java:76-90,129-137) -------
  * Sorted inner join of the search database's distinct k-mers against the reference database:
  * hit_index[i] = index (into the reference CSR) of the k-mer equal to search k-mer i, else -1.

@@ -192,9 +192,18 @@ class FileCreator:
         return KmerDatabase(self.ctx, h)
 
 
+def merge_databases(dbs):
+    """kmg_db_merge: DB.kmers over several files (DB.java:99-109) -- equal k-mers reduced with addAll."""
+    ctx = dbs[0].ctx
+    arr = (C.c_void_p * len(dbs))(*[d.h for d in dbs])
+    h = C.c_void_p()
+    ctx.check(ctx.lib.kmg_db_merge(ctx.h, arr, len(dbs), C.byref(h)))
+    return KmerDatabase(ctx, h)
+
+
 class DB:
-    """Database/DB.java over device-resident reference databases (one file only for now; the
-    multi-file merge of DB.kmers, DB.java:99-109, is a 'next' row)."""
+    """Database/DB.java over device-resident reference databases.  A multi-file database (name.1 .. name.N,
+    Matcher.java:80-89) is merged on the GPU once, at construction (DB.kmers, DB.java:99-109)."""
 
     def __init__(self, files):
         if not files:
@@ -207,9 +216,8 @@ class DB:
                 raise InconsistentDataException(
                     _lib.KMG_EINVAL, "Files contains different kmer parameters (min/max length, key length or "
                     "reverse complement included")
-        if len(files) != 1:
-            raise KmersGpuError(_lib.KMG_EUNSUPPORTED, "multi-file reference databases are not supported yet")
         self.files = list(files)
+        self.merged = files[0] if len(files) == 1 else merge_databases(self.files)
         self.ctx = f0.ctx
         self.min_length, self.max_length, self.key_length = f0.min_length, f0.max_length, f0.key_length
         self.max_key = 4 ** self.key_length
@@ -227,13 +235,13 @@ class DB:
             raise KmersGpuError(_lib.KMG_EUNSUPPORTED, "inexact search (-n > 0) is not on the GPU path")
         hit = np.empty(search.n_unique, np.int64)
         nh = C.c_uint64()
-        self.ctx.check(self.ctx.lib.kmg_match(self.ctx.h, search.h, self.files[0].h, _ptr(hit), C.byref(nh)))
+        self.ctx.check(self.ctx.lib.kmg_match(self.ctx.h, search.h, self.merged.h, _ptr(hit), C.byref(nh)))
         return hit, nh.value
 
 
 def taxa_counts(db):
     """Utils/TaxaCounts.java default mode -> (taxon[], match[], unique[]) ascending by taxon."""
-    f = db.files[0] if isinstance(db, DB) else db
+    f = db.merged if isinstance(db, DB) else db
     cap = max(f.n_values, 1)
     t = np.empty(cap, np.int32)
     m = np.empty(cap, np.int64)

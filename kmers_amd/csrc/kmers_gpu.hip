@@ -693,6 +693,108 @@ extern "C" int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint6
     return KMG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ merge
+extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, kmg_db **out) {
+    if (!ctx || !dbs || !out || n_dbs < 1) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *out = nullptr;
+    const kmg_db *d0 = dbs[0];
+    u64 Vt = 0;
+    int rc = 1;
+    for (int i = 0; i < n_dbs; i++) {
+        const kmg_db *d = dbs[i];
+        if (!d || d->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
+        if (d->kind != d0->kind) return fail(ctx, KMG_EINVAL, "Files contain different datatypes");          // DB.java:36-42
+        if (d->k != d0->k || d->key_len != d0->key_len)                                                    // DB.java:57-64
+            return fail(ctx, KMG_EINVAL, "Files contains different kmer parameters (min/max length, key length or reverse complement included");
+        Vt += d->V;
+        rc &= d->rc;
+    }
+    if (Vt >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 values in the merged database");
+    KMG_HIP(hipSetDevice(ctx->device));
+    const bool reads = d0->kind == KMG_PAYLOAD_READPOS;
+    const u32 n = (u32)Vt;
+
+    kmg_db *db = new (std::nothrow) kmg_db();
+    if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+    std::unique_ptr<kmg_db, void (*)(kmg_db *)> db_guard(db, db_release);
+    db->ctx = ctx; db->k = d0->k; db->key_len = d0->key_len; db->rc = rc; db->kind = d0->kind;
+    const u32 nbuckets = 1u << (2 * db->key_len);
+
+    PoolBuf k0(ctx), v0(ctx), k1(ctx), v1(ctx), table(ctx), agg(ctx), seg(ctx), totals(ctx), fk(ctx), fp(ctx), pk(ctx), pp(ctx);
+    KMG_ALLOC(totals, 64);
+    KMG_HIP(hipMemsetAsync(totals.p, 0, 64, ctx->stream));
+    KMG_ALLOC(k0, ((size_t)n + 1) * 8); KMG_ALLOC(v0, ((size_t)n + 1) * 8);
+    KMG_ALLOC(k1, ((size_t)n + 1) * 8); KMG_ALLOC(v1, ((size_t)n + 1) * 8);
+    u64 base = 0;
+    for (int i = 0; i < n_dbs; i++) {
+        const kmg_db *d = dbs[i];
+        if (d->V == 0) continue;
+        if (reads && !d->vals_packed && !d->val_a) return fail(ctx, KMG_ESTATE, "database has no values");
+        hipLaunchKernelGGL(mg_expand_kernel, dim3(div_up_u64(d->V, 256)), dim3(256), 0, ctx->stream, d->keys, d->val_off, d->U, d->V,
+                           d->val_a, d->val_b, reads ? d->vals_packed : nullptr, d->kind, k0.as<u64>(), v0.as<u64>(), base);
+        base += d->V;
+    }
+    bool in1 = false;
+    if (n > 0) {
+        // inside a k-mer: taxa ascending (upper payload half) | (read, pos) ascending (whole payload)
+        std::vector<SortPass> payload;
+        if (reads) for (int sh = 0; sh < 48; sh += RS_BITS) payload.push_back({sh, RS_BITS, RS_SRC_VAL64});
+        else for (int sh = 32; sh < 64; sh += RS_BITS) payload.push_back({sh, RS_BITS, RS_SRC_VAL64});
+        const int pbits = choose_pbits(n, 2 * db->k);
+        const u32 ntiles = div_up_u64(n, RS_TILE);
+        KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
+        KMG_ALLOC(agg, (size_t)(div_up_u64(std::max<u64>((u64)RS_DIGITS * ntiles, n), SCAN_TILE) + 1) * 8);
+        KMG_ALLOC(seg, (((size_t)1 << pbits) + 4) * 4);
+        KMG_TRY(hybrid_sort_records<u64>(ctx, k0.as<u64>(), v0.as<u64>(), k1.as<u64>(), v1.as<u64>(), n, 64 - 2 * db->k, payload,
+                                         table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, false, &in1));
+    } else {
+        KMG_ALLOC(agg, 64);
+    }
+    const u64 *sk = in1 ? k1.as<u64>() : k0.as<u64>();
+    const u64 *sv = in1 ? v1.as<u64>() : v0.as<u64>();
+    if (reads) {
+        KMG_TRY(reduce_read_keys(ctx, sk, n, db, totals.as<u64>()));
+        db->vals_packed = (u64 *)(in1 ? v1.detach() : v0.detach());
+    } else {
+        void *p;
+        if (ctx->pool.alloc(&p, ((size_t)n + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+        db->keys = (u64 *)p;
+        if (ctx->pool.alloc(&p, ((size_t)n + 2) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+        db->val_off = (u64 *)p;
+        if (ctx->pool.alloc(&p, ((size_t)n + 1) * 4) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+        db->val_a = (int32_t *)p;
+        if (ctx->pool.alloc(&p, ((size_t)n + 1) * 4) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+        db->val_b = (int32_t *)p;
+        if (ctx->pool.alloc(&p, ((size_t)nbuckets + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+        db->bucket_off = (u64 *)p;
+        if (n > 0) {
+            KMG_ALLOC(fk, (size_t)n * 4); KMG_ALLOC(fp, (size_t)n * 4);
+            KMG_ALLOC(pk, ((size_t)n + 1) * 8); KMG_ALLOC(pp, ((size_t)n + 1) * 8);
+            KMG_HIP(hipMemsetAsync(db->val_b, 0, ((size_t)n + 1) * 4, ctx->stream));
+            const dim3 grid(div_up_u64(n, 256)), blk(256);
+            hipLaunchKernelGGL(mg_flags_kernel, grid, blk, 0, ctx->stream, sk, sv, (u64)n, fk.as<u32>(), fp.as<u32>());
+            KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, fk.as<u32>(), pk.as<u64>(), n, OpSum(), 0ull, agg.as<u64>(),
+                                                        totals.as<u64>() + 0, false, KP_SCAN)));
+            KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, fp.as<u32>(), pp.as<u64>(), n, OpSum(), 0ull, agg.as<u64>(),
+                                                        totals.as<u64>() + 1, false, KP_SCAN)));
+            hipLaunchKernelGGL(mg_write_kernel, grid, blk, 0, ctx->stream, sk, sv, (u64)n, fk.as<u32>(), fp.as<u32>(), pk.as<u64>(),
+                               pp.as<u64>(), db->keys, db->val_off, db->val_a, reinterpret_cast<u32 *>(db->val_b));
+            hipLaunchKernelGGL(mg_clamp_kernel, grid, blk, 0, ctx->stream, reinterpret_cast<u32 *>(db->val_b), totals.as<u64>());
+        }
+        hipLaunchKernelGGL(rd_buckets_kernel, dim3(div_up_u64(nbuckets + 1, 256)), dim3(256), 0, ctx->stream, db->keys,
+                           totals.as<u64>(), db->val_off, db->bucket_off, nbuckets, db->key_len);
+    }
+    u64 tot[2] = {0, 0};
+    KMG_HIP(hipMemcpyAsync(tot, totals.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    KMG_HIP(hipGetLastError());
+    db->U = tot[0];
+    db->V = tot[1];
+    *out = db_guard.release();
+    return KMG_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ match
 static int match_locked(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, long long *d_hit, u64 *d_nhits) {
     if (search->ctx != ctx || ref->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");

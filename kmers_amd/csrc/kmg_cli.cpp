@@ -10,7 +10,7 @@
 // Appendix A.1-A.3): header | gzip-member blocks | index block | footer; every key's block is its own gzip
 // member, so blocks are deflated / inflated on a thread pool and written in key order
 // (FileCreator.java:385-391 enforces that order with OrderedLatches).  Options outside the GPU path
-// (minK != maxK, k > 32, -n > 0, -h, -p, -x, multi-file sets) exit with status 3 so that a wrapper can fall
+// (minK != maxK, k > 32, -n > 0, -h, -p, -x, -S) exit with status 3 so that a wrapper can fall
 // back to the Java program.  Plain C++17 + zlib; no HIP in this file.
 #include <stdint.h>
 #include <stdio.h>
@@ -356,6 +356,21 @@ kmg_db *open_database(const Gpu &g, const std::string &path) {
     return db;
 }
 
+// a database given as one file or as name.1 .. name.N (Matcher.java:80-89): the files are merged on the GPU
+// (DB.kmers, DB.java:99-109)
+kmg_db *open_database_set(const Gpu &g, const std::string &path) {
+    const auto files = file_set(path);
+    if (files.empty()) throw std::runtime_error("cannot open " + path);
+    std::vector<kmg_db *> dbs;
+    for (auto &f : files) dbs.push_back(open_database(g, f));
+    if (dbs.size() == 1) return dbs[0];
+    kmg_db *out = nullptr;
+    const int r = kmg_db_merge(g.ctx, dbs.data(), (int)dbs.size(), &out);
+    for (auto *d : dbs) kmg_db_free(d);
+    g.check(r);
+    return out;
+}
+
 // ---------------------------------------------------------------------------------------------- programs
 struct Args {
     std::map<char, std::string> val;
@@ -467,10 +482,8 @@ int matcher(int argc, char **argv) {
     if (a.geti('n', 0) != 0) throw Unsupported("inexact search (-n > 0) stays on the Java path");
     if (!a.has('i') || !a.has('d') || !a.has('o')) throw std::runtime_error("-i, -d and -o are required");
     g_threads = std::max(1, a.geti('t', g_threads));
-    const auto dbf = file_set(a.get('d')), sf = file_set(a.get('i'));
-    if (dbf.size() != 1 || sf.size() != 1) throw Unsupported("multi-file databases: use the Java path");
     Gpu g;
-    kmg_db *ref = open_database(g, dbf[0]), *search = open_database(g, sf[0]);
+    kmg_db *ref = open_database_set(g, a.get('d')), *search = open_database_set(g, a.get('i'));
     const DbInfo rd = db_info(ref), sd = db_info(search);
     if (!rd.rc)   // DB.java:57-64
         throw std::runtime_error("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included");
@@ -517,10 +530,8 @@ int matcher(int argc, char **argv) {
 int taxa_counts(int argc, char **argv) {
     const Args a = parse_args(argc, argv, 2, "dot", "");
     if (!a.has('d') || !a.has('o')) throw std::runtime_error("-d and -o are required");
-    const auto dbf = file_set(a.get('d'));
-    if (dbf.size() != 1) throw Unsupported("multi-file databases: use the Java path");
     Gpu g;
-    kmg_db *ref = open_database(g, dbf[0]);
+    kmg_db *ref = open_database_set(g, a.get('d'));
     const DbInfo d = db_info(ref);
     uint64_t n = std::max<uint64_t>(d.V, 1);
     std::vector<int32_t> t(n);

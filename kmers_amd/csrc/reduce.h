@@ -282,3 +282,54 @@ __global__ void enc_blockoff_kernel(const u64 *__restrict__ bucket_off, const u6
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b <= nbuckets) block_off[b] = enc_off[bucket_off[b]];
 }
+
+
+// ---- merge of databases (DB.kmers over several files, Database/DB.java:99-109: k-way merge of the files'
+// ascending k-mer streams, equal k-mers reduced with addAll -- CountMap counts add, read sets unite) --------
+// Expand one CSR into (key, payload) records appended at out[base ..): one thread per value.
+//   taxon DB : payload = (taxon ^ sign bit) << 32 | count      (sorted by the upper half inside a k-mer)
+//   read DB  : payload = read << 16 | pos16                     (sorted whole inside a k-mer)
+__global__ void mg_expand_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ val_off, u64 U, u64 V,
+                                 const int32_t *__restrict__ val_a, const int32_t *__restrict__ val_b,
+                                 const u64 *__restrict__ packed, int kind, u64 *__restrict__ out_keys,
+                                 u64 *__restrict__ out_vals, u64 base) {
+    const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    u64 lo = 0, hi = U;                       // last k-mer whose list starts at or before v
+    while (hi - lo > 1) {
+        const u64 mid = (lo + hi) >> 1;
+        if (val_off[mid] <= v) lo = mid; else hi = mid;
+    }
+    out_keys[base + v] = keys[lo];
+    u64 pay;
+    if (kind == KMG_PAYLOAD_TAXON) pay = ((u64)((u32)val_a[v] ^ 0x80000000u) << 32) | (u32)val_b[v];
+    else pay = packed ? packed[v] : (((u64)(u32)val_a[v] << 16) | (u64)((u32)val_b[v] & 0xFFFFu));
+    out_vals[base + v] = pay;
+}
+
+// sorted (key, taxon, count) records: head flags of k-mers and of (k-mer, taxon) pairs
+__global__ void mg_flags_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ vals, u64 n,
+                                u32 *__restrict__ fk, u32 *__restrict__ fp) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool hk = i == 0 || keys[i] != keys[i - 1];
+    fk[i] = hk;
+    fp[i] = hk || (vals[i] >> 32) != (vals[i - 1] >> 32);
+}
+// pk / pp = exclusive scans of the flags.  Counts of equal pairs add (saturating at INT32_MAX: the CSR holds
+// int32 counts; the reference adds longs and saturates at 255 only when it writes the byte).
+__global__ void mg_write_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ vals, u64 n,
+                                const u32 *__restrict__ fk, const u32 *__restrict__ fp, const u64 *__restrict__ pk,
+                                const u64 *__restrict__ pp, u64 *__restrict__ ukeys, u64 *__restrict__ val_off,
+                                int32_t *__restrict__ val_a, u32 *__restrict__ val_b) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 pair = pp[i] + fp[i] - 1;
+    if (fk[i]) { ukeys[pk[i]] = keys[i]; val_off[pk[i]] = pair; }
+    if (fp[i]) val_a[pair] = (int32_t)((u32)(vals[i] >> 32) ^ 0x80000000u);
+    atomicAdd(&val_b[pair], (u32)vals[i]);   // clamped to INT32_MAX afterwards (mg_clamp_kernel)
+}
+__global__ void mg_clamp_kernel(u32 *__restrict__ val_b, const u64 *__restrict__ totals) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < totals[1] && val_b[i] > 0x7FFFFFFFu) val_b[i] = 0x7FFFFFFFu;
+}

@@ -11,7 +11,7 @@ import struct
 import numpy as np
 
 from . import container, parse
-from .api import DB, KmerDatabase, KmersGpuError, READ_ID, REF_ID, match_lines, taxa_count_lines
+from .api import DB, KmerDatabase, KmersGpuError, READ_ID, REF_ID, match_lines, merge_databases, taxa_count_lines
 from ._lib import KMG_EUNSUPPORTED, PAYLOAD_READPOS, PAYLOAD_TAXON
 from .make_database import make_read_db, make_reference_db
 
@@ -82,12 +82,13 @@ def matcher(ctx, search_path, db_path, output_path, plain=False):
     gzip at the default level unless plain (-Z x)."""
     dbfiles = container.file_set(db_path)
     sfiles = container.file_set(search_path)
-    if len(dbfiles) != 1 or len(sfiles) != 1:
-        raise KmersGpuError(KMG_EUNSUPPORTED, "multi-file databases: use the Java path")
-    ref = open_database(ctx, dbfiles[0])
-    search = open_database(ctx, sfiles[0])
-    hit, _ = DB([ref]).get_nearest_kmers(search)
-    lines = match_lines(search, ref, hit)
+    if not dbfiles or not sfiles:
+        raise FileNotFoundError(db_path if not dbfiles else search_path)
+    db = DB([open_database(ctx, f) for f in dbfiles])          # name.1 .. name.N are merged (DB.java:99-109)
+    searches = [open_database(ctx, f) for f in sfiles]
+    search = searches[0] if len(searches) == 1 else merge_databases(searches)   # Matcher.java:111-128 via KmerUtils
+    hit, _ = db.get_nearest_kmers(search)
+    lines = match_lines(search, db.merged, hit)
     text = "".join(l + "\n" for l in lines).encode()
     with (open(output_path, "wb") if plain else gzip.open(output_path, "wb")) as f:
         f.write(text)
@@ -97,10 +98,9 @@ def matcher(ctx, search_path, db_path, output_path, plain=False):
 def taxa_counts(ctx, db_path, output_path):
     """TaxaCounts default mode: `taxon \\t match \\t unique`, ascending taxon, plain text (TaxaCounts.java:102-150)."""
     dbfiles = container.file_set(db_path)
-    if len(dbfiles) != 1:
-        raise KmersGpuError(KMG_EUNSUPPORTED, "multi-file databases: use the Java path")
-    ref = open_database(ctx, dbfiles[0])
-    lines = taxa_count_lines(DB([ref]))
+    if not dbfiles:
+        raise FileNotFoundError(db_path)
+    lines = taxa_count_lines(DB([open_database(ctx, f) for f in dbfiles]))
     with open(output_path, "w") as f:
         f.write("".join(l + "\n" for l in lines))
     return lines

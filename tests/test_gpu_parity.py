@@ -212,6 +212,57 @@ def test_match_sparse_and_dense_search(ctx, n_reads, genome_len):
         d.close()
 
 
+# ---------------------------------------------------------------------------- multi-file databases
+def test_merge_of_reference_files_equals_one_build(ctx):
+    """DB.kmers over name.1 .. name.N (DB.java:99-109): merging the databases of the parts of a FASTA gives
+    the database of the whole FASTA -- counts of equal (k-mer, taxon) pairs add, taxa stay ascending."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(91, 6, 4000, first_taxon=-3, shared_frac=0.4)      # negative taxa too
+    genomes = list(genomes) + [genomes[0], genomes[1][:1500]]                              # repeated sequences:
+    taxa = list(taxa) + [taxa[0], taxa[3]]                                                 # counts > 1 and shared k-mers
+    parts = [(taxa[:3], genomes[:3]), (taxa[3:5], genomes[3:5]), (taxa[5:], genomes[5:])]
+    for k, l in ((9, 3), (31, 6)):
+        dbs = [km.make_reference_db(ctx, synth.fasta_bytes(t, g), k, l) for t, g in parts]
+        db = km.DB(dbs)
+        want = OracleDB(synth.fasta_bytes(taxa, genomes), 0, k, l)
+        _same_db(db.merged, want)
+        t, m, q = km.taxa_counts(db)
+        ot, om, oq = want.taxacounts()
+        assert np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
+        reads = synth.random_reads(92, genomes[:6], 300, 90, 0.01)
+        rdb, _ = km.make_read_db(ctx, synth.fastq_bytes(reads), k, l)
+        hit, nh = db.get_nearest_kmers(rdb)
+        o_hit, o_nh = OracleDB(synth.fastq_bytes(reads), 1, k, l).match(want)
+        assert nh == o_nh and np.array_equal(hit, o_hit)
+        with pytest.raises(km.InconsistentDataException):                                   # DB.java:36-42
+            km.DB([dbs[0], rdb])
+        for d in dbs + [db.merged, rdb]:
+            d.close()
+
+
+def test_merge_of_read_files_unites_position_lists(ctx):
+    """Read DBs of two halves of a FASTQ, second half's read indices shifted as the multi-process path does
+    (dist.global_read_indices): the merge holds every (read, pos) of the whole file, ascending."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(93, 2, 2500)
+    reads = synth.random_reads(94, genomes, 400, 70, 0.01)
+    k, l = 15, 4
+    a, na = km.make_read_db(ctx, synth.fastq_bytes(reads[:170]), k, l)
+    b, nb = km.make_read_db(ctx, synth.fastq_bytes(reads[170:], first_index=170), k, l)
+    hb = b.fetch()
+    shifted = km.KmerDatabase.load(ctx, k, l, False, 1, hb["keys"], hb["val_off"], hb["val_a"] + len(na), hb["val_b"])
+    whole = OracleDB(synth.fastq_bytes(reads), 1, k, l)
+    assert na + nb == whole.names
+    merged = km.merge_databases([a, shifted])
+    _same_db(merged, whole)
+    for d in (a, b, shifted, merged):
+        d.close()
+
+
 def test_db_load_roundtrip_and_errors(ctx):
     import kmers_amd as km
     from kmers_amd import synth

@@ -125,3 +125,18 @@ def test_native_cli_matches_python_drivers(tmp_path):
     # what is not on the GPU path exits with status 3 (wrapper falls back to Java)
     run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("x.db"), "-K", "32", "-k", "24", rc=3)
     run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-n", "2", rc=3)
+    # a reference given as name.1 .. name.N is merged (DB.java:99-109): same results as the single file
+    half = len(taxa) // 2
+    open(p("h1.fa"), "wb").write(synth.fasta_bytes(taxa[:half], genomes[:half]))
+    open(p("h2.fa"), "wb").write(synth.fasta_bytes(taxa[half:], genomes[half:]))
+    run("Database.MakeDatabase", "-a", "-i", p("h1.fa"), "-o", p("set.db.1"), "-K", str(k), "-k", str(k), "-l", str(l))
+    run("Database.MakeDatabase", "-a", "-i", p("h2.fa"), "-o", p("set.db.2"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z")
+    run("Utils.TaxaCounts", "-d", p("set.db"), "-o", p("set.tsv"))
+    assert open(p("set.tsv")).read() == open(p("c.tsv")).read()
+    run("Database.Matcher", "-i", p("reads.db"), "-d", p("set.db"), "-o", p("set.txt"), "-Z", "x")
+    assert open(p("set.txt"), "rb").read() == want
+    ctx = km.Context(0)
+    assert programs.taxa_counts(ctx, p("set.db"), p("set.py.tsv")) == open(p("c.tsv")).read().splitlines()
+    programs.matcher(ctx, p("reads.db"), p("set.db"), p("set.py.txt"), plain=True)
+    assert open(p("set.py.txt"), "rb").read() == want
+    ctx.close()
