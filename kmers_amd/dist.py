@@ -4,7 +4,15 @@ shards, every rank builds the read DB of its shard against a replicated referenc
 own multi-file search convention (`reads.db.1 .. .N`, Database/Matcher.java:111-128).  The only
 cross-rank quantities are prefix sums: the global index of a shard's first read (ReadIDMapping numbers
 reads across the whole input, OtherFiles/ReadIDMapping.java:14-23) and job totals.
-`balanced_key_ranges` is the planning step of the key-range exchange, not used yet.
+
+Key-range sharding, for databases too large to replicate: rank g owns a contiguous range of the
+4^l key buckets (`balanced_key_ranges` over the all-reduced bucket histogram).  Every rank builds the database
+of its own input shard, cuts it at the range bounds -- the k-mers are sorted, so every destination's part is a
+contiguous CSR slice, no scatter kernel is needed -- and one all-to-all-v per array (`exchange_csr`) sends the
+parts to their owners, which merge them on the GPU (`kmg_db_merge`: counts add, read lists unite).  Matching
+against a range-sharded reference is the same cut on the search k-mers, one all-to-all of keys, a local join,
+and the reverse all-to-all of the hit indices (`match_by_key_range`).  The collectives are
+`torch.distributed.all_to_all_single` (RCCL grouped send/recv under "nccl"; the CPU tests run them on gloo).
 """
 import numpy as np
 import torch
@@ -63,3 +71,94 @@ def balanced_key_ranges(bucket_hist, world):
         cuts.append(min(max(k, cuts[-1]), len(h)))
     cuts.append(len(h))
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
+
+
+def range_lower_bounds(ranges, key_len):
+    """First possible k-mer (left-aligned u64) of every range, plus the end sentinel."""
+    shift = np.uint64(64 - 2 * key_len)
+    lows = [np.uint64(r[0]) << shift for r in ranges]
+    return np.array(lows, dtype=np.uint64)
+
+
+def cut_points(sorted_keys, ranges, key_len):
+    """Indices cutting ascending `sorted_keys` into one contiguous slice per range: slice g = [c[g], c[g+1])."""
+    keys = np.asarray(sorted_keys, dtype=np.uint64)
+    lows = range_lower_bounds(ranges, key_len)
+    c = np.searchsorted(keys, lows, side="left").astype(np.int64)
+    c[0] = 0
+    return np.concatenate([c, [len(keys)]])
+
+
+def all_to_all_v(chunks, dtype, device="cpu", group=None):
+    """chunks[g] = 1-D array for rank g  ->  list of arrays, one from every rank (in rank order).
+    Two collectives: the sizes, then the data."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    chunks = [np.ascontiguousarray(c, dtype=dtype) for c in chunks]
+    if world == 1:
+        return [chunks[0]]
+    assert len(chunks) == world
+    # torch has no uint64 collectives: ship the bits as int64 / int32
+    wire = {8: np.int64, 4: np.int32}[np.dtype(dtype).itemsize]
+    send_sizes = torch.tensor([len(c) for c in chunks], dtype=torch.int64, device=device)
+    recv_sizes = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(recv_sizes, send_sizes, group=group)
+    rs = [int(x) for x in recv_sizes.cpu().tolist()]
+    flat = np.concatenate(chunks) if chunks else np.zeros(0, dtype)
+    send = torch.from_numpy(flat.view(wire).copy()).to(device)
+    recv = torch.zeros(sum(rs), dtype=send.dtype, device=device)
+    dist.all_to_all_single(recv, send, output_split_sizes=rs, input_split_sizes=[len(c) for c in chunks], group=group)
+    out = recv.cpu().numpy().view(dtype)
+    offs = np.concatenate([[0], np.cumsum(rs)])
+    return [out[offs[i]:offs[i + 1]] for i in range(world)]
+
+
+def exchange_csr(csr, ranges, key_len, device="cpu", group=None):
+    """csr = dict(keys, val_off, val_a, val_b) of this rank's database (kmg_db_fetch layout).  Sends every
+    key range's slice to its owner; returns the list of CSR parts received, one per source rank, each again a
+    complete CSR (val_off starting at 0) ready for kmg_db_load + kmg_db_merge."""
+    keys = np.asarray(csr["keys"], np.uint64)
+    val_off = np.asarray(csr["val_off"], np.uint64).astype(np.int64)
+    c = cut_points(keys, ranges, key_len)
+    world = len(ranges)
+    k_parts = [keys[c[g]:c[g + 1]] for g in range(world)]
+    n_parts = [np.diff(val_off[c[g]:c[g + 1] + 1]) for g in range(world)]            # values per k-mer
+    a_parts = [np.asarray(csr["val_a"], np.int32)[val_off[c[g]]:val_off[c[g + 1]]] for g in range(world)]
+    b_parts = [np.asarray(csr["val_b"], np.int32)[val_off[c[g]]:val_off[c[g + 1]]] for g in range(world)]
+    rk = all_to_all_v(k_parts, np.uint64, device, group)
+    rn = all_to_all_v(n_parts, np.int64, device, group)
+    ra = all_to_all_v(a_parts, np.int32, device, group)
+    rb = all_to_all_v(b_parts, np.int32, device, group)
+    parts = []
+    for k, n, a, b in zip(rk, rn, ra, rb):
+        off = np.concatenate([[0], np.cumsum(n)]).astype(np.uint64)
+        parts.append(dict(keys=k.copy(), val_off=off, val_a=a.copy(), val_b=b.copy()))
+    return parts
+
+
+def build_key_range_shard(ctx, local_db, ranges, device="cpu", group=None):
+    """The exchange step of a sharded build: local_db (KmerDatabase of this rank's input shard) -> KmerDatabase
+    holding every rank's k-mers of THIS rank's key range, merged on the GPU."""
+    from .api import KmerDatabase, merge_databases
+    parts = exchange_csr(local_db.fetch(), ranges, local_db.key_length, device, group)
+    dbs = [KmerDatabase.load(ctx, local_db.k, local_db.key_length, local_db.rc, local_db.kind, p["keys"], p["val_off"],
+                             p["val_a"], p["val_b"]) for p in parts]
+    out = dbs[0] if len(dbs) == 1 else merge_databases(dbs)
+    for d in dbs:
+        if d is not out:
+            d.close()
+    return out
+
+
+def match_by_key_range(search_keys, ranges, key_len, local_match, device="cpu", group=None):
+    """Join ascending `search_keys` against a key-range-sharded reference.  local_match(keys) -> int64 hit index
+    into THIS rank's reference shard (-1 = miss) for an ascending u64 array.  Returns (owner, hit): for every
+    search k-mer the rank that owns its range and the hit index inside that rank's shard (-1 = miss)."""
+    keys = np.asarray(search_keys, np.uint64)
+    c = cut_points(keys, ranges, key_len)
+    world = len(ranges)
+    recv = all_to_all_v([keys[c[g]:c[g + 1]] for g in range(world)], np.uint64, device, group)
+    hits = [np.asarray(local_match(r), np.int64) if len(r) else np.zeros(0, np.int64) for r in recv]
+    back = all_to_all_v(hits, np.int64, device, group)
+    hit = np.concatenate(back) if back else np.zeros(0, np.int64)
+    owner = np.repeat(np.arange(world, dtype=np.int32), np.diff(c))
+    return owner, hit

@@ -78,3 +78,102 @@ def test_shard_range_and_balanced_ranges():
     r = kd.balanced_key_ranges(hist, 2)
     assert r == [(0, 1), (1, 8)]
     assert kd.balanced_key_ranges(np.zeros(16, int), 4)[-1][1] == 16
+
+
+# ---------------------------------------------------------------------------- key-range exchange
+def _merge_csr_numpy(parts, taxon_kind=True):
+    """What kmg_db_merge computes, in numpy: (key, taxon) pairs of all parts, equal pairs' counts added."""
+    rows = []
+    for p in parts:
+        n = np.diff(p["val_off"].astype(np.int64))
+        rows.append(np.stack([np.repeat(p["keys"], n).view(np.int64), p["val_a"].astype(np.int64),
+                              p["val_b"].astype(np.int64)], axis=1))
+    rows = np.concatenate(rows) if rows else np.zeros((0, 3), np.int64)
+    order = np.lexsort((rows[:, 1], rows[:, 0].view(np.uint64)))
+    rows = rows[order]
+    if len(rows) == 0:
+        return dict(keys=np.zeros(0, np.uint64), val_off=np.zeros(1, np.uint64), val_a=np.zeros(0, np.int32),
+                    val_b=np.zeros(0, np.int32))
+    newpair = np.ones(len(rows), bool)
+    newpair[1:] = (rows[1:, 0] != rows[:-1, 0]) | (rows[1:, 1] != rows[:-1, 1])
+    pair_id = np.cumsum(newpair) - 1
+    counts = np.bincount(pair_id, weights=rows[:, 2]).astype(np.int64)
+    pk, pt = rows[newpair, 0], rows[newpair, 1]
+    newkey = np.ones(len(pk), bool)
+    newkey[1:] = pk[1:] != pk[:-1]
+    val_off = np.concatenate([np.nonzero(newkey)[0], [len(pk)]]).astype(np.uint64)
+    return dict(keys=pk[newkey].view(np.uint64), val_off=val_off, val_a=pt.astype(np.int32), val_b=counts.astype(np.int32))
+
+
+def _exchange_worker(rank, world, port, fastas, fq, k, key_len, out):
+    import torch.distributed as dist
+    from kmers_amd import dist as kd
+    from oracle.c_oracle import OracleDB
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    db = OracleDB(fastas[rank], 0, k, key_len)            # stands in for the GPU build of this rank's shard
+    hist = np.diff(db.val_off.astype(np.int64)[db.bucket_off.astype(np.int64)])
+    ranges = kd.balanced_key_ranges(kd.allreduce_sum(hist), world)
+    csr = dict(keys=db.keys, val_off=db.val_off, val_a=db.val_a, val_b=db.val_b)
+    parts = kd.exchange_csr(csr, ranges, key_len)
+    shard = _merge_csr_numpy(parts)
+    # sharded match: this rank's half of the read k-mers against the range-sharded reference
+    reads = OracleDB(fq, 1, k, key_len)
+    lo, hi = kd.shard_range(len(reads.keys), rank, world)
+    mine = reads.keys[lo:hi]
+
+    def local_match(q):
+        i = np.searchsorted(shard["keys"], q)
+        ok = (i < len(shard["keys"])) & (shard["keys"][np.minimum(i, max(len(shard["keys"]) - 1, 0))] == q) if len(shard["keys"]) else np.zeros(len(q), bool)
+        return np.where(ok, i, -1)
+
+    owner, hit = kd.match_by_key_range(mine, ranges, key_len, local_match)
+    out.put((rank, ranges, shard, lo, owner, hit))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_key_range_exchange_build_and_match():
+    """Two ranks, each with half of the reference FASTA: after the exchange + merge, rank g holds exactly the
+    whole database's k-mers of its key range (counts of k-mers present in both halves added), and the sharded
+    match returns, for every read k-mer, the same reference k-mer as the single-process join."""
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(15, 4, 2500, shared_frac=0.5)
+    genomes = list(genomes) + [genomes[0]]                       # taxon 0's genome again in the second half
+    taxa = list(taxa) + [taxa[0]]
+    reads = synth.random_reads(16, genomes[:4], 200, 60, 0.01)
+    k, key_len, world = 13, 3, 2
+    fastas = [synth.fasta_bytes(taxa[:2], genomes[:2]), synth.fasta_bytes(taxa[2:], genomes[2:])]
+    fq = synth.fastq_bytes(reads)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, fastas, fq, k, key_len, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = OracleDB(synth.fasta_bytes(taxa, genomes), 0, k, key_len)
+    ranges = got[0][1]
+    assert ranges == got[1][1] and ranges[0][0] == 0 and ranges[-1][1] == 4 ** key_len
+    starts = []
+    for g in range(world):
+        u0, u1 = int(whole.bucket_off[ranges[g][0]]), int(whole.bucket_off[ranges[g][1]])
+        starts.append(u0)
+        shard = got[g][2]
+        assert np.array_equal(shard["keys"], whole.keys[u0:u1])
+        v0, v1 = int(whole.val_off[u0]), int(whole.val_off[u1])
+        assert np.array_equal(shard["val_off"].astype(np.int64), whole.val_off[u0:u1 + 1].astype(np.int64) - v0)
+        assert np.array_equal(shard["val_a"], whole.val_a[v0:v1]) and np.array_equal(shard["val_b"], whole.val_b[v0:v1])
+    assert whole.val_b.max() >= 2                                 # counts really were added across ranks
+    o_reads = OracleDB(fq, 1, k, key_len)
+    o_hit, o_nh = o_reads.match(whole)
+    glob = np.full(len(o_reads.keys), -2, np.int64)
+    for g in range(world):
+        lo, owner, hit = got[g][3], got[g][4], got[g][5]
+        glob[lo:lo + len(hit)] = np.where(hit >= 0, hit + np.array(starts)[owner], -1)
+    assert np.array_equal(glob, o_hit) and o_nh > 0

@@ -263,6 +263,42 @@ def test_merge_of_read_files_unites_position_lists(ctx):
         d.close()
 
 
+def test_key_range_shards_merge_on_the_gpu(ctx):
+    """The local step of the multi-GPU key-range exchange (kmers_amd/dist.py): CSR slices of two ranks' local
+    databases, cut at the balanced range bounds, loaded and merged with kmg_db_merge == the whole database's
+    k-mers of that range.  (The collectives themselves are covered on gloo in tests/test_dist_gloo.py.)"""
+    import kmers_amd as km
+    from kmers_amd import dist as kd, synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(97, 4, 6000, shared_frac=0.5)
+    k, l, world = 21, 4, 3
+    halves = [km.make_reference_db(ctx, synth.fasta_bytes(taxa[:2], genomes[:2]), k, l),
+              km.make_reference_db(ctx, synth.fasta_bytes(taxa[2:], genomes[2:]), k, l)]
+    whole = OracleDB(synth.fasta_bytes(taxa, genomes), 0, k, l)
+    hist = np.diff(whole.val_off.astype(np.int64)[whole.bucket_off.astype(np.int64)])
+    ranges = kd.balanced_key_ranges(hist, world)
+    assert kd.build_key_range_shard(ctx, halves[0], [(0, 4 ** l)]).n_unique == halves[0].n_unique   # world of one
+    for g in range(world):
+        parts = []
+        for h in halves:
+            f = h.fetch()
+            c = kd.cut_points(f["keys"], ranges, l)
+            vo = f["val_off"].astype(np.int64)
+            a, b = int(vo[c[g]]), int(vo[c[g + 1]])
+            parts.append(km.KmerDatabase.load(ctx, k, l, True, 0, f["keys"][c[g]:c[g + 1]],
+                                              (vo[c[g]:c[g + 1] + 1] - a).astype(np.uint64), f["val_a"][a:b], f["val_b"][a:b]))
+        shard = km.merge_databases(parts)
+        u0, u1 = int(whole.bucket_off[ranges[g][0]]), int(whole.bucket_off[ranges[g][1]])
+        v0, v1 = int(whole.val_off[u0]), int(whole.val_off[u1])
+        s = shard.fetch()
+        assert np.array_equal(s["keys"], whole.keys[u0:u1])
+        assert np.array_equal(s["val_a"], whole.val_a[v0:v1]) and np.array_equal(s["val_b"], whole.val_b[v0:v1])
+        for d in parts + [shard]:
+            d.close()
+    for h in halves:
+        h.close()
+
+
 def test_db_load_roundtrip_and_errors(ctx):
     import kmers_amd as km
     from kmers_amd import synth
