@@ -53,6 +53,7 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
     __shared__ u64 stage[WRITE ? EX_TILE : 1];
     __shared__ uint8_t sdig[WRITE ? EX_TILE : 1];
     __shared__ u32 scan_smem[EP_WAVES];
+    __shared__ u32 s_tot[2];                           // count pass: forward / RC records of the tile
     u32 *starts = WRITE ? reinterpret_cast<u32 *>(stage) : cnt32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
         } else {
             hist[0][tid] = 0;
             hist[1][tid] = 0;
+            if (tid < 2) s_tot[tid] = 0;
         }
     }
     __syncthreads();
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
     const u64 kmask = k == 32 ? ~0ull : ~(~0ull >> (2 * k));
     const u64 rcx = 0xAAAAAAAAAAAAAAAAull & kmask;
     const u32 pbase = wave * (64 * EP_ROUNDS) + lane;
-    u32 vmask = 0, rmask = 0;
+    u32 vmask = 0, rmask = 0, nfwd = 0, nrc = 0;
     // (not unrolled in the write pass: the eight copies of the window logic with both filters inlined cost
     // registers the rank and staging steps need -- spills there are real memory traffic)
 #pragma unroll WRITE ? 1 : EP_ROUNDS
@@ -177,7 +179,13 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
         if (!WRITE) {
             if (ok) atomicAdd(&hist[0][(u32)(key >> pa.dshift) & pa.dmask], 1u);
             if (emit_rc) atomicAdd(&hist[1][(u32)(rk >> pa.dshift) & pa.dmask], 1u);
+            nfwd += __popcll(__ballot(ok));          // wave-uniform running totals
+            nrc += __popcll(__ballot(emit_rc));
         }
+    }
+    if (!WRITE && lane == 0) {
+        atomicAdd(&s_tot[0], nfwd);
+        atomicAdd(&s_tot[1], nrc);
     }
     __syncthreads();
     const u32 col0 = tile * (a.rc ? 2u : 1u);
@@ -191,12 +199,9 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
             pa.table[(u64)tid * pa.ncols + col0] = hf;
             if (a.rc) pa.table[(u64)tid * pa.ncols + col0 + 1] = hr;
         }
-        u32 tf, tr;
-        block_scan_inclusive<u32, OpSum, EP_WAVES>(hf, OpSum(), scan_smem, &tf);
-        block_scan_inclusive<u32, OpSum, EP_WAVES>(hr, OpSum(), scan_smem, &tr);
         if (tid == 0) {
-            a.tile_count[tile] = tf + tr;
-            a.tile_fwd[tile] = tf;
+            a.tile_count[tile] = s_tot[0] + s_tot[1];
+            a.tile_fwd[tile] = s_tot[0];
         }
         return;
     }

@@ -159,6 +159,29 @@ def test_many_batches_equal_one_batch(ctx):
     got.close()
 
 
+def test_large_first_batch_then_more_batches(ctx):
+    """The first batch of a build is written already partitioned by the sort's first digit; a second batch
+    voids that plan (window-order append) and finish() must run every pass.  Both DB kinds, sizes well above
+    one sort segment."""
+    import kmers_amd as km
+    from kmers_amd import parse, synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(55, 5, 30000, shared_frac=0.3)
+    reads = synth.random_reads(56, genomes, 4000, 100, 0.01, n_rate=0.002)
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    for data, mode, kind, rc, cuts in ((fa, parse.FASTA, "ref", True, [0, 3, 4, 5]), (fq, parse.FASTQ, "read", False, [0, 2500, 2501, 4000])):
+        b = parse.parse(data, mode, 23).batch
+        fc = km.FileCreator(ctx, 5, 23, kind, rc=rc)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            a0, a1 = int(b.seq_off[lo]), int(b.seq_off[hi])
+            fc.add_kmers(km.SequenceBatch(b.bases[a0:a1], b.seq_off[lo:hi + 1] - b.seq_off[lo],
+                                          seq_id=None if b.seq_id is None else b.seq_id[lo:hi],
+                                          seq_tok=None if b.seq_tok is None else b.seq_tok[lo:hi]))
+        got = fc.create()
+        _same_db(got, OracleDB(data, 0 if kind == "ref" else 1, 23, 5, threads=4))
+        got.close()
+
+
 # ---------------------------------------------------------------------------- match + counts parity
 @pytest.mark.parametrize("k,key_len,seed", [(5, 2, 31), (9, 3, 32), (31, 6, 33)])
 def test_match_and_taxacounts_match_oracle(ctx, k, key_len, seed):
