@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkmers_gpu.so")
+# KMERS_GPU_LIB: another build of the same library (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get("KMERS_GPU_LIB") or os.path.join(_HERE, "libkmers_gpu.so")
 
 KMG_OK = 0
 KMG_EINVAL = -1

@@ -23,9 +23,11 @@
 #define EX_TILE (EX_BLOCK * EX_ROUNDS)   // 4096 window-start positions per tile
 #define EX_EXT 32                        // bases past the tile that its last windows may cover
 
-// tile_seq[t] = largest s in [0, nseq] with seq_off[s] <= t * EX_TILE.
+// tile_seq[t] = largest s in [0, nseq] with seq_off[s] <= t * EX_TILE;
+// tile_end[t] (optional) = largest s with seq_off[s] < (t + 1) * EX_TILE + EX_EXT: the last sequence start a
+// tile's windows can see, so that the kernels read exactly the offsets they need.
 __global__ void extract_tileseq_kernel(const u64 *__restrict__ seq_off, u64 nseq, u32 *__restrict__ tile_seq,
-                                       u32 ntiles_plus1) {
+                                       u32 *__restrict__ tile_end, u32 ntiles_plus1) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles_plus1) return;
     u64 pos = (u64)t * EX_TILE;
@@ -35,6 +37,15 @@ __global__ void extract_tileseq_kernel(const u64 *__restrict__ seq_off, u64 nseq
         if (seq_off[mid] <= pos) lo = mid + 1; else hi = mid;
     }
     tile_seq[t] = (u32)(lo == 0 ? 0 : lo - 1);
+    if (tile_end) {
+        const u64 lim = pos + EX_TILE + EX_EXT;
+        hi = nseq + 1;              // first index with seq_off >= lim (not below the first search's result)
+        while (lo < hi) {
+            u64 mid = (lo + hi) >> 1;
+            if (seq_off[mid] < lim) lo = mid + 1; else hi = mid;
+        }
+        tile_end[t] = (u32)(lo == 0 ? 0 : lo - 1);
+    }
 }
 
 __device__ __forceinline__ u64 revpairs64(u64 x) {
@@ -83,6 +94,7 @@ struct ExtractArgs {
     const int32_t *seq_id;       // taxon per sequence (kind 0)
     const int32_t *read_index;   // read number per sequence (kind 1, write pass)
     const u32 *tile_seq;
+    const u32 *tile_end;         // last sequence start visible from the tile (extract_part.h)
     int k;
     int rc;
     int kind;

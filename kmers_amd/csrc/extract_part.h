@@ -18,6 +18,10 @@
 #define EP_BLOCK 512
 #define EP_WAVES (EP_BLOCK / 64)
 #define EP_ROUNDS (EX_TILE / EP_BLOCK)   // 8 windows per thread
+#ifndef EP_SQCAP
+#define EP_SQCAP 96
+#endif
+//                    // sequences of a tile whose payload data is cached in LDS
 
 struct PartArgs {
     ExtractArgs e;
@@ -37,7 +41,8 @@ __device__ __forceinline__ u64 ep_window(const u32 *pk, u32 p, u64 kmask) {
 
 // Register budget: the write pass keeps only validity masks and ranks per window and re-reads the k-mer
 // from the LDS image where it needs it (broadcast reads), which fits 3 workgroups per CU (<= 80 VGPRs,
-// ~52 KB of LDS).
+// ~52 KB of LDS: LDS is handed out in 1280-byte granules on gfx950, 42 granules = 53,760 B is the most a
+// workgroup may take for three to fit -- 54,160 B measured as two per CU and 10 % slower).
 template <bool WRITE, typename V>
 __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(PartArgs pa) {
     const ExtractArgs &a = pa.e;
@@ -48,12 +53,16 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
     __shared__ u32 cnt32[WRITE ? 1 : EX_TILE + EX_EXT]; // sequence starts per position (write pass: inside `stage`)
     __shared__ u32 hist[2][WRITE ? 1 : RS_DIGITS];     // count pass: forward / RC digit histograms
     __shared__ uint16_t wcnt[WRITE ? EP_WAVES : 1][RS_DIGITS];
-    __shared__ u32 dstart[RS_DIGITS];
+    __shared__ uint16_t dstart[RS_DIGITS];             // <= EX_TILE
     __shared__ u32 gdelta[RS_DIGITS];
     __shared__ u64 stage[WRITE ? EX_TILE : 1];
     __shared__ uint8_t sdig[WRITE ? EX_TILE : 1];
     __shared__ u32 scan_smem[EP_WAVES];
     __shared__ u32 s_tot[2];                           // count pass: forward / RC records of the tile
+    // write pass: payload source of the tile's first EP_SQCAP sequences (taxon | read index) and the low 32 bits
+    // of t0 - seq_off[s], so that building the payloads needs no global load (later sequences: global path)
+    __shared__ u32 sq_val[WRITE ? EP_SQCAP : 1];
+    __shared__ u32 sq_neg[WRITE ? EP_SQCAP : 1];
     u32 *starts = WRITE ? reinterpret_cast<u32 *>(stage) : cnt32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,6 +72,26 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
     if (tile >= pa.ntiles) return;
     const u64 t0 = (u64)tile * EX_TILE;
     const int k = a.k;
+    const u32 col0 = tile * (a.rc ? 2u : 1u);
+    // Global loads that later phases depend on are issued up front, so that their latency overlaps the packing:
+    // the tile's sequence range, this thread's sequence start, the scanned table entries of digit `tid`.
+    const u32 s_lo = a.tile_seq[tile];
+    const u32 s_end = a.tile_end[tile];
+    const u64 my_s = (u64)s_lo + 1 + tid;
+    const u64 my_start = my_s <= s_end ? a.seq_off[my_s] : 0;
+    u32 tbl0 = 0, tbl1 = 0, out_base = 0;
+    if (WRITE) {
+        out_base = (u32)a.state[ST_NREC];
+        if (tid < RS_DIGITS) {
+            tbl0 = pa.table[(u64)tid * pa.ncols + col0];
+            if (a.rc) tbl1 = pa.table[(u64)tid * pa.ncols + col0 + 1];
+        }
+        if (tid < EP_SQCAP && (u64)s_lo + tid <= s_end) {
+            const u64 sq = (u64)s_lo + tid;
+            sq_val[tid] = a.kind == KMG_PAYLOAD_TAXON ? (u32)a.seq_id[sq] : (u32)a.read_index[sq];
+            sq_neg[tid] = (u32)(t0 - a.seq_off[sq]);
+        }
+    }
 
     // ---- 1. load + pack (as extract_kernel) --------------------------------------------------------
     const bool aligned = (((uintptr_t)a.bases) & 15) == 0;
@@ -111,12 +140,8 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
     __syncthreads();
 
     // ---- 2. sequence starts -> per-position sequence index ------------------------------------------
-    const u32 s_lo = a.tile_seq[tile];
-    for (u64 s = (u64)s_lo + 1 + tid; s <= a.nseq; s += EP_BLOCK) {
-        u64 o = a.seq_off[s];
-        if (o >= t0 + EX_TILE + EX_EXT) break;
-        atomicAdd(&starts[(u32)(o - t0)], 1u);
-    }
+    if (my_s <= s_end) atomicAdd(&starts[(u32)(my_start - t0)], 1u);
+    for (u64 s = my_s + EP_BLOCK; s <= s_end; s += EP_BLOCK) atomicAdd(&starts[(u32)(a.seq_off[s] - t0)], 1u);
     __syncthreads();
     {
         // blocked: thread owns positions 8*tid .. 8*tid+7 = byte `tid` of the MSB-first start bitmap
@@ -188,7 +213,6 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
         atomicAdd(&s_tot[1], nrc);
     }
     __syncthreads();
-    const u32 col0 = tile * (a.rc ? 2u : 1u);
 
     if (!WRITE) {
         // histogram columns + the tile's record / forward-window totals
@@ -206,7 +230,6 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
         return;
     }
 
-    const u32 out_base = (u32)a.state[ST_NREC];
     V *out_vals = reinterpret_cast<V *>(a.out_vals);
     for (int sp = 0; sp < (a.rc ? 2 : 1); sp++) {
         const u32 imask = sp == 0 ? vmask : rmask;
@@ -246,8 +269,8 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
             u32 incl = block_scan_inclusive<u32, OpSum, EP_WAVES>(run, OpSum(), scan_smem, &tile_n);
             if (tdx < RS_DIGITS) {
                 const u32 start = incl - run;
-                dstart[tdx] = start;
-                gdelta[tdx] = out_base + pa.table[(u64)tdx * pa.ncols + col0 + sp] - start;
+                dstart[tdx] = (uint16_t)start;
+                gdelta[tdx] = out_base + (sp ? tbl1 : tbl0) - start;
             }
         }
         __syncthreads();
@@ -275,13 +298,19 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
             if ((imask >> j) & 1) {
                 // payload of the window (the sequence tables are tiny and cached: a tile spans few sequences)
                 const u32 p = pb + j * 64;
-                const u32 sq = s_lo + seqrel[p];
+                const u32 rel = seqrel[p];
+                u32 sv, neg;
+                if (rel < EP_SQCAP) { sv = sq_val[rel]; neg = sq_neg[rel]; }
+                else {
+                    const u64 sq = (u64)s_lo + rel;
+                    sv = a.kind == KMG_PAYLOAD_TAXON ? (u32)a.seq_id[sq] : (u32)a.read_index[sq];
+                    neg = (u32)(t0 - a.seq_off[sq]);
+                }
                 V v;
-                if (a.kind == KMG_PAYLOAD_TAXON) v = (V)(u32)a.seq_id[sq];
-                else v = (V)(((u64)(u32)a.read_index[sq] << 16) | (u64)(((u32)t0 + p - (u32)a.seq_off[sq]) & 0xFFFFu));
+                if (a.kind == KMG_PAYLOAD_TAXON) v = (V)sv;
+                else v = (V)(((u64)sv << 16) | (u64)((p + neg) & 0xFFFFu));
                 reinterpret_cast<V *>(stage)[lpos[j]] = v;
             }
-            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four payload gathers in flight
         }
         __syncthreads();
 #pragma unroll 4

@@ -158,7 +158,7 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
 
     const u32 ntiles = div_up_u64(nbases, EX_TILE);
     PoolBuf tile_seq(ctx), tile_count(ctx), tile_fwd(ctx), tile_off(ctx), agg(ctx), has_kmer(ctx), read_index(ctx), tmp_a(ctx), tmp_b(ctx);
-    KMG_ALLOC(tile_seq, (size_t)(ntiles + 1) * 4);
+    KMG_ALLOC(tile_seq, (size_t)(ntiles + 1) * 8);   // tile_seq[ntiles + 1] then tile_end[ntiles + 1]
     KMG_ALLOC(tile_count, (size_t)ntiles * 4);
     KMG_ALLOC(tile_fwd, (size_t)ntiles * 4);
     KMG_ALLOC(tile_off, (size_t)(ntiles + 1) * 8);
@@ -167,7 +167,7 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     ExtractArgs a;
     memset(&a, 0, sizeof a);
     a.bases = d_bases; a.nbases = nbases; a.seq_off = d_seq_off; a.nseq = nseq; a.seq_id = d_seq_id;
-    a.tile_seq = tile_seq.as<u32>(); a.k = ctx->k; a.rc = ctx->rc; a.kind = ctx->kind;
+    a.tile_seq = tile_seq.as<u32>(); a.tile_end = tile_seq.as<u32>() + ntiles + 1; a.k = ctx->k; a.rc = ctx->rc; a.kind = ctx->kind;
     a.dust = ctx->dust; a.runofsame = ctx->runofsame;
     a.tile_count = tile_count.as<u32>(); a.tile_fwd = tile_fwd.as<u32>(); a.tile_off = tile_off.as<u64>();
     a.out_keys = ctx->rec_keys; a.out_vals = ctx->rec_vals; a.state = ctx->d_state;
@@ -175,7 +175,7 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     {
         ProfScope ps(ctx, KP_EXTRACT_TILESEQ, 0);
         hipLaunchKernelGGL(extract_tileseq_kernel, dim3(div_up_u64(ntiles + 1, 256)), dim3(256), 0, ctx->stream,
-                           d_seq_off, nseq, tile_seq.as<u32>(), ntiles + 1);
+                           d_seq_off, nseq, tile_seq.as<u32>(), tile_seq.as<u32>() + ntiles + 1, ntiles + 1);
     }
     int32_t *ridx = nullptr;
     if (reads) {
