@@ -144,10 +144,24 @@ def main():
     bytes_per_launch = d["bytes"] / d["launches"]
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     traffic = pmc_traffic(dom)
+    # measured device-copy ceiling of this box (report the fraction of it next to the spec peak)
+    ca = torch.empty(1 << 27, dtype=torch.int64, device=dev)
+    cb = torch.ones(1 << 27, dtype=torch.int64, device=dev)
+    ca.copy_(cb)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ca.copy_(cb)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del ca, cb
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": int(bytes_per_launch),
-                "launches_per_step": d["launches"] // prof_steps}
+                "launches_per_step": d["launches"] // prof_steps,
+                "measured_copy_GBps": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
     kernels = {k: {"ms_per_step": round(v["ms"] / prof_steps, 4), "launches_per_step": v["launches"] // prof_steps,
                    "algo_GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) if v["bytes"] else None}
                for k, v in prof.items() if v["launches"]}

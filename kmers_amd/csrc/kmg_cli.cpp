@@ -517,10 +517,19 @@ int matcher(int argc, char **argv) {
         for (auto &s : text) fwrite(s.data(), 1, s.size(), f);
         fclose(f);
     } else {
-        gzFile z = gzopen(a.get('o').c_str(), "wb");    // default level, Matcher.java:138-139
-        if (!z) throw std::runtime_error("cannot create " + a.get('o'));
-        for (auto &s : text) if (!s.empty()) gzwrite(z, s.data(), (unsigned)s.size());
-        gzclose(z);
+        // gzip at the default level (Matcher.java:138-139).  One member per 64 K lines, deflated on the pool:
+        // a multi-member file is what every gzip reader (java.util.zip.GZIPInputStream included) accepts, and
+        // single-threaded deflate of the match text would otherwise dominate the whole program.
+        std::vector<std::string> zipped(nchunk);
+        parallel_for(nchunk, [&](size_t c) {
+            zipped[c] = gzip_member((const uint8_t *)text[c].data(), text[c].size(), 6);
+            std::string().swap(text[c]);
+        });
+        FILE *f = fopen(a.get('o').c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot create " + a.get('o'));
+        if (nchunk == 0) { const std::string e = gzip_member(nullptr, 0, 6); fwrite(e.data(), 1, e.size(), f); }
+        for (auto &s : zipped) fwrite(s.data(), 1, s.size(), f);
+        fclose(f);
     }
     kmg_db_free(ref);
     kmg_db_free(search);
