@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -393,6 +394,18 @@ Args parse_args(int argc, char **argv, int from, const std::string &with_value, 
     return a;
 }
 
+// -v: wall-clock of every stage on stderr
+struct StageClock {
+    bool on;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    explicit StageClock(bool v) : on(v) {}
+    void lap(const char *what) {
+        const auto n = std::chrono::steady_clock::now();
+        if (on) fprintf(stderr, "  %-28s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
+        t = n;
+    }
+};
+
 int make_database(int argc, char **argv) {
     const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmN", "aqZv");
     for (char c : std::string("SmN")) if (a.has(c)) throw Unsupported(std::string("option -") + c + " is not on the GPU path");
@@ -404,7 +417,9 @@ int make_database(int argc, char **argv) {
     if (!a.has('i') || !a.has('o')) throw std::runtime_error("-i and -o are required");
     const bool reads = a.has('q');
     if (reads && !a.has('r')) throw std::runtime_error("-r <read map file> is required with -q");   // MakeDatabase.java:172-173
+    StageClock clk(a.has('v'));
     const std::string data = read_input(a.get('i'));
+    clk.lap("read input");
     kmh_batch *b = kmh_parse((const uint8_t *)data.data(), data.size(), reads ? 1 : 0, k);
     const uint64_t nseq = kmh_nseq(b);
     const uint64_t *off = kmh_seq_off(b);
@@ -416,7 +431,9 @@ int make_database(int argc, char **argv) {
                 throw std::runtime_error("NumberFormatException: FASTA header of sequence " + std::to_string(s) + " is not an int");
             }
     }
+    clk.lap("split records (host)");
     Gpu g;
+    clk.lap("GPU context");
     g.check(kmg_build_begin(g.ctx, k, key_len, reads ? 0 : 1, reads ? KMG_PAYLOAD_READPOS : KMG_PAYLOAD_TAXON));
     if (a.has('D') || a.has('R')) g.check(kmg_build_set_filters(g.ctx, a.geti('D', -1), a.geti('R', -1)));
     std::vector<int32_t> ridx(reads ? nseq : 0);
@@ -425,6 +442,7 @@ int make_database(int argc, char **argv) {
     kmg_db *db = nullptr;
     uint64_t nwin = 0;
     g.check(kmg_build_finish(g.ctx, &db, &nwin));
+    clk.lap("copy in + build (GPU)");
     if (reads) {
         // ReadIDMapping.geNext prints a header each time a new index is handed out (gzip text, one per line)
         gzFile z = gzopen(a.get('r').c_str(), "wb");
@@ -442,7 +460,9 @@ int make_database(int argc, char **argv) {
         gzclose(z);
     }
     kmh_free(b);
+    clk.lap("read-name map");
     write_database(g, db, a.get('o'), level);
+    clk.lap("encode + deflate + write");
     if (a.has('v')) {
         const DbInfo d = db_info(db);
         fprintf(stderr, "%llu k-mer windows, %llu distinct k-mers, %llu values\n", (unsigned long long)nwin,
