@@ -1,7 +1,7 @@
 // kmg_cli.cpp -- native (C++) host side of the hot path: the three reference programs that sit on it, driven
 // through the C ABI of libkmers_gpu.so, plus the on-disk container they read and write.
 //
-//   kmg Database.MakeDatabase -a|-q -i in -o out [-K k -k k] [-l keylen] [-z level | -Z] [-r readmap] [-D n] [-R n] [-t threads]
+//   kmg Database.MakeDatabase -a|-q -i in -o out [-K k -k k] [-l keylen] [-z level | -Z] [-S maxsize] [-r readmap] [-D n] [-R n] [-t threads]
 //   kmg Database.Matcher      -i search.db -d ref.db -o out [-Z x] [-t threads]
 //   kmg Utils.TaxaCounts      -d ref.db -o out
 //
@@ -10,7 +10,7 @@
 // Appendix A.1-A.3): header | gzip-member blocks | index block | footer; every key's block is its own gzip
 // member, so blocks are deflated / inflated on a thread pool and written in key order
 // (FileCreator.java:385-391 enforces that order with OrderedLatches).  Options outside the GPU path
-// (minK != maxK, k > 32, -n > 0, -h, -p, -x, -S) exit with status 3 so that a wrapper can fall
+// (minK != maxK, k > 32, -n > 0, -h, -p, -x) exit with status 3 so that a wrapper can fall
 // back to the Java program.  Plain C++17 + zlib; no HIP in this file.
 #include <stdint.h>
 #include <stdio.h>
@@ -22,6 +22,7 @@
 #include <atomic>
 #include <chrono>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -295,7 +296,12 @@ DbInfo db_info(const kmg_db *db) {
 
 // FileCreator.create (FileCreator.java:117-217): meta under key -1, then every key 0..4^l-1 in order (each
 // gets a block, empty ones included)
-void write_database(const Gpu &g, const kmg_db *db, const std::string &path, int level) {
+// -S maxSize (jar IndexedOutputFileSet.newFile): when the next key's block would take the file past
+// maxSize, the file is closed -- `name` becomes `name.1` at the first overflow -- and `name.N+1` is opened with
+// the meta block written again, so every file of the set is a complete database over a contiguous key range.
+// The reference checks the limit per buffered write (it can cut inside a key's block); this writer cuts at key
+// boundaries only, so the split points are equivalent, not byte-identical.
+void write_database(const Gpu &g, const kmg_db *db, const std::string &path, int level, uint64_t max_size = 0) {
     const DbInfo d = db_info(db);
     const size_t nkeys = (size_t)1 << (2 * d.key_len);
     uint64_t nbytes = 0;
@@ -311,13 +317,44 @@ void write_database(const Gpu &g, const kmg_db *db, const std::string &path, int
     std::vector<std::string> blobs(nkeys);
     if (level >= 0)
         parallel_for(nkeys, [&](size_t key) { blobs[key] = gzip_member(bytes.data() + off[key], off[key + 1] - off[key], level); });
-    IndexedOutputFile out(path, level);
-    out.add_block(-1, out.pack(meta, level));
+    std::unique_ptr<IndexedOutputFile> out(new IndexedOutputFile(path, level));
+    out->add_block(-1, out->pack(meta, level));
+    int nfiles = 1;
+    size_t keys_in_file = 0;
     for (size_t key = 0; key < nkeys; key++) {
-        if (level >= 0) out.add_block((int)key, blobs[key]);
-        else out.add_block((int)key, std::string((const char *)bytes.data() + off[key], off[key + 1] - off[key]));
+        const std::string blob = level >= 0 ? std::move(blobs[key])
+                                            : std::string((const char *)bytes.data() + off[key], off[key + 1] - off[key]);
+        const uint64_t tail = 24 * (keys_in_file + 2) + 256;     // index + footer still to come
+        if (max_size && keys_in_file > 0 && out->pos + blob.size() + tail > max_size) {
+            out->close();
+            if (nfiles == 1 && rename(path.c_str(), (path + ".1").c_str()) != 0) throw std::runtime_error("cannot rename " + path);
+            nfiles++;
+            out.reset(new IndexedOutputFile(path + "." + std::to_string(nfiles), level));
+            out->add_block(-1, out->pack(meta, level));
+            keys_in_file = 0;
+        }
+        out->add_block((int)key, blob);
+        keys_in_file++;
     }
-    out.close();
+    out->close();
+}
+
+// jar Files.SizeConvertor.fromHuman: a byte count with an optional K / M / G / T suffix (powers of 1024)
+uint64_t size_from_human(const std::string &v) {
+    char *end = nullptr;
+    double x = strtod(v.c_str(), &end);
+    uint64_t mul = 1;
+    if (end && *end) {
+        switch (*end) {
+            case 'k': case 'K': mul = 1ull << 10; break;
+            case 'm': case 'M': mul = 1ull << 20; break;
+            case 'g': case 'G': mul = 1ull << 30; break;
+            case 't': case 'T': mul = 1ull << 40; break;
+            default: throw std::runtime_error("bad size " + v);
+        }
+    }
+    if (x <= 0) throw std::runtime_error("bad size " + v);
+    return (uint64_t)(x * (double)mul);
 }
 
 // new KmerFile(file, dataType) + its decoded content uploaded to the GPU
@@ -408,7 +445,7 @@ struct StageClock {
 
 int make_database(int argc, char **argv) {
     const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmN", "aqZv");
-    for (char c : std::string("SmN")) if (a.has(c)) throw Unsupported(std::string("option -") + c + " is not on the GPU path");
+    for (char c : std::string("mN")) if (a.has(c)) throw Unsupported(std::string("option -") + c + " is not on the GPU path");
     const int k = a.geti('K', 32), min_k = a.geti('k', 24), key_len = a.geti('l', 6);     // MakeDatabase.java:106-109
     const int level = a.has('Z') ? -1 : a.geti('z', 5);
     g_threads = std::max(1, a.geti('t', g_threads));
@@ -461,7 +498,7 @@ int make_database(int argc, char **argv) {
     }
     kmh_free(b);
     clk.lap("read-name map");
-    write_database(g, db, a.get('o'), level);
+    write_database(g, db, a.get('o'), level, a.has('S') ? size_from_human(a.get('S')) : 0);
     clk.lap("encode + deflate + write");
     if (a.has('v')) {
         const DbInfo d = db_info(db);

@@ -53,7 +53,7 @@ def test_native_cli_builds_and_refuses_what_is_off_the_gpu_path():
     run = lambda *a: subprocess.run([kmg] + list(a), capture_output=True, text=True, timeout=60)
     assert run().returncode == 1
     assert run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y").returncode == 3          # default -k 24 != -K 32
-    assert run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y", "-K", "31", "-k", "31", "-S", "5").returncode == 3
+    assert run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y", "-K", "31", "-k", "31", "-m", "5").returncode == 3
     assert run("Database.Matcher", "-i", "a", "-d", "b", "-o", "c", "-n", "1").returncode == 3
     r = run("Database.MakeDatabase", "-a", "-q", "-i", "x", "-o", "y", "-K", "31", "-k", "31")
     assert r.returncode == 1 and "exactly one of" in r.stderr

@@ -140,3 +140,16 @@ def test_native_cli_matches_python_drivers(tmp_path):
     programs.matcher(ctx, p("reads.db"), p("set.db"), p("set.py.txt"), plain=True)
     assert open(p("set.py.txt"), "rb").read() == want
     ctx.close()
+    # -S: the database split into name.1 .. name.N at key boundaries, every file complete; the set reads back whole
+    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("split.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z", "-S", "200K")
+    parts = sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("split.db."))
+    assert len(parts) >= 3 and not os.path.exists(p("split.db"))
+    assert all(os.path.getsize(p(f)) <= 200 * 1024 for f in parts)
+    seen = []
+    for f in sorted(parts, key=lambda n: int(n.rsplit(".", 1)[1])):
+        blocks = R.read_indexed_file(p(f))
+        assert blocks[-1] == R.read_indexed_file(p("ref.want"))[-1]          # the meta block, in every file
+        seen += [kk for kk in sorted(blocks) if kk >= 0]
+    assert seen == list(range(4 ** l))                                       # contiguous key ranges, nothing twice
+    run("Utils.TaxaCounts", "-d", p("split.db"), "-o", p("split.tsv"))
+    assert open(p("split.tsv")).read() == open(p("c.tsv")).read()
