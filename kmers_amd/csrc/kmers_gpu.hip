@@ -797,7 +797,10 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
 
 // ------------------------------------------------------------------------------------------------ match
 static int match_locked(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, long long *d_hit, u64 *d_nhits) {
-    if (search->ctx != ctx || ref->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
+    // databases of another context of the same device are fine (they are complete once their build has
+    // finished): a caller may build the reference and the reads on two contexts side by side
+    if (search->ctx->device != ctx->device || ref->ctx->device != ctx->device)
+        return fail(ctx, KMG_EINVAL, "database belongs to another device");
     // DB.java:78-81: search k-mers must have the database's length; keys are compared per key bucket
     if (search->k != ref->k || search->key_len != ref->key_len)
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
