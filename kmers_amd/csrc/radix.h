@@ -211,12 +211,12 @@ struct SortPass {
     int src;
 };
 
-// number of prefix bits sorted by global passes for n records of `kbits` key bits: segments of ~1-2 K
-// records, and one pass fewer when that still keeps the average segment under ~2.3 K.
+// number of prefix bits sorted by global passes for n records of `kbits` key bits
 static inline int choose_pbits(u64 n, int kbits) {
+    // average segment <= 2300 records: LS_MAX = 2560 is then > 5 sigma away on uniform keys, and segments are as
+    // full as the local sort's 512-record rounds allow
     int p = 0;
-    while (p < kbits && p < 24 && (n >> p) > 2048) p++;
-    if (p > 1 && (p % RS_BITS) == 1 && (n >> (p - 1)) <= 2300) p--;
+    while (p < kbits && p < 24 && (n >> p) > 2300) p++;
     return p;
 }
 
