@@ -39,6 +39,19 @@ __device__ __forceinline__ u64 ep_window(const u32 *pk, u32 p, u64 kmask) {
     return ((hi << (2 * r)) | ((u64)pk[w + 2] >> (32 - 2 * r))) & kmask;
 }
 
+// seqrel is kept in 16 bits; a tile that sees 65535 or more sequence starts (tens of thousands of EMPTY
+// sequences inside 4 K bases) stores the clamp value and those positions look their sequence up instead:
+// the sequence of the base at absolute position g is the largest s with seq_off[s] <= g.
+#define EP_REL_CLAMP 0xFFFFu
+__device__ __forceinline__ u32 ep_seq_rel(const ExtractArgs &a, u32 s_lo, u32 s_end, u64 g) {
+    u64 lo = s_lo, hi = (u64)s_end + 1;   // first index in (s_lo, s_end] with seq_off > g
+    while (hi - lo > 1) {
+        const u64 mid = (lo + hi) >> 1;
+        if (a.seq_off[mid] <= g) lo = mid; else hi = mid;
+    }
+    return (u32)(lo - s_lo);
+}
+
 // Register budget: the write pass keeps only validity masks and ranks per window and re-reads the k-mer
 // from the LDS image where it needs it (broadcast reads), which fits 3 workgroups per CU (<= 80 VGPRs,
 // ~52 KB of LDS: LDS is handed out in 1280-byte granules on gfx950, 42 granules = 53,760 B is the most a
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             run += c[i];
-            seqrel[tid * 8 + i] = (uint16_t)run;   // <= EX_TILE + EX_EXT starts
+            seqrel[tid * 8 + i] = (uint16_t)(run < EP_REL_CLAMP ? run : EP_REL_CLAMP);
         }
     }
     __syncthreads();
@@ -189,7 +202,11 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
         bool ok = (bad >> (64 - k)) == 0;
         if (k > 1) ok = ok && (((st << 1) >> (65 - k)) == 0);
         ok = ok && (t0 + p + (u64)k <= a.nbases);
-        if (!WRITE && ok && a.has_kmer) a.has_kmer[s_lo + seqrel[p]] = 1;
+        if (!WRITE && ok && a.has_kmer) {
+            u32 rel = seqrel[p];
+            if (rel == EP_REL_CLAMP) rel = ep_seq_rel(a, s_lo, s_end, t0 + p);
+            a.has_kmer[s_lo + rel] = 1;
+        }
         if (ok && a.runofsame >= 0) ok = runofsame_keep(key, k, a.runofsame);
         if (ok && a.dust >= 0) ok = dust_keep(key, k, a.dust);
         bool emit_rc = false;
@@ -298,7 +315,8 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
             if ((imask >> j) & 1) {
                 // payload of the window (the sequence tables are tiny and cached: a tile spans few sequences)
                 const u32 p = pb + j * 64;
-                const u32 rel = seqrel[p];
+                u32 rel = seqrel[p];
+                if (rel == EP_REL_CLAMP) rel = ep_seq_rel(a, s_lo, s_end, t0 + p);
                 u32 sv, neg;
                 if (rel < EP_SQCAP) { sv = sq_val[rel]; neg = sq_neg[rel]; }
                 else {

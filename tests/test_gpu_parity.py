@@ -159,6 +159,25 @@ def test_many_batches_equal_one_batch(ctx):
     got.close()
 
 
+def test_many_empty_reads_inside_one_tile(ctx):
+    """70 000 empty FASTQ records between real reads: more sequence starts inside one 4096-base tile than the
+    extractor's 16-bit per-position sequence counter holds (clamped there, looked up instead)."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(61, 2, 3000)
+    reads = synth.random_reads(62, genomes, 120, 90, 0.01)
+    recs = [synth.fastq_bytes(reads[i:i + 1], first_index=i) for i in range(reads.shape[0])]
+    empties = b"".join(b"@e%d\n\n+\n\n" % i for i in range(70_000))
+    fq = b"".join(recs[:40]) + empties + b"".join(recs[40:])
+    for k, l in ((17, 4), (31, 6)):
+        got, names = km.make_read_db(ctx, fq, k, l)
+        want = OracleDB(fq, 1, k, l)
+        _same_db(got, want)
+        assert names == want.names and len(names) == 120
+        got.close()
+
+
 def test_large_first_batch_then_more_batches(ctx):
     """The first batch of a build is written already partitioned by the sort's first digit; a second batch
     voids that plan (window-order append) and finish() must run every pass.  Both DB kinds, sizes well above
