@@ -806,8 +806,13 @@ static int match_locked(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, l
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
     if (search->U == 0) return KMG_OK;
     ProfScope ps(ctx, KP_MATCH, 8 * (search->U + ref->U) + 8 * search->U);
-    hipLaunchKernelGGL(match_kernel, dim3(div_up_u64(search->U, MT_TILE)), dim3(MT_BLOCK), 0, ctx->stream, search->keys,
-                       search->U, ref->keys, ref->U, d_hit, d_nhits);
+    const u32 ntiles = div_up_u64(search->U, MT_TILE);
+    PoolBuf bounds(ctx);
+    KMG_ALLOC(bounds, ((size_t)ntiles + 1) * 8);
+    hipLaunchKernelGGL(match_bounds_kernel, dim3(div_up_u64(ntiles + 1, 256)), dim3(256), 0, ctx->stream, search->keys, search->U,
+                       ref->keys, ref->U, ref->bucket_off, ref->key_len, ntiles, bounds.as<u64>());
+    hipLaunchKernelGGL(match_kernel, dim3(ntiles), dim3(MT_BLOCK), 0, ctx->stream, search->keys, search->U, ref->keys,
+                       bounds.as<u64>(), d_hit, d_nhits);
     KMG_HIP(hipGetLastError());
     return KMG_OK;
 }

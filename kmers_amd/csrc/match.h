@@ -12,53 +12,39 @@
 #define MT_TILE (MT_BLOCK * MT_ITEMS)   // search k-mers per workgroup
 #define MT_RMAX 3072                    // reference k-mers staged in LDS per tile (24 KB)
 
-// number of threads of the block for which pred holds (all threads must call)
-__device__ __forceinline__ u32 mt_block_count(bool pred, u32 *smem) {
-    const u64 bal = __ballot(pred);
-    __syncthreads();                       // previous readers of smem are done
-    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = __popcll(bal);
-    __syncthreads();
-    return smem[0] + smem[1] + smem[2] + smem[3];
-}
-
-// The whole block searches [lo, hi) of the ascending array a for the first element that is not `less`
-// than key (STRICT: first element > key).  256-ary: every round each thread probes one position.
-template <bool STRICT>
-__device__ __forceinline__ u64 mt_block_bound(const u64 *__restrict__ a, u64 lo, u64 hi, u64 key, u32 *smem) {
-    const u32 t = threadIdx.x;
-    while (hi > lo) {
-        const u64 n = hi - lo;
-        if (n <= MT_BLOCK) {
-            bool before = false;
-            if (t < n) { const u64 v = a[lo + t]; before = STRICT ? v <= key : v < key; }
-            return lo + mt_block_count(before, smem);
-        }
-        // probes split [lo, hi) into 257 parts; predicates are 1..1 0..0 along t
-        const u64 p = lo + (n * (u64)(t + 1)) / (MT_BLOCK + 1);
-        const u64 v = a[p];
-        const bool before = STRICT ? v <= key : v < key;
-        const u32 c = mt_block_count(before, smem);
-        const u64 nlo = c == 0 ? lo : lo + (n * (u64)c) / (MT_BLOCK + 1) + 1;
-        const u64 nhi = c == MT_BLOCK ? hi : lo + (n * (u64)(c + 1)) / (MT_BLOCK + 1);
-        lo = nlo; hi = nhi;
+// bounds[t] = index of the first reference k-mer that is >= the first search k-mer of tile t (t < ntiles),
+// bounds[ntiles] = nr.  Search k-mers of tile t lie in [first_t, first_{t+1}), so every reference k-mer that can
+// match one of them lies in [bounds[t], bounds[t+1]).  One thread per tile: a binary search inside the k-mer's
+// key bucket (rbucket), i.e. ~log2(bucket size) probes.
+__global__ void match_bounds_kernel(const u64 *__restrict__ skeys, u64 ns, const u64 *__restrict__ rkeys, u64 nr,
+                                    const u64 *__restrict__ rbucket, int key_len, u32 ntiles, u64 *__restrict__ bounds) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > ntiles) return;
+    if (t == ntiles) { bounds[t] = nr; return; }
+    const u64 key = skeys[(u64)t * MT_TILE];
+    const u64 b = key >> (64 - 2 * key_len);
+    u64 lo = rbucket[b], hi = rbucket[b + 1];
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (rkeys[mid] < key) lo = mid + 1; else hi = mid;
     }
-    return lo;
+    bounds[t] = lo;
 }
 
-// One workgroup joins MT_TILE consecutive search k-mers.  Both sides are ascending, so the reference
-// k-mers that can match them form one contiguous range [lower_bound(first), upper_bound(last)); the block
-// finds it cooperatively, stages it in LDS (it is a few hundred k-mers when the two sets are of similar
-// density) and every search k-mer is then binary-searched in LDS instead of through L2.  Ranges that do not
-// fit are searched in place.  hit[i] = index of the k-mer in the reference, or -1.
+// One workgroup joins MT_TILE consecutive search k-mers.  Both sides are ascending, so the reference k-mers
+// that can match them form one contiguous range (match_bounds_kernel); the block stages it in LDS (it is a
+// few hundred k-mers when the two sets are of similar density) and every search k-mer is then binary-searched
+// in LDS instead of through L2.  Ranges that do not fit are searched in place.  hit[i] = index of the k-mer
+// in the reference, or -1.
 __global__ __launch_bounds__(MT_BLOCK) void match_kernel(const u64 *__restrict__ skeys, u64 ns,
-                                                          const u64 *__restrict__ rkeys, u64 nr,
+                                                          const u64 *__restrict__ rkeys,
+                                                          const u64 *__restrict__ bounds,
                                                           long long *__restrict__ hit, u64 *__restrict__ nhits) {
     __shared__ u64 sref[MT_RMAX];
     __shared__ u32 smem[4];
     const u64 q0 = (u64)blockIdx.x * MT_TILE;
     const u64 q1 = q0 + MT_TILE < ns ? q0 + MT_TILE : ns;
-    const u64 r_lo = mt_block_bound<false>(rkeys, 0, nr, skeys[q0], smem);
-    const u64 r_hi = mt_block_bound<true>(rkeys, r_lo, nr, skeys[q1 - 1], smem);
+    const u64 r_lo = bounds[blockIdx.x], r_hi = bounds[blockIdx.x + 1];
     const u32 cnt = (u32)(r_hi - r_lo < MT_RMAX ? r_hi - r_lo : MT_RMAX);
     const bool staged = r_hi - r_lo <= MT_RMAX;
     if (staged)
@@ -91,11 +77,14 @@ __global__ __launch_bounds__(MT_BLOCK) void match_kernel(const u64 *__restrict__
         }
     }
     if (nhits) {   // uniform
-        // per-thread counts <= MT_ITEMS: sum the block with one more counting round per bit
-        u32 total = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) total += mt_block_count((nfound >> b) & 1, smem) << b;
-        if (threadIdx.x == 0 && total) atomicAdd(nhits, (u64)total);
+        const u64 bal0 = __ballot(nfound & 1), bal1 = __ballot(nfound & 2), bal2 = __ballot(nfound & 4), bal3 = __ballot(nfound & 8);
+        const u32 wsum = __popcll(bal0) + 2 * __popcll(bal1) + 4 * __popcll(bal2) + 8 * __popcll(bal3);
+        if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = wsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const u32 total = smem[0] + smem[1] + smem[2] + smem[3];
+            if (total) atomicAdd(nhits, (u64)total);
+        }
     }
 }
 
