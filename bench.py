@@ -49,7 +49,9 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # KMERS_BENCH_FORCE_DIST=1: run the collective code path with a single rank too (rehearsal on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("KMERS_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     import kmers_amd as km
@@ -125,19 +127,19 @@ def main():
     for _ in range(args.warmup):
         info = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         info = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert info == (n_ref_win, n_read_win), (info, n_ref_win, n_read_win)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -213,7 +215,7 @@ def main():
         print(json.dumps(out))
     ctx.close()
     ctx_ref.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
