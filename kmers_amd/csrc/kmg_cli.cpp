@@ -1,7 +1,7 @@
 // kmg_cli.cpp -- native (C++) host side of the hot path: the three reference programs that sit on it, driven
 // through the C ABI of libkmers_gpu.so, plus the on-disk container they read and write.
 //
-//   kmg Database.MakeDatabase -a|-q -i in -o out [-K k -k k] [-l keylen] [-z level | -Z] [-S maxsize] [-r readmap] [-D n] [-R n] [-t threads]
+//   kmg Database.MakeDatabase -a|-q -i in -o out [-K k -k k] [-l keylen] [-z level | -Z] [-h] [-S maxsize] [-r readmap] [-D n] [-R n] [-t threads]
 //   kmg Database.Matcher      -i search.db -d ref.db -o out [-Z x] [-t threads]
 //   kmg Utils.TaxaCounts      -d ref.db -o out
 //
@@ -10,7 +10,7 @@
 // Appendix A.1-A.3): header | gzip-member blocks | index block | footer; every key's block is its own gzip
 // member, so blocks are deflated / inflated on a thread pool and written in key order
 // (FileCreator.java:385-391 enforces that order with OrderedLatches).  Options outside the GPU path
-// (minK != maxK, k > 32, -n > 0, -h, -p, -x) exit with status 3 so that a wrapper can fall
+// (minK != maxK, k > 32, -n > 0, -p, -x) exit with status 3 so that a wrapper can fall
 // back to the Java program.  Plain C++17 + zlib; no HIP in this file.
 #include <stdint.h>
 #include <stdio.h>
@@ -164,10 +164,11 @@ const int HEADER_ZIPPED = 64, HEADER_RAW = 41;
 struct IndexedOutputFile {
     FILE *f;
     int level;
+    bool hr;                       // MakeDatabase -h: text index, footer flag 1
     std::map<int, std::vector<std::pair<uint64_t, uint64_t>>> index;
     uint64_t pos;
 
-    IndexedOutputFile(const std::string &path, int zip_level) : level(zip_level) {
+    IndexedOutputFile(const std::string &path, int zip_level, bool human = false) : level(zip_level), hr(human) {
         f = fopen(path.c_str(), "wb");
         if (!f) throw std::runtime_error("cannot create " + path);
         std::string zeros(level < 0 ? HEADER_RAW : HEADER_ZIPPED, '\0');
@@ -185,18 +186,27 @@ struct IndexedOutputFile {
     }
     void close() {
         std::string idx;
-        put_be32(idx, (uint32_t)index.size());
-        for (auto &kv : index) {
-            put_be32(idx, (uint32_t)kv.first);
-            put_be32(idx, (uint32_t)kv.second.size());
-            for (auto &b : kv.second) { put_be64(idx, b.first); put_be64(idx, b.second); }
+        if (hr) {                  // one text line per key: key \t pos:len pos:len
+            for (auto &kv : index) {
+                idx += std::to_string(kv.first) + "\t";
+                for (size_t i = 0; i < kv.second.size(); i++)
+                    idx += (i ? " " : "") + std::to_string(kv.second[i].first) + ":" + std::to_string(kv.second[i].second);
+                idx += "\n";
+            }
+        } else {
+            put_be32(idx, (uint32_t)index.size());
+            for (auto &kv : index) {
+                put_be32(idx, (uint32_t)kv.first);
+                put_be32(idx, (uint32_t)kv.second.size());
+                for (auto &b : kv.second) { put_be64(idx, b.first); put_be64(idx, b.second); }
+            }
         }
         const std::string iblob = pack(idx, level);
         const uint64_t ipos = pos;
         fwrite(iblob.data(), 1, iblob.size(), f);
         pos += iblob.size();
         char buf[128];
-        snprintf(buf, sizeof buf, "%-19llu\n%-19llu\n%s\n%1d\n", (unsigned long long)ipos, (unsigned long long)iblob.size(), "1", 0);
+        snprintf(buf, sizeof buf, "%-19llu\n%-19llu\n%s\n%1d\n", (unsigned long long)ipos, (unsigned long long)iblob.size(), "1", hr ? 1 : 0);
         const std::string fblob = pack(buf, 0);          // footer and header: always level 0
         const uint64_t fpos = pos;
         fwrite(fblob.data(), 1, fblob.size(), f);
@@ -233,7 +243,29 @@ struct IndexedInputFile {
         if (sscanf(foot.c_str(), "%llu %llu %31s %d", &ipos, &ilen, cid, &hrflag) != 4) throw std::runtime_error("bad container footer: " + path);
         hr = hrflag == 1;
         const std::string raw = block(ipos, ilen);
-        if (hr) return;   // the caller refuses -h files before touching the index
+        if (hr) {         // text index: key \t pos:len pos:len
+            size_t p0 = 0;
+            while (p0 < raw.size()) {
+                size_t e = raw.find('\n', p0);
+                if (e == std::string::npos) e = raw.size();
+                const std::string line = raw.substr(p0, e - p0);
+                p0 = e + 1;
+                const size_t tab = line.find('\t');
+                if (tab == std::string::npos) continue;
+                auto &v = index[atoi(line.c_str())];
+                const char *q = line.c_str() + tab + 1;
+                while (*q) {
+                    char *end;
+                    const unsigned long long bp = strtoull(q, &end, 10);
+                    if (*end != ':') break;
+                    const unsigned long long bl = strtoull(end + 1, &end, 10);
+                    v.push_back({bp, bl});
+                    q = end;
+                    while (*q == ' ') q++;
+                }
+            }
+            return;
+        }
         const uint8_t *p = (const uint8_t *)raw.data();
         if (raw.size() < 4) throw std::runtime_error("bad index block");
         const uint32_t n = get_be32(p);
@@ -301,23 +333,60 @@ DbInfo db_info(const kmg_db *db) {
 // the meta block written again, so every file of the set is a complete database over a contiguous key range.
 // The reference checks the limit per buffered write (it can cut inside a key's block); this writer cuts at key
 // boundaries only, so the split points are equivalent, not byte-identical.
-void write_database(const Gpu &g, const kmg_db *db, const std::string &path, int level, uint64_t max_size = 0) {
+void write_database(const Gpu &g, const kmg_db *db, const std::string &path, int level, uint64_t max_size = 0, bool hr = false) {
     const DbInfo d = db_info(db);
     const size_t nkeys = (size_t)1 << (2 * d.key_len);
-    uint64_t nbytes = 0;
-    g.check(kmg_db_encode(g.ctx, db, nullptr, 0, &nbytes, nullptr));
-    std::vector<uint8_t> bytes(std::max<uint64_t>(nbytes, 1));
+    std::vector<uint8_t> bytes;
     std::vector<uint64_t> off(nkeys + 1);
-    g.check(kmg_db_encode(g.ctx, db, bytes.data(), nbytes, &nbytes, off.data()));
-    std::string meta;                                            // FileCreator.java:153-164
-    meta.push_back((char)d.k); meta.push_back((char)d.k); meta.push_back((char)d.key_len);
-    if (d.kind == KMG_PAYLOAD_TAXON) { put_be32(meta, 1); put_be32(meta, 2048); }                 // CountDataType.java:115-121
-    else { put_be32(meta, 2); put_be32(meta, 257); put_be32(meta, 2052); }                        // SetCompressor ++ ReadPosDataType
-    meta.push_back((char)(d.rc ? 1 : 0));
+    std::string meta;
+    if (!hr) {
+        uint64_t nbytes = 0;
+        g.check(kmg_db_encode(g.ctx, db, nullptr, 0, &nbytes, nullptr));
+        bytes.resize(std::max<uint64_t>(nbytes, 1));
+        g.check(kmg_db_encode(g.ctx, db, bytes.data(), nbytes, &nbytes, off.data()));
+        meta.push_back((char)d.k); meta.push_back((char)d.k); meta.push_back((char)d.key_len);   // FileCreator.java:153-164
+        if (d.kind == KMG_PAYLOAD_TAXON) { put_be32(meta, 1); put_be32(meta, 2048); }             // CountDataType.java:115-121
+        else { put_be32(meta, 2); put_be32(meta, 257); put_be32(meta, 2052); }                    // SetCompressor ++ ReadPosDataType
+        meta.push_back((char)(d.rc ? 1 : 0));
+    } else {
+        // MakeDatabase -h (FileCreator.java:166-179, 234-242, 349-370): text meta; per key one line per k-mer,
+        // the leading characters shared with the previous k-mer of the key block dropped (`last` starts as k
+        // spaces), TAB, values as text: TxC|TxC with the unsaturated count, or r:p r:p
+        meta = std::to_string(d.k) + "\n" + std::to_string(d.k) + "\n" + std::to_string(d.key_len) + "\n" +
+               (d.kind == KMG_PAYLOAD_TAXON ? "2048" : "257 2052") + "\n" + (d.rc ? "1" : "0") + "\n";
+        std::vector<uint64_t> keys(d.U + 1), val_off(d.U + 1), boff(nkeys + 1);
+        std::vector<int32_t> va(d.V + 1), vb(d.V + 1);
+        g.check(kmg_db_fetch(db, keys.data(), val_off.data(), va.data(), vb.data(), boff.data()));
+        std::vector<std::string> text(nkeys);
+        parallel_for(nkeys, [&](size_t key) {
+            std::string &t = text[key];
+            std::string last((size_t)d.k, ' '), nxt((size_t)d.k, ' ');
+            char buf[48];
+            for (uint64_t u = boff[key]; u < boff[key + 1]; u++) {
+                for (int p = 0; p < d.k; p++) nxt[p] = "ACTG"[(keys[u] >> (62 - 2 * p)) & 3];
+                size_t first = 0;
+                while (last[first] == nxt[first]) first++;
+                t.append(nxt, first, std::string::npos);
+                t.push_back('\t');
+                for (uint64_t v = val_off[u]; v < val_off[u + 1]; v++) {
+                    if (v != val_off[u]) t.push_back(d.kind == KMG_PAYLOAD_TAXON ? '|' : ' ');
+                    snprintf(buf, sizeof buf, d.kind == KMG_PAYLOAD_TAXON ? "%dx%d" : "%d:%d", va[v], vb[v]);
+                    t += buf;
+                }
+                t.push_back('\n');
+                last = nxt;
+            }
+        });
+        uint64_t total = 0;
+        for (size_t key = 0; key < nkeys; key++) { off[key] = total; total += text[key].size(); }
+        off[nkeys] = total;
+        bytes.resize(std::max<uint64_t>(total, 1));
+        for (size_t key = 0; key < nkeys; key++) memcpy(bytes.data() + off[key], text[key].data(), text[key].size());
+    }
     std::vector<std::string> blobs(nkeys);
     if (level >= 0)
         parallel_for(nkeys, [&](size_t key) { blobs[key] = gzip_member(bytes.data() + off[key], off[key + 1] - off[key], level); });
-    std::unique_ptr<IndexedOutputFile> out(new IndexedOutputFile(path, level));
+    std::unique_ptr<IndexedOutputFile> out(new IndexedOutputFile(path, level, hr));
     out->add_block(-1, out->pack(meta, level));
     int nfiles = 1;
     size_t keys_in_file = 0;
@@ -329,7 +398,7 @@ void write_database(const Gpu &g, const kmg_db *db, const std::string &path, int
             out->close();
             if (nfiles == 1 && rename(path.c_str(), (path + ".1").c_str()) != 0) throw std::runtime_error("cannot rename " + path);
             nfiles++;
-            out.reset(new IndexedOutputFile(path + "." + std::to_string(nfiles), level));
+            out.reset(new IndexedOutputFile(path + "." + std::to_string(nfiles), level, hr));
             out->add_block(-1, out->pack(meta, level));
             keys_in_file = 0;
         }
@@ -357,10 +426,69 @@ uint64_t size_from_human(const std::string &v) {
     return (uint64_t)(x * (double)mul);
 }
 
+// KmerFile over a human-readable file: text meta (KmerFile.java:279-283), UncompressedKmerSpliterator
+// (KmerFile.java:132-160): k-mer = previous k-mer with its tail replaced by the line's first field
+// (Kmer.java:26-44); values by CountDataType.fromString / SetDataType<ReadPos>.fromString
+kmg_db *open_hr_database(const Gpu &g, const IndexedInputFile &f, const std::string &path) {
+    const std::string m = f.read_key(-1);
+    int min_k, max_k, key_len, rc;
+    char ids[64];
+    if (sscanf(m.c_str(), "%d\n%d\n%d\n%63[^\n]\n%d", &min_k, &max_k, &key_len, ids, &rc) != 5)
+        throw std::runtime_error("bad meta block: " + path);
+    if (min_k != max_k || max_k > 32) throw Unsupported("minK != maxK or k > 32: use the Java path");
+    int kind;
+    if (std::string(ids) == "2048") kind = KMG_PAYLOAD_TAXON;
+    else if (std::string(ids) == "257 2052") kind = KMG_PAYLOAD_READPOS;
+    else throw std::runtime_error("UnexpectedDataTypeException: " + path);
+    std::vector<uint64_t> keys, val_off(1, 0);
+    std::vector<int32_t> va, vb;
+    std::string prev;
+    for (auto &kv : f.index) {
+        if (kv.first < 0) continue;
+        for (auto &b : kv.second) {
+            const std::string text = f.block(b.first, b.second);
+            size_t p0 = 0;
+            while (p0 < text.size()) {
+                size_t e = text.find('\n', p0);
+                if (e == std::string::npos) e = text.size();
+                const size_t tab = text.find('\t', p0);
+                if (tab == std::string::npos || tab > e) throw std::runtime_error("bad line in " + path);
+                const std::string part = text.substr(p0, tab - p0);
+                const std::string cur = prev.empty() || part.size() >= prev.size() ? part : prev.substr(0, prev.size() - part.size()) + part;
+                prev = cur;
+                uint64_t v = 0;
+                for (char c : cur) {
+                    const char uc = (char)(c & 0xDF);
+                    const int code = uc == 'A' ? 0 : uc == 'C' ? 1 : uc == 'T' ? 2 : uc == 'G' ? 3 : -1;
+                    if (code < 0 || cur.size() > 32) throw std::runtime_error("bad k-mer in " + path);
+                    v = (v << 2) | (uint64_t)code;
+                }
+                keys.push_back(v << (64 - 2 * cur.size()));
+                const char *q = text.c_str() + tab + 1, *qe = text.c_str() + e;
+                while (q < qe) {
+                    char *end;
+                    const long long a = strtoll(q, &end, 10);
+                    const long long bb = strtoll(end + 1, &end, 10);          // after 'x' or ':'
+                    va.push_back((int32_t)a);
+                    vb.push_back((int32_t)std::min<long long>(bb, 0x7FFFFFFF));
+                    q = end;
+                    if (q < qe) q++;                                            // '|' or ' '
+                }
+                val_off.push_back(va.size());
+                p0 = e + 1;
+            }
+        }
+    }
+    kmg_db *db = nullptr;
+    keys.push_back(0); va.push_back(0); vb.push_back(0);   // never null
+    g.check(kmg_db_load(g.ctx, max_k, key_len, rc, kind, keys.data(), keys.size() - 1, val_off.data(), va.data(), vb.data(), &db));
+    return db;
+}
+
 // new KmerFile(file, dataType) + its decoded content uploaded to the GPU
 kmg_db *open_database(const Gpu &g, const std::string &path) {
     IndexedInputFile f(path);
-    if (f.hr) throw Unsupported("human-readable (-h) databases are read by the Java path");
+    if (f.hr) return open_hr_database(g, f, path);
     const std::string m = f.read_key(-1);                                   // KmerFile.getMetaData, KmerFile.java:284-288
     if (m.size() < 8) throw std::runtime_error("bad meta block: " + path);
     const int min_k = (uint8_t)m[0], max_k = (uint8_t)m[1], key_len = (uint8_t)m[2];
@@ -444,7 +572,7 @@ struct StageClock {
 };
 
 int make_database(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmN", "aqZv");
+    const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmN", "aqZvh");
     for (char c : std::string("mN")) if (a.has(c)) throw Unsupported(std::string("option -") + c + " is not on the GPU path");
     const int k = a.geti('K', 32), min_k = a.geti('k', 24), key_len = a.geti('l', 6);     // MakeDatabase.java:106-109
     const int level = a.has('Z') ? -1 : a.geti('z', 5);
@@ -498,7 +626,7 @@ int make_database(int argc, char **argv) {
     }
     kmh_free(b);
     clk.lap("read-name map");
-    write_database(g, db, a.get('o'), level, a.has('S') ? size_from_human(a.get('S')) : 0);
+    write_database(g, db, a.get('o'), level, a.has('S') ? size_from_human(a.get('S')) : 0, a.has('h'));
     clk.lap("encode + deflate + write");
     if (a.has('v')) {
         const DbInfo d = db_info(db);

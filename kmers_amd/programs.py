@@ -11,21 +11,92 @@ import struct
 import numpy as np
 
 from . import container, parse
-from .api import DB, KmerDatabase, KmersGpuError, READ_ID, REF_ID, match_lines, merge_databases, taxa_count_lines
+from .api import DB, KmerDatabase, KmersGpuError, READ_ID, REF_ID, kmer_strings, match_lines, merge_databases, taxa_count_lines
 from ._lib import KMG_EUNSUPPORTED, PAYLOAD_READPOS, PAYLOAD_TAXON
 from .make_database import make_read_db, make_reference_db
 
 
-def write_database(db: KmerDatabase, path, zip_level=5):
+def _hr_values(kind, a, b):
+    """CountDataType.toString `TxC|TxC` (unsaturated counts, CountDataType.java:109-113) | SetDataType<ReadPos>
+    with its default separator `r:p r:p` (DataCollector.java:67, ReadPosDataType.java:46-49)."""
+    if kind == PAYLOAD_TAXON:
+        return "|".join("%dx%d" % x for x in zip(a, b))
+    return " ".join("%d:%d" % x for x in zip(a, b))
+
+
+def write_database(db: KmerDatabase, path, zip_level=5, hr=False):
     """FileCreator.create (FileCreator.java:117-217): meta under key -1, then every key 0..4^l-1 in order
-    (each gets a block, empty ones included, quirk C.12)."""
-    blocks, off = db.encode_blocks()
-    out = container.IndexedOutputFile(path, hr=False, zip_level=zip_level)
-    out.write_all(db.meta(), -1)
+    (each gets a block, empty ones included, quirk C.12).  hr = MakeDatabase -h: text meta, one text line per
+    k-mer with the characters it shares with the previous k-mer of its key block dropped
+    (FileCreator.java:166-179, 234-242, 349-370), text index."""
+    out = container.IndexedOutputFile(path, hr=hr, zip_level=zip_level)
+    if not hr:
+        blocks, off = db.encode_blocks()
+        out.write_all(db.meta(), -1)
+        for key in range(4 ** db.key_length):
+            out.set_current_key(key)
+            out.write(blocks[int(off[key]):int(off[key + 1])])
+        out.close()
+        return
+    ids = " ".join(str(i) for i in db.data_id())                     # Compressor.getStringID
+    out.write_all(("%d\n%d\n%d\n%s\n%s\n" % (db.k, db.k, db.key_length, ids, "1" if db.rc else "0")).encode(), -1)
+    h = db.fetch()
+    names = kmer_strings(h["keys"], db.k)
+    val_off, va, vb = h["val_off"].tolist(), h["val_a"].tolist(), h["val_b"].tolist()
+    boff = h["bucket_off"].tolist()
     for key in range(4 ** db.key_length):
         out.set_current_key(key)
-        out.write(blocks[int(off[key]):int(off[key + 1])])
+        last = " " * db.k
+        lines = []
+        for u in range(boff[key], boff[key + 1]):
+            nxt = names[u]
+            first = 0
+            while last[first] == nxt[first]:
+                first += 1
+            lines.append("%s\t%s\n" % (nxt[first:], _hr_values(db.kind, va[val_off[u]:val_off[u + 1]], vb[val_off[u]:val_off[u + 1]])))
+            last = nxt
+        out.write("".join(lines).encode())
     out.close()
+
+
+def _read_hr_database(ctx, f: container.IndexedInputFile):
+    """KmerFile over a human-readable file: text meta (KmerFile.java:279-283) and UncompressedKmerSpliterator
+    (KmerFile.java:132-160): k-mer = previous k-mer with its tail replaced by the line's first field
+    (Kmer.java:26-44), values parsed by CountDataType.fromString / SetDataType<ReadPos>.fromString."""
+    m = f.read_key(-1).decode().split("\n")
+    min_k, max_k, key_len = int(m[0]), int(m[1]), int(m[2])
+    ids = [int(x) for x in m[3].split()]
+    rc = m[4] == "1"
+    if min_k != max_k or max_k > 32:
+        raise KmersGpuError(KMG_EUNSUPPORTED, "minK != maxK or k > 32: use the Java path")
+    if ids == REF_ID:
+        kind = PAYLOAD_TAXON
+    elif ids == READ_ID:
+        kind = PAYLOAD_READPOS
+    else:
+        raise ValueError("UnexpectedDataTypeException")
+    code = {"A": 0, "C": 1, "T": 2, "G": 3}
+    keys, val_off, va, vb = [], [0], [], []
+    prev = None
+    for line in f.read_keys(0, f.max_index()).decode().splitlines():
+        part, vals = line.split("\t")
+        cur = part if prev is None or len(part) >= len(prev) else prev[:len(prev) - len(part)] + part
+        prev = cur
+        v = 0
+        for ch in cur:
+            v = (v << 2) | code[ch.upper()]
+        keys.append(v << (64 - 2 * len(cur)))
+        if kind == PAYLOAD_TAXON:
+            for item in vals.split("|"):
+                t, c = item.split("x")
+                va.append(int(t)); vb.append(min(int(c), 2 ** 31 - 1))
+        else:
+            for item in vals.split(" "):
+                r, p = item.split(":")
+                va.append(int(r)); vb.append(int(p))
+        val_off.append(len(va))
+    return KmerDatabase.load(ctx, max_k, key_len, rc, kind, np.array(keys, np.uint64), np.array(val_off, np.uint64),
+                             np.array(va, np.int32), np.array(vb, np.int32))
 
 
 def read_meta(f: container.IndexedInputFile):
@@ -41,7 +112,7 @@ def open_database(ctx, path) -> KmerDatabase:
     """new KmerFile(file, dataType) + its decoded content uploaded to the GPU."""
     f = container.IndexedInputFile(path)
     if f.hr:
-        raise KmersGpuError(KMG_EUNSUPPORTED, "human-readable (-h) databases are read by the Java path")
+        return _read_hr_database(ctx, f)
     min_k, max_k, key_len, ids, rc = read_meta(f)
     if min_k != max_k or max_k > 32:
         raise KmersGpuError(KMG_EUNSUPPORTED, "minK != maxK or k > 32: use the Java path")
@@ -56,7 +127,7 @@ def open_database(ctx, path) -> KmerDatabase:
 
 
 def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length=6, zip_level=5, read_map_path=None,
-                  dust=None, runofsame=None):
+                  dust=None, runofsame=None, hr=False):
     """MakeDatabase -a (mode 'a') / -q (mode 'q').  Defaults as the reference's (-K 32 -k 24 -l 6 -z 5,
     MakeDatabase.java:106-109); minK != maxK is refused (GPU path limit)."""
     if min_k != k:
@@ -73,7 +144,7 @@ def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length
                 g.write(nm + "\n")
     else:
         raise ValueError("input mode must be 'a' (FASTA reference) or 'q' (FASTQ reads)")
-    write_database(db, output_path, zip_level)
+    write_database(db, output_path, zip_level, hr)
     return db
 
 

@@ -591,9 +591,10 @@ def _gz_member(data, level):
         struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
 
 
-def write_indexed_file(path, blocks, zip_level=5):
+def write_indexed_file(path, blocks, zip_level=5, hr=False):
     """jar IndexedOutputFile (A.1): `blocks` = {key: bytes} as FileCreator.create writes them (key -1 first,
-    then 0 .. 4^l-1, one block each).  zip_level None = unzipped (41-byte header), else zipped (64-byte)."""
+    then 0 .. 4^l-1, one block each).  zip_level None = unzipped (41-byte header), else zipped (64-byte).
+    hr = the human-readable flavour (MakeDatabase -h): text index, footer flag 1."""
     z = zip_level is not None
     body = bytearray(b"\0" * (64 if z else 41))
     index = []
@@ -601,13 +602,16 @@ def write_indexed_file(path, blocks, zip_level=5):
         blob = _gz_member(blocks[key], zip_level) if z else blocks[key]
         index.append((key, len(body), len(blob)))
         body += blob
-    idx = struct.pack(">i", len(index))
-    for key, pos, ln in sorted(index):                       # TreeMap order: -1 first
-        idx += struct.pack(">ii", key, 1) + struct.pack(">qq", pos, ln)
+    if hr:                                                   # one text line per key: key \t pos:len
+        idx = "".join("%d\t%d:%d\n" % (key, pos, ln) for key, pos, ln in sorted(index)).encode()
+    else:
+        idx = struct.pack(">i", len(index))
+        for key, pos, ln in sorted(index):                   # TreeMap order: -1 first
+            idx += struct.pack(">ii", key, 1) + struct.pack(">qq", pos, ln)
     iblob = _gz_member(idx, zip_level) if z else idx
     ipos = len(body)
     body += iblob
-    footer = ("%-19d\n%-19d\n%s\n%1d\n" % (ipos, len(iblob), "1", 0)).encode()
+    footer = ("%-19d\n%-19d\n%s\n%1d\n" % (ipos, len(iblob), "1", 1 if hr else 0)).encode()
     fblob = _gz_member(footer, 0) if z else footer
     fpos = len(body)
     body += fblob
@@ -616,6 +620,35 @@ def write_indexed_file(path, blocks, zip_level=5):
     body[0:len(hblob)] = hblob
     with open(path, "wb") as f:
         f.write(bytes(body))
+
+
+def hr_database_blocks(k, key_len, rc, kind, keys, val_off, val_a, val_b, bucket_off):
+    """The blocks FileCreator.create writes with hr = true (MakeDatabase -h), from a database's CSR arrays:
+    meta = minK, maxK, keyLength, Compressor.getStringID(id), rc as text lines (FileCreator.java:166-179); per
+    key, one line per k-mer ascending: diff(last, next) + TAB + values + NEWLINE, where last starts as k spaces
+    in every key block and diff drops the leading characters next shares with last (FileCreator.java:234-242,
+    349-370); values = CountDataType.toString `TxC|TxC` with the UNSATURATED count (CountDataType.java:109-113)
+    or SetDataType<ReadPos> with its default separator: `r:p r:p` (DataCollector.java:67, ReadPosDataType.java:46-49)."""
+    ids = "2048" if kind == 0 else "257 2052"
+    blocks = {-1: ("%d\n%d\n%d\n%s\n%s\n" % (k, k, key_len, ids, "1" if rc else "0")).encode()}
+    letters = "ACTG"
+    for key in range(4 ** key_len):
+        last = " " * k
+        out = []
+        for u in range(int(bucket_off[key]), int(bucket_off[key + 1])):
+            nxt = "".join(letters[(int(keys[u]) >> (62 - 2 * i)) & 3] for i in range(k))
+            first = 0
+            while last[first] == nxt[first]:
+                first += 1
+            a, b = int(val_off[u]), int(val_off[u + 1])
+            if kind == 0:
+                vals = "|".join("%dx%d" % (int(val_a[v]), int(val_b[v])) for v in range(a, b))
+            else:
+                vals = " ".join("%d:%d" % (int(val_a[v]), int(val_b[v])) for v in range(a, b))
+            out.append(nxt[first:] + "\t" + vals + "\n")
+            last = nxt
+        blocks[key] = "".join(out).encode()
+    return blocks
 
 
 def read_indexed_file(path):
@@ -634,7 +667,12 @@ def read_indexed_file(path):
     fpos, flen = [int(x) for x in re.split(" +", blk(0, 100)[:41].decode().strip())[:2]]
     lines = blk(fpos, flen).decode().split("\n")
     raw = blk(int(lines[0].strip()), int(lines[1].strip()))
-    assert lines[3].strip() == "0", "hr files not handled by the oracle"
+    if lines[3].strip() == "1":                              # hr index: key \t pos:len pos:len
+        out = {}
+        for line in raw.decode().splitlines():
+            key, rest = line.split("\t")
+            out[int(key)] = b"".join(blk(*[int(x) for x in part.split(":")]) for part in rest.split())
+        return out
     (n,) = struct.unpack_from(">i", raw, 0)
     off, out = 4, {}
     for _ in range(n):

@@ -153,3 +153,55 @@ def test_native_cli_matches_python_drivers(tmp_path):
     assert seen == list(range(4 ** l))                                       # contiguous key ranges, nothing twice
     run("Utils.TaxaCounts", "-d", p("split.db"), "-o", p("split.tsv"))
     assert open(p("split.tsv")).read() == open(p("c.tsv")).read()
+
+
+def test_human_readable_databases(tmp_path):
+    """MakeDatabase -h (text meta, prefix-dropped k-mer lines, text index; FileCreator.java:166-179,349-370):
+    written by the Python and the C++ drivers, byte for byte what the oracle writes when unzipped (payload for
+    payload when zipped), and read back by both (KmerFile.java:132-160,279-283) with unchanged results."""
+    import subprocess
+    import kmers_amd as km
+    from kmers_amd import programs, synth
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    kmg = os.path.join(os.path.dirname(km.__file__), "kmg")
+    taxa, genomes = synth.random_genomes(85, 3, 5000, first_taxon=-1, shared_frac=0.3)
+    genomes = list(genomes) + [genomes[0]]
+    taxa = list(taxa) + [taxa[0]]                                  # counts of 2
+    reads = synth.random_reads(86, genomes[:3], 500, 80, 0.01, n_rate=0.003)
+    p = lambda n: str(tmp_path / n)
+    open(p("ref.fa"), "wb").write(synth.fasta_bytes(taxa, genomes))
+    open(p("reads.fq"), "wb").write(synth.fastq_bytes(reads))
+    k, l = 19, 3
+    o_ref = OracleDB(synth.fasta_bytes(taxa, genomes), 0, k, l)
+    o_reads = OracleDB(synth.fastq_bytes(reads), 1, k, l)
+    want_ref = R.hr_database_blocks(k, l, True, 0, o_ref.keys, o_ref.val_off, o_ref.val_a, o_ref.val_b, o_ref.bucket_off)
+    want_reads = R.hr_database_blocks(k, l, False, 1, o_reads.keys, o_reads.val_off, o_reads.val_a, o_reads.val_b, o_reads.bucket_off)
+    R.write_indexed_file(p("ref.want"), want_ref, None, hr=True)
+    R.write_indexed_file(p("reads.want"), want_reads, None, hr=True)
+
+    def run(*args):
+        r = subprocess.run([kmg] + list(args), capture_output=True, text=True, timeout=110)
+        assert r.returncode == 0, r.stderr
+
+    common = ["-K", str(k), "-k", str(k), "-l", str(l), "-h"]
+    run("Database.MakeDatabase", "-a", "-i", p("ref.fa"), "-o", p("ref.c.db"), "-Z", *common)
+    run("Database.MakeDatabase", "-q", "-i", p("reads.fq"), "-o", p("reads.c.db"), "-r", p("map.c.gz"), *common)   # zipped
+    ctx = km.Context(0)
+    programs.make_database(ctx, p("ref.fa"), p("ref.py.db"), "a", k, k, l, zip_level=7, hr=True)
+    programs.make_database(ctx, p("reads.fq"), p("reads.py.db"), "q", k, k, l, zip_level=None, read_map_path=p("map.py.gz"), hr=True)
+    assert open(p("ref.c.db"), "rb").read() == open(p("ref.want"), "rb").read()
+    assert open(p("reads.py.db"), "rb").read() == open(p("reads.want"), "rb").read()
+    assert R.read_indexed_file(p("ref.py.db")) == want_ref and R.read_indexed_file(p("reads.c.db")) == want_reads
+    assert b"\t-1x2" in want_ref[0] + want_ref[1] + b"".join(want_ref[i] for i in range(2, 4 ** l))      # unsaturated text counts
+    # read back: either driver reads either file
+    hit, _ = o_reads.match(o_ref)
+    want = o_reads.match_lines(o_ref, hit)
+    programs.matcher(ctx, p("reads.c.db"), p("ref.c.db"), p("m.py.txt"), plain=True)
+    assert open(p("m.py.txt"), "rb").read() == want
+    ctx.close()
+    run("Database.Matcher", "-i", p("reads.py.db"), "-d", p("ref.py.db"), "-o", p("m.c.txt"), "-Z", "x")
+    assert open(p("m.c.txt"), "rb").read() == want
+    run("Utils.TaxaCounts", "-d", p("ref.py.db"), "-o", p("c.tsv"))
+    t, m, q = o_ref.taxacounts()
+    assert open(p("c.tsv")).read().splitlines() == ["%d\t%d\t%d" % x for x in zip(t, m, q)]
