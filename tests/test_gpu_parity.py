@@ -362,8 +362,8 @@ def test_db_load_roundtrip_and_errors(ctx):
 
 # ---------------------------------------------------------------------------- full-size properties
 def test_cfg1_scale_properties(ctx):
-    """BASELINE config 1 at full size (5 Mbp, 1M x 150 bp, k=31): size-independent properties, plus
-    exact equality with the C oracle (multi-threaded, finishes in seconds)."""
+    """BASELINE config 1/2 at full size (5 Mbp, 1M x 150 bp, k=31): size-independent properties, plus exact
+    equality of both databases, the read-name map and every hit index with the C oracle (multi-threaded)."""
     import kmers_amd as km
     from kmers_amd import synth
     from oracle.c_oracle import OracleDB
@@ -380,16 +380,17 @@ def test_cfg1_scale_properties(ctx):
     assert nh == ref.n_unique
     want = OracleDB(fa, 0, 31, 6, threads=8)
     _same_db(ref, want)
-    nreads = 200_000                                                     # oracle-sized slice of the reads
+    nreads = reads.shape[0]                                              # all 1M reads: 120 M records
     fq = synth.fastq_bytes(reads[:nreads])
     rdb, names = km.make_read_db(ctx, fq, 31, 6)
     assert rdb.n_values == nreads * 120 == rdb.n_windows
-    o_reads = OracleDB(fq, 1, 31, 6, threads=8)
+    o_reads = OracleDB(fq, 1, 31, 6, threads=16)
     _same_db(rdb, o_reads)
+    assert names == o_reads.names and len(names) == nreads
     hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
-    o_hit, o_nh = o_reads.match(want, threads=8)
+    o_hit, o_nh = o_reads.match(want, threads=16)
     assert nh == o_nh and np.array_equal(hit, o_hit)
-    assert 0.5 < nh / rdb.n_unique < 0.9                                 # ~0.99^31 of read k-mers hit
+    assert 0.1 < nh / rdb.n_unique < 0.9                                 # error k-mers are mostly unique misses
     t, m, q = km.taxa_counts(ref)
     ot, om, oq = want.taxacounts()
     assert np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
