@@ -116,9 +116,6 @@ __global__ __launch_bounds__(RSC_BLOCK) void rs_scatter_kernel(const u64 *__rest
     const u32 tile_base = tile * RS_TILE;
     const u32 tile_n = min((u32)RS_TILE, n - tile_base);
 
-#ifdef RSC_PREFETCH   // measured slower (1.06 vs 1.02 ms): the extra early load delays the record loads
-    const u32 tbl = tid < RS_DIGITS ? table[(u64)tid * ntiles + tile] : 0u;
-#endif
     if (tid < RS_DIGITS) {
 #pragma unroll
         for (int w = 0; w < RSC_WAVES; w++) wcnt[w][tid] = 0;
@@ -166,11 +163,8 @@ __global__ __launch_bounds__(RSC_BLOCK) void rs_scatter_kernel(const u64 *__rest
         if (tid < RS_DIGITS) {
             u32 start = incl - run;
             dstart[tid] = start;
-#ifdef RSC_PREFETCH
-            gdelta[tid] = tbl - start;
-#else
+            // (loading this entry at kernel entry instead was measured slower: 1.06 vs 1.02 ms, it delays the record loads)
             gdelta[tid] = table[(u64)tid * ntiles + tile] - start;
-#endif
         }
     }
     __syncthreads();
