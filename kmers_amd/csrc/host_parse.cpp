@@ -72,7 +72,6 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
     }
     std::unordered_map<std::string_view, int64_t> intern;
     b->name_off.push_back(0);
-    b->bases.reserve(n);
     int state = S_OTHER;
     uint64_t id_start = 0, id_len = 0;
     int32_t cur_id = 0; uint8_t cur_ok = 0; int64_t cur_tok = -1;
@@ -94,15 +93,24 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
             } else cur_tok = it->second;
         }
     };
-    auto close_seq = [&]() {
-        if (in_seq) { b->seq_off.push_back(b->bases.size()); in_seq = false; }
-    };
     b->seq_off.push_back(0);   // seq_off = [0, end_0, end_1, ...]: a sequence is opened/closed in turn
-    for (uint64_t i = 0; i < n; i++) {
-        uint8_t c = data[i];
-        int ns = trans[state][c];
+    // bases are written through a raw pointer into a buffer sized for the whole input (it can only shrink)
+    b->bases.resize(n);
+    uint8_t *out = b->bases.data();
+    uint64_t nout = 0;
+    auto close_seq_fast = [&]() {
+        if (in_seq) { b->seq_off.push_back(nout); in_seq = false; }
+    };
+    // is there any transition out of `st` on character c?
+    bool special[3][256];
+    for (int st = 0; st < 3; st++)
+        for (int c = 0; c < 256; c++) special[st][c] = trans[st][c] >= 0;
+    uint64_t i = 0;
+    while (i < n) {
+        const uint8_t c = data[i];
+        const int ns = trans[state][c];
         if (ns >= 0) {
-            if (state == S_KMER) close_seq();
+            if (state == S_KMER) close_seq_fast();
             state = ns;
             last_was_base = false;
             if (state == S_ID) { id_start = i + 1; id_len = 0; id_done = false; }
@@ -113,13 +121,29 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
                 if (mode == 0) { b->seq_id.push_back(cur_id); b->id_ok.push_back(cur_ok); }
                 else b->seq_tok.push_back(cur_tok);
             }
+            i++;
             continue;
         }
-        if (state == S_ID) { id_len++; continue; }
-        if (state != S_KMER) continue;
-        if (c > 32) { b->bases.push_back(c); last_was_base = true; }
-        else last_was_base = false;
+        // a run of characters without a transition: handled in one go per state
+        const bool *sp = special[state];
+        uint64_t j = i + 1;
+        if (state == S_KMER) {
+            // sequence characters: everything > 32 is a base position (KmersFromFile.java:154-158)
+            if (c > 32) { out[nout++] = c; last_was_base = true; } else last_was_base = false;
+            while (j < n && !sp[data[j]]) {
+                const uint8_t d = data[j++];
+                if (d > 32) { out[nout++] = d; last_was_base = true; } else last_was_base = false;
+            }
+        } else {
+            while (j < n && !sp[data[j]]) j++;
+            if (state == S_ID) id_len += j - i;
+        }
+        i = j;
     }
+    b->bases.resize(nout);
+    auto close_seq = [&]() {
+        if (in_seq) { b->seq_off.push_back(b->bases.size()); in_seq = false; }
+    };
     const bool ended_in_kmer = state == S_KMER && in_seq && last_was_base;
     close_seq();
     const size_t nseq = b->seq_off.size() - 1;
