@@ -3,6 +3,7 @@
 # Runs config 1 through out/Kmers.jar and through `python -m kmers_amd`, then diffs at tier T1:
 # unzipped DB files byte for byte (reference DB), block payloads (read DB, read lists sorted), match lines
 # (read lists sorted) and TaxaCounts lines.  Usage: tools/jar_crosscheck.sh /path/to/Kmers.jar [workdir]
+# KMG_DRIVER="kmers_amd/kmg" checks the native C++ drivers instead of the Python ones.
 set -euo pipefail
 JAR=${1:?path to Kmers.jar}
 WORK=${2:-/tmp/kmers_crosscheck}
@@ -22,10 +23,11 @@ T=$(nproc)
 /usr/bin/time -v java -cp "$JAR" Database.Matcher -i java_reads/reads.db -d java_ref/ref.db -o java.matches.txt -Z x -t "$T"
 java -cp "$JAR" Utils.TaxaCounts -d java_ref/ref.db -o java.counts.tsv
 cd "$ROOT"
-python3 -m kmers_amd Database.MakeDatabase -a -i "$WORK/ref.fa"   -o "$WORK/gpu/ref.db"   -K 31 -k 31 -Z
-python3 -m kmers_amd Database.MakeDatabase -q -i "$WORK/reads.fq" -o "$WORK/gpu/reads.db" -r "$WORK/gpu/reads.map.gz" -K 31 -k 31 -Z
-python3 -m kmers_amd Database.Matcher -i "$WORK/gpu/reads.db" -d "$WORK/gpu/ref.db" -o "$WORK/gpu.matches.txt" -Z x
-python3 -m kmers_amd Utils.TaxaCounts -d "$WORK/gpu/ref.db" -o "$WORK/gpu.counts.tsv"
+DRIVER=${KMG_DRIVER:-python3 -m kmers_amd}
+$DRIVER Database.MakeDatabase -a -i "$WORK/ref.fa"   -o "$WORK/gpu/ref.db"   -K 31 -k 31 -Z
+$DRIVER Database.MakeDatabase -q -i "$WORK/reads.fq" -o "$WORK/gpu/reads.db" -r "$WORK/gpu/reads.map.gz" -K 31 -k 31 -Z
+$DRIVER Database.Matcher -i "$WORK/gpu/reads.db" -d "$WORK/gpu/ref.db" -o "$WORK/gpu.matches.txt" -Z x
+$DRIVER Utils.TaxaCounts -d "$WORK/gpu/ref.db" -o "$WORK/gpu.counts.tsv"
 cmp "$WORK/java_ref/ref.db" "$WORK/gpu/ref.db" && echo "reference DB: byte-identical"
 diff <(zcat "$WORK/java_reads/reads.map.gz") <(zcat "$WORK/gpu/reads.map.gz") && echo "read map: identical"
 python3 - <<PY
