@@ -457,3 +457,73 @@ def test_dust_and_runofsame_filters_match_oracle(ctx, k, dust, run):
     assert names == wr.names          # reads are numbered before the filters
     ref.close()
     rdb.close()
+
+
+# ---------------------------------------------------------------------------- randomised configurations
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_against_oracle(ctx, seed):
+    """Random k, key length, input shape, batch cuts and filters -- sized so that the sort plans 1..12 prefix
+    bits (fused first digit of 1..8 bits, index local sort on and off, segments near their cap)."""
+    import kmers_amd as km
+    from kmers_amd import parse, synth
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.integers(8, 33))
+    l = int(rng.integers(1, min(k, 6) + 1))
+    n_gen, glen = int(rng.integers(1, 6)), int(rng.integers(500, 40000))
+    taxa, genomes = synth.random_genomes(seed, n_gen, glen, first_taxon=int(rng.integers(-5, 1000)),
+                                         shared_frac=float(rng.choice([0.0, 0.3, 0.9])))
+    if rng.random() < 0.3:                                              # low complexity: skewed prefixes
+        genomes[0][: glen // 2] = ord("A")
+    n_reads, rlen = int(rng.integers(50, 6000)), int(rng.integers(k, 260))
+    reads = synth.random_reads(seed + 1, genomes, n_reads, rlen, 0.02, n_rate=float(rng.choice([0.0, 0.01])))
+    if rng.random() < 0.5:
+        reads[rng.integers(0, n_reads, size=n_reads // 10)] |= 0x20     # lower case
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    dust = int(rng.integers(1, 4)) if rng.random() < 0.25 else None
+    run = int(rng.integers(3, 9)) if rng.random() < 0.25 else None
+    for data, mode, kind, rc in ((fa, parse.FASTA, "ref", True), (fq, parse.FASTQ, "read", False)):
+        b = parse.parse(data, mode, k).batch
+        ncut = int(rng.integers(0, 3))
+        cuts = [0] + sorted(int(x) for x in rng.integers(0, b.nseq + 1, size=ncut)) + [b.nseq]
+        fc = km.FileCreator(ctx, l, k, kind, rc=rc, dust=dust, runofsame=run)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            a0, a1 = int(b.seq_off[lo]), int(b.seq_off[hi])
+            fc.add_kmers(km.SequenceBatch(b.bases[a0:a1], b.seq_off[lo:hi + 1] - b.seq_off[lo],
+                                          seq_id=None if b.seq_id is None else b.seq_id[lo:hi],
+                                          seq_tok=None if b.seq_tok is None else b.seq_tok[lo:hi]))
+        got = fc.create()
+        want = OracleDB(data, 0 if kind == "ref" else 1, k, l, threads=4, dust=-1 if dust is None else dust,
+                        runofsame=-1 if run is None else run)
+        _same_db(got, want)
+        if kind == "ref":
+            ref, o_ref = got, want
+        else:
+            hit, nh = km.DB([ref]).get_nearest_kmers(got)
+            o_hit, o_nh = want.match(o_ref)
+            assert nh == o_nh and np.array_equal(hit, o_hit)
+            got.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("k,l,n_reads,rlen", [(32, 6, 120_000, 150), (24, 5, 60_000, 250), (17, 4, 150_000, 60), (31, 6, 30_000, 1000)])
+def test_medium_builds_against_oracle(ctx, k, l, n_reads, rlen):
+    """5-30 M records: 11-14 prefix bits, the one-word local sort with its k-mer-run epilogue at k = 32 (no spare
+    low key bits) and below, reads longer than a tile's share."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(k, 4, 200_000, shared_frac=0.2)
+    reads = synth.random_reads(k + 1, genomes, n_reads, rlen, 0.01, n_rate=0.001)
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    ref = km.make_reference_db(ctx, fa, k, l)
+    rdb, names = km.make_read_db(ctx, fq, k, l)
+    o_ref, o_reads = OracleDB(fa, 0, k, l, threads=16), OracleDB(fq, 1, k, l, threads=16)
+    _same_db(ref, o_ref)
+    _same_db(rdb, o_reads)
+    assert names == o_reads.names
+    hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
+    o_hit, o_nh = o_reads.match(o_ref, threads=16)
+    assert nh == o_nh and np.array_equal(hit, o_hit)
+    ref.close()
+    rdb.close()
