@@ -188,7 +188,11 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     }
     // First batch: plan the sort's prefix bits from the record upper bound and let the extractor write the
     // records partitioned by the first prefix digit.  Later batches append in window order (and void it).
-    const int plan = ctx->n_adds == 0 ? choose_pbits(upper, 2 * ctx->k) : 0;
+    // (planned from the expected record count -- every sequence long enough, every window valid -- rather than
+    // from the upper bound: any plan is correct, a tight one fills the local sort's segments)
+    const u64 short_by = std::min<u64>(nbases, nseq * (u64)(ctx->k - 1));
+    const u64 expect = std::max<u64>(nbases - short_by, nbases / 16) * (ctx->rc ? 2 : 1);
+    const int plan = ctx->n_adds == 0 ? choose_pbits(expect, 2 * ctx->k) : 0;
     const bool part = plan > 0 && nbases < 0xFFFFFFF0ull / 2;
     ctx->prepart = part;
     ctx->plan_pbits = plan;

@@ -205,12 +205,22 @@ struct SortPass {
     int src;
 };
 
+#define LS_BLOCK 512
+#define LS_WAVES (LS_BLOCK / 64)
+#ifndef LS_ITEMS
+#define LS_ITEMS 5
+#endif
+#ifndef LS_MINWAVES
+#define LS_MINWAVES 6
+#endif
+#define LS_MAX (LS_BLOCK * LS_ITEMS)   // 2560 records per segment at most (48 KB of LDS: 3 blocks per CU)
+
 // number of prefix bits sorted by global passes for n records of `kbits` key bits
 static inline int choose_pbits(u64 n, int kbits) {
     // average segment <= 2300 records: LS_MAX = 2560 is then > 5 sigma away on uniform keys, and segments are as
     // full as the local sort's 512-record rounds allow
     int p = 0;
-    while (p < kbits && p < 24 && (n >> p) > 2300) p++;
+    while (p < kbits && p < 24 && (n >> p) > (u64)(LS_BLOCK * LS_ITEMS) * 9 / 10) p++;
     return p;
 }
 
@@ -276,10 +286,6 @@ static int radix_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 
 // Correctness: the prefix passes are a stable sort by prefix; a stable sort of each equal-prefix segment
 // by (payload digits, low key bits) then yields the same order as the full LSD sort.
 // ------------------------------------------------------------------------------------------------------
-#define LS_BLOCK 512
-#define LS_WAVES (LS_BLOCK / 64)
-#define LS_ITEMS 5
-#define LS_MAX (LS_BLOCK * LS_ITEMS)   // 2560 records per segment at most (48 KB of LDS: 3 blocks per CU)
 #define LS_MAX_PASSES 16
 
 #define LS_TOP 2        // key digits sorted by counting passes before the comparison finish
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
 // index of each one's first record (vals_in[s0 ..], as 64-bit words), their number to ucount[segment], and
 // only the payloads to vals_out: the per-record sorted keys are never needed again.
 template <typename V, bool HEADS>
-__global__ __launch_bounds__(LS_BLOCK, 6) void ls_sortidx_kernel(u64 *keys_in, V *vals_in, u64 *__restrict__ keys_out,
+__global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *keys_in, V *vals_in, u64 *__restrict__ keys_out,
                                                                V *__restrict__ vals_out, const u32 *__restrict__ seg_off,
                                                                LocalPasses lp, int pbits, u32 *__restrict__ ucount) {
     __shared__ uint16_t wcnt[LS_WAVES][RS_DIGITS];
