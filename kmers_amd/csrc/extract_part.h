@@ -19,9 +19,8 @@
 #define EP_WAVES (EP_BLOCK / 64)
 #define EP_ROUNDS (EX_TILE / EP_BLOCK)   // 8 windows per thread
 #ifndef EP_SQCAP
-#define EP_SQCAP 96
+#define EP_SQCAP 96                      // sequences of a tile whose payload data is cached in LDS
 #endif
-//                    // sequences of a tile whose payload data is cached in LDS
 
 struct PartArgs {
     ExtractArgs e;
