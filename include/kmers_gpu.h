@@ -114,6 +114,22 @@ int kmg_db_fetch(const kmg_db *db, uint64_t *keys, uint64_t *val_off, int32_t *v
 int kmg_db_load(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *keys,
                 uint64_t n_unique, const uint64_t *val_off, const int32_t *val_a, const int32_t *val_b,
                 kmg_db **out);
+/* Device-resident variants (no counterpart in the reference: they exist so that a multi-GPU caller can move
+ * database slices between GPUs -- kmers_amd/dist.py, the key-range exchange of SURVEY 8e -- without staging
+ * them through host memory).
+ * kmg_db_copy_dev: copy elements [first, first + count) of one CSR array of `db` into caller-owned DEVICE memory
+ *   (u64 for keys / val_off / bucket_off, int32 for val_a / val_b); synchronises before returning.
+ * kmg_db_load_dev: kmg_db_load from DEVICE arrays (copied; the caller keeps ownership).  Checked on the device:
+ *   keys strictly ascending, val_off running from 0 to n_values (KMG_EINVAL otherwise). */
+#define KMG_DB_KEYS       0
+#define KMG_DB_VAL_OFF    1
+#define KMG_DB_VAL_A      2
+#define KMG_DB_VAL_B      3
+#define KMG_DB_BUCKET_OFF 4
+int kmg_db_copy_dev(const kmg_db *db, int which, void *d_dst, uint64_t first, uint64_t count);
+int kmg_db_load_dev(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *d_keys,
+                    uint64_t n_unique, const uint64_t *d_val_off, const int32_t *d_val_a, const int32_t *d_val_b,
+                    uint64_t n_values, kmg_db **out);
 void kmg_db_free(kmg_db *db);
 /* kmg_db_encode: the per-key block bytes MakeAndWriteKey writes (FileCreator.java:312-347:
  *   [shared-prefix byte][rest of compressedBytes][CountDataType | SetCompressor<ReadPos> bytes]),

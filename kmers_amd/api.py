@@ -34,6 +34,7 @@ class Context:
         if rc != 0:
             raise KmersGpuError(rc, "kmg_create failed (is a GPU visible?)")
         self.h = h
+        self.device = device
 
     def check(self, rc):
         if rc == 0:
@@ -105,6 +106,45 @@ class KmerDatabase:
         ctx.check(ctx.lib.kmg_db_load(ctx.h, k, key_length, 1 if rc else 0, kind, _ptr(keys), len(keys), _ptr(val_off),
                                       _ptr(val_a), _ptr(val_b), C.byref(h)))
         return cls(ctx, h)
+
+    @classmethod
+    def load_tensors(cls, ctx, k, key_length, rc, kind, keys, val_off, val_a, val_b):
+        """load() from torch tensors on the context's GPU (int64 key bits / offsets, int32 values): kmg_db_load_dev.
+        The caller synchronises the stream that produced them first."""
+        import torch
+        want = torch.device("cuda", ctx.device)
+        for t, dt in ((keys, torch.int64), (val_off, torch.int64), (val_a, torch.int32), (val_b, torch.int32)):
+            if t.device != want or t.dtype != dt or t.dim() != 1:
+                raise ValueError("load_tensors wants 1-D int64/int64/int32/int32 tensors on %s" % want)
+        if val_off.numel() != keys.numel() + 1 or val_a.numel() != val_b.numel():
+            raise ValueError("val_off must hold one more element than keys; val_a and val_b the same number")
+        keys, val_off, val_a, val_b = keys.contiguous(), val_off.contiguous(), val_a.contiguous(), val_b.contiguous()
+        h = C.c_void_p()
+        ctx.check(ctx.lib.kmg_db_load_dev(ctx.h, k, key_length, 1 if rc else 0, kind, keys.data_ptr(), keys.numel(),
+                                          val_off.data_ptr(), val_a.data_ptr() if val_a.numel() else None,
+                                          val_b.data_ptr() if val_b.numel() else None, val_a.numel(), C.byref(h)))
+        return cls(ctx, h)
+
+    def to_tensors(self, device=None):
+        """-> (keys int64[U], val_off int64[U+1], val_a int32[V], val_b int32[V]) torch tensors on the context's
+        GPU, copied device to device (kmg_db_copy_dev)."""
+        import torch
+        dev = torch.device("cuda", self.ctx.device) if device is None else torch.device(device)
+        U, V = self.n_unique, self.n_values
+        out = (torch.empty(U, dtype=torch.int64, device=dev), torch.empty(U + 1, dtype=torch.int64, device=dev),
+               torch.empty(V, dtype=torch.int32, device=dev), torch.empty(V, dtype=torch.int32, device=dev))
+        torch.cuda.synchronize(dev)
+        for which, t in enumerate(out):
+            self.ctx.check(self.ctx.lib.kmg_db_copy_dev(self.h, which, t.data_ptr() if t.numel() else None, 0, t.numel()))
+        return out
+
+    def bucket_offsets(self):
+        """Host copy of bucket_off[4^l + 1] alone (index of every key bucket's first k-mer)."""
+        if self._host is not None:
+            return self._host["bucket_off"]
+        boff = np.empty(4 ** self.key_length + 1, np.uint64)
+        self.ctx.check(self.ctx.lib.kmg_db_fetch(self.h, None, None, None, None, _ptr(boff)))
+        return boff
 
     def data_id(self):
         return REF_ID if self.kind == PAYLOAD_TAXON else READ_ID

@@ -606,19 +606,17 @@ extern "C" int kmg_db_fetch(const kmg_db *db, uint64_t *keys, uint64_t *val_off,
     return KMG_OK;
 }
 
-extern "C" int kmg_db_load(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *keys,
-                           uint64_t n_unique, const uint64_t *val_off, const int32_t *val_a, const int32_t *val_b,
-                           kmg_db **out) {
-    if (!ctx || !out) return KMG_EINVAL;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    *out = nullptr;
-    if (k < 1 || key_len < 1) return fail(ctx, KMG_EINVAL, "k and key_len must be positive");
-    if (k > 32 || key_len > k || key_len > 12) return fail(ctx, KMG_EUNSUPPORTED, "k > 32 or key_len > min(k, 12)");
-    if (!val_off || (n_unique && !keys)) return fail(ctx, KMG_EINVAL, "null keys / val_off");
-    const u64 V = val_off[n_unique];
-    if (V && (!val_a || !val_b)) return fail(ctx, KMG_EINVAL, "null values");
-    for (u64 i = 1; i < n_unique; i++)
-        if (keys[i - 1] >= keys[i]) return fail(ctx, KMG_EINVAL, "keys must be strictly ascending");
+// device check of a key array handed over by the caller: *bad += 1 wherever keys[i - 1] >= keys[i]
+__global__ void keys_ascending_kernel(const u64 *__restrict__ keys, u64 n, u32 *bad) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (i < n && keys[i - 1] >= keys[i]) atomicAdd(bad, 1u);
+}
+
+// shared by kmg_db_load (host arrays) and kmg_db_load_dev (device arrays); caller holds ctx->mu and has
+// validated the arguments it can see
+static int db_load_common(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const u64 *keys, u64 n_unique,
+                          const u64 *val_off, const int32_t *val_a, const int32_t *val_b, u64 V, hipMemcpyKind how,
+                          kmg_db **out) {
     KMG_HIP(hipSetDevice(ctx->device));
     kmg_db *db = new (std::nothrow) kmg_db();
     if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
@@ -636,20 +634,88 @@ extern "C" int kmg_db_load(kmg_ctx *ctx, int k, int key_len, int rc, int payload
     if (r == KMG_OK && totals.alloc(64) != KMG_OK) r = KMG_ENOMEM;
     if (r != KMG_OK) { db_release(db); return fail(ctx, KMG_ENOMEM, "device allocation failed"); }
     hipError_t e = hipSuccess;
-    if (n_unique) e = hipMemcpyAsync(db->keys, keys, n_unique * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(db->val_off, val_off, (n_unique + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && V) e = hipMemcpyAsync(db->val_a, val_a, V * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && V) e = hipMemcpyAsync(db->val_b, val_b, V * 4, hipMemcpyHostToDevice, ctx->stream);
-    u64 tot[2] = {n_unique, V};
-    if (e == hipSuccess) e = hipMemcpyAsync(totals.p, tot, 16, hipMemcpyHostToDevice, ctx->stream);
+    if (n_unique) e = hipMemcpyAsync(db->keys, keys, n_unique * 8, how, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db->val_off, val_off, (n_unique + 1) * 8, how, ctx->stream);
+    if (e == hipSuccess && V) e = hipMemcpyAsync(db->val_a, val_a, V * 4, how, ctx->stream);
+    if (e == hipSuccess && V) e = hipMemcpyAsync(db->val_b, val_b, V * 4, how, ctx->stream);
+    u64 tot[4] = {n_unique, V, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(totals.p, tot, 32, hipMemcpyHostToDevice, ctx->stream);
+    u64 check[3] = {0, V, 0};   // val_off[0], val_off[n_unique], #descents in keys
     if (e == hipSuccess) {
+        if (how == hipMemcpyDeviceToDevice) {
+            if (n_unique > 1)
+                hipLaunchKernelGGL(keys_ascending_kernel, dim3(div_up_u64(n_unique, 256)), dim3(256), 0, ctx->stream, db->keys,
+                                   n_unique, reinterpret_cast<u32 *>(totals.as<u64>() + 2));
+            e = hipMemcpyAsync(&check[0], db->val_off, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&check[1], db->val_off + n_unique, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&check[2], totals.as<u64>() + 2, 8, hipMemcpyDeviceToHost, ctx->stream);
+        }
         hipLaunchKernelGGL(rd_buckets_kernel, dim3(div_up_u64(nbuckets + 1, 256)), dim3(256), 0, ctx->stream, db->keys,
                            totals.as<u64>(), db->val_off, db->bucket_off, nbuckets, key_len);
-        e = hipGetLastError();
+        if (e == hipSuccess) e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx->err = hipGetErrorString(e); db_release(db); return KMG_EDEVICE; }
+    if (check[0] != 0 || check[1] != V) { db_release(db); return fail(ctx, KMG_EINVAL, "val_off must run from 0 to n_values"); }
+    if (check[2] != 0) { db_release(db); return fail(ctx, KMG_EINVAL, "keys must be strictly ascending"); }
     *out = db;
+    return KMG_OK;
+}
+
+extern "C" int kmg_db_load(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *keys,
+                           uint64_t n_unique, const uint64_t *val_off, const int32_t *val_a, const int32_t *val_b,
+                           kmg_db **out) {
+    if (!ctx || !out) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *out = nullptr;
+    if (k < 1 || key_len < 1) return fail(ctx, KMG_EINVAL, "k and key_len must be positive");
+    if (k > 32 || key_len > k || key_len > 12) return fail(ctx, KMG_EUNSUPPORTED, "k > 32 or key_len > min(k, 12)");
+    if (!val_off || (n_unique && !keys)) return fail(ctx, KMG_EINVAL, "null keys / val_off");
+    const u64 V = val_off[n_unique];
+    if (V && (!val_a || !val_b)) return fail(ctx, KMG_EINVAL, "null values");
+    for (u64 i = 1; i < n_unique; i++)
+        if (keys[i - 1] >= keys[i]) return fail(ctx, KMG_EINVAL, "keys must be strictly ascending");
+    return db_load_common(ctx, k, key_len, rc, payload_kind, reinterpret_cast<const u64 *>(keys), n_unique,
+                          reinterpret_cast<const u64 *>(val_off), val_a, val_b, V, hipMemcpyHostToDevice, out);
+}
+
+extern "C" int kmg_db_load_dev(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *d_keys,
+                               uint64_t n_unique, const uint64_t *d_val_off, const int32_t *d_val_a,
+                               const int32_t *d_val_b, uint64_t n_values, kmg_db **out) {
+    if (!ctx || !out) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *out = nullptr;
+    if (k < 1 || key_len < 1) return fail(ctx, KMG_EINVAL, "k and key_len must be positive");
+    if (k > 32 || key_len > k || key_len > 12) return fail(ctx, KMG_EUNSUPPORTED, "k > 32 or key_len > min(k, 12)");
+    if (!d_val_off || (n_unique && !d_keys)) return fail(ctx, KMG_EINVAL, "null keys / val_off");
+    if (n_values && (!d_val_a || !d_val_b)) return fail(ctx, KMG_EINVAL, "null values");
+    return db_load_common(ctx, k, key_len, rc, payload_kind, reinterpret_cast<const u64 *>(d_keys), n_unique,
+                          reinterpret_cast<const u64 *>(d_val_off), d_val_a, d_val_b, n_values,
+                          hipMemcpyDeviceToDevice, out);
+}
+
+extern "C" int kmg_db_copy_dev(const kmg_db *db, int which, void *d_dst, uint64_t first, uint64_t count) {
+    if (!db || (count && !d_dst)) return KMG_EINVAL;
+    kmg_ctx *ctx = db->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    const void *src = nullptr;
+    size_t elem = 8;
+    u64 limit = 0;
+    switch (which) {
+        case KMG_DB_KEYS: src = db->keys; limit = db->U; break;
+        case KMG_DB_VAL_OFF: src = db->val_off; limit = db->U + 1; break;
+        case KMG_DB_VAL_A:
+        case KMG_DB_VAL_B:
+            KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(db)));
+            src = which == KMG_DB_VAL_A ? db->val_a : db->val_b; elem = 4; limit = db->V; break;
+        case KMG_DB_BUCKET_OFF: src = db->bucket_off; limit = ((u64)1 << (2 * db->key_len)) + 1; break;
+        default: return fail(ctx, KMG_EINVAL, "unknown array id");
+    }
+    if (first > limit || count > limit - first) return fail(ctx, KMG_EINVAL, "slice outside the array");
+    if (count)
+        KMG_HIP(hipMemcpyAsync(d_dst, (const char *)src + first * elem, count * elem, hipMemcpyDeviceToDevice, ctx->stream));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
     return KMG_OK;
 }
 

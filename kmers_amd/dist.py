@@ -89,59 +89,89 @@ def cut_points(sorted_keys, ranges, key_len):
     return np.concatenate([c, [len(keys)]])
 
 
-def all_to_all_v(chunks, dtype, device="cpu", group=None):
-    """chunks[g] = 1-D array for rank g  ->  list of arrays, one from every rank (in rank order).
-    Two collectives: the sizes, then the data."""
+def all_to_all_tensor(t, send_counts, group=None):
+    """1-D tensor `t` (on the CPU under gloo, on this rank's GPU under nccl), cut into consecutive chunks of
+    send_counts[g] elements for rank g  ->  (tensor of everything received, in rank order; recv_counts).
+    Two collectives: the sizes, then the data; nothing leaves the tensor's device."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    chunks = [np.ascontiguousarray(c, dtype=dtype) for c in chunks]
+    send_counts = [int(x) for x in send_counts]
+    assert sum(send_counts) == t.numel()
     if world == 1:
-        return [chunks[0]]
-    assert len(chunks) == world
+        return t, send_counts
+    assert len(send_counts) == world
+    ss = torch.tensor(send_counts, dtype=torch.int64, device=t.device)
+    rs_t = torch.zeros(world, dtype=torch.int64, device=t.device)
+    dist.all_to_all_single(rs_t, ss, group=group)
+    rs = [int(x) for x in rs_t.cpu().tolist()]
+    recv = torch.empty(sum(rs), dtype=t.dtype, device=t.device)
+    dist.all_to_all_single(recv, t.contiguous(), output_split_sizes=rs, input_split_sizes=send_counts, group=group)
+    return recv, rs
+
+
+def all_to_all_v(chunks, dtype, device="cpu", group=None):
+    """numpy front of all_to_all_tensor: chunks[g] = 1-D array for rank g -> list of arrays, one from every rank."""
+    chunks = [np.ascontiguousarray(c, dtype=dtype) for c in chunks]
     # torch has no uint64 collectives: ship the bits as int64 / int32
     wire = {8: np.int64, 4: np.int32}[np.dtype(dtype).itemsize]
-    send_sizes = torch.tensor([len(c) for c in chunks], dtype=torch.int64, device=device)
-    recv_sizes = torch.zeros(world, dtype=torch.int64, device=device)
-    dist.all_to_all_single(recv_sizes, send_sizes, group=group)
-    rs = [int(x) for x in recv_sizes.cpu().tolist()]
     flat = np.concatenate(chunks) if chunks else np.zeros(0, dtype)
-    send = torch.from_numpy(flat.view(wire).copy()).to(device)
-    recv = torch.zeros(sum(rs), dtype=send.dtype, device=device)
-    dist.all_to_all_single(recv, send, output_split_sizes=rs, input_split_sizes=[len(c) for c in chunks], group=group)
+    recv, rs = all_to_all_tensor(torch.from_numpy(flat.view(wire).copy()).to(device), [len(c) for c in chunks], group)
     out = recv.cpu().numpy().view(dtype)
     offs = np.concatenate([[0], np.cumsum(rs)])
-    return [out[offs[i]:offs[i + 1]] for i in range(world)]
+    return [out[offs[i]:offs[i + 1]] for i in range(len(rs))]
 
 
-def exchange_csr(csr, ranges, key_len, device="cpu", group=None):
-    """csr = dict(keys, val_off, val_a, val_b) of this rank's database (kmg_db_fetch layout).  Sends every
-    key range's slice to its owner; returns the list of CSR parts received, one per source rank, each again a
-    complete CSR (val_off starting at 0) ready for kmg_db_load + kmg_db_merge."""
-    keys = np.asarray(csr["keys"], np.uint64)
-    val_off = np.asarray(csr["val_off"], np.uint64).astype(np.int64)
-    c = cut_points(keys, ranges, key_len)
-    world = len(ranges)
-    k_parts = [keys[c[g]:c[g + 1]] for g in range(world)]
-    n_parts = [np.diff(val_off[c[g]:c[g + 1] + 1]) for g in range(world)]            # values per k-mer
-    a_parts = [np.asarray(csr["val_a"], np.int32)[val_off[c[g]]:val_off[c[g + 1]]] for g in range(world)]
-    b_parts = [np.asarray(csr["val_b"], np.int32)[val_off[c[g]]:val_off[c[g + 1]]] for g in range(world)]
-    rk = all_to_all_v(k_parts, np.uint64, device, group)
-    rn = all_to_all_v(n_parts, np.int64, device, group)
-    ra = all_to_all_v(a_parts, np.int32, device, group)
-    rb = all_to_all_v(b_parts, np.int32, device, group)
-    parts = []
-    for k, n, a, b in zip(rk, rn, ra, rb):
-        off = np.concatenate([[0], np.cumsum(n)]).astype(np.uint64)
-        parts.append(dict(keys=k.copy(), val_off=off, val_a=a.copy(), val_b=b.copy()))
+def exchange_csr_tensors(keys, val_off, val_a, val_b, cuts, group=None):
+    """The exchange itself, on tensors that stay where they are (GPU tensors under nccl: RCCL moves them over xGMI
+    peer to peer; CPU tensors under gloo).  keys int64[U] (the u64 bits), val_off int64[U+1], val_a / val_b
+    int32[V]; cuts[g] .. cuts[g+1] = the k-mers that go to rank g.  -> list of (keys, val_off, val_a, val_b), one
+    complete CSR (val_off from 0) per source rank.  Four data collectives, whatever the number of ranks."""
+    world = len(cuts) - 1
+    cuts_t = torch.as_tensor(cuts, dtype=torch.int64, device=keys.device)
+    vcuts = [int(x) for x in val_off[cuts_t].cpu().tolist()]
+    kc = [int(cuts[g + 1] - cuts[g]) for g in range(world)]
+    vc = [vcuts[g + 1] - vcuts[g] for g in range(world)]
+    lo, hi = int(cuts[0]), int(cuts[-1])
+    rk, rkc = all_to_all_tensor(keys[lo:hi], kc, group)
+    rn, _ = all_to_all_tensor(val_off[lo + 1:hi + 1] - val_off[lo:hi], kc, group)        # values per k-mer
+    ra, rvc = all_to_all_tensor(val_a[vcuts[0]:vcuts[-1]], vc, group)
+    rb, _ = all_to_all_tensor(val_b[vcuts[0]:vcuts[-1]], vc, group)
+    parts, ko, vo = [], 0, 0
+    for nk, nv in zip(rkc, rvc):
+        off = torch.zeros(nk + 1, dtype=torch.int64, device=keys.device)
+        torch.cumsum(rn[ko:ko + nk], 0, out=off[1:])
+        parts.append((rk[ko:ko + nk], off, ra[vo:vo + nv], rb[vo:vo + nv]))
+        ko += nk
+        vo += nv
     return parts
 
 
-def build_key_range_shard(ctx, local_db, ranges, device="cpu", group=None):
+def exchange_csr(csr, ranges, key_len, device="cpu", group=None):
+    """csr = dict(keys, val_off, val_a, val_b) of this rank's database as host arrays (kmg_db_fetch layout).
+    Sends every key range's slice to its owner; returns the list of CSR parts received, one per source rank,
+    each again a complete CSR (val_off starting at 0) ready for kmg_db_load + kmg_db_merge."""
+    keys = np.ascontiguousarray(csr["keys"], np.uint64)
+    c = cut_points(keys, ranges, key_len)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(device)
+    parts = exchange_csr_tensors(t(keys, np.int64), t(np.asarray(csr["val_off"], np.uint64), np.int64),
+                                 t(np.asarray(csr["val_a"], np.int32), np.int32),
+                                 t(np.asarray(csr["val_b"], np.int32), np.int32), c, group)
+    return [dict(keys=k.cpu().numpy().view(np.uint64).copy(), val_off=o.cpu().numpy().view(np.uint64).copy(),
+                 val_a=a.cpu().numpy().copy(), val_b=b.cpu().numpy().copy()) for k, o, a, b in parts]
+
+
+def build_key_range_shard(ctx, local_db, ranges, device=None, group=None):
     """The exchange step of a sharded build: local_db (KmerDatabase of this rank's input shard) -> KmerDatabase
-    holding every rank's k-mers of THIS rank's key range, merged on the GPU."""
+    holding every rank's k-mers of THIS rank's key range, merged on the GPU.  Device-resident end to end: the
+    CSR arrays are copied out of the library into torch tensors on the context's GPU (kmg_db_copy_dev), cut at
+    the bucket offsets the database already holds, exchanged GPU to GPU and handed back with kmg_db_load_dev."""
     from .api import KmerDatabase, merge_databases
-    parts = exchange_csr(local_db.fetch(), ranges, local_db.key_length, device, group)
-    dbs = [KmerDatabase.load(ctx, local_db.k, local_db.key_length, local_db.rc, local_db.kind, p["keys"], p["val_off"],
-                             p["val_a"], p["val_b"]) for p in parts]
+    dev = torch.device("cuda", ctx.device) if device is None else torch.device(device)
+    keys, val_off, val_a, val_b = local_db.to_tensors(dev)
+    boff = local_db.bucket_offsets()
+    cuts = [int(boff[r[0]]) for r in ranges] + [int(boff[ranges[-1][1]])]
+    parts = exchange_csr_tensors(keys, val_off, val_a, val_b, cuts, group)
+    torch.cuda.synchronize(dev)                    # the library reads the parts on its own stream
+    dbs = [KmerDatabase.load_tensors(ctx, local_db.k, local_db.key_length, local_db.rc, local_db.kind, *p) for p in parts]
     out = dbs[0] if len(dbs) == 1 else merge_databases(dbs)
     for d in dbs:
         if d is not out:

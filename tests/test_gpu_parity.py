@@ -8,6 +8,7 @@ nondeterministic).
 """
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -337,8 +338,72 @@ def test_key_range_shards_merge_on_the_gpu(ctx):
         assert np.array_equal(s["val_a"], whole.val_a[v0:v1]) and np.array_equal(s["val_b"], whole.val_b[v0:v1])
         for d in parts + [shard]:
             d.close()
+        # the same slice the device-resident way: tensors on the GPU, cut at the stored bucket offsets, CSR rebuilt
+        # by exchange_csr_tensors (a world of one here: the slice comes straight back), kmg_db_load_dev
+        parts = []
+        for h in halves:
+            boff = h.bucket_offsets()
+            cut = [int(boff[ranges[g][0]]), int(boff[ranges[g][1]])]
+            (p,) = kd.exchange_csr_tensors(*h.to_tensors(), cut)
+            torch.cuda.synchronize()
+            parts.append(km.KmerDatabase.load_tensors(ctx, k, l, True, 0, *p))
+        shard = km.merge_databases(parts)
+        s2 = shard.fetch()
+        for name in ("keys", "val_off", "val_a", "val_b", "bucket_off"):
+            assert np.array_equal(s2[name], s[name]), name
+        for d in parts + [shard]:
+            d.close()
     for h in halves:
         h.close()
+
+
+def test_device_resident_copy_and_load(ctx):
+    """kmg_db_copy_dev / kmg_db_load_dev: a database copied into torch tensors and loaded back is the same
+    database; slices are bounds-checked; the device-side checks reject what kmg_db_load rejects on the host."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    taxa, genomes = synth.random_genomes(43, 3, 3000)
+    reads = synth.random_reads(44, genomes, 300, 80, 0.01)
+    for db in (km.make_reference_db(ctx, synth.fasta_bytes(taxa, genomes), 17, 5),
+               km.make_read_db(ctx, synth.fastq_bytes(reads), 17, 5)[0]):
+        keys, val_off, val_a, val_b = db.to_tensors()
+        h = db.fetch()
+        assert np.array_equal(keys.cpu().numpy().view(np.uint64), h["keys"])
+        assert np.array_equal(val_off.cpu().numpy().view(np.uint64), h["val_off"])
+        assert np.array_equal(val_a.cpu().numpy(), h["val_a"]) and np.array_equal(val_b.cpu().numpy(), h["val_b"])
+        again = km.KmerDatabase.load_tensors(ctx, db.k, db.key_length, db.rc, db.kind, keys, val_off, val_a, val_b)
+        g = again.fetch()
+        for name in ("keys", "val_off", "val_a", "val_b", "bucket_off"):
+            assert np.array_equal(g[name], h[name]), name
+        again.close()
+        # a slice
+        part = torch.empty(10, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.check(ctx.lib.kmg_db_copy_dev(db.h, 0, part.data_ptr(), 5, 10))
+        assert np.array_equal(part.cpu().numpy().view(np.uint64), h["keys"][5:15])
+        with pytest.raises(km.InconsistentDataException):
+            ctx.check(ctx.lib.kmg_db_copy_dev(db.h, 0, part.data_ptr(), db.n_unique - 5, 10))
+        with pytest.raises(km.InconsistentDataException):
+            ctx.check(ctx.lib.kmg_db_copy_dev(db.h, 9, part.data_ptr(), 0, 1))
+        # descending keys / val_off not ending at n_values
+        bad = keys.clone()
+        bad[[3, 4]] = bad[[4, 3]]
+        torch.cuda.synchronize()
+        with pytest.raises(km.InconsistentDataException):
+            km.KmerDatabase.load_tensors(ctx, db.k, db.key_length, db.rc, db.kind, bad, val_off, val_a, val_b)
+        bad_off = val_off.clone()
+        bad_off[-1] -= 1
+        torch.cuda.synchronize()
+        with pytest.raises(km.InconsistentDataException):
+            km.KmerDatabase.load_tensors(ctx, db.k, db.key_length, db.rc, db.kind, keys, bad_off, val_a, val_b)
+        db.close()
+    # an empty database
+    empty = km.KmerDatabase.load_tensors(ctx, 17, 5, True, 0, torch.empty(0, dtype=torch.int64, device="cuda"),
+                                         torch.zeros(1, dtype=torch.int64, device="cuda"),
+                                         torch.empty(0, dtype=torch.int32, device="cuda"),
+                                         torch.empty(0, dtype=torch.int32, device="cuda"))
+    assert empty.n_unique == 0 and empty.n_values == 0
+    empty.close()
 
 
 def test_db_load_roundtrip_and_errors(ctx):
