@@ -279,6 +279,21 @@ class DB:
         return hit, nh.value
 
 
+def match_into(ctx, search, ref, out):
+    """kmg_match_dev: hit index of every k-mer of `search` in `ref` (-1 = miss) into the int64 torch tensor `out`
+    on the context's GPU; returns once the result is there."""
+    import torch
+    if out.dtype != torch.int64 or out.numel() != search.n_unique or out.device != torch.device("cuda", ctx.device) \
+            or not out.is_contiguous():
+        raise ValueError("match_into wants a contiguous int64 tensor of search.n_unique elements on the context's GPU")
+    if search.n_unique == 0:
+        return out
+    torch.cuda.synchronize(out.device)
+    ctx.check(ctx.lib.kmg_match_dev(ctx.h, search.h, ref.h, out.data_ptr()))
+    torch.cuda.ExternalStream(ctx.stream, device=out.device).synchronize()
+    return out
+
+
 def taxa_counts(db):
     """Utils/TaxaCounts.java default mode -> (taxon[], match[], unique[]) ascending by taxon."""
     f = db.merged if isinstance(db, DB) else db

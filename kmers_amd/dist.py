@@ -179,16 +179,70 @@ def build_key_range_shard(ctx, local_db, ranges, device=None, group=None):
     return out
 
 
+def match_by_key_range_tensors(keys, cuts, local_match, group=None):
+    """Join ascending search k-mers (int64 tensor holding the u64 bits, on the CPU or on this rank's GPU) against a
+    key-range-sharded reference: keys[cuts[g] : cuts[g+1]] go to rank g, every owner joins what it received --
+    local_match(tensor of ascending keys from ONE source rank) -> int64 hit indices into its shard, -1 = miss --
+    and the reverse all-to-all brings the hits back in the order of `keys`.  -> (owner int32[n], hit int64[n])."""
+    world = len(cuts) - 1
+    kc = [int(cuts[g + 1] - cuts[g]) for g in range(world)]
+    recv, rc = all_to_all_tensor(keys[int(cuts[0]):int(cuts[-1])], kc, group)
+    hits = torch.empty(recv.numel(), dtype=torch.int64, device=keys.device)
+    o = 0
+    for n in rc:
+        if n:
+            hits[o:o + n] = local_match(recv[o:o + n])
+        o += n
+    back, _ = all_to_all_tensor(hits, rc, group)
+    owner = torch.repeat_interleave(torch.arange(world, dtype=torch.int32, device=keys.device),
+                                    torch.tensor(kc, dtype=torch.int64, device=keys.device))
+    return owner, back
+
+
 def match_by_key_range(search_keys, ranges, key_len, local_match, device="cpu", group=None):
-    """Join ascending `search_keys` against a key-range-sharded reference.  local_match(keys) -> int64 hit index
-    into THIS rank's reference shard (-1 = miss) for an ascending u64 array.  Returns (owner, hit): for every
-    search k-mer the rank that owns its range and the hit index inside that rank's shard (-1 = miss)."""
-    keys = np.asarray(search_keys, np.uint64)
+    """numpy front of match_by_key_range_tensors.  local_match(keys) -> int64 hit index into THIS rank's reference
+    shard (-1 = miss) for an ascending u64 array.  Returns (owner, hit): for every search k-mer the rank that owns
+    its range and the hit index inside that rank's shard (-1 = miss)."""
+    keys = np.ascontiguousarray(search_keys, np.uint64)
     c = cut_points(keys, ranges, key_len)
-    world = len(ranges)
-    recv = all_to_all_v([keys[c[g]:c[g + 1]] for g in range(world)], np.uint64, device, group)
-    hits = [np.asarray(local_match(r), np.int64) if len(r) else np.zeros(0, np.int64) for r in recv]
-    back = all_to_all_v(hits, np.int64, device, group)
-    hit = np.concatenate(back) if back else np.zeros(0, np.int64)
-    owner = np.repeat(np.arange(world, dtype=np.int32), np.diff(c))
-    return owner, hit
+
+    def lm(t):
+        h = np.asarray(local_match(t.cpu().numpy().view(np.uint64)), np.int64)
+        return torch.from_numpy(np.ascontiguousarray(h)).to(t.device)
+
+    owner, hit = match_by_key_range_tensors(torch.from_numpy(keys.view(np.int64).copy()).to(device), c, lm, group)
+    return owner.cpu().numpy(), hit.cpu().numpy()
+
+
+def shard_matcher(ctx, like_db, ref_shard):
+    """-> local_match for match_by_key_range_tensors on the GPU: ascending key tensor -> hit indices into
+    ref_shard (kmg_db_load_dev of a keys-only database shaped like `like_db`, then kmg_match_dev)."""
+    from .api import KmerDatabase, match_into
+    dev = torch.device("cuda", ctx.device)
+    no_vals = torch.empty(0, dtype=torch.int32, device=dev)
+
+    def local_match(part):
+        part = part.contiguous()
+        torch.cuda.synchronize(dev)
+        q = KmerDatabase.load_tensors(ctx, like_db.k, like_db.key_length, like_db.rc, like_db.kind, part,
+                                      torch.zeros(part.numel() + 1, dtype=torch.int64, device=dev), no_vals, no_vals)
+        out = torch.empty(part.numel(), dtype=torch.int64, device=dev)
+        match_into(ctx, q, ref_shard, out)
+        q.close()
+        return out
+
+    return local_match
+
+
+def match_key_range_shard(ctx, search_db, ref_shard, ranges, group=None):
+    """The sharded Matcher join, device-resident: search_db's k-mers (this rank's read database) are cut at the
+    key-range bounds, exchanged GPU to GPU, joined by every owner against its reference shard and the hit indices
+    come back the same way.  -> (owner int32 tensor, hit int64 tensor) on the context's GPU, one entry per k-mer
+    of search_db."""
+    dev = torch.device("cuda", ctx.device)
+    keys = torch.empty(search_db.n_unique, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    ctx.check(ctx.lib.kmg_db_copy_dev(search_db.h, 0, keys.data_ptr() if keys.numel() else None, 0, keys.numel()))
+    boff = search_db.bucket_offsets()
+    cuts = [int(boff[r[0]]) for r in ranges] + [int(boff[ranges[-1][1]])]
+    return match_by_key_range_tensors(keys, cuts, shard_matcher(ctx, search_db, ref_shard), group)

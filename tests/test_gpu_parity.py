@@ -357,6 +357,43 @@ def test_key_range_shards_merge_on_the_gpu(ctx):
         h.close()
 
 
+def test_key_range_sharded_match_on_the_gpu(ctx):
+    """Device-resident sharded join (dist.match_key_range_shard and its pieces): the read k-mers cut at the range
+    bounds, each slice joined against that range's reference shard, give the hits of the whole-database join."""
+    import kmers_amd as km
+    from kmers_amd import dist as kd, synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(51, 4, 5000, shared_frac=0.3)
+    reads = synth.random_reads(52, genomes, 500, 90, 0.01)
+    k, l, world = 19, 4, 3
+    ref = km.make_reference_db(ctx, synth.fasta_bytes(taxa, genomes), k, l)
+    rdb, _ = km.make_read_db(ctx, synth.fastq_bytes(reads), k, l)
+    o_ref, o_reads = OracleDB(synth.fasta_bytes(taxa, genomes), 0, k, l), OracleDB(synth.fastq_bytes(reads), 1, k, l)
+    o_hit, o_nh = o_reads.match(o_ref)
+    assert o_nh > 0
+    # a world of one: the whole thing through the public entry
+    owner, hit = kd.match_key_range_shard(ctx, rdb, ref, [(0, 4 ** l)])
+    assert np.array_equal(hit.cpu().numpy(), o_hit) and int(owner.max()) == 0
+    # three ranges, every owner's part by hand
+    hist = np.diff(o_ref.val_off.astype(np.int64)[o_ref.bucket_off.astype(np.int64)])
+    ranges = kd.balanced_key_ranges(hist, world)
+    keys = rdb.to_tensors()[0]
+    sb, rb = rdb.bucket_offsets(), ref.bucket_offsets()
+    got = np.full(rdb.n_unique, -2, np.int64)
+    for g in range(world):
+        (p,) = kd.exchange_csr_tensors(*ref.to_tensors(), [int(rb[ranges[g][0]]), int(rb[ranges[g][1]])])
+        torch.cuda.synchronize()
+        shard = km.KmerDatabase.load_tensors(ctx, k, l, True, 0, *p)
+        c0, c1 = int(sb[ranges[g][0]]), int(sb[ranges[g][1]])
+        _, h = kd.match_by_key_range_tensors(keys, [c0, c1], kd.shard_matcher(ctx, rdb, shard))
+        h = h.cpu().numpy()
+        got[c0:c1] = np.where(h >= 0, h + int(rb[ranges[g][0]]), -1)
+        shard.close()
+    assert np.array_equal(got, o_hit)
+    ref.close()
+    rdb.close()
+
+
 def test_device_resident_copy_and_load(ctx):
     """kmg_db_copy_dev / kmg_db_load_dev: a database copied into torch tensors and loaded back is the same
     database; slices are bounds-checked; the device-side checks reject what kmg_db_load rejects on the host."""
