@@ -156,6 +156,10 @@ struct kmg_ctx {
     int n_adds = 0;
     bool prepart = false;
     int plan_pbits = 0;          // prefix bits the partition digit was planned for
+    // read builds whose (read, pos) pairs fit 32 bits keep them as (read << compact_pb | pos) through the sort:
+    // 12-byte records instead of 16.  0 = off (payloads are read << 16 | pos16 in 64 bits).
+    int compact_pb = 0;
+    bool sort_as_reads = false;  // profiling only: attribute 32-bit-payload sort launches to the read kernels
     u64 *d_state = nullptr;      // ST_WORDS device words
     std::vector<void *> staged;  // device copies of host batches, released at finish
 
@@ -175,6 +179,8 @@ struct kmg_db {
     int32_t *val_a = nullptr;   // V
     int32_t *val_b = nullptr;   // V
     u64 *vals_packed = nullptr; // read DBs built here: V x (read << 16 | pos16); val_a/val_b unpacked on demand
+    u32 *vals_packed32 = nullptr; // ... or V x (read << pos_bits | pos) when the build ran compact
+    int pos_bits = 16;
     u64 *bucket_off = nullptr;  // 4^key_len + 1
 };
 

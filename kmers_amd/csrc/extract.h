@@ -109,6 +109,8 @@ struct ExtractArgs {
     u64 *out_keys;
     void *out_vals;
     u64 *state;                  // device build state (ST_*)
+    int pos_bits;                // read payload = read << pos_bits | (pos & pos_mask): 16 / 0xFFFF unless compact
+    u32 pos_mask;
 };
 
 template <bool WRITE>

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
                 }
                 V v;
                 if (a.kind == KMG_PAYLOAD_TAXON) v = (V)sv;
-                else v = (V)(((u64)sv << 16) | (u64)((p + neg) & 0xFFFFu));
+                else v = (V)(((u64)sv << a.pos_bits) | (u64)((p + neg) & a.pos_mask));
                 reinterpret_cast<V *>(stage)[lpos[j]] = v;
             }
         }

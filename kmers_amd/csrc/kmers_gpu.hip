@@ -94,7 +94,7 @@ extern "C" int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int pay
     ctx->k = k; ctx->key_len = key_len; ctx->rc = rc ? 1 : 0; ctx->kind = payload_kind;
     ctx->dust = -1; ctx->runofsame = -1;
     ctx->rec_upper = 0;
-    ctx->n_adds = 0; ctx->prepart = false; ctx->plan_pbits = 0;
+    ctx->n_adds = 0; ctx->prepart = false; ctx->plan_pbits = 0; ctx->compact_pb = 0;
     u64 init[ST_WORDS];
     memset(init, 0, sizeof init);
     init[ST_ID_AND] = 0xFFFFFFFFull;
@@ -153,6 +153,17 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     if (nseq >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "too many sequences in one batch");
     if (nbases >= (u64)0xFFFFFFF0ull * 1024) return fail(ctx, KMG_EUNSUPPORTED, "batch too large");
 
+    if (ctx->compact_pb) {
+        // a second batch: the first one's 32-bit payloads go back to the 64-bit form every other path uses
+        void *wide = nullptr;
+        if (ctx->pool.alloc(&wide, ctx->rec_cap * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "record buffer allocation failed");
+        if (ctx->rec_upper)
+            hipLaunchKernelGGL(rd_widen_kernel, dim3(div_up_u64(ctx->rec_upper, 256)), dim3(256), 0, ctx->stream,
+                               (const u32 *)ctx->rec_vals, ctx->rec_upper, ctx->compact_pb, (u64 *)wide);
+        ctx->pool.release(ctx->rec_vals);
+        ctx->rec_vals = wide;
+        ctx->compact_pb = 0;
+    }
     const u64 upper = ctx->rec_upper + nbases * (ctx->rc ? 2 : 1);
     KMG_TRY(ensure_record_capacity(ctx, upper));
 
@@ -171,6 +182,7 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     a.dust = ctx->dust; a.runofsame = ctx->runofsame;
     a.tile_count = tile_count.as<u32>(); a.tile_fwd = tile_fwd.as<u32>(); a.tile_off = tile_off.as<u64>();
     a.out_keys = ctx->rec_keys; a.out_vals = ctx->rec_vals; a.state = ctx->d_state;
+    a.pos_bits = 16; a.pos_mask = 0xFFFFu;
 
     {
         ProfScope ps(ctx, KP_EXTRACT_TILESEQ, 0);
@@ -199,6 +211,28 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     ctx->n_adds++;
     PartArgs pa;
     PoolBuf table(ctx), tagg(ctx);
+    if (part && reads) {
+        // Compact payloads: when every (read, pos) of the batch fits 32 bits -- pos < 2^pb from the longest
+        // sequence, read < nseq < 2^(32 - pb) -- the records carry read << pb | pos in 4 bytes through the
+        // partition, the sort and into the database (12-byte records instead of 16).  The one host round trip
+        // of an add: 4 bytes, before anything else of this batch is queued.
+        PoolBuf mx(ctx);
+        KMG_ALLOC(mx, 64);
+        KMG_HIP(hipMemsetAsync(mx.p, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(seq_maxlen_kernel, dim3(std::min<u32>(div_up_u64(nseq, 256), 2048)), dim3(256), 0, ctx->stream,
+                           d_seq_off, nseq, mx.as<u32>());
+        u32 maxlen = 0;
+        KMG_HIP(hipMemcpyAsync(&maxlen, mx.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KMG_HIP(hipStreamSynchronize(ctx->stream));
+        const u32 maxpos = maxlen > (u32)ctx->k ? maxlen - (u32)ctx->k : 0;
+        int pb = 1;
+        while (pb < 32 && (maxpos >> pb) != 0) pb++;
+        if (pb <= 16 && nseq < ((u64)1 << (32 - pb))) {
+            ctx->compact_pb = pb;
+            a.pos_bits = pb; a.pos_mask = (1u << pb) - 1u;
+        }
+    }
+    const bool compact = ctx->compact_pb > 0;
     if (part) {
         const SortPass d0 = prefix_digits(plan)[0];
         pa.dshift = d0.shift; pa.dmask = (1u << d0.bits) - 1u;
@@ -215,7 +249,7 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         ProfScope ps(ctx, KP_EXTRACT_COUNT, nbases);
         if (part) {
             pa.e = a;
-            if (reads) hipLaunchKernelGGL((extract_part_kernel<false, u64>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+            if (reads && !compact) hipLaunchKernelGGL((extract_part_kernel<false, u64>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
             else hipLaunchKernelGGL((extract_part_kernel<false, u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
         } else hipLaunchKernelGGL((extract_kernel<false>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
         hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_fwd.as<u32>(),
@@ -247,7 +281,7 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
                                                     0u, tagg.as<u32>(), nullptr, false, KP_SCAN)));
         ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases /* + records * rec_b, added at finish when N is known */);
         pa.e = a;
-        if (reads) hipLaunchKernelGGL((extract_part_kernel<true, u64>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+        if (reads && !compact) hipLaunchKernelGGL((extract_part_kernel<true, u64>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
         else hipLaunchKernelGGL((extract_part_kernel<true, u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
         hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_count.as<u32>(),
                            ntiles, ctx->d_state + ST_NREC);
@@ -321,6 +355,7 @@ static void db_release(kmg_db *db) {
     ctx->pool.release(db->val_a);
     ctx->pool.release(db->val_b);
     ctx->pool.release(db->vals_packed);
+    ctx->pool.release(db->vals_packed32);
     ctx->pool.release(db->bucket_off);
     delete db;
 }
@@ -452,8 +487,12 @@ static int reduce_read_heads(kmg_ctx *ctx, const SortHeads &h, u32 n, kmg_db *db
     hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, d_totals + 1, (u64)n);
     {
         ProfScope ps(ctx, KP_REDUCE_WRITE, 0 /* 32 B per unique k-mer, added when U is known */);
-        hipLaunchKernelGGL(ls_heads_gather_kernel, dim3(h.nseg), dim3(256), 0, ctx->stream, h.head_keys, h.head_first,
-                           h.seg_off, h.ucount, ubase.as<u64>(), db->keys, db->val_off);
+        if (h.first_bytes == 8)
+            hipLaunchKernelGGL((ls_heads_gather_kernel<u64>), dim3(h.nseg), dim3(256), 0, ctx->stream, h.head_keys,
+                               (const u64 *)h.head_first, h.seg_off, h.ucount, ubase.as<u64>(), db->keys, db->val_off);
+        else
+            hipLaunchKernelGGL((ls_heads_gather_kernel<u32>), dim3(h.nseg), dim3(256), 0, ctx->stream, h.head_keys,
+                               (const u32 *)h.head_first, h.seg_off, h.ucount, ubase.as<u64>(), db->keys, db->val_off);
     }
     {
         ProfScope ps(ctx, KP_BUCKETS, 0);
@@ -466,15 +505,18 @@ static int reduce_read_heads(kmg_ctx *ctx, const SortHeads &h, u32 n, kmg_db *db
 
 // val_a / val_b of a read DB are materialised from the packed payloads the first time they are needed.
 static int ensure_vals(kmg_ctx *ctx, kmg_db *db) {
-    if (db->val_a || !db->vals_packed) return KMG_OK;
+    if (db->val_a || (!db->vals_packed && !db->vals_packed32)) return KMG_OK;
     void *a = nullptr, *b = nullptr;
     if (ctx->pool.alloc(&a, (db->V + 1) * 4) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
     if (ctx->pool.alloc(&b, (db->V + 1) * 4) != KMG_OK) { ctx->pool.release(a); return fail(ctx, KMG_ENOMEM, "db allocation failed"); }
     db->val_a = (int32_t *)a;
     db->val_b = (int32_t *)b;
-    if (db->V)
+    if (db->V && db->vals_packed)
         hipLaunchKernelGGL(rd_unpack_kernel, dim3(div_up_u64(db->V, 256)), dim3(256), 0, ctx->stream, db->vals_packed, db->V,
                            db->val_a, db->val_b);
+    else if (db->V)
+        hipLaunchKernelGGL(rd_unpack32_kernel, dim3(div_up_u64(db->V, 256)), dim3(256), 0, ctx->stream, db->vals_packed32, db->V,
+                           db->pos_bits, db->val_a, db->val_b);
     KMG_HIP(hipGetLastError());
     return KMG_OK;
 }
@@ -493,9 +535,12 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     const u64 N = st[ST_NREC];
     if (n_windows) *n_windows = st[ST_NWIN];
     if (N >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 records in one build");
-    if (ctx->prof_on) ctx->prof[KP_EXTRACT_WRITE].bytes += N * (8 + val_bytes(ctx->kind));
     const u32 n = (u32)N;
     const bool reads = ctx->kind == KMG_PAYLOAD_READPOS;
+    const bool compact = reads && ctx->compact_pb > 0;          // single-batch read build with 32-bit payloads
+    const int pos_bits = compact ? ctx->compact_pb : 16;
+    const size_t vb = compact ? 4 : val_bytes(ctx->kind);
+    if (ctx->prof_on) ctx->prof[KP_EXTRACT_WRITE].bytes += N * (8 + vb);
 
     kmg_db *db = new (std::nothrow) kmg_db();
     if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
@@ -510,8 +555,8 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
             if ((varying >> (8 * b)) & 0xFFu) payload.push_back({8 * b, 8, RS_SRC_VAL32});
     } else if (st[ST_DUP_READS]) {
         // canonical (read, pos) order inside a k-mer when sequences shared a read index
-        int bits = 16;
-        while (bits < 48 && (st[ST_READ_BASE] >> (bits - 16)) != 0) bits++;
+        int bits = pos_bits;
+        while (bits < pos_bits + 32 && (st[ST_READ_BASE] >> (bits - pos_bits)) != 0) bits++;
         for (int shift = 0; shift < bits; shift += RS_BITS) payload.push_back({shift, std::min(RS_BITS, bits - shift), RS_SRC_VAL64});
     }
     // prefix bits for the global passes: segments of ~1-2 K records on uniform data
@@ -522,7 +567,6 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx), seg(ctx), ucount(ctx);
     SortHeads heads;
     memset(&heads, 0, sizeof heads);
-    const size_t vb = val_bytes(ctx->kind);
     const u32 ntiles = n ? div_up_u64(n, RS_TILE) : 1;
     KMG_ALLOC(totals, 64);
     int r = KMG_OK;
@@ -538,7 +582,12 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
         if (reads) {
             KMG_ALLOC(ucount, (((size_t)1 << pbits) + 1) * 4);
             heads.ucount = ucount.as<u32>();
-            r = hybrid_sort_records<u64>(ctx, ctx->rec_keys, (u64 *)ctx->rec_vals, k1.as<u64>(), v1.as<u64>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1, &heads);
+            if (compact) {
+                ctx->sort_as_reads = true;
+                r = hybrid_sort_records<u32>(ctx, ctx->rec_keys, (u32 *)ctx->rec_vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1, &heads);
+                ctx->sort_as_reads = false;
+            } else
+                r = hybrid_sort_records<u64>(ctx, ctx->rec_keys, (u64 *)ctx->rec_vals, k1.as<u64>(), v1.as<u64>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1, &heads);
         }
         else r = hybrid_sort_records<u32>(ctx, ctx->rec_keys, (u32 *)ctx->rec_vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1);
     }
@@ -549,8 +598,11 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
             r = heads.done ? reduce_read_heads(ctx, heads, n, db, totals.as<u64>())
                            : reduce_read_keys(ctx, sk, n, db, totals.as<u64>());
             // the sorted payload buffer changes owner: it is the DB's value array now
-            if (in1) db->vals_packed = (u64 *)v1.detach();
-            else { db->vals_packed = (u64 *)ctx->rec_vals; ctx->rec_vals = nullptr; }
+            void *sorted_vals;
+            if (in1) sorted_vals = v1.detach();
+            else { sorted_vals = ctx->rec_vals; ctx->rec_vals = nullptr; }
+            if (compact) { db->vals_packed32 = (u32 *)sorted_vals; db->pos_bits = pos_bits; }
+            else db->vals_packed = (u64 *)sorted_vals;
         } else r = reduce_records<u32, true>(ctx, sk, (const u32 *)sv, n, db, totals.as<u64>());
     }
     u64 tot[2] = {0, 0};
@@ -562,14 +614,14 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     // the record buffers go back to the pool: the next build (or the DB arrays of this one) reuses them
     ctx->pool.release(ctx->rec_keys);
     ctx->pool.release(ctx->rec_vals);
-    ctx->rec_keys = nullptr; ctx->rec_vals = nullptr; ctx->rec_cap = 0; ctx->rec_upper = 0;
+    ctx->rec_keys = nullptr; ctx->rec_vals = nullptr; ctx->rec_cap = 0; ctx->rec_upper = 0; ctx->compact_pb = 0;
     if (r != KMG_OK) return r;
     db->U = tot[0];
     db->V = tot[1];
     if (ctx->prof_on)
     {
         ctx->prof[KP_REDUCE_WRITE].bytes += db->U * (heads.done ? 32 : 16) + (reads ? 0 : db->V * 8);
-        if (heads.done) ctx->prof[KP_SORT_LOCAL_V64].bytes += db->U * 16;
+        if (heads.done) ctx->prof[KP_SORT_LOCAL_V64].bytes += db->U * (8 + vb);
     }
     *out = db_guard.release();
     return KMG_OK;
@@ -800,6 +852,7 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
     for (int i = 0; i < n_dbs; i++) {
         const kmg_db *d = dbs[i];
         if (d->V == 0) continue;
+        if (reads && d->vals_packed32) KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(d)));
         if (reads && !d->vals_packed && !d->val_a) return fail(ctx, KMG_ESTATE, "database has no values");
         hipLaunchKernelGGL(mg_expand_kernel, dim3(div_up_u64(d->V, 256)), dim3(256), 0, ctx->stream, d->keys, d->val_off, d->U, d->V,
                            d->val_a, d->val_b, reads ? d->vals_packed : nullptr, d->kind, k0.as<u64>(), v0.as<u64>(), base);

@@ -257,7 +257,7 @@ static int radix_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 
         V *vo = flip ? v0 : v1;
         const u32 mask = (1u << p.bits) - 1u;
         {
-            ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_HIST_V64 : KP_SORT_HIST_V32, (u64)n * (p.src ? sizeof(V) : 8));
+            ProfScope ps(ctx, sizeof(V) == 8 || ctx->sort_as_reads ? KP_SORT_HIST_V64 : KP_SORT_HIST_V32, (u64)n * (p.src ? sizeof(V) : 8));
             // tiles per block: as many as keep >= ~2048 blocks in flight (small inputs: one tile per block)
             int tpb = 1;
             while (tpb < RSH_TILES && ntiles / (tpb * 2) >= 2048) tpb *= 2;
@@ -267,7 +267,7 @@ static int radix_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 
         KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, table, table, (u64)RS_DIGITS * ntiles, OpSum(), 0u, agg,
                                                     nullptr, false, KP_SORT_SCAN)));
         {
-            ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_SCATTER_V64 : KP_SORT_SCATTER_V32, (u64)n * (8 + sizeof(V)) * 2);
+            ProfScope ps(ctx, sizeof(V) == 8 || ctx->sort_as_reads ? KP_SORT_SCATTER_V64 : KP_SORT_SCATTER_V32, (u64)n * (8 + sizeof(V)) * 2);
             hipLaunchKernelGGL((rs_scatter_kernel<V>), dim3(((ntiles + 7) / 8) * 8), dim3(RSC_BLOCK), 0, ctx->stream, ki, vi, ko, vo, n,
                                p.shift, mask, p.src, table, ntiles);
         }
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
 // HEADS (read DBs): the k-mer runs are found while the sorted segment is still in LDS, so no later pass has
 // to read the sorted keys again.  The block writes, compacted at the start of its own slice of the INPUT
 // buffers (whose records it holds in LDS by then), the segment's distinct k-mers (keys_in[s0 ..]) and the
-// index of each one's first record (vals_in[s0 ..], as 64-bit words), their number to ucount[segment], and
+// index of each one's first record (vals_in[s0 ..], in the payload's own width), their number to ucount[segment], and
 // only the payloads to vals_out: the per-record sorted keys are never needed again.
 template <typename V, bool HEADS>
 __global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *keys_in, V *vals_in, u64 *__restrict__ keys_out,
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *
             if ((hmask >> r) & 1) {
                 const u32 slot = s0 + base + hbelow[r];
                 keys_in[slot] = seg_prefix | ((hw[r] & ~0xFFFull) >> pbits);
-                reinterpret_cast<u64 *>(vals_in)[slot] = (u64)(s0 + r * LS_BLOCK + tid);
+                vals_in[slot] = (V)(s0 + r * LS_BLOCK + tid);
             }
         }
     }
@@ -658,7 +658,8 @@ __global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *
 }
 
 // Gathers what ls_sortidx_kernel<.., true> left per segment into the DB arrays: one block per segment.
-__global__ __launch_bounds__(256) void ls_heads_gather_kernel(const u64 *__restrict__ head_keys, const u64 *__restrict__ head_first,
+template <typename V>
+__global__ __launch_bounds__(256) void ls_heads_gather_kernel(const u64 *__restrict__ head_keys, const V *__restrict__ head_first,
                                                              const u32 *__restrict__ seg_off, const u32 *__restrict__ ucount,
                                                              const u64 *__restrict__ ubase, u64 *__restrict__ ukeys,
                                                              u64 *__restrict__ val_off) {
@@ -678,7 +679,8 @@ struct SortHeads {
     u32 *ucount;
     bool done;
     const u64 *head_keys;
-    const u64 *head_first;
+    const void *head_first;   // u64 or u32 per distinct k-mer, as the payload type of the sort
+    int first_bytes;
     const u32 *seg_off;
     u32 nseg;
 };
@@ -754,17 +756,17 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
         // Read DBs always run the full digit list: deep read sets hold ~9 copies of every k-mer plus its
         // sequencing-error variants, so every run is ~10-20 records long and walking it is a chain of
         // dependent LDS reads (measured 2.6 -> 5.9 ms).
-        lp.fast_from = (sizeof(V) == 4 && lp.n > LS_TOP && (lp.n - (int)payload_passes.size()) >= LS_TOP) ? lp.n - LS_TOP : 0;
+        lp.fast_from = (sizeof(V) == 4 && !heads && lp.n > LS_TOP && (lp.n - (int)payload_passes.size()) >= LS_TOP) ? lp.n - LS_TOP : 0;
         lp.cmp_shift = lp.fast_from > 0 ? rest[lp.fast_from].shift : 0;
         lp.pay_mode = payload_passes.empty() ? 0 : (payload_passes[0].src == RS_SRC_VAL32 ? 1 : 2);
         for (int i = 0; i < lp.n; i++) { lp.shift[i] = rest[i].shift; lp.bits[i] = rest[i].bits; lp.src[i] = rest[i].src; }
         if (lp.n == 0) { *result_in_1 = in1; return KMG_OK; }
         {
             const bool idx_kernel = lp.fast_from == 0 && payload_passes.empty() && pbits + low_bit >= 12 && pbits < 64;
-            const bool with_heads = idx_kernel && heads && sizeof(V) == 8 && big.empty();
+            const bool with_heads = idx_kernel && heads && big.empty();
             // algorithmic bytes: records in, records out -- with heads only the payloads go out (+ 16 B per distinct
             // k-mer, added by the caller once their number is known)
-            ProfScope ps(ctx, sizeof(V) == 8 ? KP_SORT_LOCAL_V64 : KP_SORT_LOCAL_V32,
+            ProfScope ps(ctx, sizeof(V) == 8 || ctx->sort_as_reads ? KP_SORT_LOCAL_V64 : KP_SORT_LOCAL_V32,
                          (u64)n * (8 + sizeof(V)) + (u64)n * (with_heads ? sizeof(V) : 8 + sizeof(V)));
             // key digits only and room for a 12-bit index under the key: the one-word-per-record kernel
             if (idx_kernel) {
@@ -773,7 +775,8 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
                                        lp, pbits, heads->ucount);
                     heads->done = true;
                     heads->head_keys = ka;
-                    heads->head_first = reinterpret_cast<u64 *>(va);
+                    heads->head_first = va;
+                    heads->first_bytes = (int)sizeof(V);
                     heads->seg_off = seg;
                     heads->nseg = nseg;
                 } else

@@ -182,6 +182,38 @@ __global__ void rd_unpack_kernel(const u64 *__restrict__ packed, u64 V, int32_t 
     }
 }
 
+// ... and from the compact 32-bit form (read << pos_bits | pos)
+__global__ void rd_unpack32_kernel(const u32 *__restrict__ packed, u64 V, int pos_bits, int32_t *__restrict__ val_a,
+                                   int32_t *__restrict__ val_b) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < V) {
+        const u32 p = packed[i];
+        val_a[i] = (int32_t)(p >> pos_bits);
+        val_b[i] = (int32_t)(int16_t)(p & ((1u << pos_bits) - 1u));
+    }
+}
+
+// length of the longest sequence of a batch
+__global__ void seq_maxlen_kernel(const u64 *__restrict__ seq_off, u64 nseq, u32 *out) {
+    u32 m = 0;
+    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < nseq; s += (u64)gridDim.x * blockDim.x) {
+        const u64 len = seq_off[s + 1] - seq_off[s];
+        m = max(m, len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)len);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (u32)__shfl_down(m, d, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// compact payloads back to the 64-bit form (a second batch arrived)
+__global__ void rd_widen_kernel(const u32 *__restrict__ in, u64 n, int pos_bits, u64 *__restrict__ out) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const u32 p = in[i];
+        out[i] = ((u64)(p >> pos_bits) << 16) | (u64)(p & ((1u << pos_bits) - 1u));
+    }
+}
+
 // counts of a reference DB: occurrences of each (k-mer, taxon) = distance to the next run start
 __global__ void rd_counts_kernel(const u32 *__restrict__ vstart, const u64 *__restrict__ totals /*[0]=U,[1]=V*/,
                                  u32 n, int32_t *__restrict__ val_b) {
