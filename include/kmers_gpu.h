@@ -104,6 +104,10 @@ int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows);
  *               ((k-mer, taxon) pairs | (read, pos) occurrences). */
 int kmg_db_info(const kmg_db *db, int *k, int *key_len, int *rc, int *payload_kind,
                 uint64_t *n_unique, uint64_t *n_values);
+/* Width of the packed (read, pos) values a read database built here holds on the device: 32 when the build could
+ * keep them in 32 bits (one batch, pos < 2^b from its longest read, fewer than 2^(32-b) reads), else 64; 0 for
+ * taxon databases and loaded ones.  Introspection for tests and sizing -- no counterpart in the reference. */
+int kmg_db_payload_bits(const kmg_db *db);
 /* kmg_db_fetch: copy the CSR to host buffers (any may be NULL to skip):
  *   keys[n_unique] ascending; val_off[n_unique+1]; val_a[n_values] = taxon | read;
  *   val_b[n_values] = count | pos; bucket_off[4^key_len + 1] = first k-mer index of each

@@ -20,7 +20,7 @@ PAYLOAD_READPOS = 1
 SYMBOLS = [
     "kmg_create", "kmg_destroy", "kmg_last_error", "kmg_stream",
     "kmg_build_begin", "kmg_build_set_filters", "kmg_build_add", "kmg_build_add_dev", "kmg_build_finish",
-    "kmg_db_info", "kmg_db_fetch", "kmg_db_load", "kmg_db_free", "kmg_db_encode", "kmg_db_merge", "kmg_db_copy_dev", "kmg_db_load_dev",
+    "kmg_db_info", "kmg_db_fetch", "kmg_db_load", "kmg_db_free", "kmg_db_encode", "kmg_db_merge", "kmg_db_copy_dev", "kmg_db_load_dev", "kmg_db_payload_bits",
     "kmg_match", "kmg_match_dev", "kmg_taxacounts",
     "kmg_prof_enable", "kmg_prof_reset", "kmg_prof_get", "kmg_prof_count", "kmg_prof_name", "kmg_calib_copy",
 ]
@@ -69,6 +69,7 @@ def load():
     lib.kmg_db_free.restype = None
     lib.kmg_db_encode.argtypes = [vp, vp, vp, u64, P(u64), vp]
     lib.kmg_db_merge.argtypes = [vp, P(vp), i32, P(vp)]
+    lib.kmg_db_payload_bits.argtypes = [vp]
     lib.kmg_db_copy_dev.argtypes = [vp, i32, vp, u64, u64]
     lib.kmg_db_load_dev.argtypes = [vp, i32, i32, i32, i32, vp, u64, vp, vp, vp, u64, P(vp)]
     lib.kmg_match.argtypes = [vp, vp, vp, vp, P(u64)]

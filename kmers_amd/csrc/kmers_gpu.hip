@@ -640,6 +640,11 @@ extern "C" int kmg_db_info(const kmg_db *db, int *k, int *key_len, int *rc, int 
     return KMG_OK;
 }
 
+extern "C" int kmg_db_payload_bits(const kmg_db *db) {
+    if (!db) return 0;
+    return db->vals_packed32 ? 32 : (db->vals_packed ? 64 : 0);
+}
+
 extern "C" int kmg_db_fetch(const kmg_db *db, uint64_t *keys, uint64_t *val_off, int32_t *val_a, int32_t *val_b,
                             uint64_t *bucket_off) {
     if (!db) return KMG_EINVAL;

@@ -141,6 +141,45 @@ def test_long_read_position_wraps_like_java_short(ctx):
     got.close()
 
 
+def test_compact_read_payload_limits(ctx):
+    """Read builds carry (read, pos) in 32 bits when the batch allows it (pos bits from the longest read, the rest
+    for the read number).  Both sides of the limits, against the oracle: short reads (compact), neighbouring records
+    with equal headers (one read index shared: the payload digits are sorted too), a read longer than 65536 + k
+    (not compact, positions wrap as Java's short does), and compact followed by a second batch (widened)."""
+    import kmers_amd as km
+    from kmers_amd import parse, synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(71, 3, 20000, shared_frac=0.2)
+    reads = synth.random_reads(72, genomes, 3000, 80, 0.01)
+    k, l = 21, 4
+    fq = synth.fastq_bytes(reads)
+    # pairs of records with the same header
+    recs = fq.split(b"@")[1:]
+    paired = b"".join(b"@" + (recs[i - (i & 1)].split(b"\n", 1)[0]) + b"\n" + recs[i].split(b"\n", 1)[1] for i in range(len(recs)))
+    rng = np.random.default_rng(73)
+    long_seq = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=70_000).tolist())
+    with_long = fq + b"@long\n%s\n+\n%s\n" % (long_seq, b"I" * len(long_seq))
+    for data, bits in ((fq, 32), (paired, 32), (with_long, 64)):
+        got, names = km.make_read_db(ctx, data, k, l)
+        assert ctx.lib.kmg_db_payload_bits(got.h) == bits
+        want = OracleDB(data, 1, k, l)
+        _same_db(got, want)
+        assert names == want.names
+        gb, goff = got.encode_blocks()
+        wb, woff = want.encode_blocks()
+        assert gb == wb and np.array_equal(goff, woff)
+        got.close()
+    b = parse.parse(fq, parse.FASTQ, k).batch
+    fc = km.FileCreator(ctx, l, k, "read", rc=False)
+    for lo, hi in ((0, 2900), (2900, 3000)):
+        a0, a1 = int(b.seq_off[lo]), int(b.seq_off[hi])
+        fc.add_kmers(km.SequenceBatch(b.bases[a0:a1], b.seq_off[lo:hi + 1] - b.seq_off[lo], seq_tok=b.seq_tok[lo:hi]))
+    got = fc.create()
+    assert ctx.lib.kmg_db_payload_bits(got.h) == 64
+    _same_db(got, OracleDB(fq, 1, k, l))
+    got.close()
+
+
 def test_many_batches_equal_one_batch(ctx):
     """addKmers may be called many times (FileCreator.java:65); read numbering carries across calls."""
     import kmers_amd as km
