@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <map>
 #include <mutex>
@@ -161,6 +162,7 @@ struct kmg_ctx {
     int compact_pb = 0;
     bool sort_as_reads = false;  // profiling only: attribute 32-bit-payload sort launches to the read kernels
     u64 *d_state = nullptr;      // ST_WORDS device words
+    void *h_pin = nullptr;       // PIN_BYTES of pinned host memory: landing pad of the small result readbacks
     std::vector<void *> staged;  // device copies of host batches, released at finish
 
     // profiling
@@ -183,6 +185,20 @@ struct kmg_db {
     int pos_bits = 16;
     u64 *bucket_off = nullptr;  // 4^key_len + 1
 };
+
+#define PIN_BYTES 256
+// Small device -> host readback + stream sync.  Through the context's pinned block: a pageable destination makes
+// the runtime stage the copy with a blit kernel and a second wait (visible as ~50 us GPU-idle gaps in the trace).
+static inline hipError_t read_back(kmg_ctx *ctx, void *dst, const void *d_src, size_t bytes) {
+    if (!ctx->h_pin || bytes > PIN_BYTES) {
+        hipError_t e = hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
+    }
+    hipError_t e = hipMemcpyAsync(ctx->h_pin, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) memcpy(dst, ctx->h_pin, bytes);
+    return e;
+}
 
 static inline int val_bytes(int kind) { return kind == KMG_PAYLOAD_TAXON ? 4 : 8; }
 

@@ -63,6 +63,7 @@ extern "C" int kmg_create(int device, kmg_ctx **out) {
         return KMG_ENOMEM;
     }
     ctx->d_state = (u64 *)st;
+    if (hipHostMalloc(&ctx->h_pin, PIN_BYTES, hipHostMallocDefault) != hipSuccess) ctx->h_pin = nullptr;   // optional
     *out = ctx;
     return KMG_OK;
 }
@@ -74,6 +75,7 @@ extern "C" void kmg_destroy(kmg_ctx *ctx) {
     prof_drain(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->pool.destroy();
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -95,12 +97,10 @@ extern "C" int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int pay
     ctx->dust = -1; ctx->runofsame = -1;
     ctx->rec_upper = 0;
     ctx->n_adds = 0; ctx->prepart = false; ctx->plan_pbits = 0; ctx->compact_pb = 0;
-    u64 init[ST_WORDS];
-    memset(init, 0, sizeof init);
-    init[ST_ID_AND] = 0xFFFFFFFFull;
-    // stream-ordered: the pageable source is consumed before hipMemcpyAsync returns
-    KMG_HIP(hipMemcpyAsync(ctx->d_state, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    // stream-ordered, no host round trip
+    KMG_HIP(hipMemsetAsync(ctx->d_state, 0, ST_WORDS * sizeof(u64), ctx->stream));
+    hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state + ST_ID_AND, (u64)0xFFFFFFFFull);
+    KMG_HIP(hipGetLastError());
     ctx->building = true;
     return KMG_OK;
 }
@@ -222,8 +222,7 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         hipLaunchKernelGGL(seq_maxlen_kernel, dim3(std::min<u32>(div_up_u64(nseq, 256), 2048)), dim3(256), 0, ctx->stream,
                            d_seq_off, nseq, mx.as<u32>());
         u32 maxlen = 0;
-        KMG_HIP(hipMemcpyAsync(&maxlen, mx.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-        KMG_HIP(hipStreamSynchronize(ctx->stream));
+        KMG_HIP(read_back(ctx, &maxlen, mx.p, 4));
         const u32 maxpos = maxlen > (u32)ctx->k ? maxlen - (u32)ctx->k : 0;
         int pb = 1;
         while (pb < 32 && (maxpos >> pb) != 0) pb++;
@@ -530,8 +529,7 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     ctx->building = false;
 
     u64 st[ST_WORDS];
-    KMG_HIP(hipMemcpyAsync(st, ctx->d_state, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
-    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    KMG_HIP(read_back(ctx, st, ctx->d_state, sizeof st));
     const u64 N = st[ST_NREC];
     if (n_windows) *n_windows = st[ST_NWIN];
     if (N >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 records in one build");
@@ -607,8 +605,7 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     }
     u64 tot[2] = {0, 0};
     if (r == KMG_OK) {
-        hipError_t e = hipMemcpyAsync(tot, totals.p, 16, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        hipError_t e = read_back(ctx, tot, totals.p, 16);
         if (e != hipSuccess) { ctx->err = hipGetErrorString(e); r = KMG_EDEVICE; }
     }
     // the record buffers go back to the pool: the next build (or the DB arrays of this one) reuses them

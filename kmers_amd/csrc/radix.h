@@ -714,8 +714,7 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
         hipLaunchKernelGGL(ls_maxseg_kernel, dim3(div_up_u64(nseg, 256)), dim3(256), 0, ctx->stream, seg, nseg, max_seg);
     }
     u32 h_max = 0;
-    KMG_HIP(hipMemcpyAsync(&h_max, max_seg, 4, hipMemcpyDeviceToHost, ctx->stream));
-    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    KMG_HIP(read_back(ctx, &h_max, max_seg, 4));
 
     // remaining digits, least significant first: payload, then key bits [low_bit, 64 - pbits)
     std::vector<SortPass> rest = payload_passes;
