@@ -219,7 +219,7 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         PoolBuf mx(ctx);
         KMG_ALLOC(mx, 64);
         KMG_HIP(hipMemsetAsync(mx.p, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(seq_maxlen_kernel, dim3(std::min<u32>(div_up_u64(nseq, 256), 2048)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(seq_maxlen_kernel, dim3(std::min<u32>(div_up_u64(nseq, 1024), 1024)), dim3(256), 0, ctx->stream,
                            d_seq_off, nseq, mx.as<u32>());
         u32 maxlen = 0;
         KMG_HIP(read_back(ctx, &maxlen, mx.p, 4));

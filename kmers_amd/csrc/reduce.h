@@ -202,7 +202,14 @@ __global__ void seq_maxlen_kernel(const u64 *__restrict__ seq_off, u64 nseq, u32
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (u32)__shfl_down(m, d, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    // one atomic per block, and only if it can raise the maximum (a million same-address atomics took ~100 us)
+    __shared__ u32 wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+        if (m > *reinterpret_cast<volatile u32 *>(out)) atomicMax(out, m);
+    }
 }
 
 // compact payloads back to the 64-bit form (a second batch arrived)

@@ -30,7 +30,7 @@ def run_pass(counter):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter:
                 continue
-            name = row["Kernel_Name"]
+            name = (row["Kernel_Name"], int(row["Grid_Size"]))
             s = per.setdefault(name, [0.0, 0])
             s[0] += float(row["Counter_Value"])
             s[1] += 1
@@ -39,6 +39,13 @@ def run_pass(counter):
 
 def main():
     fetch, write = run_pass("FETCH_SIZE"), run_pass("WRITE_SIZE")
+    # launches of one kernel with different grids (the read build's and the reference build's) are kept apart
+    grids = {}
+    for name, g in fetch:
+        grids.setdefault(name, set()).add(g)
+    label = lambda k: k[0] if len(grids[k[0]]) == 1 else "%s [grid %d]" % k
+    fetch = {label(k): v for k, v in fetch.items()}
+    write = {label(k): v for k, v in write.items()}
     cal = [k for k in fetch if "calib_copy_kernel" in k][0]
     # counters are reported in KiB
     f_fac = CALIB_BYTES / (fetch[cal][0] / fetch[cal][1] * 1024.0)
