@@ -164,6 +164,25 @@ int kmg_match_dev(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t
 int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, int64_t *match, int64_t *unique,
                    uint64_t *n_taxa);
 
+/* ---- per-read aggregation downstream of the exact match ---------------------
+ * Both join `search` (a read database) against `ref` (a reference database) themselves.
+ * kmg_collect_by_read: Utils/CollectByRead.java:159-184 (processKmer) + :105-124 (ProcessIndex): every
+ *   (read, pos) occurrence of every search k-mer that has a match, in ReadPos order (Reads/ReadPos.java:27-35:
+ *   read, then pos as a signed short), each with the index of the reference k-mer it hit -- the line
+ *   `read:pos \t 0:TxC|TxC` of the reference's output is (read[i], pos[i]) + the taxa of ref k-mer ref_index[i]
+ *   (counts capped at 255 as CountDataType.compress does on the way through its temp file).  The reference keys
+ *   its output blocks by (read / 1000) * 1000; the caller cuts the arrays there.  read == NULL: only *n_out.
+ *   Capacity of the three arrays: n_values of `search` always suffices.  Where two sequences share a read index
+ *   one (read, pos) can occur twice; both records are returned, smaller k-mer first (the reference's TreeSet
+ *   keeps whichever it meets first, in an order it does not define).
+ * kmg_classify_reads: Utils/ReadClassifier.java:178-220 (processRead) over the same records, without
+ *   materialising them: call[r] = the one taxon t >= 0 such that every single-taxon hit of read r names t and
+ *   every hit's taxon set contains t, else -1 (no line in the reference's output).  n_reads = number of read
+ *   indices (KMG_EINVAL if the database holds a larger one). */
+int kmg_collect_by_read(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t *n_out, int32_t *read,
+                        int32_t *pos, int64_t *ref_index);
+int kmg_classify_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t n_reads, int32_t *call);
+
 /* ---- measurement hook (bench.py) --------------------------------------------------------------
  * Total device time in ms, measured with HIP events on kmg_stream(), of the launches of one
  * kernel (ids 0 .. kmg_prof_count()-1, names from kmg_prof_name) since the last kmg_prof_reset,

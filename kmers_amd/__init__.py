@@ -1,9 +1,10 @@
 """kmers_amd -- MI355X-native k-mer hot path (extract, sort+dedup, match, TaxaCounts) behind a C ABI.
 Mirrors the interfaces of danielmoney/kmers for that path only; see DESIGN.md."""
 from .api import (Context, DB, FileCreator, KmerDatabase, SequenceBatch, InconsistentDataException,
-                  KmersGpuError, match_lines, merge_databases, taxa_counts, taxa_count_lines, kmer_strings)
+                  KmersGpuError, match_lines, merge_databases, taxa_counts, taxa_count_lines, kmer_strings,
+                  collect_by_read, collect_by_read_blocks, classify_reads)
 from .make_database import make_read_db, make_reference_db
 
 __all__ = ["Context", "DB", "FileCreator", "KmerDatabase", "SequenceBatch", "InconsistentDataException",
            "KmersGpuError", "match_lines", "merge_databases", "taxa_counts", "taxa_count_lines", "kmer_strings",
-           "make_read_db", "make_reference_db"]
+           "collect_by_read", "collect_by_read_blocks", "classify_reads", "make_read_db", "make_reference_db"]

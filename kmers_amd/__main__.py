@@ -1,4 +1,4 @@
-"""python -m kmers_amd <Database.MakeDatabase | Database.Matcher | Utils.TaxaCounts> <options>
+"""python -m kmers_amd <Database.MakeDatabase | Database.Matcher | Utils.TaxaCounts | Utils.CollectByRead | Utils.ReadClassifier> <options>
 -- the reference's option letters for the hot path (README.md:9-12 `java -cp Kmers.jar <Class> <opts>`)."""
 import argparse
 import sys
@@ -35,6 +35,11 @@ def main(argv=None):
             ap.add_argument("-" + f)
         a = ap.parse_args(rest)
         programs.taxa_counts(Context(0), a.d, a.o)
+    elif prog in ("CollectByRead", "ReadClassifier"):
+        for f in "ioft":
+            ap.add_argument("-" + f)
+        a = ap.parse_args(rest)
+        (programs.collect_by_read if prog == "CollectByRead" else programs.read_classifier)(Context(0), a.i, a.o)
     else:
         raise SystemExit("unknown program %s" % argv[0])
     return 0

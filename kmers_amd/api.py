@@ -312,6 +312,52 @@ def taxa_count_lines(db):
     return ["%d\t%d\t%d" % x for x in zip(t.tolist(), m.tolist(), q.tolist())]
 
 
+def collect_by_read(search, ref):
+    """Utils/CollectByRead.java over the join of a read database and a reference database (kmg_collect_by_read)
+    -> (read[], pos[], ref_index[]) in ReadPos order."""
+    ref = ref.merged if isinstance(ref, DB) else ref
+    ctx = search.ctx
+    cap = max(search.n_values, 1)
+    read, pos, idx = np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.int64)
+    n = C.c_uint64()
+    ctx.check(ctx.lib.kmg_collect_by_read(ctx.h, search.h, ref.h, C.byref(n), _ptr(read), _ptr(pos), _ptr(idx)))
+    return read[:n.value], pos[:n.value], idx[:n.value]
+
+
+def collect_by_read_blocks(search, ref):
+    """The blocks of CollectByRead's output file: {(read / 1000) * 1000: lines `r:p \\t 0:TxC|TxC` joined by
+    "\\n"} (CollectByRead.java:105-124,159-184); counts capped at 255 as on the reference's way through its
+    temp file; of two records with one (read, pos) the first is kept (TreeSet.add)."""
+    ref = ref.merged if isinstance(ref, DB) else ref
+    read, pos, idx = collect_by_read(search, ref)
+    r = ref.fetch()
+    out, lines, cur, last = {}, [], None, None
+    for rd, ps, h in zip(read.tolist(), pos.tolist(), idx.tolist()):
+        if (rd, ps) == last:
+            continue
+        last = (rd, ps)
+        key = (rd // 1000) * 1000
+        if key != cur:
+            if cur is not None:
+                out[cur] = "\n".join(lines).encode()
+            cur, lines = key, []
+        c, d = int(r["val_off"][h]), int(r["val_off"][h + 1])
+        lines.append("%d:%d\t0:%s" % (rd, ps, "|".join("%dx%d" % (x, min(y, 255)) for x, y in
+                                                         zip(r["val_a"][c:d].tolist(), r["val_b"][c:d].tolist()))))
+    if cur is not None:
+        out[cur] = "\n".join(lines).encode()
+    return out
+
+
+def classify_reads(search, ref, n_reads):
+    """Utils/ReadClassifier.java processRead for every read (kmg_classify_reads) -> call[n_reads], -1 = no call."""
+    ref = ref.merged if isinstance(ref, DB) else ref
+    ctx = search.ctx
+    call = np.empty(max(n_reads, 1), np.int32)
+    ctx.check(ctx.lib.kmg_classify_reads(ctx.h, search.h, ref.h, n_reads, _ptr(call)))
+    return call[:n_reads]
+
+
 _BASES = np.frombuffer(b"ACTG", dtype=np.uint8)
 
 

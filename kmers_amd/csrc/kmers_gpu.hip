@@ -8,6 +8,7 @@
 #include "radix.h"
 #include "reduce.h"
 #include "match.h"
+#include "collect.h"
 
 #include <algorithm>
 #include <cstring>
@@ -967,6 +968,123 @@ extern "C" int kmg_match(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, 
 }
 
 // ------------------------------------------------------------------------------------------------ taxa counts
+// ------------------------------------------------------------------------------------------------ per read
+// the join both per-read entry points start from: hit index of every search k-mer, on the device
+static int join_for_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, PoolBuf &d_hit) {
+    if (search->kind != KMG_PAYLOAD_READPOS || ref->kind != KMG_PAYLOAD_TAXON)
+        return fail(ctx, KMG_EINVAL, "per-read aggregation joins a read database against a reference database");
+    if (ref->U >= 0xFFFFFFF0ull || search->V >= 0xFFFFFFF0ull)
+        return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 reference k-mers or read occurrences");
+    KMG_ALLOC(d_hit, (search->U + 1) * 8);
+    KMG_TRY(match_locked(ctx, search, ref, d_hit.as<long long>(), nullptr));
+    KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(search)));
+    return KMG_OK;
+}
+
+extern "C" int kmg_collect_by_read(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t *n_out,
+                                   int32_t *read, int32_t *pos, int64_t *ref_index) {
+    if (!ctx || !search || !ref || !n_out) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    *n_out = 0;
+    PoolBuf d_hit(ctx);
+    KMG_TRY(join_for_reads(ctx, search, ref, d_hit));
+    const u64 U = search->U, V = search->V;
+    if (U == 0 || V == 0) { KMG_HIP(hipStreamSynchronize(ctx->stream)); return KMG_OK; }
+
+    PoolBuf cnt(ctx), off(ctx), agg(ctx), small(ctx);
+    KMG_ALLOC(cnt, U * 4);
+    KMG_ALLOC(off, (U + 1) * 8);
+    KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
+    KMG_ALLOC(small, 64);                     // [0] = number of records (u64), [1] = largest read index (u32)
+    KMG_HIP(hipMemsetAsync(small.p, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(cbr_count_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, search->val_off,
+                       d_hit.as<long long>(), U, cnt.as<u32>());
+    KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt.as<u32>(), off.as<u64>(), U, OpSum(), 0ull, agg.as<u64>(),
+                                                small.as<u64>() + 0, false, KP_SCAN)));
+    hipLaunchKernelGGL(cbr_maxread_kernel, dim3(std::min<u32>(div_up_u64(V, 1024), 1024)), dim3(256), 0, ctx->stream,
+                       search->val_a, V, reinterpret_cast<u32 *>(small.as<u64>() + 1));
+    u64 hs[2] = {0, 0};
+    KMG_HIP(read_back(ctx, hs, small.p, 16));
+    const u64 n = hs[0];
+    *n_out = n;
+    if (n == 0 || !read) return KMG_OK;       // count only
+    if (!pos || !ref_index) return fail(ctx, KMG_EINVAL, "read, pos and ref_index go together");
+
+    int rbits = 1;
+    while (rbits < 32 && (((u32)hs[1]) >> rbits) != 0) rbits++;
+    const int nbits = 16 + rbits, shift = 64 - nbits;
+    const int pbits = choose_pbits(n, nbits);
+    const u32 ntiles = div_up_u64(n, RS_TILE);
+    PoolBuf k0(ctx), v0(ctx), k1(ctx), v1(ctx), table(ctx), sagg(ctx), seg(ctx);
+    KMG_ALLOC(k0, (n + 1) * 8); KMG_ALLOC(v0, (n + 1) * 4);
+    KMG_ALLOC(k1, (n + 1) * 8); KMG_ALLOC(v1, (n + 1) * 4);
+    KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
+    KMG_ALLOC(sagg, (size_t)(div_up_u64((u64)RS_DIGITS * ntiles, SCAN_TILE) + 1) * 8);
+    KMG_ALLOC(seg, (((size_t)1 << pbits) + 4) * 4);
+    hipLaunchKernelGGL(cbr_emit_kernel, dim3(div_up_u64(U * 64, 256)), dim3(256), 0, ctx->stream, search->val_off,
+                       search->val_a, search->val_b, d_hit.as<long long>(), off.as<u64>(), U, shift, k0.as<u64>(), v0.as<u32>());
+    KMG_HIP(hipGetLastError());
+    // ReadPos order = unsigned order of the used key bits; equal (read, pos) pairs (two sequences sharing a read
+    // index) keep k-mer order -- the sort is stable
+    bool in1 = false;
+    KMG_TRY(hybrid_sort_records<u32>(ctx, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), (u32)n, shift, {},
+                                     table.as<u32>(), sagg.as<u32>(), seg.as<u32>(), pbits, false, &in1));
+    const u64 *sk = in1 ? k1.as<u64>() : k0.as<u64>();
+    const u32 *sv = in1 ? v1.as<u32>() : v0.as<u32>();
+    // the other buffer pair is free now: unpack into it, then copy out
+    int32_t *d_read = reinterpret_cast<int32_t *>(in1 ? k0.p : k1.p);
+    int32_t *d_pos = d_read + n;
+    PoolBuf d_ref(ctx);
+    KMG_ALLOC(d_ref, n * 8);
+    hipLaunchKernelGGL(cbr_unpack_kernel, dim3(div_up_u64(n, 256)), dim3(256), 0, ctx->stream, sk, sv, n, shift, d_read, d_pos,
+                       d_ref.as<long long>());
+    KMG_HIP(hipGetLastError());
+    KMG_HIP(hipMemcpyAsync(read, d_read, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(hipMemcpyAsync(pos, d_pos, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(hipMemcpyAsync(ref_index, d_ref.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    return KMG_OK;
+}
+
+extern "C" int kmg_classify_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t n_reads, int32_t *call) {
+    if (!ctx || !search || !ref || (n_reads && !call)) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    if (n_reads >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "too many reads");
+    PoolBuf d_hit(ctx);
+    KMG_TRY(join_for_reads(ctx, search, ref, d_hit));
+    if (n_reads == 0) {
+        if (search->V) return fail(ctx, KMG_EINVAL, "read index outside n_reads");
+        return KMG_OK;
+    }
+    PoolBuf mn(ctx), mx(ctx), bad(ctx), d_call(ctx);
+    KMG_ALLOC(mn, n_reads * 4); KMG_ALLOC(mx, n_reads * 4);
+    KMG_ALLOC(bad, (n_reads + 16) * 4);               // [n_reads] = error flag
+    KMG_ALLOC(d_call, n_reads * 4);
+    const dim3 gr(div_up_u64(n_reads, 256)), b(256);
+    hipLaunchKernelGGL(fill_i32_kernel, gr, b, 0, ctx->stream, mn.as<int32_t>(), n_reads, (int32_t)0x7FFFFFFF);
+    hipLaunchKernelGGL(fill_i32_kernel, gr, b, 0, ctx->stream, mx.as<int32_t>(), n_reads, (int32_t)0x80000000);
+    KMG_HIP(hipMemsetAsync(bad.p, 0, (n_reads + 16) * 4, ctx->stream));
+    u32 *err = bad.as<u32>() + n_reads;
+    const u64 U = search->U;
+    if (U) {
+        const dim3 gk(div_up_u64(U * 64, 256));
+        hipLaunchKernelGGL(rc_single_kernel, gk, b, 0, ctx->stream, search->val_off, search->val_a, d_hit.as<long long>(), U,
+                           ref->val_off, ref->val_a, n_reads, mn.as<int32_t>(), mx.as<int32_t>(), err);
+        hipLaunchKernelGGL(rc_check_kernel, gk, b, 0, ctx->stream, search->val_off, search->val_a, d_hit.as<long long>(), U,
+                           ref->val_off, ref->val_a, n_reads, mn.as<int32_t>(), mx.as<int32_t>(), bad.as<u32>());
+    }
+    hipLaunchKernelGGL(rc_call_kernel, gr, b, 0, ctx->stream, mn.as<int32_t>(), mx.as<int32_t>(), bad.as<u32>(), n_reads,
+                       d_call.as<int32_t>());
+    KMG_HIP(hipGetLastError());
+    u32 h_err = 0;
+    KMG_HIP(hipMemcpyAsync(call, d_call.p, n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(read_back(ctx, &h_err, err, 4));
+    if (h_err) return fail(ctx, KMG_EINVAL, "read index outside n_reads");
+    return KMG_OK;
+}
+
 extern "C" int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, int64_t *match, int64_t *unique,
                               uint64_t *n_taxa) {
     if (!ctx || !db || !n_taxa) return KMG_EINVAL;

@@ -4,6 +4,7 @@ without a JVM):
   make_database  <- Database/MakeDatabase.java  (-a | -q, -i -o -K -k -l -z|-Z -r -D -R)
   matcher        <- Database/Matcher.java       (-i -d -o -z|-Z)
   taxa_counts    <- Utils/TaxaCounts.java       (-d -o)
+  collect_by_read <- Utils/CollectByRead.java   (-i -o)      read_classifier <- Utils/ReadClassifier.java (-i -o)
 """
 import gzip
 import struct
@@ -11,7 +12,8 @@ import struct
 import numpy as np
 
 from . import container, parse
-from .api import DB, KmerDatabase, KmersGpuError, READ_ID, REF_ID, kmer_strings, match_lines, merge_databases, taxa_count_lines
+from .api import (DB, KmerDatabase, KmersGpuError, READ_ID, REF_ID, classify_reads, collect_by_read_blocks, kmer_strings,
+                  match_lines, merge_databases, taxa_count_lines)
 from ._lib import KMG_EUNSUPPORTED, PAYLOAD_READPOS, PAYLOAD_TAXON
 from .make_database import make_read_db, make_reference_db
 
@@ -175,3 +177,112 @@ def taxa_counts(ctx, db_path, output_path):
     with open(output_path, "w") as f:
         f.write("".join(l + "\n" for l in lines))
     return lines
+
+
+_CODE = {65: 0, 67: 1, 84: 2, 71: 3}        # A C T G (Base.java:17-41)
+
+
+def _kmer_key(text):
+    """Left-aligned 2-bit value of a k-mer string (Sequence.cBytes read big-endian)."""
+    v = 0
+    for ch in text.encode():
+        v = (v << 2) | _CODE[ch]
+    return v << (64 - 2 * len(text))
+
+
+def _open_text(path):
+    """Zip.ZipOrNot.getBufferedReader: gzip if the file starts with the gzip magic."""
+    with open(path, "rb") as f:
+        magic = f.read(2)
+    return gzip.open(path, "rt") if magic == b"\x1f\x8b" else open(path, "r")
+
+
+def _write_text_blocks(path, blocks):
+    """new IndexedOutputFile<>(f, new IntCompressor(), true, 5): human-readable flavour, zip level 5, one block
+    per key in ascending order, no meta block (CollectByRead.java:66-67,116-119; ReadClassifier.java:52-53,157-160)."""
+    out = container.IndexedOutputFile(path, hr=True, zip_level=5)
+    for key in sorted(blocks):
+        out.set_current_key(key)
+        out.write(blocks[key])
+    out.close()
+
+
+def collect_by_read(ctx, input_path, output_path):
+    """Utils.CollectByRead -i <Matcher output> -o <file>.  The match lines are loaded back as a read database and
+    a reference database over the same k-mers (every k-mer hits itself) and transposed on the GPU."""
+    keys, s_off, s_read, s_pos, r_off, r_tax, r_cnt = [], [0], [], [], [0], [], []
+    k = None
+    with _open_text(input_path) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if not line:
+                continue
+            kmer, reads_s, matches_s = line.split("\t", 2)
+            ents = matches_s.split(" ")
+            if len(ents) != 1 or not ents[0].startswith("-|"):
+                raise SystemExit("inexact matches stay on the Java path")
+            k = len(kmer) if k is None else k
+            keys.append(_kmer_key(kmer))
+            for rp in reads_s.split("|"):
+                r, p = rp.split(":")
+                s_read.append(int(r))
+                s_pos.append(int(p))
+            s_off.append(len(s_read))
+            for tc in ents[0][2:].split("|"):
+                t, c = tc.split("x")
+                r_tax.append(int(t))
+                r_cnt.append(int(c))
+            r_off.append(len(r_tax))
+    if k is None:
+        _write_text_blocks(output_path, {})
+        return {}
+    kl = min(k, 6)
+    search = KmerDatabase.load(ctx, k, kl, False, PAYLOAD_READPOS, np.array(keys, np.uint64), np.array(s_off, np.uint64),
+                               np.array(s_read, np.int32), np.array(s_pos, np.int32))
+    ref = KmerDatabase.load(ctx, k, kl, True, PAYLOAD_TAXON, np.array(keys, np.uint64), np.array(r_off, np.uint64),
+                            np.array(r_tax, np.int32), np.array(r_cnt, np.int32))
+    blocks = collect_by_read_blocks(search, ref)
+    search.close()
+    ref.close()
+    _write_text_blocks(output_path, blocks)
+    return blocks
+
+
+def read_classifier(ctx, input_path, output_path):
+    """Utils.ReadClassifier -i <CollectByRead output> -o <file>.  Every line becomes one pseudo k-mer (its line
+    number as a 32-mer) of a read database holding the line's (read, pos) and of a reference database holding its
+    dist-0 taxa; kmg_classify_reads then does processRead for all reads at once."""
+    f = container.IndexedInputFile(input_path)
+    s_read, s_pos, r_off, r_tax, block_reads = [], [], [0], [], {}
+    for key in sorted(f.index):
+        text = f.read_key(key).decode()
+        reads = block_reads.setdefault(key, [])
+        for line in (text.split("\n") if text else []):
+            rp_s, map_s = line.split("\t", 1)
+            r, p = rp_s.split(":")
+            if not reads or reads[-1] != int(r):
+                reads.append(int(r))
+            for ent in map_s.split(" "):
+                dist, counts = ent.split(":")
+                if int(dist) == 0:                            # ReadClassifier.java:109,125: only the dist-0 map
+                    s_read.append(int(r))
+                    s_pos.append(int(p))
+                    for tc in counts.split("|"):
+                        r_tax.append(int(tc.split("x")[0]))
+                    r_off.append(len(r_tax))
+    n = len(s_read)
+    blocks = {key: b"" for key in block_reads}
+    if n:
+        keys = np.arange(n, dtype=np.uint64)
+        one = np.arange(n + 1, dtype=np.uint64)
+        search = KmerDatabase.load(ctx, 32, 6, False, PAYLOAD_READPOS, keys, one, np.array(s_read, np.int32), np.array(s_pos, np.int32))
+        ref = KmerDatabase.load(ctx, 32, 6, True, PAYLOAD_TAXON, keys, np.array(r_off, np.uint64), np.array(r_tax, np.int32),
+                                np.ones(len(r_tax), np.int32))
+        n_reads = max(s_read) + 1
+        call = classify_reads(search, ref, n_reads)
+        search.close()
+        ref.close()
+        for key, reads in block_reads.items():
+            blocks[key] = "".join("%d\t%d\n" % (r, int(call[r])) for r in reads if r < n_reads and call[r] >= 0).encode()
+    _write_text_blocks(output_path, blocks)
+    return blocks

@@ -580,6 +580,110 @@ def taxa_counts(db):
     return ["%d\t%d\t%d" % (t, match[t], unique.get(t, 0)) for t in sorted(match)]
 
 
+# --------------------------------------------------------------------- Utils/CollectByRead.java
+def _counts_from_string(s):
+    """CountDataType.fromString with separators "x" and "|" (CountDataType.java:97-107)."""
+    m = {}
+    for p in s.split("|"):
+        t, c = p.split("x")
+        m[int(t)] = int(c)
+    return m
+
+
+def _counts_to_string(m):
+    """CountDataType.toString (CountDataType.java:109-113): ascending taxon (TreeCountMap)."""
+    return "|".join("%dx%d" % (t, m[t]) for t in sorted(m))
+
+
+def collect_by_read(match_lines_):
+    """CollectByRead.main (CollectByRead.java:62-83) over the lines of a Matcher output (ResultsFile.java:23-26).
+    processKmer (:159-184): dist -> summed taxon counts of the line's matches; one record (ReadPos, that map) per
+    ReadPos of the line, filed under (read / 1000) * 1000.  The record goes through odt.compress (:177), whose
+    CountDataType.compress caps every count at 255 (CountDataType.java:40).  ProcessIndex (:105-124): a TreeSet
+    ordered by ReadPos alone (an equal ReadPos met later is dropped), printed `r:p \t dist:TxC|TxC dist:...`
+    (DataPairDataType.java:43-50, jar MapCompressor.toString: entries `key:value` joined by " ") and joined
+    by "\n" without a trailing newline.  -> {index: text bytes}, the blocks of the output IndexedFile."""
+    per = {}
+    for line in match_lines_:
+        kmer, rest = line.split("\t", 1)                       # KmerWithDataDataType.fromString
+        reads_s, matches_s = rest.split("\t", 1)               # DataPairDataType "\t", limit 2
+        dist_taxa = {}
+        for ent in matches_s.split(" "):                       # SetDataType " "
+            diff_s, counts_s = ent.split("|", 1)               # DataPairDataType "|", limit 2
+            if diff_s != "-":
+                raise NotImplementedError("inexact matches (KmerDiff with diffs) are outside the exact path")
+            d = dist_taxa.setdefault(0, {})                    # KmerDiff.dist() of "-" = 0
+            for t, c in _counts_from_string(counts_s).items():
+                d[t] = d.get(t, 0) + c                         # TreeCountMap.addAll
+        capped = {dist: {t: min(c, 255) for t, c in m.items()} for dist, m in dist_taxa.items()}
+        for rp in reads_s.split("|"):                          # SetDataType<ReadPos> "|"
+            r, p = rp.split(":")
+            r, p = int(r), _sshort(int(p))
+            per.setdefault((r // 1000) * 1000, []).append(((r, p), capped))
+    out = {}
+    for index in sorted(per):
+        seen, rows = set(), []
+        for rp, m in per[index]:
+            if rp not in seen:                                 # TreeSet.add keeps the element already present
+                seen.add(rp)
+                rows.append((rp, m))
+        rows.sort(key=lambda x: x[0])                          # ReadPos.compareTo: read, then (short) pos
+        out[index] = "\n".join("%d:%d\t%s" % (rp[0], rp[1], " ".join("%d:%s" % (dist, _counts_to_string(m[dist]))
+                                                                     for dist in sorted(m))) for rp, m in rows).encode()
+    return out
+
+
+# --------------------------------------------------------------------- Utils/ReadClassifier.java
+def _process_read(taxids):
+    """ReadClassifier.ProcessIndex.processRead (ReadClassifier.java:178-220), literally."""
+    call = -1
+    for tids in taxids:
+        if len(tids) == 1:
+            cur = next(iter(tids))
+            if call == -1:
+                call = cur
+            elif cur != call:
+                call = -2
+    if call >= 0:
+        for tids in taxids:
+            if call not in tids:
+                call = -2
+    return call if call >= 0 else None
+
+
+def read_classifier(collect_blocks):
+    """ReadClassifier.ProcessIndex.call (ReadClassifier.java:95-176) over the blocks of a CollectByRead file:
+    per block the lines in order, a read's taxon sets are the key sets of its dist-0 maps; one line
+    `read \t call \n` per called read.  Every input block gives an output block (possibly empty)."""
+    out = {}
+    for index in sorted(collect_blocks):
+        text = collect_blocks[index].decode()
+        lines = text.split("\n") if text else []
+        called, cur_read, taxids = [], -1, []
+        first = True
+        for line in lines:
+            rp_s, map_s = line.split("\t", 1)
+            read = int(rp_s.split(":")[0])
+            m = {}
+            for ent in map_s.split(" "):                       # jar MapCompressor.fromString
+                kv = ent.split(":")
+                m[int(kv[0])] = _counts_from_string(kv[1])
+            if first:
+                cur_read, first = read, False
+            elif read != cur_read:
+                call = _process_read(taxids)
+                if call is not None:
+                    called.append((cur_read, call))
+                cur_read, taxids = read, []
+            if 0 in m:
+                taxids.append(set(m[0]))
+        call = _process_read(taxids)
+        if call is not None:
+            called.append((cur_read, call))
+        out[index] = "".join("%d\t%d\n" % rc for rc in called).encode()
+    return out
+
+
 # ------------------------------------------------ jar IndexedFiles.* (SURVEY.md Appendix A.1, A.2)
 def _gz_member(data, level):
     """jar GzipCompressorOutputStream + GzipParameters (A.2): mtime 0, XFL 2/4/0, OS 255, raw deflate."""
@@ -598,7 +702,7 @@ def write_indexed_file(path, blocks, zip_level=5, hr=False):
     z = zip_level is not None
     body = bytearray(b"\0" * (64 if z else 41))
     index = []
-    for key in [-1] + [k for k in sorted(blocks) if k >= 0]:
+    for key in ([-1] if -1 in blocks else []) + [k for k in sorted(blocks) if k >= 0]:   # (downstream tools: no meta block)
         blob = _gz_member(blocks[key], zip_level) if z else blocks[key]
         index.append((key, len(body), len(blob)))
         body += blob

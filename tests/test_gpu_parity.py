@@ -668,3 +668,82 @@ def test_medium_builds_against_oracle(ctx, k, l, n_reads, rlen):
     assert nh == o_nh and np.array_equal(hit, o_hit)
     ref.close()
     rdb.close()
+
+
+def _classifier_blocks(call, collect_blocks):
+    """ReadClassifier's output blocks from the dense calls: the reads of each CollectByRead block, in order."""
+    out = {}
+    for key, text in collect_blocks.items():
+        reads = []
+        for line in (text.decode().split("\n") if text else []):
+            r = int(line.split(":", 1)[0])
+            if not reads or reads[-1] != r:
+                reads.append(r)
+        out[key] = "".join("%d\t%d\n" % (r, int(call[r])) for r in reads if call[r] >= 0).encode()
+    return out
+
+
+@pytest.mark.parametrize("k,l,n_reads,rlen,paired", [(21, 4, 2500, 90, False), (31, 6, 6000, 150, False), (15, 3, 1800, 70, True)])
+def test_collect_by_read_and_classifier_match_oracle(ctx, k, l, n_reads, rlen, paired):
+    """kmg_collect_by_read / kmg_classify_reads against the restated CollectByRead + ReadClassifier run on the match
+    lines of the same join.  Genomes share 40 % of their sequence (multi-taxon hits), reads carry errors, and in
+    the `paired` case neighbouring records share a header (one read index, (read, pos) pairs occurring twice)."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle import slow_ref as R
+    taxa, genomes = synth.random_genomes(81 + k, 6, 12000, shared_frac=0.4)
+    reads = synth.random_reads(82 + k, genomes, n_reads, rlen, 0.01)
+    fq = synth.fastq_bytes(reads)
+    if paired:
+        recs = fq.split(b"@")[1:]
+        fq = b"".join(b"@" + (recs[i - (i & 1)].split(b"\n", 1)[0]) + b"\n" + recs[i].split(b"\n", 1)[1] for i in range(len(recs)))
+    ref = km.make_reference_db(ctx, synth.fasta_bytes(taxa, genomes), k, l)
+    rdb, names = km.make_read_db(ctx, fq, k, l)
+    hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
+    assert nh > 1000
+    lines = km.match_lines(rdb, ref, hit)
+    want = R.collect_by_read(lines)
+    got = km.collect_by_read_blocks(rdb, ref)
+    assert got.keys() == want.keys()
+    for key in want:
+        assert got[key] == want[key], key
+    read, pos, idx = km.collect_by_read(rdb, ref)
+    assert len(read) == int(rdb.fetch()["val_off"][np.nonzero(hit >= 0)[0] + 1].astype(np.int64).sum()
+                            - rdb.fetch()["val_off"][np.nonzero(hit >= 0)[0]].astype(np.int64).sum())
+    order = read.astype(np.int64) * 65536 + (pos.astype(np.int64) + 32768)
+    assert np.all(np.diff(order) >= 0) and (paired or np.all(np.diff(order) > 0))
+    call = km.classify_reads(rdb, ref, len(names))
+    assert _classifier_blocks(call, want) == R.read_classifier(want)
+    assert (call >= 0).sum() > 100 and (call < 0).sum() > 0
+    with pytest.raises(km.InconsistentDataException):
+        km.classify_reads(rdb, ref, len(names) - 1)                  # a read index outside n_reads
+    with pytest.raises(km.InconsistentDataException):
+        km.collect_by_read(ref, ref)                                 # not a read database
+    ref.close()
+    rdb.close()
+
+
+def test_collect_by_read_skew_and_empty(ctx):
+    """One k-mer that occurs in every read (a shared adapter) -- a value list of thousands of entries handled by one
+    wave -- and the empty join."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle import slow_ref as R
+    taxa, genomes = synth.random_genomes(91, 3, 5000)
+    adapter = genomes[0][:40]
+    reads = synth.random_reads(92, genomes, 3000, 60, 0.0)
+    reads = np.concatenate([np.tile(adapter, (reads.shape[0], 1)), reads], axis=1)
+    k, l = 17, 4
+    ref = km.make_reference_db(ctx, synth.fasta_bytes(taxa, genomes), k, l)
+    rdb, names = km.make_read_db(ctx, synth.fastq_bytes(reads), k, l)
+    hit, _ = km.DB([ref]).get_nearest_kmers(rdb)
+    want = R.collect_by_read(km.match_lines(rdb, ref, hit))
+    assert km.collect_by_read_blocks(rdb, ref) == want
+    assert _classifier_blocks(km.classify_reads(rdb, ref, len(names)), want) == R.read_classifier(want)
+    other_taxa, other = synth.random_genomes(93, 1, 4000)
+    stranger, _ = km.make_read_db(ctx, synth.fastq_bytes(synth.random_reads(94, other, 50, 60, 0.0)), k, l)
+    r, p, i = km.collect_by_read(stranger, ref)
+    assert len(r) == 0 and km.collect_by_read_blocks(stranger, ref) == {}
+    assert np.all(km.classify_reads(stranger, ref, 50) == -1)
+    for d in (ref, rdb, stranger):
+        d.close()

@@ -56,7 +56,19 @@ def test_programs_end_to_end(tmp_path):
     counts = programs.taxa_counts(ctx, refdb, str(tmp_path / "counts.tsv"))
     t, m, q = o_ref.taxacounts()
     assert open(str(tmp_path / "counts.tsv")).read().splitlines() == ["%d\t%d\t%d" % x for x in zip(t, m, q)] == counts
+    # downstream of the match: Utils.CollectByRead and Utils.ReadClassifier, file to file
+    cb = programs.collect_by_read(ctx, str(tmp_path / "matches.gz"), str(tmp_path / "collected"))
+    want_cb = R.collect_by_read(lines)
+    assert cb == want_cb and len(want_cb) == 2                                # reads 0..999 and 1000..1499
+    R.write_indexed_file(str(tmp_path / "collected.oracle"), want_cb, 5, hr=True)
+    assert R.read_indexed_file(str(tmp_path / "collected")) == R.read_indexed_file(str(tmp_path / "collected.oracle"))
+    rcb = programs.read_classifier(ctx, str(tmp_path / "collected"), str(tmp_path / "calls"))
+    assert rcb == R.read_classifier(want_cb) and sum(len(v) for v in rcb.values()) > 1000
+    assert R.read_indexed_file(str(tmp_path / "calls")) == rcb
     ctx.close()
+    assert cli(["Utils.CollectByRead", "-i", str(tmp_path / "matches.gz"), "-o", str(tmp_path / "cli.collected")]) == 0
+    assert cli(["Utils.ReadClassifier", "-i", str(tmp_path / "cli.collected"), "-o", str(tmp_path / "cli.calls")]) == 0
+    assert R.read_indexed_file(str(tmp_path / "cli.calls")) == rcb
 
     # the same through the reference's command lines
     assert cli(["Database.MakeDatabase", "-a", "-i", fa, "-o", str(tmp_path / "cli.db"), "-K", str(k), "-k", str(k),

@@ -157,3 +157,24 @@ def test_multi_file_db_counts_add_without_saturation():  # SURVEY App. C.9, DB.j
     got = dict((str(k), d) for k, d in db.kmers(R.Kmer(list(b"ACGT")).key(2)))
     one = dict((str(k), d) for k, d in R.DB([a]).kmers(R.Kmer(list(b"ACGT")).key(2)))
     assert got["ACGT"][5] == 2 * one["ACGT"][5]
+
+
+def test_collect_by_read_and_read_classifier_hand_example():
+    """CollectByRead.java:105-124,159-184 and ReadClassifier.java:95-220 on five match lines worked by hand:
+    counts are capped at 255 on the way through the temp file (CountDataType.java:40), records are filed under
+    (read / 1000) * 1000 and ordered by (read, (short) pos), a read is called only if all its single-taxon hits
+    agree and every hit's taxon set contains that taxon."""
+    lines = ["AAC\t0:0|0:1\t-|5x2|7x300",
+             "ACC\t0:2|1001:0\t-|5x1",
+             "CCC\t1001:5\t-|7x1",
+             "GGG\t2:-32768|2:7\t-|9x1|10x1",
+             "GGT\t3:4\t-|9x1|10x1"]
+    blocks = R.collect_by_read(lines)
+    assert blocks == {
+        0: b"0:0\t0:5x2|7x255\n0:1\t0:5x2|7x255\n0:2\t0:5x1\n2:-32768\t0:9x1|10x1\n2:7\t0:9x1|10x1\n3:4\t0:9x1|10x1",
+        1000: b"1001:0\t0:5x1\n1001:5\t0:7x1"}
+    # read 0: {5,7} {5,7} {5} -> 5; read 2, 3: no single-taxon hit -> none; read 1001: {5} vs {7} -> none
+    assert R.read_classifier(blocks) == {0: b"0\t5\n", 1000: b""}
+    # a single-taxon hit that another hit's set does not contain
+    assert R.read_classifier({0: b"4:0\t0:5x1\n4:1\t0:6x1|7x1"}) == {0: b""}
+    assert R.read_classifier({0: b"4:0\t0:5x1\n4:1\t0:5x3|7x1\n5:0\t0:8x1"}) == {0: b"4\t5\n5\t8\n"}
