@@ -33,19 +33,20 @@ __global__ void cbr_maxread_kernel(const int32_t *__restrict__ val_a, u64 V, u32
     }
 }
 
-// One wave per search k-mer (lists are short on average, but a low-complexity k-mer can hold millions of
-// occurrences): record = key (read << 16 | pos16 with the sign bit flipped, left-aligned by `shift`) + hit index.
+// CB_LANES lanes per search k-mer (lists hold 3-4 occurrences on average, but a low-complexity k-mer can hold
+// thousands): record = key (read << 16 | pos16 with the sign bit flipped, left-aligned by `shift`) + hit index.
+#define CB_LANES 8
 __global__ __launch_bounds__(256) void cbr_emit_kernel(const u64 *__restrict__ val_off, const int32_t *__restrict__ val_a,
                                                        const int32_t *__restrict__ val_b, const long long *__restrict__ hit,
                                                        const u64 *__restrict__ out_off, u64 U, int shift,
                                                        u64 *__restrict__ out_keys, u32 *__restrict__ out_hit) {
-    const u64 s = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const u32 lane = threadIdx.x & 63;
+    const u64 s = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / CB_LANES;
+    const u32 lane = threadIdx.x % CB_LANES;
     if (s >= U) return;
     const long long h = hit[s];
     if (h < 0) return;
     const u64 v0 = val_off[s], n = val_off[s + 1] - v0, o = out_off[s];
-    for (u64 j = lane; j < n; j += 64) {
+    for (u64 j = lane; j < n; j += CB_LANES) {
         const u64 rp = ((u64)(u32)val_a[v0 + j] << 16) | (u64)(((u32)val_b[v0 + j] ^ 0x8000u) & 0xFFFFu);
         out_keys[o + j] = rp << shift;
         out_hit[o + j] = (u32)h;
@@ -69,18 +70,23 @@ __global__ __launch_bounds__(256) void rc_single_kernel(const u64 *__restrict__ 
                                                         const long long *__restrict__ hit, u64 U,
                                                         const u64 *__restrict__ r_off, const int32_t *__restrict__ r_taxon,
                                                         u64 n_reads, int32_t *mn, int32_t *mx, u32 *err) {
-    const u64 s = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const u32 lane = threadIdx.x & 63;
+    const u64 s = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / CB_LANES;
+    const u32 lane = threadIdx.x % CB_LANES;
     if (s >= U) return;
     const long long h = hit[s];
     if (h < 0) return;
     const u64 v0 = s_off[s], n = s_off[s + 1] - v0;
     const bool single = r_off[h + 1] - r_off[h] == 1;
     const int32_t t = single ? r_taxon[r_off[h]] : 0;
-    for (u64 j = lane; j < n; j += 64) {
+    for (u64 j = lane; j < n; j += CB_LANES) {
         const u32 r = (u32)s_read[v0 + j];
         if (r >= n_reads) { atomicOr(err, 1u); continue; }
-        if (single) { atomicMin(&mn[r], t); atomicMax(&mx[r], t); }
+        if (single) {
+            // mn only falls and mx only rises, so a plain look first is safe and spares most of the ~100 atomics
+            // a read's occurrences would aim at its two words
+            if (*reinterpret_cast<volatile int32_t *>(&mn[r]) > t) atomicMin(&mn[r], t);
+            if (*reinterpret_cast<volatile int32_t *>(&mx[r]) < t) atomicMax(&mx[r], t);
+        }
     }
 }
 
@@ -89,14 +95,14 @@ __global__ __launch_bounds__(256) void rc_check_kernel(const u64 *__restrict__ s
                                                        const u64 *__restrict__ r_off, const int32_t *__restrict__ r_taxon,
                                                        u64 n_reads, const int32_t *__restrict__ mn, const int32_t *__restrict__ mx,
                                                        u32 *bad) {
-    const u64 s = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const u32 lane = threadIdx.x & 63;
+    const u64 s = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / CB_LANES;
+    const u32 lane = threadIdx.x % CB_LANES;
     if (s >= U) return;
     const long long h = hit[s];
     if (h < 0) return;
     const u64 v0 = s_off[s], n = s_off[s + 1] - v0;
     const u64 t0 = r_off[h], tn = r_off[h + 1] - t0;
-    for (u64 j = lane; j < n; j += 64) {
+    for (u64 j = lane; j < n; j += CB_LANES) {
         const u32 r = (u32)s_read[v0 + j];
         if (r >= n_reads) continue;
         const int32_t t = mn[r];

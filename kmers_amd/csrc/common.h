@@ -50,6 +50,9 @@ enum {
     KP_MATCH,
     KP_TAXA,
     KP_ENCODE,
+    KP_COLLECT_EMIT,
+    KP_COLLECT_UNPACK,
+    KP_CLASSIFY,
     KP_COUNT_
 };
 
@@ -57,7 +60,8 @@ static const char *const kp_names[KP_COUNT_] = {
     "extract_tileseq", "extract_count", "extract_write", "number_reads", "scan",
     "sort_hist_ref",   "sort_hist_reads", "sort_scan", "sort_scatter_ref", "sort_scatter_reads",
     "sort_segments",   "sort_local_ref", "sort_local_reads", "reduce_flag",  "reduce_write",
-    "bucket_offsets",  "match",         "taxacounts",    "encode"};
+    "bucket_offsets",  "match",         "taxacounts",    "encode",
+    "collect_emit",    "collect_unpack", "classify_reads"};
 
 // Grow-only caching device allocator: blocks freed to the pool are reused by later requests of a
 // similar size, so a steady-state loop (bench steps, repeated builds) calls hipMalloc only once.

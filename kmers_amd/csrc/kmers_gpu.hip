@@ -1022,14 +1022,19 @@ extern "C" int kmg_collect_by_read(kmg_ctx *ctx, const kmg_db *search, const kmg
     KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
     KMG_ALLOC(sagg, (size_t)(div_up_u64((u64)RS_DIGITS * ntiles, SCAN_TILE) + 1) * 8);
     KMG_ALLOC(seg, (((size_t)1 << pbits) + 4) * 4);
-    hipLaunchKernelGGL(cbr_emit_kernel, dim3(div_up_u64(U * 64, 256)), dim3(256), 0, ctx->stream, search->val_off,
-                       search->val_a, search->val_b, d_hit.as<long long>(), off.as<u64>(), U, shift, k0.as<u64>(), v0.as<u32>());
+    {
+        // in: offsets + hit + output offset per k-mer, (read, pos) per occurrence; out: 12-byte records
+        ProfScope ps(ctx, KP_COLLECT_EMIT, U * 24 + V * 8 + n * 12);
+        hipLaunchKernelGGL(cbr_emit_kernel, dim3(div_up_u64(U * CB_LANES, 256)), dim3(256), 0, ctx->stream, search->val_off,
+                           search->val_a, search->val_b, d_hit.as<long long>(), off.as<u64>(), U, shift, k0.as<u64>(), v0.as<u32>());
+    }
     KMG_HIP(hipGetLastError());
     // ReadPos order = unsigned order of the used key bits; equal (read, pos) pairs (two sequences sharing a read
     // index) keep k-mer order -- the sort is stable
     bool in1 = false;
     KMG_TRY(hybrid_sort_records<u32>(ctx, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), (u32)n, shift, {},
-                                     table.as<u32>(), sagg.as<u32>(), seg.as<u32>(), pbits, false, &in1));
+                                     table.as<u32>(), sagg.as<u32>(), seg.as<u32>(), pbits, false, &in1, nullptr,
+                                     /* counting passes only: the low key bits (pos) repeat in long runs */ false));
     const u64 *sk = in1 ? k1.as<u64>() : k0.as<u64>();
     const u32 *sv = in1 ? v1.as<u32>() : v0.as<u32>();
     // the other buffer pair is free now: unpack into it, then copy out
@@ -1037,8 +1042,11 @@ extern "C" int kmg_collect_by_read(kmg_ctx *ctx, const kmg_db *search, const kmg
     int32_t *d_pos = d_read + n;
     PoolBuf d_ref(ctx);
     KMG_ALLOC(d_ref, n * 8);
-    hipLaunchKernelGGL(cbr_unpack_kernel, dim3(div_up_u64(n, 256)), dim3(256), 0, ctx->stream, sk, sv, n, shift, d_read, d_pos,
-                       d_ref.as<long long>());
+    {
+        ProfScope ps(ctx, KP_COLLECT_UNPACK, n * 12 + n * 16);
+        hipLaunchKernelGGL(cbr_unpack_kernel, dim3(div_up_u64(n, 256)), dim3(256), 0, ctx->stream, sk, sv, n, shift, d_read, d_pos,
+                           d_ref.as<long long>());
+    }
     KMG_HIP(hipGetLastError());
     KMG_HIP(hipMemcpyAsync(read, d_read, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     KMG_HIP(hipMemcpyAsync(pos, d_pos, n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1069,7 +1077,10 @@ extern "C" int kmg_classify_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_
     u32 *err = bad.as<u32>() + n_reads;
     const u64 U = search->U;
     if (U) {
-        const dim3 gk(div_up_u64(U * 64, 256));
+        const dim3 gk(div_up_u64(U * CB_LANES, 256));
+        // two passes over the join: offsets + hit per search k-mer, one read index per occurrence (+ the hit k-mers'
+        // taxa, cache-resident), per-read words updated in place
+        ProfScope ps(ctx, KP_CLASSIFY, 2 * (U * 16 + search->V * 4) + n_reads * 16);
         hipLaunchKernelGGL(rc_single_kernel, gk, b, 0, ctx->stream, search->val_off, search->val_a, d_hit.as<long long>(), U,
                            ref->val_off, ref->val_a, n_reads, mn.as<int32_t>(), mx.as<int32_t>(), err);
         hipLaunchKernelGGL(rc_check_kernel, gk, b, 0, ctx->stream, search->val_off, search->val_a, d_hit.as<long long>(), U,

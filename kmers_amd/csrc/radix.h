@@ -691,7 +691,8 @@ struct SortHeads {
 template <typename V>
 static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 n, int low_bit,
                                const std::vector<SortPass> &payload_passes, u32 *table, u32 *agg, u32 *seg,
-                               int pbits, bool skip_first, bool *result_in_1, SortHeads *heads = nullptr) {
+                               int pbits, bool skip_first, bool *result_in_1, SortHeads *heads = nullptr,
+                               bool allow_cmp_finish = true) {
     *result_in_1 = false;
     if (heads) heads->done = false;
     if (n == 0) return KMG_OK;
@@ -755,7 +756,7 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
         // Read DBs always run the full digit list: deep read sets hold ~9 copies of every k-mer plus its
         // sequencing-error variants, so every run is ~10-20 records long and walking it is a chain of
         // dependent LDS reads (measured 2.6 -> 5.9 ms).
-        lp.fast_from = (sizeof(V) == 4 && !heads && lp.n > LS_TOP && (lp.n - (int)payload_passes.size()) >= LS_TOP) ? lp.n - LS_TOP : 0;
+        lp.fast_from = (sizeof(V) == 4 && !heads && allow_cmp_finish && lp.n > LS_TOP && (lp.n - (int)payload_passes.size()) >= LS_TOP) ? lp.n - LS_TOP : 0;
         lp.cmp_shift = lp.fast_from > 0 ? rest[lp.fast_from].shift : 0;
         lp.pay_mode = payload_passes.empty() ? 0 : (payload_passes[0].src == RS_SRC_VAL32 ? 1 : 2);
         for (int i = 0; i < lp.n; i++) { lp.shift[i] = rest[i].shift; lp.bits[i] = rest[i].bits; lp.src[i] = rest[i].src; }
