@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Writes the golden vectors tests/golden/case_*.json.
+
+The reference (danielmoney/kmers) ships no tests, fixtures or golden files and cannot be run here (Java, no JVM;
+its prebuilt jar is never executed), so these vectors do NOT come from the reference: they are the outputs of
+the literal restatement oracle/slow_ref.py -- every function of which cites the reference lines it follows -- on
+small seeded inputs, frozen so that neither the restatements nor the GPU path can drift unnoticed.  Parity against
+Kmers.jar itself stays unpinned.  At generation time each case is also checked against the
+independent C restatement (oracle/kmers_oracle.c).
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import slow_ref as R  # noqa: E402
+from oracle.c_oracle import OracleDB  # noqa: E402
+
+CASES = [
+    # name, k, key_len, seed, #genomes, genome length, #reads, read length, fasta alphabet, dust, runofsame, paired headers
+    ("basic_k11", 11, 2, 101, 3, 300, 40, 60, b"ACGT", None, None, False),
+    ("messy_k31", 31, 3, 102, 4, 400, 50, 90, b"ACGTacgtN", None, None, True),
+    ("even_k8_palindromes", 8, 2, 103, 3, 250, 30, 50, b"AACGTT", None, None, False),
+    ("filters_k12", 12, 3, 104, 3, 300, 40, 70, b"AAACGT", 1, 3, False),
+]
+
+
+def make_inputs(seed, ng, glen, nr, rlen, alphabet, paired):
+    rng = np.random.default_rng(seed)
+    al = np.frombuffer(alphabet, np.uint8)
+    genomes = [bytes(rng.choice(al, size=glen).tolist()) for _ in range(ng)]
+    genomes[-1] = genomes[0][:glen // 2] + genomes[-1][glen // 2:]          # shared k-mers between two taxa
+    fa = b"".join(b">%d\n%s\n" % (500 + i, g) for i, g in enumerate(genomes)) + b">77\n\n"   # + an empty sequence
+    recs = []
+    for i in range(nr):
+        g = genomes[int(rng.integers(ng))].upper().replace(b"N", b"A")
+        o = int(rng.integers(0, glen - rlen))
+        s = bytearray(g[o:o + rlen])
+        for j in np.nonzero(rng.random(rlen) < 0.02)[0].tolist():
+            s[j] = int(rng.choice(np.frombuffer(b"ACGTN", np.uint8)))
+        name = b"r%d" % (i - (i & 1) if paired else i)
+        recs.append(b"@%s\n%s\n+\n%s\n" % (name, bytes(s), b"I" * rlen))
+    return fa, b"".join(recs)
+
+
+def main():
+    for name, k, l, seed, ng, glen, nr, rlen, alphabet, dust, run, paired in CASES:
+        fa, fq = make_inputs(seed, ng, glen, nr, rlen, alphabet, paired)
+        ref = R.build_ref_db(fa, k, l, dust=dust, runofsame=run)
+        reads, names = R.build_read_db(fq, k, l, dust=dust, runofsame=run)
+        db = R.DB([ref])
+        lines = R.match_lines(reads, db)
+        counts = R.taxa_counts(db)
+        collected = R.collect_by_read(lines)
+        calls = R.read_classifier(collected)
+        # the independent C restatement must agree before anything is frozen
+        c_ref = OracleDB(fa, 0, k, l, dust=-1 if dust is None else dust, runofsame=-1 if run is None else run)
+        c_reads = OracleDB(fq, 1, k, l, dust=-1 if dust is None else dust, runofsame=-1 if run is None else run)
+        assert c_ref.encode_blocks()[0] == b"".join(ref[key] for key in range(4 ** l)), name
+        assert c_reads.encode_blocks()[0] == b"".join(reads[key] for key in range(4 ** l)) and c_reads.names == names, name
+        hit, _ = c_reads.match(c_ref)
+        assert c_reads.match_lines(c_ref, hit).decode().splitlines() == lines, name
+        out = {
+            "comment": "outputs of oracle/slow_ref.py (restatement of the reference), not of Kmers.jar; see make_golden.py",
+            "k": k, "key_len": l, "dust": dust, "runofsame": run,
+            "fasta": fa.decode(), "fastq": fq.decode(),
+            "ref_blocks": {str(key): ref[key].hex() for key in sorted(ref)},
+            "read_blocks": {str(key): reads[key].hex() for key in sorted(reads)},
+            "read_names": names, "match_lines": lines, "taxa_counts": counts,
+            "collect_by_read": {str(key): collected[key].decode() for key in sorted(collected)},
+            "read_classifier": {str(key): calls[key].decode() for key in sorted(calls)},
+        }
+        path = os.path.join(ROOT, "tests", "golden", "case_%s.json" % name)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=0, sort_keys=True)
+            f.write("\n")
+        print(name, len(lines), "match lines,", os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

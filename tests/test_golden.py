@@ -1,0 +1,88 @@
+"""The frozen vectors of tests/golden/ (written by tests/golden/make_golden.py from oracle/slow_ref.py -- the reference
+has no fixtures of its own and cannot run here, so these pin the restatements and the GPU path to each other, not to
+Kmers.jar).  CPU: both restatements still produce them.  GPU: the C ABI produces them."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "case_*.json")))
+
+
+def _load(path):
+    g = json.load(open(path))
+    g["ref_blocks"] = {int(k): bytes.fromhex(v) for k, v in g["ref_blocks"].items()}
+    g["read_blocks"] = {int(k): bytes.fromhex(v) for k, v in g["read_blocks"].items()}
+    g["collect_by_read"] = {int(k): v.encode() for k, v in g["collect_by_read"].items()}
+    g["read_classifier"] = {int(k): v.encode() for k, v in g["read_classifier"].items()}
+    return g
+
+
+def test_golden_files_exist():
+    assert len(CASES) >= 4
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[5:-5] for p in CASES])
+def test_restatements_reproduce_golden(path):
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    g = _load(path)
+    k, l, dust, run = g["k"], g["key_len"], g["dust"], g["runofsame"]
+    fa, fq = g["fasta"].encode(), g["fastq"].encode()
+    ref = R.build_ref_db(fa, k, l, dust=dust, runofsame=run)
+    reads, names = R.build_read_db(fq, k, l, dust=dust, runofsame=run)
+    assert ref == g["ref_blocks"] and reads == g["read_blocks"] and names == g["read_names"]
+    db = R.DB([ref])
+    lines = R.match_lines(reads, db)
+    assert lines == g["match_lines"] and R.taxa_counts(db) == g["taxa_counts"]
+    collected = R.collect_by_read(lines)
+    assert collected == g["collect_by_read"] and R.read_classifier(collected) == g["read_classifier"]
+    cd, cr = (-1 if dust is None else dust), (-1 if run is None else run)
+    c_ref, c_reads = OracleDB(fa, 0, k, l, dust=cd, runofsame=cr), OracleDB(fq, 1, k, l, dust=cd, runofsame=cr)
+    blob, off = c_ref.encode_blocks()
+    for key in range(4 ** l):
+        assert blob[int(off[key]):int(off[key + 1])] == g["ref_blocks"][key]
+    blob, off = c_reads.encode_blocks()
+    for key in range(4 ** l):
+        assert blob[int(off[key]):int(off[key + 1])] == g["read_blocks"][key]
+    assert c_reads.names == g["read_names"]
+    hit, _ = c_reads.match(c_ref)
+    assert c_reads.match_lines(c_ref, hit).decode().splitlines() == g["match_lines"]
+    t, m, q = c_ref.taxacounts()
+    assert ["%d\t%d\t%d" % x for x in zip(t, m, q)] == g["taxa_counts"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[5:-5] for p in CASES])
+def test_gpu_reproduces_golden(path):
+    import kmers_amd as km
+    g = _load(path)
+    k, l, dust, run = g["k"], g["key_len"], g["dust"], g["runofsame"]
+    ctx = km.Context(0)
+    ref = km.make_reference_db(ctx, g["fasta"].encode(), k, l, dust=dust, runofsame=run)
+    reads, names = km.make_read_db(ctx, g["fastq"].encode(), k, l, dust=dust, runofsame=run)
+    for db, want in ((ref, g["ref_blocks"]), (reads, g["read_blocks"])):
+        blob, off = db.encode_blocks()
+        assert db.meta() == want[-1]
+        for key in range(4 ** l):
+            assert blob[int(off[key]):int(off[key + 1])] == want[key], key
+    assert names == g["read_names"]
+    hit, nh = km.DB([ref]).get_nearest_kmers(reads)
+    assert km.match_lines(reads, ref, hit) == g["match_lines"] and nh == len(g["match_lines"])
+    assert km.taxa_count_lines(ref) == g["taxa_counts"]
+    assert km.collect_by_read_blocks(reads, ref) == g["collect_by_read"]
+    call = km.classify_reads(reads, ref, len(names))
+    want_calls = {}
+    for key, text in g["collect_by_read"].items():
+        rs = []
+        for line in text.decode().split("\n"):
+            r = int(line.split(":", 1)[0])
+            if not rs or rs[-1] != r:
+                rs.append(r)
+        want_calls[key] = "".join("%d\t%d\n" % (r, int(call[r])) for r in rs if call[r] >= 0).encode()
+    assert want_calls == g["read_classifier"]
+    for d in (ref, reads):
+        d.close()
+    ctx.close()
