@@ -535,6 +535,35 @@ def test_cfg1_scale_properties(ctx):
     t, m, q = km.taxa_counts(ref)
     ot, om, oq = want.taxacounts()
     assert np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
+    # per-read aggregation at full size, against numpy on the oracle's arrays: the transposed join ...
+    read, pos, idx = km.collect_by_read(rdb, ref)
+    sv = o_reads.val_off.astype(np.int64)
+    per_kmer = np.where(o_hit >= 0, sv[1:] - sv[:-1], 0)
+    assert len(read) == int(per_kmer.sum())
+    okey = np.repeat(np.arange(len(o_hit)), sv[1:] - sv[:-1])                      # search k-mer of every occurrence
+    keep = o_hit[okey] >= 0
+    want_rp = o_reads.val_a.astype(np.int64)[keep] * 65536 + o_reads.val_b.astype(np.int64)[keep]
+    order = np.argsort(want_rp, kind="stable")
+    assert np.array_equal(read.astype(np.int64) * 65536 + pos, want_rp[order])
+    assert np.array_equal(idx, o_hit[okey][keep][order])
+    # ... and the classifier: every taxon set here is a singleton or a pair, so processRead in numpy is short
+    rv = want.val_off.astype(np.int64)
+    nt = (rv[1:] - rv[:-1])[idx]
+    first = want.val_a[rv[idx]]
+    single = nt == 1
+    mn = np.full(nreads, np.iinfo(np.int32).max, np.int64)
+    mx = np.full(nreads, np.iinfo(np.int32).min, np.int64)
+    np.minimum.at(mn, read[single], first[single])
+    np.maximum.at(mx, read[single], first[single])
+    cand = np.where(mn == mx, mn, -1)
+    assert int(nt.max()) <= 2
+    second = want.val_a[np.minimum(rv[idx] + 1, len(want.val_a) - 1)]
+    has = (first == cand[read]) | ((nt == 2) & (second == cand[read]))
+    bad = np.zeros(nreads, bool)
+    bad[read[~has]] = True
+    want_call = np.where((cand >= 0) & ~bad, cand, -1)
+    call = km.classify_reads(rdb, ref, nreads)
+    assert np.array_equal(call, want_call) and (call >= 0).sum() > 0.9 * nreads
     ref.close()
     rdb.close()
 
