@@ -739,11 +739,199 @@ int taxa_counts(int argc, char **argv) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- per-read tools
+// new IndexedOutputFile<>(f, new IntCompressor(), true, 5): human-readable flavour, zip level 5, one block per key
+// ascending, no meta block (CollectByRead.java:66-67,116-119; ReadClassifier.java:52-53,157-160)
+void write_text_blocks(const std::string &path, const std::vector<std::pair<int, std::string>> &blocks) {
+    std::vector<std::string> blobs(blocks.size());
+    parallel_for(blocks.size(), [&](size_t i) {
+        blobs[i] = gzip_member((const uint8_t *)blocks[i].second.data(), blocks[i].second.size(), 5);
+    });
+    IndexedOutputFile out(path, 5, true);
+    for (size_t i = 0; i < blocks.size(); i++) out.add_block(blocks[i].first, blobs[i]);
+    out.close();
+}
+
+// the two databases a list of (k-mer | line, occurrences, taxa) rows stands for
+struct JoinRows {
+    std::vector<uint64_t> keys, s_off{0}, r_off{0};
+    std::vector<int32_t> s_read, s_pos, r_tax, r_cnt;
+    void load(Gpu &g, int k, int key_len, kmg_db **search, kmg_db **ref) {
+        g.check(kmg_db_load(g.ctx, k, key_len, 0, KMG_PAYLOAD_READPOS, keys.data(), keys.size(), s_off.data(), s_read.data(),
+                            s_pos.data(), search));
+        g.check(kmg_db_load(g.ctx, k, key_len, 1, KMG_PAYLOAD_TAXON, keys.data(), keys.size(), r_off.data(), r_tax.data(),
+                            r_cnt.data(), ref));
+    }
+};
+
+// TxC|TxC... up to `end` (CountDataType.fromString, separators "x" and "|")
+void parse_counts(const char *q, const char *end, JoinRows &j) {
+    while (q < end) {
+        char *e;
+        const long t = strtol(q, &e, 10);
+        if (e >= end || *e != 'x') throw std::runtime_error("bad taxon count list");
+        const long c = strtol(e + 1, &e, 10);
+        j.r_tax.push_back((int32_t)t);
+        j.r_cnt.push_back((int32_t)std::min<long>(c, 0x7FFFFFFF));
+        q = (e < end && *e == '|') ? e + 1 : end;
+    }
+    j.r_off.push_back(j.r_tax.size());
+}
+
+// Utils.CollectByRead -i <Matcher output> -o <file> (CollectByRead.java:28-90): the match lines are loaded back as
+// a read database and a reference database over the same k-mers (every k-mer hits itself) and transposed on the GPU.
+int collect_by_read(int argc, char **argv) {
+    const Args a = parse_args(argc, argv, 2, "iof", "");
+    if (!a.has('i') || !a.has('o')) throw std::runtime_error("-i and -o are required");
+    const std::string text = read_input(a.get('i'));
+    JoinRows j;
+    int k = -1;
+    size_t p0 = 0;
+    while (p0 < text.size()) {
+        size_t e = text.find('\n', p0);
+        if (e == std::string::npos) e = text.size();
+        if (e > p0) {
+            const char *line = text.data() + p0, *lend = text.data() + e;
+            const char *t1 = (const char *)memchr(line, '\t', lend - line);
+            const char *t2 = t1 ? (const char *)memchr(t1 + 1, '\t', lend - t1 - 1) : nullptr;
+            if (!t2) throw std::runtime_error("bad match line");
+            if (k < 0) k = (int)(t1 - line);
+            if ((int)(t1 - line) != k || k < 1 || k > 32) throw Unsupported("k-mers of different lengths or longer than 32");
+            uint64_t v = 0;
+            for (const char *c = line; c < t1; c++) {
+                int b;
+                switch (*c) { case 'A': b = 0; break; case 'C': b = 1; break; case 'T': b = 2; break; case 'G': b = 3; break;
+                              default: throw std::runtime_error("bad k-mer in match line"); }
+                v = (v << 2) | (uint64_t)b;
+            }
+            j.keys.push_back(k == 32 ? v : v << (64 - 2 * k));
+            for (const char *q = t1 + 1; q < t2;) {                       // r:p|r:p
+                char *en;
+                const long r = strtol(q, &en, 10);
+                if (*en != ':') throw std::runtime_error("bad read position list");
+                const long ps = strtol(en + 1, &en, 10);
+                j.s_read.push_back((int32_t)r);
+                j.s_pos.push_back((int32_t)ps);
+                q = (*en == '|') ? en + 1 : t2;
+            }
+            j.s_off.push_back(j.s_read.size());
+            // exact matches only: one entry, diff "-"
+            if (t2 + 2 >= lend || t2[1] != '-' || t2[2] != '|' || memchr(t2 + 1, ' ', lend - t2 - 1))
+                throw Unsupported("inexact matches stay on the Java path");
+            parse_counts(t2 + 3, lend, j);
+        }
+        p0 = e + 1;
+    }
+    std::vector<std::pair<int, std::string>> blocks;
+    if (!j.keys.empty()) {
+        Gpu g;
+        kmg_db *search = nullptr, *ref = nullptr;
+        j.load(g, k, std::min(k, 6), &search, &ref);
+        const uint64_t cap = std::max<uint64_t>(j.s_read.size(), 1);
+        std::vector<int32_t> read(cap), pos(cap);
+        std::vector<int64_t> idx(cap);
+        uint64_t n = 0;
+        g.check(kmg_collect_by_read(g.ctx, search, ref, &n, read.data(), pos.data(), idx.data()));
+        kmg_db_free(search);
+        kmg_db_free(ref);
+        // block bounds: (read / 1000) * 1000; of two records with one (read, pos) the first is kept (TreeSet.add)
+        std::vector<uint64_t> starts;
+        for (uint64_t i = 0; i < n; i++)
+            if (i == 0 || read[i] / 1000 != read[i - 1] / 1000) starts.push_back(i);
+        starts.push_back(n);
+        blocks.resize(starts.size() - 1);
+        parallel_for(blocks.size(), [&](size_t b) {
+            std::string out;
+            char buf[64];
+            for (uint64_t i = starts[b]; i < starts[b + 1]; i++) {
+                if (i > starts[b] && read[i] == read[i - 1] && pos[i] == pos[i - 1]) continue;
+                if (!out.empty()) out += '\n';
+                out.append(buf, snprintf(buf, sizeof buf, "%d:%d\t0:", read[i], pos[i]));
+                for (uint64_t t = j.r_off[idx[i]]; t < j.r_off[idx[i] + 1]; t++) {
+                    if (t > j.r_off[idx[i]]) out += '|';
+                    out.append(buf, snprintf(buf, sizeof buf, "%dx%d", j.r_tax[t], std::min(j.r_cnt[t], 255)));
+                }
+            }
+            blocks[b] = {(read[starts[b]] / 1000) * 1000, std::move(out)};
+        });
+    }
+    write_text_blocks(a.get('o'), blocks);
+    return 0;
+}
+
+// Utils.ReadClassifier -i <CollectByRead output> -o <file> (ReadClassifier.java:28-78): every line becomes one
+// pseudo k-mer (its line number as a 32-mer) of a read database holding the line's (read, pos) and of a reference
+// database holding its dist-0 taxa; kmg_classify_reads then does processRead for all reads at once.
+int read_classifier(int argc, char **argv) {
+    const Args a = parse_args(argc, argv, 2, "iot", "");
+    if (!a.has('i') || !a.has('o')) throw std::runtime_error("-i and -o are required");
+    g_threads = std::max(1, a.geti('t', g_threads));
+    IndexedInputFile in(a.get('i'));
+    JoinRows j;
+    std::vector<std::pair<int, std::vector<int32_t>>> block_reads;
+    int32_t max_read = -1;
+    for (auto &kv : in.index) {
+        const std::string text = in.read_key(kv.first);
+        block_reads.push_back({kv.first, {}});
+        auto &reads = block_reads.back().second;
+        size_t p0 = 0;
+        while (p0 < text.size()) {
+            size_t e = text.find('\n', p0);
+            if (e == std::string::npos) e = text.size();
+            if (e > p0) {
+                const char *line = text.data() + p0, *lend = text.data() + e;
+                char *en;
+                const long r = strtol(line, &en, 10);
+                if (*en != ':') throw std::runtime_error("bad CollectByRead line");
+                const long ps = strtol(en + 1, &en, 10);
+                if (*en != '\t') throw std::runtime_error("bad CollectByRead line");
+                if (reads.empty() || reads.back() != (int32_t)r) reads.push_back((int32_t)r);
+                for (const char *q = en + 1; q < lend;) {                  // dist:TxC|TxC entries joined by " "
+                    const char *sp = (const char *)memchr(q, ' ', lend - q);
+                    const char *ee = sp ? sp : lend;
+                    char *c;
+                    const long dist = strtol(q, &c, 10);
+                    if (*c != ':') throw std::runtime_error("bad CollectByRead line");
+                    if (dist == 0) {                                        // ReadClassifier.java:109,125
+                        j.keys.push_back(j.keys.size());
+                        j.s_read.push_back((int32_t)r);
+                        j.s_pos.push_back((int32_t)ps);
+                        j.s_off.push_back(j.s_read.size());
+                        parse_counts(c + 1, ee, j);
+                        max_read = std::max(max_read, (int32_t)r);
+                    }
+                    q = sp ? sp + 1 : lend;
+                }
+            }
+            p0 = e + 1;
+        }
+    }
+    std::vector<int32_t> call((size_t)std::max<int32_t>(max_read + 1, 1), -1);
+    if (!j.keys.empty()) {
+        Gpu g;
+        kmg_db *search = nullptr, *ref = nullptr;
+        j.load(g, 32, 6, &search, &ref);
+        g.check(kmg_classify_reads(g.ctx, search, ref, (uint64_t)max_read + 1, call.data()));
+        kmg_db_free(search);
+        kmg_db_free(ref);
+    }
+    std::vector<std::pair<int, std::string>> blocks;
+    for (auto &br : block_reads) {
+        std::string out;
+        char buf[48];
+        for (int32_t r : br.second)
+            if (r >= 0 && r <= max_read && call[r] >= 0) out.append(buf, snprintf(buf, sizeof buf, "%d\t%d\n", r, call[r]));
+        blocks.push_back({br.first, std::move(out)});
+    }
+    write_text_blocks(a.get('o'), blocks);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: kmg Database.MakeDatabase|Database.Matcher|Utils.TaxaCounts <options>\n");
+        fprintf(stderr, "usage: kmg Database.MakeDatabase|Database.Matcher|Utils.TaxaCounts|Utils.CollectByRead|Utils.ReadClassifier <options>\n");
         return 1;
     }
     std::string prog = argv[1];
@@ -753,6 +941,8 @@ int main(int argc, char **argv) {
         if (prog == "MakeDatabase") return make_database(argc, argv);
         if (prog == "Matcher") return matcher(argc, argv);
         if (prog == "TaxaCounts") return taxa_counts(argc, argv);
+        if (prog == "CollectByRead") return collect_by_read(argc, argv);
+        if (prog == "ReadClassifier") return read_classifier(argc, argv);
         fprintf(stderr, "unknown program %s\n", argv[1]);
         return 1;
     } catch (const Unsupported &e) {

@@ -129,6 +129,18 @@ def test_native_cli_matches_python_drivers(tmp_path):
     run("Utils.TaxaCounts", "-d", p("refz.db"), "-o", p("c.tsv"))
     t, m, q = o_ref.taxacounts()
     assert open(p("c.tsv")).read().splitlines() == ["%d\t%d\t%d" % x for x in zip(t, m, q)]
+    # per-read tools downstream of the match, native: same blocks as the restated CollectByRead / ReadClassifier
+    want_cb = R.collect_by_read(want.decode().splitlines())
+    run("Utils.CollectByRead", "-i", p("m.gz"), "-o", p("by_read"))
+    assert R.read_indexed_file(p("by_read")) == want_cb and len(want_cb) == 2
+    run("Utils.ReadClassifier", "-i", p("by_read"), "-o", p("calls"))
+    want_calls = R.read_classifier(want_cb)
+    assert R.read_indexed_file(p("calls")) == want_calls and sum(len(v) for v in want_calls.values()) > 500
+    open(p("empty.txt"), "wb").close()
+    run("Utils.CollectByRead", "-i", p("empty.txt"), "-o", p("by_read.empty"))
+    assert R.read_indexed_file(p("by_read.empty")) == {}
+    run("Utils.ReadClassifier", "-i", p("by_read.empty"), "-o", p("calls.empty"))
+    assert R.read_indexed_file(p("calls.empty")) == {}
     # -D / -R filters reach the kernel
     run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("f.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z", "-D", "2", "-R", "5")
     o_f = OracleDB(synth.fasta_bytes(taxa, genomes), 0, k, l, dust=2, runofsame=5)

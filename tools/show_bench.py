@@ -1,4 +1,6 @@
-import json, sys
+import json
+import signal
+signal.signal(signal.SIGPIPE, signal.SIG_DFL)   # `| head` is fine, sys
 for l in open(sys.argv[1]):
     i = l.find('{"metric')
     if i >= 0:
