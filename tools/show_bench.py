@@ -1,6 +1,8 @@
 import json
 import signal
-signal.signal(signal.SIGPIPE, signal.SIG_DFL)   # `| head` is fine, sys
+import sys
+
+signal.signal(signal.SIGPIPE, signal.SIG_DFL)   # `| head` is fine
 for l in open(sys.argv[1]):
     i = l.find('{"metric')
     if i >= 0:
