@@ -57,6 +57,35 @@ def allreduce_sum(array, device="cpu", group=None):
     return t.cpu().numpy()
 
 
+def taxa_counts_sharded(taxon, match, unique, device="cpu", group=None):
+    """TaxaCounts over a key-range-sharded reference: every rank counts its own shard
+    (kmg_taxacounts: ascending taxa with their match / unique counts); a k-mer lives in exactly one shard, so
+    the whole database's counts are the per-taxon sums.  The taxon lists differ between ranks, so the triples
+    are all-gathered (padded to the longest list) and summed by taxon on every rank.
+    -> (taxon[], match[], unique[]) ascending by taxon, identical on all ranks."""
+    taxon = np.asarray(taxon, np.int64)
+    rows = np.stack([taxon, np.asarray(match, np.int64), np.asarray(unique, np.int64)], axis=1) if len(taxon) else np.zeros((0, 3), np.int64)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        n = torch.tensor([len(rows)], dtype=torch.int64, device=device)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n, group=group)
+        sizes = [int(x.item()) for x in sizes]
+        width = max(max(sizes), 1)
+        mine = torch.zeros((width, 3), dtype=torch.int64, device=device)
+        if len(rows):
+            mine[:len(rows)] = torch.from_numpy(rows).to(device)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        rows = np.concatenate([p.cpu().numpy()[:sz] for p, sz in zip(parts, sizes)]) if sum(sizes) else np.zeros((0, 3), np.int64)
+    if len(rows) == 0:
+        return np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.int64)
+    t, inv = np.unique(rows[:, 0], return_inverse=True)
+    m = np.bincount(inv, weights=rows[:, 1], minlength=len(t)).astype(np.int64)
+    q = np.bincount(inv, weights=rows[:, 2], minlength=len(t)).astype(np.int64)
+    return t.astype(np.int32), m, q
+
+
 def balanced_key_ranges(bucket_hist, world):
     """Split the 4^l key buckets into `world` contiguous ranges of near-equal record counts (skew-aware:
     poly-A piles into bucket 0).  -> list of (first_key, end_key).  Every rank computes the same answer

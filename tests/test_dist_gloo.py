@@ -129,7 +129,15 @@ def _exchange_worker(rank, world, port, fastas, fq, k, key_len, out):
         return np.where(ok, i, -1)
 
     owner, hit = kd.match_by_key_range(mine, ranges, key_len, local_match)
-    out.put((rank, ranges, shard, lo, owner, hit))
+    # TaxaCounts of the shard (what kmg_taxacounts returns for it), then the cross-rank sum
+    n_tax = np.diff(shard["val_off"].astype(np.int64))
+    st, sm = np.unique(shard["val_a"], return_counts=True)
+    su = np.zeros(len(st), np.int64)
+    single = shard["val_a"][shard["val_off"].astype(np.int64)[:-1][n_tax == 1]]
+    ut, uc = np.unique(single, return_counts=True)
+    su[np.searchsorted(st, ut)] = uc
+    counts = kd.taxa_counts_sharded(st, sm, su)
+    out.put((rank, ranges, shard, lo, owner, hit, counts))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -177,3 +185,8 @@ def test_key_range_exchange_build_and_match():
         lo, owner, hit = got[g][3], got[g][4], got[g][5]
         glob[lo:lo + len(hit)] = np.where(hit >= 0, hit + np.array(starts)[owner], -1)
     assert np.array_equal(glob, o_hit) and o_nh > 0
+    t, m, q = whole.taxacounts()
+    for g in range(world):                                         # every rank ends up with the whole database's counts
+        gt, gm, gq = got[g][6]
+        assert np.array_equal(gt, t) and np.array_equal(gm, m) and np.array_equal(gq, q)
+    assert (np.asarray(q) < np.asarray(m)).any()
