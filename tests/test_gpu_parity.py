@@ -776,3 +776,77 @@ def test_collect_by_read_skew_and_empty(ctx):
     assert np.all(km.classify_reads(stranger, ref, 50) == -1)
     for d in (ref, rdb, stranger):
         d.close()
+
+
+# ---------------------------------------------------------------------------- BASELINE configs 3 and 5, scaled down
+def test_cfg3_flavour_many_taxa(ctx):
+    """Config 3 in small: 3000 taxa x 2 kbp, 20 % of each genome copied from its sibling (multi-taxon k-mers,
+    unique < match), more taxa than the LDS histogram of TaxaCounts holds; reads in several batches; the whole chain
+    (both databases, match, TaxaCounts, per-read calls) against the C oracle."""
+    import kmers_amd as km
+    from kmers_amd import parse, synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(3, 3000, 2000, first_taxon=5, shared_frac=0.2)
+    reads = synth.random_reads(4, genomes, 30000, 150, 0.01)
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    k, l = 31, 6
+    ref = km.make_reference_db(ctx, fa, k, l)
+    o_ref = OracleDB(fa, 0, k, l, threads=8)
+    _same_db(ref, o_ref)
+    b = parse.parse(fq, parse.FASTQ, k).batch
+    fc = km.FileCreator(ctx, l, k, "read", rc=False)
+    for lo, hi in ((0, 12000), (12000, 12001), (12001, 30000)):                       # streamed in chunks
+        a0, a1 = int(b.seq_off[lo]), int(b.seq_off[hi])
+        fc.add_kmers(km.SequenceBatch(b.bases[a0:a1], b.seq_off[lo:hi + 1] - b.seq_off[lo], seq_tok=b.seq_tok[lo:hi]))
+    rdb = fc.create()
+    o_reads = OracleDB(fq, 1, k, l, threads=8)
+    _same_db(rdb, o_reads)
+    hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
+    o_hit, o_nh = o_reads.match(o_ref)
+    assert nh == o_nh and np.array_equal(hit, o_hit)
+    t, m, q = km.taxa_counts(ref)
+    ot, om, oq = o_ref.taxacounts()
+    assert len(t) == 3000 and np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
+    assert (q < m).sum() > 2000                                                        # shared k-mers everywhere
+    call = km.classify_reads(rdb, ref, reads.shape[0])
+    assert (call >= 0).sum() > 0.5 * reads.shape[0] and (call < 0).sum() > 0
+    ref.close()
+    rdb.close()
+
+
+@pytest.mark.parametrize("k", [21, 25, 31])
+def test_cfg5_flavour_long_noisy_reads(ctx, k):
+    """Config 5 in small: 10 kbp reads with 15 % substitutions and 0.5 % N, genome sizes spread over two orders of
+    magnitude, 5 % of the bases in homopolymer / dinucleotide tracts (bucket skew), k in {21, 25, 31}."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(700 + k)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    sizes = [10_000, 14_000, 25_000, 60_000, 150_000, 400_000]                          # Zipf-like spread
+    genomes = []
+    for n in sizes:
+        g = acgt[rng.integers(0, 4, size=n)]
+        for _ in range(max(1, n // 4000)):                                             # low-complexity tracts, ~5 %
+            s, ln = int(rng.integers(0, n - 250)), int(rng.integers(100, 250))
+            if rng.random() < 0.5:
+                g[s:s + ln] = acgt[int(rng.integers(0, 4))]
+            else:
+                g[s:s + ln:2], g[s + 1:s + ln:2] = acgt[int(rng.integers(0, 4))], acgt[int(rng.integers(0, 4))]
+        genomes.append(g)
+    taxa = list(range(9000, 9000 + len(sizes)))
+    reads = synth.random_reads(701 + k, genomes, 300, 10_000, 0.15, n_rate=0.005)
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    ref = km.make_reference_db(ctx, fa, k, 6)
+    o_ref = OracleDB(fa, 0, k, 6, threads=8)
+    _same_db(ref, o_ref)
+    rdb, names = km.make_read_db(ctx, fq, k, 6)
+    o_reads = OracleDB(fq, 1, k, 6, threads=8)
+    _same_db(rdb, o_reads)
+    assert names == o_reads.names
+    assert ctx.lib.kmg_db_payload_bits(rdb.h) == 32                                    # 14 position bits + 9 read bits
+    hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
+    o_hit, o_nh = o_reads.match(o_ref)
+    assert nh == o_nh and np.array_equal(hit, o_hit)
+    ref.close()
+    rdb.close()
