@@ -16,11 +16,11 @@ def main(argv=None):
     if prog == "MakeDatabase":
         for f in "ioKklzrDR":
             ap.add_argument("-" + f)
-        for f in "aqZvh":
+        for f in "aqpZvh":
             ap.add_argument("-" + f, action="store_true")
         a = ap.parse_args(rest)
         ctx = Context(0)
-        programs.make_database(ctx, a.i, a.o, "a" if a.a else "q", int(a.K or 32), int(a.k or 24), int(a.l or 6),
+        programs.make_database(ctx, a.i, a.o, "a" if a.a else ("p" if a.p else "q"), int(a.K or 32), int(a.k or 24), int(a.l or 6),
                                None if a.Z else int(a.z or 5), a.r, None if a.D is None else int(a.D),
                                None if a.R is None else int(a.R), hr=a.h)
     elif prog == "Matcher":

@@ -116,14 +116,23 @@ class IndexedInputFile:
         lines = self._block(fpos, flen).decode().split("\n")
         ipos, ilen = int(lines[0].strip()), int(lines[1].strip())
         self.hr = lines[3].strip() == "1"
+        # key codec by its id string: "1" IntCompressor, "2" StringCompressor ([short length][bytes]; the
+        # preprocessed input of MakeDatabase -p)
+        self.string_keys = lines[2].strip() == "2"
         raw = self._block(ipos, ilen)
         self.index = {}
         if not self.hr:
             (n,) = struct.unpack_from(">i", raw, 0)
             off = 4
             for _ in range(n):
-                key, nb = struct.unpack_from(">ii", raw, off)
-                off += 8
+                if self.string_keys:
+                    (kl,) = struct.unpack_from(">h", raw, off)
+                    key = raw[off + 2:off + 2 + kl].decode()
+                    (nb,) = struct.unpack_from(">i", raw, off + 2 + kl)
+                    off += 2 + kl + 4
+                else:
+                    key, nb = struct.unpack_from(">ii", raw, off)
+                    off += 8
                 blocks = []
                 for _ in range(nb):
                     blocks.append(struct.unpack_from(">qq", raw, off))
@@ -132,7 +141,7 @@ class IndexedInputFile:
         else:
             for line in raw.decode().splitlines():
                 key, rest = line.split("\t")
-                self.index[int(key)] = [tuple(int(x) for x in b.split(":")) for b in rest.split()]
+                self.index[key if self.string_keys else int(key)] = [tuple(int(x) for x in b.split(":")) for b in rest.split()]
 
     def _block(self, pos, length):
         blob = self.data[pos:pos + length]

@@ -224,7 +224,9 @@ struct IndexedOutputFile {
 struct IndexedInputFile {
     std::string data;
     bool zipped, hr;
+    bool string_keys = false;      // key codec "2" = jar StringCompressor ([short length][bytes]): MakeDatabase -p input
     std::map<int, std::vector<std::pair<uint64_t, uint64_t>>> index;
+    std::map<std::string, std::vector<std::pair<uint64_t, uint64_t>>> sindex;
 
     std::string block(uint64_t p, uint64_t len) const {
         if (p > data.size()) throw std::runtime_error("block outside the file");
@@ -242,6 +244,7 @@ struct IndexedInputFile {
         char cid[32];
         if (sscanf(foot.c_str(), "%llu %llu %31s %d", &ipos, &ilen, cid, &hrflag) != 4) throw std::runtime_error("bad container footer: " + path);
         hr = hrflag == 1;
+        string_keys = strcmp(cid, "2") == 0;
         const std::string raw = block(ipos, ilen);
         if (hr) {         // text index: key \t pos:len pos:len
             size_t p0 = 0;
@@ -252,7 +255,7 @@ struct IndexedInputFile {
                 p0 = e + 1;
                 const size_t tab = line.find('\t');
                 if (tab == std::string::npos) continue;
-                auto &v = index[atoi(line.c_str())];
+                auto &v = string_keys ? sindex[line.substr(0, tab)] : index[atoi(line.c_str())];
                 const char *q = line.c_str() + tab + 1;
                 while (*q) {
                     char *end;
@@ -271,11 +274,22 @@ struct IndexedInputFile {
         const uint32_t n = get_be32(p);
         size_t off = 4;
         for (uint32_t i = 0; i < n; i++) {
-            if (off + 8 > raw.size()) throw std::runtime_error("bad index block");
-            const int key = (int)get_be32(p + off);
-            const uint32_t nb = get_be32(p + off + 4);
-            off += 8;
-            auto &v = index[key];
+            std::vector<std::pair<uint64_t, uint64_t>> *vp;
+            uint32_t nb;
+            if (string_keys) {
+                if (off + 2 > raw.size()) throw std::runtime_error("bad index block");
+                const size_t kl = ((size_t)p[off] << 8) | p[off + 1];
+                if (off + 2 + kl + 4 > raw.size()) throw std::runtime_error("bad index block");
+                vp = &sindex[std::string((const char *)p + off + 2, kl)];
+                nb = get_be32(p + off + 2 + kl);
+                off += 2 + kl + 4;
+            } else {
+                if (off + 8 > raw.size()) throw std::runtime_error("bad index block");
+                vp = &index[(int)get_be32(p + off)];
+                nb = get_be32(p + off + 4);
+                off += 8;
+            }
+            auto &v = *vp;
             for (uint32_t b = 0; b < nb; b++) {
                 if (off + 16 > raw.size()) throw std::runtime_error("bad index block");
                 v.push_back({get_be64(p + off), get_be64(p + off + 8)});
@@ -571,15 +585,76 @@ struct StageClock {
     }
 };
 
+// MakeDatabase -p (MakeDatabase.java:186-237,320-420): the input is the IndexedFile OtherFiles.SeqToTaxID writes --
+// String keys, blocks of (taxid, Sequence) records, binary [int taxid][int length][2 bits per base] or
+// human-readable lines `taxid ~ SEQUENCE` -- and every window of every sequence goes into one reference database.
+int make_database_preprocessed(const Args &a, int k, int key_len, int level) {
+    StageClock clk(a.has('v'));
+    IndexedInputFile in(a.get('i'));
+    if (!in.string_keys) throw std::runtime_error("not a preprocessed file (its keys are not strings): " + a.get('i'));
+    std::string bases;
+    std::vector<uint64_t> off{0};
+    std::vector<int32_t> ids;
+    static const char LET[4] = {'A', 'C', 'T', 'G'};
+    for (auto &kv : in.sindex) {
+        std::string data;
+        for (auto &b : kv.second) data += in.block(b.first, b.second);
+        if (in.hr) {
+            size_t p0 = 0;
+            while (p0 < data.size()) {
+                size_t e = data.find('\n', p0);
+                if (e == std::string::npos) e = data.size();
+                const size_t sep = data.find(" ~ ", p0);
+                if (e > p0) {
+                    if (sep == std::string::npos || sep >= e) throw std::runtime_error("bad preprocessed line");
+                    ids.push_back((int32_t)strtol(data.c_str() + p0, nullptr, 10));
+                    bases.append(data, sep + 3, e - sep - 3);
+                    off.push_back(bases.size());
+                }
+                p0 = e + 1;
+            }
+        } else {
+            const uint8_t *p = (const uint8_t *)data.data();
+            size_t o = 0;
+            while (o + 8 <= data.size()) {
+                const int32_t t = (int32_t)get_be32(p + o);
+                const uint32_t n = get_be32(p + o + 4);
+                const size_t nb = n ? (n - 1) / 4 + 1 : 0;
+                if (o + 8 + nb > data.size()) throw std::runtime_error("truncated preprocessed record");
+                for (uint32_t i = 0; i < n; i++) bases.push_back(LET[(p[o + 8 + i / 4] >> (6 - 2 * (i & 3))) & 3]);
+                ids.push_back(t);
+                off.push_back(bases.size());
+                o += 8 + nb;
+            }
+        }
+    }
+    clk.lap("read + unpack input");
+    Gpu g;
+    g.check(kmg_build_begin(g.ctx, k, key_len, 1, KMG_PAYLOAD_TAXON));
+    if (a.has('D') || a.has('R')) g.check(kmg_build_set_filters(g.ctx, a.geti('D', -1), a.geti('R', -1)));
+    if (!ids.empty())
+        g.check(kmg_build_add(g.ctx, (const uint8_t *)bases.data(), bases.size(), off.data(), ids.data(), nullptr, ids.size(), nullptr));
+    kmg_db *db = nullptr;
+    uint64_t nwin = 0;
+    g.check(kmg_build_finish(g.ctx, &db, &nwin));
+    clk.lap("copy in + build (GPU)");
+    write_database(g, db, a.get('o'), level, a.has('S') ? size_from_human(a.get('S')) : 0, a.has('h'));
+    clk.lap("encode + deflate + write");
+    kmg_db_free(db);
+    return 0;
+}
+
 int make_database(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmN", "aqZvh");
+    const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmN", "aqpZvh");
     for (char c : std::string("mN")) if (a.has(c)) throw Unsupported(std::string("option -") + c + " is not on the GPU path");
     const int k = a.geti('K', 32), min_k = a.geti('k', 24), key_len = a.geti('l', 6);     // MakeDatabase.java:106-109
     const int level = a.has('Z') ? -1 : a.geti('z', 5);
     g_threads = std::max(1, a.geti('t', g_threads));
     if (min_k != k) throw Unsupported("minK != maxK is not supported on the GPU path");
-    if (a.has('a') == a.has('q')) throw std::runtime_error("exactly one of -a (FASTA reference) / -q (FASTQ reads) is required");
+    if ((int)a.has('a') + (int)a.has('q') + (int)a.has('p') != 1)
+        throw std::runtime_error("exactly one of -a (FASTA reference) / -q (FASTQ reads) / -p (preprocessed) is required");
     if (!a.has('i') || !a.has('o')) throw std::runtime_error("-i and -o are required");
+    if (a.has('p')) return make_database_preprocessed(a, k, key_len, level);
     const bool reads = a.has('q');
     if (reads && !a.has('r')) throw std::runtime_error("-r <read map file> is required with -q");   // MakeDatabase.java:172-173
     StageClock clk(a.has('v'));

@@ -128,12 +128,54 @@ def open_database(ctx, path) -> KmerDatabase:
     return KmerDatabase.load(ctx, max_k, key_len, rc, kind, keys, val_off, val_a, val_b)
 
 
+_UNPACK = np.array([[65, 67, 84, 71][(b >> s) & 3] for b in range(256) for s in (6, 4, 2, 0)], np.uint8).reshape(256, 4)
+
+
+def read_preprocessed(path):
+    """The input of MakeDatabase -p (written by OtherFiles.SeqToTaxID): an IndexedFile keyed by String whose blocks
+    hold (taxid, Sequence) records -- binary [int taxid][int length][2 bits per base] (IntCompressor +
+    SequenceDataType.java:21-34) or human-readable lines `taxid ~ SEQUENCE`.  -> SequenceBatch of every record
+    (MakeDatabase.java:192-237 hands every index to the same FileCreator)."""
+    from .api import SequenceBatch
+    f = container.IndexedInputFile(path)
+    parts, ids, lens = [], [], []
+    for key in sorted(f.index):
+        data = f.read_key(key)
+        if f.hr:
+            for line in data.decode().splitlines():
+                t, s = line.split(" ~ ", 1)
+                ids.append(int(t))
+                lens.append(len(s))
+                parts.append(np.frombuffer(s.encode(), np.uint8))
+        else:
+            off = 0
+            while off < len(data):
+                t, n = struct.unpack_from(">ii", data, off)
+                nb = (n - 1) // 4 + 1
+                packed = np.frombuffer(data, np.uint8, nb, off + 8)
+                parts.append(_UNPACK[packed].reshape(-1)[:n])
+                ids.append(t)
+                lens.append(n)
+                off += 8 + nb
+    bases = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    seq_off = np.concatenate([[0], np.cumsum(np.array(lens, np.uint64))]).astype(np.uint64)
+    return SequenceBatch(bases, seq_off, seq_id=np.array(ids, np.int32))
+
+
 def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length=6, zip_level=5, read_map_path=None,
                   dust=None, runofsame=None, hr=False):
-    """MakeDatabase -a (mode 'a') / -q (mode 'q').  Defaults as the reference's (-K 32 -k 24 -l 6 -z 5,
-    MakeDatabase.java:106-109); minK != maxK is refused (GPU path limit)."""
+    """MakeDatabase -a (mode 'a') / -q (mode 'q') / -p (mode 'p', preprocessed input).  Defaults as the reference's
+    (-K 32 -k 24 -l 6 -z 5, MakeDatabase.java:106-109); minK != maxK is refused (GPU path limit)."""
     if min_k != k:
         raise KmersGpuError(KMG_EUNSUPPORTED, "minK != maxK is not supported on the GPU path")
+    if mode == "p":
+        # MakeDatabase.java:186-237: reference payload, reverse complements included, every index of the input
+        from .api import FileCreator
+        fc = FileCreator(ctx, key_length, k, "ref", rc=True, dust=dust, runofsame=runofsame)
+        fc.add_kmers(read_preprocessed(input_path))
+        db = fc.create()
+        write_database(db, output_path, zip_level, hr)
+        return db
     data = open(input_path, "rb").read()
     if mode == "a":
         db = make_reference_db(ctx, data, k, key_length, dust, runofsame)

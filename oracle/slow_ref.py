@@ -726,6 +726,65 @@ def write_indexed_file(path, blocks, zip_level=5, hr=False):
         f.write(bytes(body))
 
 
+# ---------------------------------------------------- MakeDatabase -p input (OtherFiles/SeqToTaxID.java output)
+def sequence_compress(seq):
+    """Sequence.compressedBytes (Sequence.java:82-115): [int length] + 2 bits per base, first base in the top bits."""
+    code = {"A": 0, "C": 1, "T": 2, "G": 3}
+    out = bytearray(struct.pack(">i", len(seq)))
+    for i in range(0, len(seq), 4):
+        chunk = seq[i:i + 4]
+        b = 0
+        for ch in chunk:
+            b = (b << 2) | code[ch]
+        out.append((b << (2 * (4 - len(chunk)))) & 0xFF)
+    return bytes(out)
+
+
+def write_preprocessed_file(path, groups, zip_level=5, hr=False):
+    """The file SeqToTaxID writes and MakeDatabase -p reads (SeqToTaxID.java:127-135,190-200; MakeDatabase.java:192,
+    320-420): an IndexedFile keyed by String (jar StringCompressor: [short length][bytes], compressor id "2"),
+    one block per key; a block holds records [int taxid][Sequence.compressedBytes] or, human-readable, lines
+    `taxid ~ SEQUENCE` (DataPairDataType's default separator, DataPairDataType.java:17-20).
+    groups = {index string: [(taxid, "ACGT...")]}."""
+    z = zip_level is not None
+    body = bytearray(b"\0" * (64 if z else 41))
+    index = []
+    for key in sorted(groups):
+        if hr:
+            raw = "".join("%d ~ %s\n" % (t, s) for t, s in groups[key]).encode()
+        else:
+            raw = b"".join(struct.pack(">i", t) + sequence_compress(s) for t, s in groups[key])
+        blob = _gz_member(raw, zip_level) if z else raw
+        index.append((key, len(body), len(blob)))
+        body += blob
+    if hr:
+        idx = "".join("%s\t%d:%d\n" % (key, pos, ln) for key, pos, ln in index).encode()
+    else:
+        idx = struct.pack(">i", len(index))
+        for key, pos, ln in index:
+            kb = key.encode()
+            idx += struct.pack(">h", len(kb)) + kb + struct.pack(">i", 1) + struct.pack(">qq", pos, ln)
+    iblob = _gz_member(idx, zip_level) if z else idx
+    ipos = len(body)
+    body += iblob
+    footer = ("%-19d\n%-19d\n%s\n%1d\n" % (ipos, len(iblob), "2", 1 if hr else 0)).encode()
+    fblob = _gz_member(footer, 0) if z else footer
+    fpos = len(body)
+    body += fblob
+    header = ("%-19d %-19d%s" % (fpos, len(fblob), " \n")).encode()
+    hblob = _gz_member(header, 0) if z else header
+    body[0:len(hblob)] = hblob
+    with open(path, "wb") as f:
+        f.write(bytes(body))
+
+
+def preprocessed_kmers_as_fasta(groups):
+    """PreProcessedSpliterator.tryAdvance (MakeDatabase.java:358-407) with minK == maxK emits every window of
+    every sequence with its taxid -- what the FASTA path emits for the same sequences under the same ids (the
+    stored sequences hold valid bases only).  -> the equivalent FASTA bytes, for build_ref_db."""
+    return b"".join(b">%d\n%s\n" % (t, s.encode()) for key in sorted(groups) for t, s in groups[key])
+
+
 def hr_database_blocks(k, key_len, rc, kind, keys, val_off, val_a, val_b, bucket_off):
     """The blocks FileCreator.create writes with hr = true (MakeDatabase -h), from a database's CSR arrays:
     meta = minK, maxK, keyLength, Compressor.getStringID(id), rc as text lines (FileCreator.java:166-179); per

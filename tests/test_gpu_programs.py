@@ -229,3 +229,43 @@ def test_human_readable_databases(tmp_path):
     run("Utils.TaxaCounts", "-d", p("ref.py.db"), "-o", p("c.tsv"))
     t, m, q = o_ref.taxacounts()
     assert open(p("c.tsv")).read().splitlines() == ["%d\t%d\t%d" % x for x in zip(t, m, q)]
+
+
+def test_preprocessed_input(tmp_path):
+    """MakeDatabase -p: the IndexedFile OtherFiles.SeqToTaxID writes (String keys; binary or human-readable records),
+    here produced by the restated writer; both drivers give the database the FASTA route gives for the same
+    sequences (PreProcessedSpliterator emits every window, MakeDatabase.java:358-407), byte for byte when unzipped."""
+    import subprocess
+    import kmers_amd as km
+    from kmers_amd import programs, synth
+    from kmers_amd.__main__ import main as cli
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(131, 5, 7000, first_taxon=77, shared_frac=0.3)
+    groups = {}
+    for i, (t, g) in enumerate(zip(taxa, genomes)):                      # three sequences per taxon, keyed like accessions
+        s = g.tobytes().decode()
+        for j, part in enumerate((s[:2500], s[2500:2503], s[2503:])):    # a 3-base sequence: shorter than k
+            groups.setdefault("NC%02d" % ((i * 3 + j) % 4), []).append((t, part))
+    k, l = 23, 5
+    fa = R.preprocessed_kmers_as_fasta(groups)
+    want = OracleDB(fa, 0, k, l)
+    R.write_indexed_file(str(tmp_path / "want.db"), _oracle_blocks(want), None)
+    kmg = os.path.join(os.path.dirname(km.__file__), "kmg")
+    ctx = km.Context(0)
+    for name, z, hr in (("pp.bin", 5, False), ("pp.raw", None, False), ("pp.hr", 5, True)):
+        path = str(tmp_path / name)
+        R.write_preprocessed_file(path, groups, z, hr)
+        programs.make_database(ctx, path, path + ".py.db", "p", k, k, l, zip_level=None)
+        assert open(path + ".py.db", "rb").read() == open(str(tmp_path / "want.db"), "rb").read()
+        r = subprocess.run([kmg, "Database.MakeDatabase", "-p", "-i", path, "-o", path + ".kmg.db", "-K", str(k), "-k", str(k),
+                            "-l", str(l), "-Z"], capture_output=True, text=True, timeout=110)
+        assert r.returncode == 0, r.stderr
+        assert open(path + ".kmg.db", "rb").read() == open(str(tmp_path / "want.db"), "rb").read()
+    ctx.close()
+    assert cli(["Database.MakeDatabase", "-p", "-i", str(tmp_path / "pp.bin"), "-o", str(tmp_path / "cli.db"), "-K", str(k),
+                "-k", str(k), "-l", str(l), "-Z"]) == 0
+    assert open(str(tmp_path / "cli.db"), "rb").read() == open(str(tmp_path / "want.db"), "rb").read()
+    r = subprocess.run([kmg, "Database.MakeDatabase", "-p", "-i", str(tmp_path / "want.db"), "-o", str(tmp_path / "x.db"),
+                        "-K", str(k), "-k", str(k), "-l", str(l)], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 1 and "not a preprocessed file" in r.stderr
