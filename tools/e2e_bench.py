@@ -41,7 +41,9 @@ res["make_reads_z5_s"] = run("Database.MakeDatabase", "-q", "-i", fq, "-o", p("r
 res["make_reads_unzipped_s"] = run("Database.MakeDatabase", "-q", "-i", fq, "-o", p("readsZ.db"), "-r", p("mapZ.gz"), "-Z", *common)
 res["matcher_s"] = run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("matches.gz"), "-t", "16")
 res["taxacounts_s"] = run("Utils.TaxaCounts", "-d", p("ref.db"), "-o", p("counts.tsv"))
-res["sizes_MB"] = {n: round(os.path.getsize(p(n)) / 1e6, 1) for n in ("ref.db", "reads.db", "readsZ.db", "matches.gz")}
+res["collect_by_read_s"] = run("Utils.CollectByRead", "-i", p("matches.gz"), "-o", p("by_read"))
+res["read_classifier_s"] = run("Utils.ReadClassifier", "-i", p("by_read"), "-o", p("calls"), "-t", "16")
+res["sizes_MB"] = {n: round(os.path.getsize(p(n)) / 1e6, 1) for n in ("ref.db", "reads.db", "readsZ.db", "matches.gz", "by_read", "calls")}
 res["built_kmers_per_s_end_to_end"] = (n_ref_win + n_read_win) / (res["make_ref_z5_s"] + res["make_reads_z5_s"])
 print(json.dumps(res))
 subprocess.run(["rm", "-rf", d])
