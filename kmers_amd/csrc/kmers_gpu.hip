@@ -1066,13 +1066,12 @@ extern "C" int kmg_classify_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_
         if (search->V) return fail(ctx, KMG_EINVAL, "read index outside n_reads");
         return KMG_OK;
     }
-    PoolBuf mn(ctx), mx(ctx), bad(ctx), d_call(ctx);
-    KMG_ALLOC(mn, n_reads * 4); KMG_ALLOC(mx, n_reads * 4);
+    PoolBuf mm(ctx), bad(ctx), d_call(ctx);
+    KMG_ALLOC(mm, n_reads * 8);
     KMG_ALLOC(bad, (n_reads + 16) * 4);               // [n_reads] = error flag
     KMG_ALLOC(d_call, n_reads * 4);
     const dim3 gr(div_up_u64(n_reads, 256)), b(256);
-    hipLaunchKernelGGL(fill_i32_kernel, gr, b, 0, ctx->stream, mn.as<int32_t>(), n_reads, (int32_t)0x7FFFFFFF);
-    hipLaunchKernelGGL(fill_i32_kernel, gr, b, 0, ctx->stream, mx.as<int32_t>(), n_reads, (int32_t)0x80000000);
+    hipLaunchKernelGGL(rc_init_kernel, gr, b, 0, ctx->stream, mm.as<int2>(), n_reads);
     KMG_HIP(hipMemsetAsync(bad.p, 0, (n_reads + 16) * 4, ctx->stream));
     u32 *err = bad.as<u32>() + n_reads;
     const u64 U = search->U;
@@ -1082,12 +1081,11 @@ extern "C" int kmg_classify_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_
         // taxa, cache-resident), per-read words updated in place
         ProfScope ps(ctx, KP_CLASSIFY, 2 * (U * 16 + search->V * 4) + n_reads * 16);
         hipLaunchKernelGGL(rc_single_kernel, gk, b, 0, ctx->stream, search->val_off, search->val_a, d_hit.as<long long>(), U,
-                           ref->val_off, ref->val_a, n_reads, mn.as<int32_t>(), mx.as<int32_t>(), err);
+                           ref->val_off, ref->val_a, n_reads, mm.as<int2>(), err);
         hipLaunchKernelGGL(rc_check_kernel, gk, b, 0, ctx->stream, search->val_off, search->val_a, d_hit.as<long long>(), U,
-                           ref->val_off, ref->val_a, n_reads, mn.as<int32_t>(), mx.as<int32_t>(), bad.as<u32>());
+                           ref->val_off, ref->val_a, n_reads, mm.as<int2>(), bad.as<u32>());
     }
-    hipLaunchKernelGGL(rc_call_kernel, gr, b, 0, ctx->stream, mn.as<int32_t>(), mx.as<int32_t>(), bad.as<u32>(), n_reads,
-                       d_call.as<int32_t>());
+    hipLaunchKernelGGL(rc_call_kernel, gr, b, 0, ctx->stream, mm.as<int2>(), bad.as<u32>(), n_reads, d_call.as<int32_t>());
     KMG_HIP(hipGetLastError());
     u32 h_err = 0;
     KMG_HIP(hipMemcpyAsync(call, d_call.p, n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
