@@ -38,6 +38,15 @@ __device__ __forceinline__ u64 ep_window(const u32 *pk, u32 p, u64 kmask) {
     return ((hi << (2 * r)) | ((u64)pk[w + 2] >> (32 - 2 * r))) & kmask;
 }
 
+// OR of x << j for j = 0 .. n-1 (1 <= n <= 32), by doubling: bit p of the result (MSB first) says whether any of the
+// n positions p .. p+n-1 is set in x
+__device__ __forceinline__ u64 ep_or_span(u64 x, int n) {
+    int have = 1;
+    while (have * 2 <= n) { x |= x << have; have *= 2; }
+    if (have < n) x |= x << (n - have);
+    return x;
+}
+
 // seqrel is kept in 16 bits; a tile that sees 65535 or more sequence starts (tens of thousands of EMPTY
 // sequences inside 4 K bases) stores the clamp value and those positions look their sequence up instead:
 // the sequence of the base at absolute position g is the largest s with seq_off[s] <= g.
@@ -182,6 +191,21 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
             seqrel[tid * 8 + i] = (uint16_t)(run < EP_REL_CLAMP ? run : EP_REL_CLAMP);
         }
     }
+    // Window validity for the whole tile, 32 positions per thread and bit-parallel: a window [p, p+k) is good when
+    // it holds no invalid base, no sequence starts at p+1 .. p+k-1, and it ends inside the input.  (stb is complete:
+    // the scan above had barriers after its last store.)  The bitmap replaces `inv`, which nothing reads afterwards.
+    u32 vw = 0;
+    if (tid < EX_TILE / 32) {
+        const u64 B = ((u64)inv[tid] << 32) | inv[tid + 1];
+        const u64 S = ((u64)stb[tid] << 32) | stb[tid + 1];
+        u64 bad_any = ep_or_span(B, k);
+        if (k > 1) bad_any |= ep_or_span(S << 1, k - 1);
+        const long long last = (long long)a.nbases - k - (long long)t0 - 32ll * tid;   // last good position of this word
+        const u32 in_range = last < 0 ? 0u : (last >= 31 ? ~0u : ~(~0u >> (u32)(last + 1)));
+        vw = ~(u32)(bad_any >> 32) & in_range;
+    }
+    __syncthreads();
+    if (tid < EX_TILE / 32) inv[tid] = vw;
     __syncthreads();
 
     // ---- 3. windows: a wave owns positions wave*512 .. +511, round j covers 64 consecutive ones ------
@@ -195,12 +219,7 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
     for (int j = 0; j < EP_ROUNDS; j++) {
         const u32 p = pbase + j * 64;
         const u64 key = ep_window(pk, p, kmask);
-        const u32 w2 = p >> 5, r2 = p & 31;
-        u64 bad = (((u64)inv[w2] << 32) | inv[w2 + 1]) << r2;
-        u64 st = (((u64)stb[w2] << 32) | stb[w2 + 1]) << r2;
-        bool ok = (bad >> (64 - k)) == 0;
-        if (k > 1) ok = ok && (((st << 1) >> (65 - k)) == 0);
-        ok = ok && (t0 + p + (u64)k <= a.nbases);
+        bool ok = (inv[p >> 5] >> (31 - (p & 31))) & 1u;
         if (!WRITE && ok && a.has_kmer) {
             u32 rel = seqrel[p];
             if (rel == EP_REL_CLAMP) rel = ep_seq_rel(a, s_lo, s_end, t0 + p);
