@@ -97,6 +97,12 @@ int kmg_build_add(kmg_ctx *ctx, const uint8_t *bases, uint64_t nbases, const uin
 int kmg_build_add_dev(kmg_ctx *ctx, const uint8_t *d_bases, uint64_t nbases, const uint64_t *d_seq_off,
                       const int32_t *d_seq_id, const int64_t *d_seq_tok, uint64_t nseq,
                       int32_t *d_read_index_out);
+/* kmg_build_add_packed: the same for 2-bit packed sequences as MakeDatabase -p reads them (MakeDatabase.java:320-420,
+ *   SequenceDataType.java:21-34): `packed` = Sequence.cBytes of every sequence back to back (first base in the top
+ *   bits of a byte, every sequence on a byte boundary), byte_off[nseq+1] its byte offsets, seq_off[nseq+1] the base
+ *   offsets.  A quarter of the bytes cross PCIe; the letters are restored on the device.  Taxon payload only. */
+int kmg_build_add_packed(kmg_ctx *ctx, const uint8_t *packed, uint64_t nbytes, const uint64_t *seq_off,
+                         const uint64_t *byte_off, const int32_t *seq_id, uint64_t nseq);
 int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows);
 
 /* ---- database handles ----------------------------------------------------------------------- */

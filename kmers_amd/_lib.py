@@ -20,7 +20,7 @@ PAYLOAD_READPOS = 1
 SYMBOLS = [
     "kmg_create", "kmg_destroy", "kmg_last_error", "kmg_stream",
     "kmg_build_begin", "kmg_build_set_filters", "kmg_build_add", "kmg_build_add_dev", "kmg_build_finish",
-    "kmg_db_info", "kmg_db_fetch", "kmg_db_load", "kmg_db_free", "kmg_db_encode", "kmg_db_merge", "kmg_db_copy_dev", "kmg_db_load_dev", "kmg_db_payload_bits",
+    "kmg_db_info", "kmg_db_fetch", "kmg_db_load", "kmg_db_free", "kmg_db_encode", "kmg_db_merge", "kmg_db_copy_dev", "kmg_db_load_dev", "kmg_db_payload_bits", "kmg_build_add_packed",
     "kmg_match", "kmg_match_dev", "kmg_taxacounts", "kmg_collect_by_read", "kmg_classify_reads",
     "kmg_prof_enable", "kmg_prof_reset", "kmg_prof_get", "kmg_prof_count", "kmg_prof_name", "kmg_calib_copy",
 ]
@@ -61,6 +61,7 @@ def load():
     lib.kmg_build_set_filters.argtypes = [vp, i32, i32]
     lib.kmg_build_add.argtypes = [vp, vp, u64, vp, vp, vp, u64, vp]
     lib.kmg_build_add_dev.argtypes = [vp, vp, u64, vp, vp, vp, u64, vp]
+    lib.kmg_build_add_packed.argtypes = [vp, vp, u64, vp, vp, vp, u64]
     lib.kmg_build_finish.argtypes = [vp, P(vp), P(u64)]
     lib.kmg_db_info.argtypes = [vp, P(i32), P(i32), P(i32), P(i32), P(u64), P(u64)]
     lib.kmg_db_fetch.argtypes = [vp, vp, vp, vp, vp, vp]

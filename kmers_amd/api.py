@@ -223,6 +223,18 @@ class FileCreator:
                                                   _ptr(batch.seq_id), _ptr(batch.seq_tok), batch.nseq, _ptr(ridx)))
         return ridx
 
+    def add_packed(self, packed, seq_off, byte_off, seq_id):
+        """addKmers for 2-bit packed sequences as MakeDatabase -p reads them (kmg_build_add_packed): `packed` holds
+        Sequence.cBytes of every sequence back to back; the letters are restored on the device."""
+        packed = np.ascontiguousarray(packed, np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, np.uint64)
+        byte_off = np.ascontiguousarray(byte_off, np.uint64)
+        seq_id = np.ascontiguousarray(seq_id, np.int32)
+        if self.min_k == -1:
+            self.min_k = self.max_k
+        self.ctx.check(self.ctx.lib.kmg_build_add_packed(self.ctx.h, _ptr(packed), len(packed), _ptr(seq_off), _ptr(byte_off),
+                                                         _ptr(seq_id), len(seq_id)))
+
     def create(self):
         """FileCreator.create's compute -> KmerDatabase (the caller writes it through the container)."""
         h = C.c_void_p()

@@ -375,3 +375,24 @@ __global__ void number_carry_kernel(const int32_t *__restrict__ prev_emit, const
     }
     state[ST_READ_BASE] += incl_new[n - 1];
 }
+
+
+// MakeDatabase -p input as it lies in the file: Sequence.cBytes (Sequence.java:90-115) of every sequence, 2 bits per
+// base, first base in the top bits of a byte, every sequence starting on a byte boundary.  One thread per packed byte
+// finds its sequence in byte_off (ascending, nseq + 1 entries) and writes up to four base letters.
+__global__ void unpack2bit_kernel(const uint8_t *__restrict__ packed, u64 nbytes, const u64 *__restrict__ byte_off,
+                                  const u64 *__restrict__ seq_off, u64 nseq, uint8_t *__restrict__ out) {
+    const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbytes) return;
+    u64 lo = 0, hi = nseq;                       // last sequence with byte_off <= b
+    while (hi - lo > 1) {
+        const u64 mid = (lo + hi) >> 1;
+        if (byte_off[mid] <= b) lo = mid; else hi = mid;
+    }
+    const u64 first = seq_off[lo] + 4 * (b - byte_off[lo]), end = seq_off[lo + 1];
+    const u32 v = packed[b];
+    const u32 letters = 0x47544341u;             // 'A' 'C' 'T' 'G' for codes 0..3 (Base.java:7-41)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (first + i < end) out[first + i] = (uint8_t)(letters >> (8 * ((v >> (6 - 2 * i)) & 3u)));
+}

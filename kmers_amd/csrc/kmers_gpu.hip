@@ -347,6 +347,42 @@ extern "C" int kmg_build_add(kmg_ctx *ctx, const uint8_t *bases, uint64_t nbases
     return KMG_OK;
 }
 
+extern "C" int kmg_build_add_packed(kmg_ctx *ctx, const uint8_t *packed, uint64_t nbytes, const uint64_t *seq_off,
+                                    const uint64_t *byte_off, const int32_t *seq_id, uint64_t nseq) {
+    if (!ctx) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!ctx->building) return fail(ctx, KMG_ESTATE, "kmg_build_add_packed before kmg_build_begin");
+    if (ctx->kind != KMG_PAYLOAD_TAXON) return fail(ctx, KMG_EINVAL, "packed input carries taxon ids (MakeDatabase -p)");
+    if (nseq == 0) return KMG_OK;
+    if (!seq_off || !byte_off || !seq_id || (nbytes && !packed)) return fail(ctx, KMG_EINVAL, "null argument");
+    if (seq_off[0] != 0 || byte_off[0] != 0 || byte_off[nseq] != nbytes) return fail(ctx, KMG_EINVAL, "offsets must run from 0 to the end");
+    for (u64 i = 0; i < nseq; i++) {
+        if (seq_off[i] > seq_off[i + 1] || byte_off[i] > byte_off[i + 1])
+            return fail(ctx, KMG_EINVAL, "offsets must be non-decreasing");
+        if ((seq_off[i + 1] - seq_off[i] + 3) / 4 != byte_off[i + 1] - byte_off[i])
+            return fail(ctx, KMG_EINVAL, "a sequence of n bases takes ceil(n / 4) bytes");
+    }
+    const u64 nbases = seq_off[nseq];
+    if (nbases == 0) return KMG_OK;
+    KMG_HIP(hipSetDevice(ctx->device));
+    PoolBuf d_packed(ctx), d_boff(ctx), d_off(ctx), d_id(ctx), d_bases(ctx);
+    KMG_ALLOC(d_packed, nbytes + 64);
+    KMG_ALLOC(d_boff, (nseq + 1) * 8);
+    KMG_ALLOC(d_off, (nseq + 1) * 8);
+    KMG_ALLOC(d_id, nseq * 4);
+    KMG_ALLOC(d_bases, nbases + 64);
+    KMG_HIP(hipMemcpyAsync(d_packed.p, packed, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    KMG_HIP(hipMemcpyAsync(d_boff.p, byte_off, (nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    KMG_HIP(hipMemcpyAsync(d_off.p, seq_off, (nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    KMG_HIP(hipMemcpyAsync(d_id.p, seq_id, nseq * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(unpack2bit_kernel, dim3(div_up_u64(nbytes, 256)), dim3(256), 0, ctx->stream, d_packed.as<uint8_t>(), nbytes,
+                       d_boff.as<u64>(), d_off.as<u64>(), nseq, d_bases.as<uint8_t>());
+    KMG_HIP(hipGetLastError());
+    KMG_TRY(build_add_locked(ctx, d_bases.as<uint8_t>(), nbases, d_off.as<u64>(), d_id.as<int32_t>(), nullptr, nseq, nullptr));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));      // the host buffers may go away as soon as we return
+    return KMG_OK;
+}
+
 static void db_release(kmg_db *db) {
     if (!db) return;
     kmg_ctx *ctx = db->ctx;

@@ -592,10 +592,9 @@ int make_database_preprocessed(const Args &a, int k, int key_len, int level) {
     StageClock clk(a.has('v'));
     IndexedInputFile in(a.get('i'));
     if (!in.string_keys) throw std::runtime_error("not a preprocessed file (its keys are not strings): " + a.get('i'));
-    std::string bases;
-    std::vector<uint64_t> off{0};
+    std::string bases;                 // letters (human-readable input) or packed bytes (binary input)
+    std::vector<uint64_t> off{0}, boff{0};
     std::vector<int32_t> ids;
-    static const char LET[4] = {'A', 'C', 'T', 'G'};
     for (auto &kv : in.sindex) {
         std::string data;
         for (auto &b : kv.second) data += in.block(b.first, b.second);
@@ -621,9 +620,10 @@ int make_database_preprocessed(const Args &a, int k, int key_len, int level) {
                 const uint32_t n = get_be32(p + o + 4);
                 const size_t nb = n ? (n - 1) / 4 + 1 : 0;
                 if (o + 8 + nb > data.size()) throw std::runtime_error("truncated preprocessed record");
-                for (uint32_t i = 0; i < n; i++) bases.push_back(LET[(p[o + 8 + i / 4] >> (6 - 2 * (i & 3))) & 3]);
+                bases.append((const char *)p + o + 8, nb);       // stays packed: the device restores the letters
                 ids.push_back(t);
-                off.push_back(bases.size());
+                off.push_back(off.back() + n);
+                boff.push_back(bases.size());
                 o += 8 + nb;
             }
         }
@@ -632,8 +632,12 @@ int make_database_preprocessed(const Args &a, int k, int key_len, int level) {
     Gpu g;
     g.check(kmg_build_begin(g.ctx, k, key_len, 1, KMG_PAYLOAD_TAXON));
     if (a.has('D') || a.has('R')) g.check(kmg_build_set_filters(g.ctx, a.geti('D', -1), a.geti('R', -1)));
-    if (!ids.empty())
-        g.check(kmg_build_add(g.ctx, (const uint8_t *)bases.data(), bases.size(), off.data(), ids.data(), nullptr, ids.size(), nullptr));
+    if (!ids.empty()) {
+        if (in.hr)
+            g.check(kmg_build_add(g.ctx, (const uint8_t *)bases.data(), bases.size(), off.data(), ids.data(), nullptr, ids.size(), nullptr));
+        else
+            g.check(kmg_build_add_packed(g.ctx, (const uint8_t *)bases.data(), bases.size(), off.data(), boff.data(), ids.data(), ids.size()));
+    }
     kmg_db *db = nullptr;
     uint64_t nwin = 0;
     g.check(kmg_build_finish(g.ctx, &db, &nwin));

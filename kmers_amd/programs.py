@@ -131,13 +131,30 @@ def open_database(ctx, path) -> KmerDatabase:
 _UNPACK = np.array([[65, 67, 84, 71][(b >> s) & 3] for b in range(256) for s in (6, 4, 2, 0)], np.uint8).reshape(256, 4)
 
 
-def read_preprocessed(path):
+def read_preprocessed(path, packed=False):
     """The input of MakeDatabase -p (written by OtherFiles.SeqToTaxID): an IndexedFile keyed by String whose blocks
     hold (taxid, Sequence) records -- binary [int taxid][int length][2 bits per base] (IntCompressor +
     SequenceDataType.java:21-34) or human-readable lines `taxid ~ SEQUENCE`.  -> SequenceBatch of every record
-    (MakeDatabase.java:192-237 hands every index to the same FileCreator)."""
+    (MakeDatabase.java:192-237 hands every index to the same FileCreator); with packed=True and a binary file
+    -> (packed bytes, seq_off, byte_off, seq_id) for FileCreator.add_packed, the bases left as they are."""
     from .api import SequenceBatch
     f = container.IndexedInputFile(path)
+    if packed and not f.hr:
+        chunks, ids, lens = [], [], []
+        for key in sorted(f.index):
+            data = f.read_key(key)
+            off = 0
+            while off < len(data):
+                t, n = struct.unpack_from(">ii", data, off)
+                nb = (n - 1) // 4 + 1 if n > 0 else 0
+                chunks.append(data[off + 8:off + 8 + nb])
+                ids.append(t)
+                lens.append(n)
+                off += 8 + nb
+        lens = np.array(lens, np.uint64)
+        seq_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        byte_off = np.concatenate([[0], np.cumsum((lens + np.uint64(3)) // np.uint64(4))]).astype(np.uint64)
+        return np.frombuffer(b"".join(chunks), np.uint8), seq_off, byte_off, np.array(ids, np.int32)
     parts, ids, lens = [], [], []
     for key in sorted(f.index):
         data = f.read_key(key)
@@ -172,7 +189,12 @@ def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length
         # MakeDatabase.java:186-237: reference payload, reverse complements included, every index of the input
         from .api import FileCreator
         fc = FileCreator(ctx, key_length, k, "ref", rc=True, dust=dust, runofsame=runofsame)
-        fc.add_kmers(read_preprocessed(input_path))
+        got = read_preprocessed(input_path, packed=True)
+        if isinstance(got, tuple):                       # binary file: the packed bases go to the device as they are
+            if len(got[3]):
+                fc.add_packed(*got)
+        else:
+            fc.add_kmers(got)
         db = fc.create()
         write_database(db, output_path, zip_level, hr)
         return db

@@ -850,3 +850,33 @@ def test_cfg5_flavour_long_noisy_reads(ctx, k):
     assert nh == o_nh and np.array_equal(hit, o_hit)
     ref.close()
     rdb.close()
+
+
+def test_packed_input_equals_letters(ctx):
+    """kmg_build_add_packed (2-bit packed sequences, MakeDatabase -p records) against the same sequences as letters:
+    lengths that are and are not multiples of four, a sequence shorter than k, an empty one; and its argument checks."""
+    import kmers_amd as km
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(17)
+    seqs = ["".join("ACGT"[i] for i in rng.integers(0, 4, size=n)) for n in (4001, 64, 3, 0, 1234, 8192, 777)]
+    ids = [11, 12, 12, 13, 14, 11, 15]
+    k, l = 19, 4
+    packed = b"".join(R.sequence_compress(s)[4:] for s in seqs)
+    lens = np.array([len(s) for s in seqs], np.uint64)
+    seq_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    byte_off = np.concatenate([[0], np.cumsum((lens + np.uint64(3)) // np.uint64(4))]).astype(np.uint64)
+    fc = km.FileCreator(ctx, l, k, "ref", rc=True)
+    fc.add_packed(np.frombuffer(packed, np.uint8), seq_off, byte_off, np.array(ids, np.int32))
+    got = fc.create()
+    want = OracleDB(b"".join(b">%d\n%s\n" % (t, s.encode()) for t, s in zip(ids, seqs)), 0, k, l)
+    _same_db(got, want)
+    got.close()
+    fc = km.FileCreator(ctx, l, k, "ref", rc=True)
+    with pytest.raises(km.InconsistentDataException):
+        fc.add_packed(np.frombuffer(packed, np.uint8), seq_off, byte_off + np.uint64(1), np.array(ids, np.int32))
+    fc.create().close()
+    fc = km.FileCreator(ctx, l, k, "read", rc=False)
+    with pytest.raises(km.InconsistentDataException):
+        fc.add_packed(np.frombuffer(packed, np.uint8), seq_off, byte_off, np.array(ids, np.int32))
+    fc.create().close()
