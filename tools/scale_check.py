@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""One-off exactness check above the sizes the test suite covers (run ON the GPU box): builds BASELINE config 2 scaled
+by `scale` on the GPU and with the C oracle and compares every array.  tools/scale_check.py [scale]
+scale 1.7 -> 204 M read records: 17 prefix bits, i.e. three prefix digits (fused first digit + TWO global passes)."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import kmers_amd as km  # noqa: E402
+from kmers_amd import synth  # noqa: E402
+from oracle.c_oracle import OracleDB  # noqa: E402
+
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.7
+K, L = 31, 6
+taxa, genomes, reads = synth.cfg1(scale)
+fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+ctx = km.Context(0)
+t0 = time.perf_counter()
+ref = km.make_reference_db(ctx, fa, K, L)
+rdb, names = km.make_read_db(ctx, fq, K, L)
+hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
+t1 = time.perf_counter()
+o_ref = OracleDB(fa, 0, K, L, threads=16)
+o_reads = OracleDB(fq, 1, K, L, threads=16)
+o_hit, o_nh = o_reads.match(o_ref, threads=16)
+t2 = time.perf_counter()
+ok = True
+for name, g, o in (("ref", ref, o_ref), ("reads", rdb, o_reads)):
+    h = g.fetch()
+    for arr in ("keys", "val_off", "val_a", "val_b", "bucket_off"):
+        same = np.array_equal(h[arr], getattr(o, arr))
+        ok &= same
+        if not same:
+            print("MISMATCH", name, arr)
+ok &= names == o_reads.names and nh == o_nh and np.array_equal(hit, o_hit)
+print(json.dumps({"scale": scale, "read_records": int(rdb.n_values), "read_kmers": int(rdb.n_unique), "hits": int(nh),
+                  "payload_bits": ctx.lib.kmg_db_payload_bits(rdb.h), "gpu_incl_host_parse_s": round(t1 - t0, 2),
+                  "oracle_s": round(t2 - t1, 2), "identical": bool(ok)}))
+sys.exit(0 if ok else 1)
