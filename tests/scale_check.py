@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off exactness check above the sizes the test suite covers (run ON the GPU box): builds BASELINE config 2 scaled
-by `scale` on the GPU and with the C oracle and compares every array.  tools/scale_check.py [scale]
+by `scale` on the GPU and with the C oracle and compares every array.  Not collected by pytest (the oracle is a checker: it lives under tests/).
+python tests/scale_check.py [scale [batches]]
 scale 1.7 -> 204 M read records: 17 prefix bits, i.e. three prefix digits (fused first digit + TWO global passes)."""
 import json
 import sys
