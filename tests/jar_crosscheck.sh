@@ -2,7 +2,7 @@
 # Cross-check against the real reference when a JVM exists (none in the build container or on the GPU box).
 # Runs config 1 through out/Kmers.jar and through `python -m kmers_amd`, then diffs at tier T1:
 # unzipped DB files byte for byte (reference DB), block payloads (read DB, read lists sorted), match lines
-# (read lists sorted) and TaxaCounts lines.  Usage: tests/jar_crosscheck.sh /path/to/Kmers.jar [workdir]
+# (read lists sorted), TaxaCounts lines and the blocks of CollectByRead / ReadClassifier.  Usage: tests/jar_crosscheck.sh /path/to/Kmers.jar [workdir]
 # KMG_DRIVER="kmers_amd/kmg" checks the native C++ drivers instead of the Python ones.
 set -euo pipefail
 JAR=${1:?path to Kmers.jar}
@@ -22,12 +22,16 @@ T=$(nproc)
 ( cd java_reads && /usr/bin/time -v java -cp "$JAR" Database.MakeDatabase -q -i ../reads.fq -o reads.db -r reads.map.gz -K 31 -k 31 -Z -t "$T" )
 /usr/bin/time -v java -cp "$JAR" Database.Matcher -i java_reads/reads.db -d java_ref/ref.db -o java.matches.txt -Z x -t "$T"
 java -cp "$JAR" Utils.TaxaCounts -d java_ref/ref.db -o java.counts.tsv
+java -cp "$JAR" Utils.CollectByRead -i java.matches.txt -o java.by_read
+java -cp "$JAR" Utils.ReadClassifier -i java.by_read -o java.calls -t "$T"
 cd "$ROOT"
 DRIVER=${KMG_DRIVER:-python3 -m kmers_amd}
 $DRIVER Database.MakeDatabase -a -i "$WORK/ref.fa"   -o "$WORK/gpu/ref.db"   -K 31 -k 31 -Z
 $DRIVER Database.MakeDatabase -q -i "$WORK/reads.fq" -o "$WORK/gpu/reads.db" -r "$WORK/gpu/reads.map.gz" -K 31 -k 31 -Z
 $DRIVER Database.Matcher -i "$WORK/gpu/reads.db" -d "$WORK/gpu/ref.db" -o "$WORK/gpu.matches.txt" -Z x
 $DRIVER Utils.TaxaCounts -d "$WORK/gpu/ref.db" -o "$WORK/gpu.counts.tsv"
+$DRIVER Utils.CollectByRead -i "$WORK/gpu.matches.txt" -o "$WORK/gpu.by_read"
+$DRIVER Utils.ReadClassifier -i "$WORK/gpu.by_read" -o "$WORK/gpu.calls"
 cmp "$WORK/java_ref/ref.db" "$WORK/gpu/ref.db" && echo "reference DB: byte-identical"
 diff <(zcat "$WORK/java_reads/reads.map.gz") <(zcat "$WORK/gpu/reads.map.gz") && echo "read map: identical"
 python3 - <<PY
@@ -44,4 +48,6 @@ def lines(p):
     return out
 assert lines("$WORK/java.matches.txt") == lines("$WORK/gpu.matches.txt"); print("match lines: identical (read lists sorted)")
 assert open("$WORK/java.counts.tsv").read() == open("$WORK/gpu.counts.tsv").read(); print("TaxaCounts: identical")
+assert R.read_indexed_file("$WORK/java.by_read") == R.read_indexed_file("$WORK/gpu.by_read"); print("CollectByRead: identical blocks")
+assert R.read_indexed_file("$WORK/java.calls") == R.read_indexed_file("$WORK/gpu.calls"); print("ReadClassifier: identical blocks")
 PY
