@@ -654,7 +654,7 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     db->V = tot[1];
     if (ctx->prof_on)
     {
-        ctx->prof[KP_REDUCE_WRITE].bytes += db->U * (heads.done ? 32 : 16) + (reads ? 0 : db->V * 8);
+        ctx->prof[KP_REDUCE_WRITE].bytes += db->U * (heads.done ? (8 + vb) + 16 : 16) + (reads ? 0 : db->V * 8);
         if (heads.done) ctx->prof[KP_SORT_LOCAL_V64].bytes += db->U * (8 + vb);
     }
     *out = db_guard.release();
