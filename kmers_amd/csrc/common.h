@@ -167,6 +167,11 @@ struct kmg_ctx {
     bool sort_as_reads = false;  // profiling only: attribute 32-bit-payload sort launches to the read kernels
     u64 *d_state = nullptr;      // ST_WORDS device words
     void *h_pin = nullptr;       // PIN_BYTES of pinned host memory: landing pad of the small result readbacks
+    // Readbacks that do not stop the stream: the copy into h_snap is queued where its value is final, an event
+    // follows it, and the host waits for the event only when it needs the value -- later kernels are queued by then.
+    void *h_snap = nullptr;      // [0, 128) build state after the count-time kernels, [128, 132) longest sequence
+    hipEvent_t ev_len = nullptr, ev_snap = nullptr;
+    bool snap_valid = false;     // h_snap holds the state finish() needs (single fused batch)
     std::vector<void *> staged;  // device copies of host batches, released at finish
 
     // profiling

@@ -29,6 +29,7 @@ struct PartArgs {
     u32 *table;        // [digit][column] counts (count pass) / exclusive offsets (write pass)
     u32 ncols;         // columns = tiles * (rc ? 2 : 1)
     u32 ntiles;
+    u32 out_base;      // records already in the buffers (0: the fused path is the first batch of a build)
 };
 
 // the k-mer starting at tile position p, from the packed LDS image (3 words that the whole wave shares)
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
     const u64 my_start = my_s <= s_end ? a.seq_off[my_s] : 0;
     u32 tbl0 = 0, tbl1 = 0, out_base = 0;
     if (WRITE) {
-        out_base = (u32)a.state[ST_NREC];
+        out_base = pa.out_base;
         if (tid < RS_DIGITS) {
             tbl0 = pa.table[(u64)tid * pa.ncols + col0];
             if (a.rc) tbl1 = pa.table[(u64)tid * pa.ncols + col0 + 1];

@@ -65,6 +65,12 @@ extern "C" int kmg_create(int device, kmg_ctx **out) {
     }
     ctx->d_state = (u64 *)st;
     if (hipHostMalloc(&ctx->h_pin, PIN_BYTES, hipHostMallocDefault) != hipSuccess) ctx->h_pin = nullptr;   // optional
+    if (hipHostMalloc(&ctx->h_snap, PIN_BYTES, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_len, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_snap, hipEventDisableTiming) != hipSuccess) {
+        if (ctx->h_snap) (void)hipHostFree(ctx->h_snap);
+        ctx->h_snap = nullptr;                                                                             // optional too
+    }
     *out = ctx;
     return KMG_OK;
 }
@@ -77,6 +83,9 @@ extern "C" void kmg_destroy(kmg_ctx *ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->pool.destroy();
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->h_snap) (void)hipHostFree(ctx->h_snap);
+    if (ctx->ev_len) (void)hipEventDestroy(ctx->ev_len);
+    if (ctx->ev_snap) (void)hipEventDestroy(ctx->ev_snap);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -97,7 +106,7 @@ extern "C" int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int pay
     ctx->k = k; ctx->key_len = key_len; ctx->rc = rc ? 1 : 0; ctx->kind = payload_kind;
     ctx->dust = -1; ctx->runofsame = -1;
     ctx->rec_upper = 0;
-    ctx->n_adds = 0; ctx->prepart = false; ctx->plan_pbits = 0; ctx->compact_pb = 0;
+    ctx->n_adds = 0; ctx->prepart = false; ctx->plan_pbits = 0; ctx->compact_pb = 0; ctx->snap_valid = false;
     // stream-ordered, no host round trip
     KMG_HIP(hipMemsetAsync(ctx->d_state, 0, ST_WORDS * sizeof(u64), ctx->stream));
     hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state + ST_ID_AND, (u64)0xFFFFFFFFull);
@@ -210,29 +219,27 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     ctx->prepart = part;
     ctx->plan_pbits = plan;
     ctx->n_adds++;
+    ctx->snap_valid = false;
     PartArgs pa;
-    PoolBuf table(ctx), tagg(ctx);
+    memset(&pa, 0, sizeof pa);
+    PoolBuf table(ctx), tagg(ctx), mx(ctx);
+    bool len_pending = false;
     if (part && reads) {
         // Compact payloads: when every (read, pos) of the batch fits 32 bits -- pos < 2^pb from the longest
         // sequence, read < nseq < 2^(32 - pb) -- the records carry read << pb | pos in 4 bytes through the
-        // partition, the sort and into the database (12-byte records instead of 16).  The one host round trip
-        // of an add: 4 bytes, before anything else of this batch is queued.
-        PoolBuf mx(ctx);
+        // partition, the sort and into the database (12-byte records instead of 16).  The longest sequence is
+        // found first and fetched behind an event; the host looks at it only before the write pass, with the
+        // count pass, the numbering and the table scan already queued.
         KMG_ALLOC(mx, 64);
         KMG_HIP(hipMemsetAsync(mx.p, 0, 4, ctx->stream));
         hipLaunchKernelGGL(seq_maxlen_kernel, dim3(std::min<u32>(div_up_u64(nseq, 1024), 1024)), dim3(256), 0, ctx->stream,
                            d_seq_off, nseq, mx.as<u32>());
-        u32 maxlen = 0;
-        KMG_HIP(read_back(ctx, &maxlen, mx.p, 4));
-        const u32 maxpos = maxlen > (u32)ctx->k ? maxlen - (u32)ctx->k : 0;
-        int pb = 1;
-        while (pb < 32 && (maxpos >> pb) != 0) pb++;
-        if (pb <= 16 && nseq < ((u64)1 << (32 - pb))) {
-            ctx->compact_pb = pb;
-            a.pos_bits = pb; a.pos_mask = (1u << pb) - 1u;
+        if (ctx->h_snap) {
+            KMG_HIP(hipMemcpyAsync((char *)ctx->h_snap + 128, mx.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            KMG_HIP(hipEventRecord(ctx->ev_len, ctx->stream));
         }
+        len_pending = true;
     }
-    const bool compact = ctx->compact_pb > 0;
     if (part) {
         const SortPass d0 = prefix_digits(plan)[0];
         pa.dshift = d0.shift; pa.dmask = (1u << d0.bits) - 1u;
@@ -249,8 +256,8 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         ProfScope ps(ctx, KP_EXTRACT_COUNT, nbases);
         if (part) {
             pa.e = a;
-            if (reads && !compact) hipLaunchKernelGGL((extract_part_kernel<false, u64>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
-            else hipLaunchKernelGGL((extract_part_kernel<false, u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+            // (the payload type only matters to the write pass)
+            hipLaunchKernelGGL((extract_part_kernel<false, u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
         } else hipLaunchKernelGGL((extract_kernel<false>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
         hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_fwd.as<u32>(),
                            ntiles, ctx->d_state + ST_NWIN);
@@ -277,14 +284,37 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
                            d_seq_id, nseq, ctx->d_state);
     }
     if (part) {
-        KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, table.as<u32>(), table.as<u32>(), (u64)RS_DIGITS * pa.ncols, OpSum(),
-                                                    0u, tagg.as<u32>(), nullptr, false, KP_SCAN)));
-        ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases /* + records * rec_b, added at finish when N is known */);
-        pa.e = a;
-        if (reads && !compact) hipLaunchKernelGGL((extract_part_kernel<true, u64>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
-        else hipLaunchKernelGGL((extract_part_kernel<true, u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+        // the record count is final once the tiles are counted (the write pass starts at record 0: first batch);
+        // with it the build state is complete, and finish() reads this snapshot instead of stopping the stream
         hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_count.as<u32>(),
                            ntiles, ctx->d_state + ST_NREC);
+        if (ctx->h_snap) {
+            KMG_HIP(hipMemcpyAsync(ctx->h_snap, ctx->d_state, ST_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+            KMG_HIP(hipEventRecord(ctx->ev_snap, ctx->stream));
+            ctx->snap_valid = true;
+        }
+        KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, table.as<u32>(), table.as<u32>(), (u64)RS_DIGITS * pa.ncols, OpSum(),
+                                                    0u, tagg.as<u32>(), nullptr, false, KP_SCAN)));
+        if (len_pending) {
+            u32 maxlen = 0;
+            if (ctx->h_snap) {
+                KMG_HIP(hipEventSynchronize(ctx->ev_len));
+                memcpy(&maxlen, (char *)ctx->h_snap + 128, 4);
+            } else KMG_HIP(read_back(ctx, &maxlen, mx.p, 4));
+            const u32 maxpos = maxlen > (u32)ctx->k ? maxlen - (u32)ctx->k : 0;
+            int pb = 1;
+            while (pb < 32 && (maxpos >> pb) != 0) pb++;
+            if (pb <= 16 && nseq < ((u64)1 << (32 - pb))) {
+                ctx->compact_pb = pb;
+                a.pos_bits = pb; a.pos_mask = (1u << pb) - 1u;
+            }
+        }
+        const bool compact = ctx->compact_pb > 0;
+        ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases /* + records * rec_b, added at finish when N is known */);
+        pa.e = a;
+        pa.out_base = 0;
+        if (reads && !compact) hipLaunchKernelGGL((extract_part_kernel<true, u64>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+        else hipLaunchKernelGGL((extract_part_kernel<true, u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
     } else {
         KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, tile_count.as<u32>(), tile_off.as<u64>(), ntiles, OpSum(), 0ull,
                                                     agg.as<u64>(), nullptr, true, KP_SCAN)));
@@ -566,7 +596,12 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     ctx->building = false;
 
     u64 st[ST_WORDS];
-    KMG_HIP(read_back(ctx, st, ctx->d_state, sizeof st));
+    if (ctx->snap_valid && ctx->n_adds == 1) {
+        // single fused batch: the state was final before the write pass and is already here (see build_add_locked)
+        KMG_HIP(hipEventSynchronize(ctx->ev_snap));
+        memcpy(st, ctx->h_snap, sizeof st);
+    } else KMG_HIP(read_back(ctx, st, ctx->d_state, sizeof st));
+    ctx->snap_valid = false;
     const u64 N = st[ST_NREC];
     if (n_windows) *n_windows = st[ST_NWIN];
     if (N >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 records in one build");
