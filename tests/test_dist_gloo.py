@@ -137,7 +137,19 @@ def _exchange_worker(rank, world, port, fastas, fq, k, key_len, out):
     ut, uc = np.unique(single, return_counts=True)
     su[np.searchsorted(st, ut)] = uc
     counts = kd.taxa_counts_sharded(st, sm, su)
-    out.put((rank, ranges, shard, lo, owner, hit, counts))
+    # a read database goes through the same exchange: this rank holds the occurrences of every other read
+    sv = reads.val_off.astype(np.int64)
+    kidx = np.repeat(np.arange(len(reads.keys)), np.diff(sv))
+    mine_v = reads.val_a % world == rank
+    cnt = np.bincount(kidx[mine_v], minlength=len(reads.keys))
+    has = cnt > 0
+    part = dict(keys=reads.keys[has], val_off=np.concatenate([[0], np.cumsum(cnt[has])]).astype(np.uint64),
+                val_a=reads.val_a[mine_v], val_b=reads.val_b[mine_v])
+    got_parts = kd.exchange_csr(part, ranges, key_len)
+    rows = np.concatenate([np.stack([np.repeat(p["keys"], np.diff(p["val_off"].astype(np.int64))).view(np.int64),
+                                     p["val_a"].astype(np.int64), p["val_b"].astype(np.int64)], axis=1) for p in got_parts])
+    rows = rows[np.lexsort((rows[:, 2], rows[:, 1], rows[:, 0].view(np.uint64)))]          # k-mer, read, pos
+    out.put((rank, ranges, shard, lo, owner, hit, counts, rows))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -190,3 +202,14 @@ def test_key_range_exchange_build_and_match():
         gt, gm, gq = got[g][6]
         assert np.array_equal(gt, t) and np.array_equal(gm, m) and np.array_equal(gq, q)
     assert (np.asarray(q) < np.asarray(m)).any()
+    # read database: rank g ends up with every occurrence of the k-mers of its range, whoever held them
+    rsv = o_reads.val_off.astype(np.int64)
+    for g in range(world):
+        shift = np.uint64(64 - 2 * key_len)
+        lo_key, hi_key = np.uint64(ranges[g][0]) << shift, (np.uint64(ranges[g][1]) << shift if ranges[g][1] < 4 ** key_len else None)
+        sel = (o_reads.keys >= lo_key) & ((o_reads.keys < hi_key) if hi_key is not None else True)
+        idx = np.nonzero(sel)[0]
+        want_rows = np.stack([np.repeat(o_reads.keys[idx], rsv[idx + 1] - rsv[idx]).view(np.int64),
+                              np.concatenate([o_reads.val_a[rsv[i]:rsv[i + 1]] for i in idx]).astype(np.int64),
+                              np.concatenate([o_reads.val_b[rsv[i]:rsv[i + 1]] for i in idx]).astype(np.int64)], axis=1)
+        assert np.array_equal(got[g][7], want_rows)
