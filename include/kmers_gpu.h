@@ -184,10 +184,16 @@ int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, int64_t *matc
  * kmg_classify_reads: Utils/ReadClassifier.java:178-220 (processRead) over the same records, without
  *   materialising them: call[r] = the one taxon t >= 0 such that every single-taxon hit of read r names t and
  *   every hit's taxon set contains t, else -1 (no line in the reference's output).  n_reads = number of read
- *   indices (KMG_EINVAL if the database holds a larger one). */
+ *   indices (KMG_EINVAL if the database holds a larger one).
+ * kmg_classify_reads_hits: the same, and has_hit[r] = 1 if read r has at least one matched k-mer -- what decides
+ *   whether the reference's output holds a block for (r / 1000) * 1000 at all (ReadClassifier.java:157-160 writes
+ *   one block per block of CollectByRead's output, and CollectByRead.java:105-124 one per group of reads with a
+ *   record), so a caller can write ReadClassifier's file straight from two databases. */
 int kmg_collect_by_read(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t *n_out, int32_t *read,
                         int32_t *pos, int64_t *ref_index);
 int kmg_classify_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t n_reads, int32_t *call);
+int kmg_classify_reads_hits(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t n_reads, int32_t *call,
+                            uint8_t *has_hit);
 
 /* ---- measurement hook (bench.py) --------------------------------------------------------------
  * Total device time in ms, measured with HIP events on kmg_stream(), of the launches of one

@@ -1,5 +1,7 @@
 """python -m kmers_amd <Database.MakeDatabase | Database.Matcher | Utils.TaxaCounts | Utils.CollectByRead | Utils.ReadClassifier> <options>
--- the reference's option letters for the hot path (README.md:9-12 `java -cp Kmers.jar <Class> <opts>`)."""
+-- the reference's option letters for the hot path (README.md:9-12 `java -cp Kmers.jar <Class> <opts>`).
+Pipeline.ReadCalls -q reads.fq (-d database | -a reference.fa) -o calls [-K k -l key_length -r read_map.gz]: the chain
+MakeDatabase -q | Matcher | CollectByRead | ReadClassifier without its intermediate files (no reference counterpart)."""
 import argparse
 import sys
 
@@ -40,6 +42,12 @@ def main(argv=None):
             ap.add_argument("-" + f)
         a = ap.parse_args(rest)
         (programs.collect_by_read if prog == "CollectByRead" else programs.read_classifier)(Context(0), a.i, a.o)
+    elif prog == "ReadCalls":
+        for f in "qdaoKlr":
+            ap.add_argument("-" + f)
+        a = ap.parse_args(rest)
+        programs.read_calls(Context(0), a.q, a.o, db_path=a.d, fasta_path=a.a, k=int(a.K or 32), key_length=int(a.l or 6),
+                            read_map_path=a.r)
     else:
         raise SystemExit("unknown program %s" % argv[0])
     return 0

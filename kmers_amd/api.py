@@ -361,13 +361,30 @@ def collect_by_read_blocks(search, ref):
     return out
 
 
-def classify_reads(search, ref, n_reads):
-    """Utils/ReadClassifier.java processRead for every read (kmg_classify_reads) -> call[n_reads], -1 = no call."""
+def classify_reads(search, ref, n_reads, with_hits=False):
+    """Utils/ReadClassifier.java processRead for every read (kmg_classify_reads) -> call[n_reads], -1 = no call.
+    with_hits: -> (call, has_hit) with has_hit[r] = 1 if read r has a matched k-mer (kmg_classify_reads_hits)."""
     ref = ref.merged if isinstance(ref, DB) else ref
     ctx = search.ctx
     call = np.empty(max(n_reads, 1), np.int32)
-    ctx.check(ctx.lib.kmg_classify_reads(ctx.h, search.h, ref.h, n_reads, _ptr(call)))
-    return call[:n_reads]
+    if not with_hits:
+        ctx.check(ctx.lib.kmg_classify_reads(ctx.h, search.h, ref.h, n_reads, _ptr(call)))
+        return call[:n_reads]
+    seen = np.zeros(max(n_reads, 1), np.uint8)
+    ctx.check(ctx.lib.kmg_classify_reads_hits(ctx.h, search.h, ref.h, n_reads, _ptr(call), _ptr(seen)))
+    return call[:n_reads], seen[:n_reads]
+
+
+def read_call_blocks(call, has_hit):
+    """The blocks of ReadClassifier's output file from per-read calls: one block per (read / 1000) * 1000 that
+    holds a read with a matched k-mer (CollectByRead.java:105-124 writes no other), lines `read \t call \n` for
+    the reads that have a call (ReadClassifier.java:140-160)."""
+    call, has_hit = np.asarray(call), np.asarray(has_hit)
+    out = {}
+    for key in np.unique((np.nonzero(has_hit)[0] // 1000) * 1000).tolist():
+        seg = call[key:key + 1000]
+        out[key] = "".join("%d\t%d\n" % (key + i, c) for i, c in enumerate(seg.tolist()) if c >= 0).encode()
+    return out
 
 
 _BASES = np.frombuffer(b"ACTG", dtype=np.uint8)

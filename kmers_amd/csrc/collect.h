@@ -72,7 +72,7 @@ __global__ void cbr_unpack_kernel(const u64 *__restrict__ keys, const u32 *__res
 __global__ __launch_bounds__(256) void rc_single_kernel(const u64 *__restrict__ s_off, const int32_t *__restrict__ s_read,
                                                         const long long *__restrict__ hit, u64 U,
                                                         const u64 *__restrict__ r_off, const int32_t *__restrict__ r_taxon,
-                                                        u64 n_reads, int2 *mm, u32 *err) {
+                                                        u64 n_reads, int2 *mm, u32 *err, uint8_t *seen) {
     const u64 s = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / CB_LANES;
     const u32 lane = threadIdx.x % CB_LANES;
     if (s >= U) return;
@@ -84,6 +84,8 @@ __global__ __launch_bounds__(256) void rc_single_kernel(const u64 *__restrict__ 
     for (u64 j = lane; j < n; j += CB_LANES) {
         const u32 r = (u32)s_read[v0 + j];
         if (r >= n_reads) { atomicOr(err, 1u); continue; }
+        // (same look-first rule: a read's ~100 occurrences would all store the same byte)
+        if (seen && !*reinterpret_cast<volatile uint8_t *>(&seen[r])) seen[r] = 1;
         if (single) {
             // mn only falls and mx only rises, so a plain look first is safe and spares most of the ~100 atomics
             // a read's occurrences would aim at its two words

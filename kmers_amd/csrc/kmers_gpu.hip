@@ -1126,9 +1126,8 @@ extern "C" int kmg_collect_by_read(kmg_ctx *ctx, const kmg_db *search, const kmg
     return KMG_OK;
 }
 
-extern "C" int kmg_classify_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t n_reads, int32_t *call) {
-    if (!ctx || !search || !ref || (n_reads && !call)) return KMG_EINVAL;
-    std::lock_guard<std::mutex> g(ctx->mu);
+static int classify_locked(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t n_reads, int32_t *call,
+                           uint8_t *has_hit) {
     KMG_HIP(hipSetDevice(ctx->device));
     if (n_reads >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "too many reads");
     PoolBuf d_hit(ctx);
@@ -1137,7 +1136,11 @@ extern "C" int kmg_classify_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_
         if (search->V) return fail(ctx, KMG_EINVAL, "read index outside n_reads");
         return KMG_OK;
     }
-    PoolBuf mm(ctx), bad(ctx), d_call(ctx);
+    PoolBuf mm(ctx), bad(ctx), d_call(ctx), seen(ctx);
+    if (has_hit) {
+        KMG_ALLOC(seen, n_reads);
+        KMG_HIP(hipMemsetAsync(seen.p, 0, n_reads, ctx->stream));
+    }
     KMG_ALLOC(mm, n_reads * 8);
     KMG_ALLOC(bad, (n_reads + 16) * 4);               // [n_reads] = error flag
     KMG_ALLOC(d_call, n_reads * 4);
@@ -1152,7 +1155,7 @@ extern "C" int kmg_classify_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_
         // taxa, cache-resident), per-read words updated in place
         ProfScope ps(ctx, KP_CLASSIFY, 2 * (U * 16 + search->V * 4) + n_reads * 16);
         hipLaunchKernelGGL(rc_single_kernel, gk, b, 0, ctx->stream, search->val_off, search->val_a, d_hit.as<long long>(), U,
-                           ref->val_off, ref->val_a, n_reads, mm.as<int2>(), err);
+                           ref->val_off, ref->val_a, n_reads, mm.as<int2>(), err, seen.as<uint8_t>());
         hipLaunchKernelGGL(rc_check_kernel, gk, b, 0, ctx->stream, search->val_off, search->val_a, d_hit.as<long long>(), U,
                            ref->val_off, ref->val_a, n_reads, mm.as<int2>(), bad.as<u32>());
     }
@@ -1160,9 +1163,23 @@ extern "C" int kmg_classify_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_
     KMG_HIP(hipGetLastError());
     u32 h_err = 0;
     KMG_HIP(hipMemcpyAsync(call, d_call.p, n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (has_hit) KMG_HIP(hipMemcpyAsync(has_hit, seen.p, n_reads, hipMemcpyDeviceToHost, ctx->stream));
     KMG_HIP(read_back(ctx, &h_err, err, 4));
     if (h_err) return fail(ctx, KMG_EINVAL, "read index outside n_reads");
     return KMG_OK;
+}
+
+extern "C" int kmg_classify_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t n_reads, int32_t *call) {
+    if (!ctx || !search || !ref || (n_reads && !call)) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return classify_locked(ctx, search, ref, n_reads, call, nullptr);
+}
+
+extern "C" int kmg_classify_reads_hits(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t n_reads, int32_t *call,
+                                       uint8_t *has_hit) {
+    if (!ctx || !search || !ref || (n_reads && (!call || !has_hit))) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return classify_locked(ctx, search, ref, n_reads, call, has_hit);
 }
 
 extern "C" int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, int64_t *match, int64_t *unique,

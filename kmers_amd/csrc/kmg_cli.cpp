@@ -648,6 +648,58 @@ int make_database_preprocessed(const Args &a, int k, int key_len, int level) {
     return 0;
 }
 
+// FASTA (reference) or FASTQ (reads) text -> database on the GPU; for reads also the read-name map file
+// (ReadIDMapping.geNext prints a header each time a new index is handed out: gzip text, one per line) unless
+// read_map is empty, and the number of read indices.
+kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int key_len, bool filters, int dust, int runofsame,
+                        const std::string &read_map, uint64_t *n_reads, uint64_t *nwin, StageClock &clk) {
+    const std::string data = read_input(path);
+    clk.lap("read input");
+    kmh_batch *b = kmh_parse((const uint8_t *)data.data(), data.size(), reads ? 1 : 0, k);
+    const uint64_t nseq = kmh_nseq(b);
+    const uint64_t *off = kmh_seq_off(b);
+    if (!reads) {
+        const uint8_t *ok = kmh_id_ok(b);
+        for (uint64_t s = 0; s < nseq; s++)   // Integer.parseInt throws at the sequence's first k-mer
+            if (!ok[s] && off[s + 1] - off[s] >= (uint64_t)k) {
+                kmh_free(b);
+                throw std::runtime_error("NumberFormatException: FASTA header of sequence " + std::to_string(s) + " is not an int");
+            }
+    }
+    clk.lap("split records (host)");
+    g.check(kmg_build_begin(g.ctx, k, key_len, reads ? 0 : 1, reads ? KMG_PAYLOAD_READPOS : KMG_PAYLOAD_TAXON));
+    if (filters) g.check(kmg_build_set_filters(g.ctx, dust, runofsame));
+    std::vector<int32_t> ridx(reads ? nseq : 0);
+    g.check(kmg_build_add(g.ctx, kmh_bases(b), kmh_nbases(b), off, reads ? nullptr : kmh_seq_id(b),
+                          reads ? kmh_seq_tok(b) : nullptr, nseq, reads ? ridx.data() : nullptr));
+    kmg_db *db = nullptr;
+    g.check(kmg_build_finish(g.ctx, &db, nwin));
+    clk.lap("copy in + build (GPU)");
+    if (reads) {
+        int32_t top = -1;
+        for (uint64_t s = 0; s < nseq; s++) top = std::max(top, ridx[s]);
+        if (n_reads) *n_reads = (uint64_t)(top + 1);
+        if (!read_map.empty()) {
+            gzFile z = gzopen(read_map.c_str(), "wb");
+            if (!z) { kmh_free(b); kmg_db_free(db); throw std::runtime_error("cannot create " + read_map); }
+            const int64_t *tok = kmh_seq_tok(b);
+            const uint64_t *noff = kmh_name_off(b);
+            const char *names = kmh_names(b);
+            int32_t last = -1;
+            for (uint64_t s = 0; s < nseq; s++)
+                if (ridx[s] >= 0 && ridx[s] != last) {
+                    gzwrite(z, names + noff[tok[s]], (unsigned)(noff[tok[s] + 1] - noff[tok[s]]));
+                    gzwrite(z, "\n", 1);
+                    last = ridx[s];
+                }
+            gzclose(z);
+            clk.lap("read-name map");
+        }
+    }
+    kmh_free(b);
+    return db;
+}
+
 int make_database(int argc, char **argv) {
     const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmN", "aqpZvh");
     for (char c : std::string("mN")) if (a.has(c)) throw Unsupported(std::string("option -") + c + " is not on the GPU path");
@@ -662,49 +714,11 @@ int make_database(int argc, char **argv) {
     const bool reads = a.has('q');
     if (reads && !a.has('r')) throw std::runtime_error("-r <read map file> is required with -q");   // MakeDatabase.java:172-173
     StageClock clk(a.has('v'));
-    const std::string data = read_input(a.get('i'));
-    clk.lap("read input");
-    kmh_batch *b = kmh_parse((const uint8_t *)data.data(), data.size(), reads ? 1 : 0, k);
-    const uint64_t nseq = kmh_nseq(b);
-    const uint64_t *off = kmh_seq_off(b);
-    if (!reads) {
-        const uint8_t *ok = kmh_id_ok(b);
-        for (uint64_t s = 0; s < nseq; s++)   // Integer.parseInt throws at the sequence's first k-mer
-            if (!ok[s] && off[s + 1] - off[s] >= (uint64_t)k) {
-                kmh_free(b);
-                throw std::runtime_error("NumberFormatException: FASTA header of sequence " + std::to_string(s) + " is not an int");
-            }
-    }
-    clk.lap("split records (host)");
     Gpu g;
     clk.lap("GPU context");
-    g.check(kmg_build_begin(g.ctx, k, key_len, reads ? 0 : 1, reads ? KMG_PAYLOAD_READPOS : KMG_PAYLOAD_TAXON));
-    if (a.has('D') || a.has('R')) g.check(kmg_build_set_filters(g.ctx, a.geti('D', -1), a.geti('R', -1)));
-    std::vector<int32_t> ridx(reads ? nseq : 0);
-    g.check(kmg_build_add(g.ctx, kmh_bases(b), kmh_nbases(b), off, reads ? nullptr : kmh_seq_id(b),
-                          reads ? kmh_seq_tok(b) : nullptr, nseq, reads ? ridx.data() : nullptr));
-    kmg_db *db = nullptr;
     uint64_t nwin = 0;
-    g.check(kmg_build_finish(g.ctx, &db, &nwin));
-    clk.lap("copy in + build (GPU)");
-    if (reads) {
-        // ReadIDMapping.geNext prints a header each time a new index is handed out (gzip text, one per line)
-        gzFile z = gzopen(a.get('r').c_str(), "wb");
-        if (!z) throw std::runtime_error("cannot create " + a.get('r'));
-        const int64_t *tok = kmh_seq_tok(b);
-        const uint64_t *noff = kmh_name_off(b);
-        const char *names = kmh_names(b);
-        int32_t last = -1;
-        for (uint64_t s = 0; s < nseq; s++)
-            if (ridx[s] >= 0 && ridx[s] != last) {
-                gzwrite(z, names + noff[tok[s]], (unsigned)(noff[tok[s] + 1] - noff[tok[s]]));
-                gzwrite(z, "\n", 1);
-                last = ridx[s];
-            }
-        gzclose(z);
-    }
-    kmh_free(b);
-    clk.lap("read-name map");
+    kmg_db *db = build_from_text(g, a.get('i'), reads, k, key_len, a.has('D') || a.has('R'), a.geti('D', -1), a.geti('R', -1),
+                                 reads ? a.get('r') : "", nullptr, &nwin, clk);
     write_database(g, db, a.get('o'), level, a.has('S') ? size_from_human(a.get('S')) : 0, a.has('h'));
     clk.lap("encode + deflate + write");
     if (a.has('v')) {
@@ -1006,11 +1020,60 @@ int read_classifier(int argc, char **argv) {
     return 0;
 }
 
+// Pipeline.ReadCalls -q reads.fq (-d database | -a reference.fa) -o calls [-K k -l key_length -r read_map.gz]
+// The file the chain MakeDatabase -q | Matcher | CollectByRead | ReadClassifier ends with, byte for byte, without the
+// three files in between: both databases stay on the GPU, the join feeds kmg_classify_reads_hits and only the
+// `read \t call` lines leave.  No counterpart program in the reference.
+int read_calls(int argc, char **argv) {
+    const Args a = parse_args(argc, argv, 2, "qdaoKlrt", "v");
+    if (!a.has('q') || !a.has('o') || a.has('d') == a.has('a'))
+        throw std::runtime_error("-q, -o and exactly one of -d (database) / -a (FASTA reference) are required");
+    g_threads = std::max(1, a.geti('t', g_threads));
+    StageClock clk(a.has('v'));
+    Gpu g;
+    clk.lap("GPU context");
+    int k = a.geti('K', 32), key_len = a.geti('l', 6);
+    kmg_db *ref = nullptr;
+    if (a.has('d')) {
+        ref = open_database_set(g, a.get('d'));
+        const DbInfo rd = db_info(ref);
+        k = rd.k; key_len = rd.key_len;
+        clk.lap("read + decode database");
+    } else ref = build_from_text(g, a.get('a'), false, k, key_len, false, -1, -1, "", nullptr, nullptr, clk);
+    if (!db_info(ref).rc)   // DB.java:57-64
+        throw std::runtime_error("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included");
+    uint64_t n_reads = 0;
+    kmg_db *reads = build_from_text(g, a.get('q'), true, k, key_len, false, -1, -1, a.get('r'), &n_reads, nullptr, clk);
+    std::vector<int32_t> call(std::max<uint64_t>(n_reads, 1), -1);
+    std::vector<uint8_t> seen(std::max<uint64_t>(n_reads, 1), 0);
+    g.check(kmg_classify_reads_hits(g.ctx, reads, ref, n_reads, call.data(), seen.data()));
+    kmg_db_free(reads);
+    kmg_db_free(ref);
+    clk.lap("join + classify (GPU)");
+    // one block per (read / 1000) * 1000 that holds a read with a matched k-mer (CollectByRead.java:105-124 writes no
+    // other); inside, the reads that have a call (ReadClassifier.java:140-160)
+    std::vector<std::pair<int, std::string>> blocks;
+    for (uint64_t base = 0; base < n_reads; base += 1000) {
+        const uint64_t end = std::min(n_reads, base + 1000);
+        bool any = false;
+        std::string out;
+        char buf[48];
+        for (uint64_t r = base; r < end; r++) {
+            any |= seen[r] != 0;
+            if (call[r] >= 0) out.append(buf, snprintf(buf, sizeof buf, "%llu\t%d\n", (unsigned long long)r, call[r]));
+        }
+        if (any) blocks.push_back({(int)base, std::move(out)});
+    }
+    write_text_blocks(a.get('o'), blocks);
+    clk.lap("write calls");
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: kmg Database.MakeDatabase|Database.Matcher|Utils.TaxaCounts|Utils.CollectByRead|Utils.ReadClassifier <options>\n");
+        fprintf(stderr, "usage: kmg Database.MakeDatabase|Database.Matcher|Utils.TaxaCounts|Utils.CollectByRead|Utils.ReadClassifier|Pipeline.ReadCalls <options>\n");
         return 1;
     }
     std::string prog = argv[1];
@@ -1022,6 +1085,7 @@ int main(int argc, char **argv) {
         if (prog == "TaxaCounts") return taxa_counts(argc, argv);
         if (prog == "CollectByRead") return collect_by_read(argc, argv);
         if (prog == "ReadClassifier") return read_classifier(argc, argv);
+        if (prog == "ReadCalls") return read_calls(argc, argv);
         fprintf(stderr, "unknown program %s\n", argv[1]);
         return 1;
     } catch (const Unsupported &e) {

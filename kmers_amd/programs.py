@@ -5,6 +5,7 @@ without a JVM):
   matcher        <- Database/Matcher.java       (-i -d -o -z|-Z)
   taxa_counts    <- Utils/TaxaCounts.java       (-d -o)
   collect_by_read <- Utils/CollectByRead.java   (-i -o)      read_classifier <- Utils/ReadClassifier.java (-i -o)
+  read_calls     = MakeDatabase -q + Matcher + CollectByRead + ReadClassifier in one go, no intermediate files
 """
 import gzip
 import struct
@@ -13,7 +14,7 @@ import numpy as np
 
 from . import container, parse
 from .api import (DB, KmerDatabase, KmersGpuError, READ_ID, REF_ID, classify_reads, collect_by_read_blocks, kmer_strings,
-                  match_lines, merge_databases, taxa_count_lines)
+                  match_lines, merge_databases, read_call_blocks, taxa_count_lines)
 from ._lib import KMG_EUNSUPPORTED, PAYLOAD_READPOS, PAYLOAD_TAXON
 from .make_database import make_read_db, make_reference_db
 
@@ -348,5 +349,35 @@ def read_classifier(ctx, input_path, output_path):
         ref.close()
         for key, reads in block_reads.items():
             blocks[key] = "".join("%d\t%d\n" % (r, int(call[r])) for r in reads if r < n_reads and call[r] >= 0).encode()
+    _write_text_blocks(output_path, blocks)
+    return blocks
+
+
+def read_calls(ctx, reads_path, output_path, db_path=None, fasta_path=None, k=32, key_length=6, read_map_path=None):
+    """FASTQ reads + a reference (database file set -d, or FASTA -a) -> the file the reference's four-stage chain
+    MakeDatabase -q | Matcher | CollectByRead | ReadClassifier ends with, byte for byte, without the three files in
+    between (a 1M-read sample's match text alone is ~600 MB gzipped): both databases stay on the GPU, the join
+    feeds kmg_classify_reads_hits, and only `read \t call` lines leave.  No counterpart program in the reference."""
+    if (db_path is None) == (fasta_path is None):
+        raise ValueError("exactly one of -d (database) / -a (FASTA reference)")
+    if fasta_path is not None:
+        ref = make_reference_db(ctx, open(fasta_path, "rb").read(), k, key_length)
+    else:
+        files = container.file_set(db_path)
+        if not files:
+            raise FileNotFoundError(db_path)
+        ref = DB([open_database(ctx, f) for f in files]).merged
+        k, key_length = ref.k, ref.key_length
+    if not ref.rc:       # DB.java:57-64
+        raise ValueError("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included")
+    rdb, names = make_read_db(ctx, open(reads_path, "rb").read(), k, key_length)
+    if read_map_path is not None:
+        with gzip.open(read_map_path, "wt") as g:
+            for nm in names:
+                g.write(nm + "\n")
+    call, seen = classify_reads(rdb, ref, len(names), with_hits=True)
+    blocks = read_call_blocks(call, seen)
+    rdb.close()
+    ref.close()
     _write_text_blocks(output_path, blocks)
     return blocks

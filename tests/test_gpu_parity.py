@@ -747,6 +747,12 @@ def test_collect_by_read_and_classifier_match_oracle(ctx, k, l, n_reads, rlen, p
     call = km.classify_reads(rdb, ref, len(names))
     assert _classifier_blocks(call, want) == R.read_classifier(want)
     assert (call >= 0).sum() > 100 and (call < 0).sum() > 0
+    # kmg_classify_reads_hits: the same calls + which reads have a matched k-mer = ReadClassifier's file without the
+    # match text and CollectByRead's file in between
+    call2, seen = km.classify_reads(rdb, ref, len(names), with_hits=True)
+    assert np.array_equal(call2, call)
+    assert np.array_equal(np.nonzero(seen)[0], np.unique(read))
+    assert km.read_call_blocks(call2, seen) == R.read_classifier(want)
     with pytest.raises(km.InconsistentDataException):
         km.classify_reads(rdb, ref, len(names) - 1)                  # a read index outside n_reads
     with pytest.raises(km.InconsistentDataException):
@@ -777,6 +783,8 @@ def test_collect_by_read_skew_and_empty(ctx):
     r, p, i = km.collect_by_read(stranger, ref)
     assert len(r) == 0 and km.collect_by_read_blocks(stranger, ref) == {}
     assert np.all(km.classify_reads(stranger, ref, 50) == -1)
+    c, s = km.classify_reads(stranger, ref, 50, with_hits=True)
+    assert np.all(c == -1) and not s.any() and km.read_call_blocks(c, s) == {}
     for d in (ref, rdb, stranger):
         d.close()
 

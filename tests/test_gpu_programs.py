@@ -65,7 +65,14 @@ def test_programs_end_to_end(tmp_path):
     rcb = programs.read_classifier(ctx, str(tmp_path / "collected"), str(tmp_path / "calls"))
     assert rcb == R.read_classifier(want_cb) and sum(len(v) for v in rcb.values()) > 1000
     assert R.read_indexed_file(str(tmp_path / "calls")) == rcb
+    # the four-stage chain in one go, nothing in between on disk: the same file, from the database and from the FASTA
+    assert programs.read_calls(ctx, fq, str(tmp_path / "calls.fused"), db_path=refdb, read_map_path=str(tmp_path / "map2.gz")) == rcb
+    assert open(str(tmp_path / "calls.fused"), "rb").read() == open(str(tmp_path / "calls"), "rb").read()
+    assert gzip.open(str(tmp_path / "map2.gz"), "rt").read().splitlines() == o_reads.names
+    assert programs.read_calls(ctx, fq, str(tmp_path / "calls.fused2"), fasta_path=fa, k=k, key_length=l) == rcb
     ctx.close()
+    assert cli(["Pipeline.ReadCalls", "-q", fq, "-d", refdb, "-o", str(tmp_path / "cli.fused")]) == 0
+    assert R.read_indexed_file(str(tmp_path / "cli.fused")) == rcb
     assert cli(["Utils.CollectByRead", "-i", str(tmp_path / "matches.gz"), "-o", str(tmp_path / "cli.collected")]) == 0
     assert cli(["Utils.ReadClassifier", "-i", str(tmp_path / "cli.collected"), "-o", str(tmp_path / "cli.calls")]) == 0
     assert R.read_indexed_file(str(tmp_path / "cli.calls")) == rcb
@@ -136,6 +143,15 @@ def test_native_cli_matches_python_drivers(tmp_path):
     run("Utils.ReadClassifier", "-i", p("by_read"), "-o", p("calls"))
     want_calls = R.read_classifier(want_cb)
     assert R.read_indexed_file(p("calls")) == want_calls and sum(len(v) for v in want_calls.values()) > 500
+    # the chain in one process, nothing in between on disk: the same file
+    run("Pipeline.ReadCalls", "-q", fq, "-d", p("refz.db"), "-o", p("calls.fused"), "-r", p("map2.gz"))
+    assert open(p("calls.fused"), "rb").read() == open(p("calls"), "rb").read()
+    assert gzip.open(p("map2.gz"), "rt").read().splitlines() == o_reads.names
+    run("Pipeline.ReadCalls", "-q", fq, "-a", fa, "-o", p("calls.fused2"), "-K", str(k), "-l", str(l))
+    assert R.read_indexed_file(p("calls.fused2")) == want_calls
+    open(p("none.fq"), "wb").write(b"@r\nNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN\n+\n" + b"I" * 40 + b"\n")
+    run("Pipeline.ReadCalls", "-q", p("none.fq"), "-d", p("ref.db"), "-o", p("calls.none"))
+    assert R.read_indexed_file(p("calls.none")) == {}
     open(p("empty.txt"), "wb").close()
     run("Utils.CollectByRead", "-i", p("empty.txt"), "-o", p("by_read.empty"))
     assert R.read_indexed_file(p("by_read.empty")) == {}

@@ -43,6 +43,11 @@ res["matcher_s"] = run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"
 res["taxacounts_s"] = run("Utils.TaxaCounts", "-d", p("ref.db"), "-o", p("counts.tsv"))
 res["collect_by_read_s"] = run("Utils.CollectByRead", "-i", p("matches.gz"), "-o", p("by_read"))
 res["read_classifier_s"] = run("Utils.ReadClassifier", "-i", p("by_read"), "-o", p("calls"), "-t", "16")
+# the same calls file from the reads and the reference database in one process, nothing in between on disk
+res["read_calls_fused_s"] = run("Pipeline.ReadCalls", "-q", fq, "-d", p("ref.db"), "-o", p("calls.fused"), "-t", "16", "-v")
+res["read_calls_fused_from_fasta_s"] = run("Pipeline.ReadCalls", "-q", fq, "-a", fa, "-o", p("calls.fused2"), "-K", "31", "-l", "6", "-t", "16")
+res["fused_equals_staged"] = open(p("calls.fused"), "rb").read() == open(p("calls"), "rb").read() == open(p("calls.fused2"), "rb").read()
+res["staged_chain_s"] = res["make_reads_z5_s"] + res["matcher_s"] + res["collect_by_read_s"] + res["read_classifier_s"]
 res["sizes_MB"] = {n: round(os.path.getsize(p(n)) / 1e6, 1) for n in ("ref.db", "reads.db", "readsZ.db", "matches.gz", "by_read", "calls")}
 res["built_kmers_per_s_end_to_end"] = (n_ref_win + n_read_win) / (res["make_ref_z5_s"] + res["make_reads_z5_s"])
 print(json.dumps(res))
