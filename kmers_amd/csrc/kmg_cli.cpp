@@ -516,23 +516,44 @@ kmg_db *open_database(const Gpu &g, const std::string &path) {
     if (ids == std::vector<uint32_t>{2048}) kind = KMG_PAYLOAD_TAXON;
     else if (ids == std::vector<uint32_t>{257, 2052}) kind = KMG_PAYLOAD_READPOS;
     else throw std::runtime_error("UnexpectedDataTypeException: " + path);   // KmerFile.java:30-33
-    // blocks of every key >= 0, inflated in parallel, concatenated in key order
-    std::vector<std::pair<uint64_t, uint64_t>> blocks;
-    for (auto &kv : f.index) if (kv.first >= 0) for (auto &b : kv.second) blocks.push_back(b);
-    std::vector<std::string> parts(blocks.size());
-    parallel_for(blocks.size(), [&](size_t i) { parts[i] = f.block(blocks[i].first, blocks[i].second); });
-    std::string all;
-    size_t total = 0;
-    for (auto &p : parts) total += p.size();
-    all.reserve(total);
-    for (auto &p : parts) { all += p; std::string().swap(p); }
-    kmh_batch *dec = kmh_decode_blocks((const uint8_t *)all.data(), all.size(), kind);
-    if (!dec) throw std::runtime_error("corrupt k-mer blocks (or k > 32): " + path);
+    // Every key's block is a stream of its own (its first record shares nothing, FileCreator.java:315), so the keys
+    // are inflated and decoded side by side and their arrays laid end to end in key order.
+    std::vector<const std::vector<std::pair<uint64_t, uint64_t>> *> per_key;
+    for (auto &kv : f.index) if (kv.first >= 0) per_key.push_back(&kv.second);
+    const size_t nk = per_key.size();
+    std::vector<kmh_batch *> dec(nk, nullptr);
+    std::atomic<bool> bad{false};
+    parallel_for(nk, [&](size_t i) {
+        std::string bytes;
+        for (auto &b : *per_key[i]) bytes += f.block(b.first, b.second);
+        dec[i] = kmh_decode_blocks((const uint8_t *)bytes.data(), bytes.size(), kind);
+        if (!dec[i]) bad = true;
+    });
+    std::vector<uint64_t> kbase(nk + 1, 0), vbase(nk + 1, 0);
+    for (size_t i = 0; i < nk && !bad; i++) {
+        kbase[i + 1] = kbase[i] + kmh_decoded_nkeys(dec[i]);
+        vbase[i + 1] = vbase[i] + kmh_decoded_nvals(dec[i]);
+    }
+    std::vector<uint64_t> keys, val_off;
+    std::vector<int32_t> va, vb;
+    if (!bad) {
+        keys.resize(kbase[nk] + 1); val_off.resize(kbase[nk] + 1); va.resize(vbase[nk] + 1); vb.resize(vbase[nk] + 1);
+        parallel_for(nk, [&](size_t i) {
+            const uint64_t n = kmh_decoded_nkeys(dec[i]), v = kmh_decoded_nvals(dec[i]);
+            if (n) memcpy(&keys[kbase[i]], kmh_decoded_keys(dec[i]), n * 8);
+            const uint64_t *o = kmh_decoded_val_off(dec[i]);
+            for (uint64_t j = 0; j < n; j++) val_off[kbase[i] + j] = vbase[i] + o[j];
+            if (v) {
+                memcpy(&va[vbase[i]], kmh_decoded_val_a(dec[i]), v * 4);
+                memcpy(&vb[vbase[i]], kmh_decoded_val_b(dec[i]), v * 4);
+            }
+        });
+        val_off[kbase[nk]] = vbase[nk];
+    }
+    for (auto d : dec) if (d) kmh_decoded_free(d);
+    if (bad) throw std::runtime_error("corrupt k-mer blocks (or k > 32): " + path);
     kmg_db *db = nullptr;
-    const int r = kmg_db_load(g.ctx, max_k, key_len, rc, kind, kmh_decoded_keys(dec), kmh_decoded_nkeys(dec),
-                              kmh_decoded_val_off(dec), kmh_decoded_val_a(dec), kmh_decoded_val_b(dec), &db);
-    kmh_decoded_free(dec);
-    g.check(r);
+    g.check(kmg_db_load(g.ctx, max_k, key_len, rc, kind, keys.data(), kbase[nk], val_off.data(), va.data(), vb.data(), &db));
     return db;
 }
 
@@ -655,16 +676,15 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
                         const std::string &read_map, uint64_t *n_reads, uint64_t *nwin, StageClock &clk) {
     const std::string data = read_input(path);
     clk.lap("read input");
-    kmh_batch *b = kmh_parse((const uint8_t *)data.data(), data.size(), reads ? 1 : 0, k);
+    const std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch(kmh_parse((const uint8_t *)data.data(), data.size(), reads ? 1 : 0, k), kmh_free);
+    const kmh_batch *b = batch.get();
     const uint64_t nseq = kmh_nseq(b);
     const uint64_t *off = kmh_seq_off(b);
     if (!reads) {
         const uint8_t *ok = kmh_id_ok(b);
         for (uint64_t s = 0; s < nseq; s++)   // Integer.parseInt throws at the sequence's first k-mer
-            if (!ok[s] && off[s + 1] - off[s] >= (uint64_t)k) {
-                kmh_free(b);
+            if (!ok[s] && off[s + 1] - off[s] >= (uint64_t)k)
                 throw std::runtime_error("NumberFormatException: FASTA header of sequence " + std::to_string(s) + " is not an int");
-            }
     }
     clk.lap("split records (host)");
     g.check(kmg_build_begin(g.ctx, k, key_len, reads ? 0 : 1, reads ? KMG_PAYLOAD_READPOS : KMG_PAYLOAD_TAXON));
@@ -681,7 +701,7 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
         if (n_reads) *n_reads = (uint64_t)(top + 1);
         if (!read_map.empty()) {
             gzFile z = gzopen(read_map.c_str(), "wb");
-            if (!z) { kmh_free(b); kmg_db_free(db); throw std::runtime_error("cannot create " + read_map); }
+            if (!z) { kmg_db_free(db); throw std::runtime_error("cannot create " + read_map); }
             const int64_t *tok = kmh_seq_tok(b);
             const uint64_t *noff = kmh_name_off(b);
             const char *names = kmh_names(b);
@@ -696,7 +716,6 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
             clk.lap("read-name map");
         }
     }
-    kmh_free(b);
     return db;
 }
 
@@ -745,19 +764,29 @@ HostDb fetch(const Gpu &g, const kmg_db *db) {
 
 // "r:p|r:p" (SetCompressor.toString over ReadPosDataType.java:46-49) or "TxC|TxC" (CountDataType.java:109-113;
 // counts print as the stored byte, i.e. saturated at 255, CountDataType.java:40)
+// decimal text of a Java int, appended (the match text holds hundreds of millions of them)
+inline void append_int(std::string &s, int32_t v) {
+    char buf[12];
+    char *e = buf + sizeof buf, *p = e;
+    uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+    do { *--p = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *--p = '-';
+    s.append(p, (size_t)(e - p));
+}
 void append_values(std::string &s, const HostDb &h, uint64_t i) {
-    char buf[48];
+    const bool reads = h.d.kind == KMG_PAYLOAD_READPOS;
     for (uint64_t v = h.val_off[i]; v < h.val_off[i + 1]; v++) {
         if (v != h.val_off[i]) s.push_back('|');
-        if (h.d.kind == KMG_PAYLOAD_READPOS) snprintf(buf, sizeof buf, "%d:%d", h.a[v], h.b[v]);
-        else snprintf(buf, sizeof buf, "%dx%d", h.a[v], std::min(h.b[v], 255));
-        s += buf;
+        append_int(s, h.a[v]);
+        s.push_back(reads ? ':' : 'x');
+        append_int(s, reads ? h.b[v] : std::min(h.b[v], 255));
     }
 }
 
 int matcher(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "idozZnt", "");
+    const Args a = parse_args(argc, argv, 2, "idozZnt", "v");
     if (a.geti('n', 0) != 0) throw Unsupported("inexact search (-n > 0) stays on the Java path");
+    StageClock clk(a.has('v'));
     if (!a.has('i') || !a.has('d') || !a.has('o')) throw std::runtime_error("-i, -d and -o are required");
     g_threads = std::max(1, a.geti('t', g_threads));
     Gpu g;
@@ -767,8 +796,10 @@ int matcher(int argc, char **argv) {
         throw std::runtime_error("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included");
     std::vector<int64_t> hit(sd.U + 1);
     uint64_t nh = 0;
+    clk.lap("read + decode databases");
     g.check(kmg_match(g.ctx, search, ref, hit.data(), &nh));
     const HostDb hs = fetch(g, search), hr = fetch(g, ref);
+    clk.lap("match (GPU) + fetch");
     // one line per matched search k-mer, ascending (Matcher.java:247-249, ResultsDataType.java:15-35):
     //   KMER \t values of the search k-mer \t -|values of the reference k-mer       ("-" = empty KmerDiff)
     std::vector<uint64_t> rows;
@@ -779,6 +810,7 @@ int matcher(int argc, char **argv) {
     parallel_for(nchunk, [&](size_t c) {
         std::string &s = text[c];
         const size_t lo = c * 65536, hi = std::min(rows.size(), lo + 65536);
+        s.reserve((hi - lo) * (size_t)(sd.k + 48));
         for (size_t r = lo; r < hi; r++) {
             const uint64_t i = rows[r], key = hs.keys[i];
             for (int p = 0; p < sd.k; p++) s.push_back("ACTG"[(key >> (62 - 2 * p)) & 3]);   // Sequence.java:117-134
@@ -789,6 +821,7 @@ int matcher(int argc, char **argv) {
             s.push_back('\n');
         }
     });
+    clk.lap("format match lines");
     if (a.has('Z')) {
         FILE *f = fopen(a.get('o').c_str(), "wb");
         if (!f) throw std::runtime_error("cannot create " + a.get('o'));
@@ -809,6 +842,7 @@ int matcher(int argc, char **argv) {
         for (auto &s : zipped) fwrite(s.data(), 1, s.size(), f);
         fclose(f);
     }
+    clk.lap("deflate + write");
     kmg_db_free(ref);
     kmg_db_free(search);
     return 0;
@@ -874,47 +908,99 @@ void parse_counts(const char *q, const char *end, JoinRows &j) {
 // Utils.CollectByRead -i <Matcher output> -o <file> (CollectByRead.java:28-90): the match lines are loaded back as
 // a read database and a reference database over the same k-mers (every k-mer hits itself) and transposed on the GPU.
 int collect_by_read(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "iof", "");
+    const Args a = parse_args(argc, argv, 2, "iof", "v");
     if (!a.has('i') || !a.has('o')) throw std::runtime_error("-i and -o are required");
+    StageClock clk(a.has('v'));
     const std::string text = read_input(a.get('i'));
+    clk.lap("read + inflate match text");
+    // the lines are parsed in slices cut at line ends, side by side, and the slices' arrays laid end to end
+    const size_t nslice = std::max<size_t>(1, std::min<size_t>((size_t)g_threads * 4, text.size() / (1 << 20)));
+    std::vector<size_t> cut(nslice + 1, text.size());
+    cut[0] = 0;
+    for (size_t c = 1; c < nslice; c++) {
+        const size_t at = text.find('\n', std::max(cut[c - 1], text.size() / nslice * c));
+        cut[c] = at == std::string::npos ? text.size() : at + 1;
+    }
+    std::vector<JoinRows> part(nslice);
+    std::vector<int> part_k(nslice, -1);
+    std::vector<std::string> unsupported(nslice);
+    parallel_for(nslice, [&](size_t c) {
+        JoinRows &j = part[c];
+        int &k = part_k[c];
+        size_t p0 = cut[c];
+        const size_t stop = cut[c + 1];
+        while (p0 < stop) {
+            size_t e = text.find('\n', p0);
+            if (e == std::string::npos) e = text.size();
+            if (e > p0) {
+                const char *line = text.data() + p0, *lend = text.data() + e;
+                const char *t1 = (const char *)memchr(line, '\t', lend - line);
+                const char *t2 = t1 ? (const char *)memchr(t1 + 1, '\t', lend - t1 - 1) : nullptr;
+                if (!t2) throw std::runtime_error("bad match line");
+                if (k < 0) k = (int)(t1 - line);
+                if ((int)(t1 - line) != k || k < 1 || k > 32) { unsupported[c] = "k-mers of different lengths or longer than 32"; return; }
+                uint64_t v = 0;
+                for (const char *ch = line; ch < t1; ch++) {
+                    int b;
+                    switch (*ch) { case 'A': b = 0; break; case 'C': b = 1; break; case 'T': b = 2; break; case 'G': b = 3; break;
+                                   default: throw std::runtime_error("bad k-mer in match line"); }
+                    v = (v << 2) | (uint64_t)b;
+                }
+                j.keys.push_back(k == 32 ? v : v << (64 - 2 * k));
+                for (const char *q = t1 + 1; q < t2;) {                       // r:p|r:p
+                    char *en;
+                    const long r = strtol(q, &en, 10);
+                    if (*en != ':') throw std::runtime_error("bad read position list");
+                    const long ps = strtol(en + 1, &en, 10);
+                    j.s_read.push_back((int32_t)r);
+                    j.s_pos.push_back((int32_t)ps);
+                    q = (*en == '|') ? en + 1 : t2;
+                }
+                j.s_off.push_back(j.s_read.size());
+                // exact matches only: one entry, diff "-"
+                if (t2 + 2 >= lend || t2[1] != '-' || t2[2] != '|' || memchr(t2 + 1, ' ', lend - t2 - 1)) {
+                    unsupported[c] = "inexact matches stay on the Java path";
+                    return;
+                }
+                parse_counts(t2 + 3, lend, j);
+            }
+            p0 = e + 1;
+        }
+    });
     JoinRows j;
     int k = -1;
-    size_t p0 = 0;
-    while (p0 < text.size()) {
-        size_t e = text.find('\n', p0);
-        if (e == std::string::npos) e = text.size();
-        if (e > p0) {
-            const char *line = text.data() + p0, *lend = text.data() + e;
-            const char *t1 = (const char *)memchr(line, '\t', lend - line);
-            const char *t2 = t1 ? (const char *)memchr(t1 + 1, '\t', lend - t1 - 1) : nullptr;
-            if (!t2) throw std::runtime_error("bad match line");
-            if (k < 0) k = (int)(t1 - line);
-            if ((int)(t1 - line) != k || k < 1 || k > 32) throw Unsupported("k-mers of different lengths or longer than 32");
-            uint64_t v = 0;
-            for (const char *c = line; c < t1; c++) {
-                int b;
-                switch (*c) { case 'A': b = 0; break; case 'C': b = 1; break; case 'T': b = 2; break; case 'G': b = 3; break;
-                              default: throw std::runtime_error("bad k-mer in match line"); }
-                v = (v << 2) | (uint64_t)b;
-            }
-            j.keys.push_back(k == 32 ? v : v << (64 - 2 * k));
-            for (const char *q = t1 + 1; q < t2;) {                       // r:p|r:p
-                char *en;
-                const long r = strtol(q, &en, 10);
-                if (*en != ':') throw std::runtime_error("bad read position list");
-                const long ps = strtol(en + 1, &en, 10);
-                j.s_read.push_back((int32_t)r);
-                j.s_pos.push_back((int32_t)ps);
-                q = (*en == '|') ? en + 1 : t2;
-            }
-            j.s_off.push_back(j.s_read.size());
-            // exact matches only: one entry, diff "-"
-            if (t2 + 2 >= lend || t2[1] != '-' || t2[2] != '|' || memchr(t2 + 1, ' ', lend - t2 - 1))
-                throw Unsupported("inexact matches stay on the Java path");
-            parse_counts(t2 + 3, lend, j);
-        }
-        p0 = e + 1;
+    for (size_t c = 0; c < nslice; c++) {
+        if (!unsupported[c].empty()) throw Unsupported(unsupported[c]);
+        if (part_k[c] < 0) continue;
+        if (k < 0) k = part_k[c];
+        if (part_k[c] != k) throw Unsupported("k-mers of different lengths or longer than 32");
     }
+    {
+        std::vector<uint64_t> kb(nslice + 1, 0), sb(nslice + 1, 0), rb(nslice + 1, 0);
+        for (size_t c = 0; c < nslice; c++) {
+            kb[c + 1] = kb[c] + part[c].keys.size();
+            sb[c + 1] = sb[c] + part[c].s_read.size();
+            rb[c + 1] = rb[c] + part[c].r_tax.size();
+        }
+        j.keys.resize(kb[nslice]); j.s_off.resize(kb[nslice] + 1); j.r_off.resize(kb[nslice] + 1);
+        j.s_read.resize(sb[nslice]); j.s_pos.resize(sb[nslice]); j.r_tax.resize(rb[nslice]); j.r_cnt.resize(rb[nslice]);
+        parallel_for(nslice, [&](size_t c) {
+            JoinRows &q = part[c];
+            std::copy(q.keys.begin(), q.keys.end(), j.keys.begin() + kb[c]);
+            for (size_t i = 0; i < q.keys.size(); i++) {
+                j.s_off[kb[c] + i] = sb[c] + q.s_off[i];
+                j.r_off[kb[c] + i] = rb[c] + q.r_off[i];
+            }
+            std::copy(q.s_read.begin(), q.s_read.end(), j.s_read.begin() + sb[c]);
+            std::copy(q.s_pos.begin(), q.s_pos.end(), j.s_pos.begin() + sb[c]);
+            std::copy(q.r_tax.begin(), q.r_tax.end(), j.r_tax.begin() + rb[c]);
+            std::copy(q.r_cnt.begin(), q.r_cnt.end(), j.r_cnt.begin() + rb[c]);
+            q = JoinRows();
+        });
+        j.s_off[kb[nslice]] = sb[nslice];
+        j.r_off[kb[nslice]] = rb[nslice];
+    }
+    clk.lap("parse match lines");
     std::vector<std::pair<int, std::string>> blocks;
     if (!j.keys.empty()) {
         Gpu g;
@@ -927,6 +1013,7 @@ int collect_by_read(int argc, char **argv) {
         g.check(kmg_collect_by_read(g.ctx, search, ref, &n, read.data(), pos.data(), idx.data()));
         kmg_db_free(search);
         kmg_db_free(ref);
+        clk.lap("load + transpose (GPU)");
         // block bounds: (read / 1000) * 1000; of two records with one (read, pos) the first is kept (TreeSet.add)
         std::vector<uint64_t> starts;
         for (uint64_t i = 0; i < n; i++)
@@ -935,20 +1022,30 @@ int collect_by_read(int argc, char **argv) {
         blocks.resize(starts.size() - 1);
         parallel_for(blocks.size(), [&](size_t b) {
             std::string out;
-            char buf[64];
+            out.reserve((starts[b + 1] - starts[b]) * 32);
             for (uint64_t i = starts[b]; i < starts[b + 1]; i++) {
+                // the hit k-mers' taxa lie anywhere in the reference arrays: fetch ahead
+                if (i + 16 < starts[b + 1]) __builtin_prefetch(&j.r_off[idx[i + 16]]);
+                if (i + 8 < starts[b + 1]) { __builtin_prefetch(&j.r_tax[j.r_off[idx[i + 8]]]); __builtin_prefetch(&j.r_cnt[j.r_off[idx[i + 8]]]); }
                 if (i > starts[b] && read[i] == read[i - 1] && pos[i] == pos[i - 1]) continue;
                 if (!out.empty()) out += '\n';
-                out.append(buf, snprintf(buf, sizeof buf, "%d:%d\t0:", read[i], pos[i]));
+                append_int(out, read[i]);
+                out += ':';
+                append_int(out, pos[i]);
+                out += "\t0:";
                 for (uint64_t t = j.r_off[idx[i]]; t < j.r_off[idx[i] + 1]; t++) {
                     if (t > j.r_off[idx[i]]) out += '|';
-                    out.append(buf, snprintf(buf, sizeof buf, "%dx%d", j.r_tax[t], std::min(j.r_cnt[t], 255)));
+                    append_int(out, j.r_tax[t]);
+                    out += 'x';
+                    append_int(out, std::min(j.r_cnt[t], 255));
                 }
             }
             blocks[b] = {(read[starts[b]] / 1000) * 1000, std::move(out)};
         });
+        clk.lap("format lines");
     }
     write_text_blocks(a.get('o'), blocks);
+    clk.lap("deflate + write");
     return 0;
 }
 
@@ -956,17 +1053,24 @@ int collect_by_read(int argc, char **argv) {
 // pseudo k-mer (its line number as a 32-mer) of a read database holding the line's (read, pos) and of a reference
 // database holding its dist-0 taxa; kmg_classify_reads then does processRead for all reads at once.
 int read_classifier(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "iot", "");
+    const Args a = parse_args(argc, argv, 2, "iot", "v");
     if (!a.has('i') || !a.has('o')) throw std::runtime_error("-i and -o are required");
     g_threads = std::max(1, a.geti('t', g_threads));
+    StageClock clk(a.has('v'));
     IndexedInputFile in(a.get('i'));
-    JoinRows j;
-    std::vector<std::pair<int, std::vector<int32_t>>> block_reads;
-    int32_t max_read = -1;
-    for (auto &kv : in.index) {
-        const std::string text = in.read_key(kv.first);
-        block_reads.push_back({kv.first, {}});
-        auto &reads = block_reads.back().second;
+    // every block is inflated and parsed on its own, side by side; the blocks' rows are then laid end to end
+    std::vector<int> block_key;
+    for (auto &kv : in.index) block_key.push_back(kv.first);
+    const size_t nb = block_key.size();
+    std::vector<JoinRows> part(nb);
+    std::vector<std::pair<int, std::vector<int32_t>>> block_reads(nb);
+    std::vector<int32_t> part_max(nb, -1);
+    parallel_for(nb, [&](size_t bi) {
+        const std::string text = in.read_key(block_key[bi]);
+        JoinRows &j = part[bi];
+        block_reads[bi].first = block_key[bi];
+        auto &reads = block_reads[bi].second;
+        int32_t &max_read = part_max[bi];
         size_t p0 = 0;
         while (p0 < text.size()) {
             size_t e = text.find('\n', p0);
@@ -986,10 +1090,8 @@ int read_classifier(int argc, char **argv) {
                     const long dist = strtol(q, &c, 10);
                     if (*c != ':') throw std::runtime_error("bad CollectByRead line");
                     if (dist == 0) {                                        // ReadClassifier.java:109,125
-                        j.keys.push_back(j.keys.size());
-                        j.s_read.push_back((int32_t)r);
+                        j.s_read.push_back((int32_t)r);      // (keys and offsets are the line numbers: filled in below)
                         j.s_pos.push_back((int32_t)ps);
-                        j.s_off.push_back(j.s_read.size());
                         parse_counts(c + 1, ee, j);
                         max_read = std::max(max_read, (int32_t)r);
                     }
@@ -998,7 +1100,35 @@ int read_classifier(int argc, char **argv) {
             }
             p0 = e + 1;
         }
+    });
+    JoinRows j;
+    int32_t max_read = -1;
+    {
+        std::vector<uint64_t> kb(nb + 1, 0), rb(nb + 1, 0);
+        for (size_t c = 0; c < nb; c++) {
+            kb[c + 1] = kb[c] + part[c].s_read.size();
+            rb[c + 1] = rb[c] + part[c].r_tax.size();
+            max_read = std::max(max_read, part_max[c]);
+        }
+        j.keys.resize(kb[nb]); j.s_off.resize(kb[nb] + 1); j.r_off.resize(kb[nb] + 1);
+        j.s_read.resize(kb[nb]); j.s_pos.resize(kb[nb]); j.r_tax.resize(rb[nb]); j.r_cnt.resize(rb[nb]);
+        parallel_for(nb, [&](size_t c) {
+            JoinRows &q = part[c];
+            for (size_t i = 0; i < q.s_read.size(); i++) {
+                j.keys[kb[c] + i] = kb[c] + i;                   // one pseudo k-mer per line: its number
+                j.s_off[kb[c] + i] = kb[c] + i;
+                j.r_off[kb[c] + i] = rb[c] + q.r_off[i];
+            }
+            std::copy(q.s_read.begin(), q.s_read.end(), j.s_read.begin() + kb[c]);
+            std::copy(q.s_pos.begin(), q.s_pos.end(), j.s_pos.begin() + kb[c]);
+            std::copy(q.r_tax.begin(), q.r_tax.end(), j.r_tax.begin() + rb[c]);
+            std::copy(q.r_cnt.begin(), q.r_cnt.end(), j.r_cnt.begin() + rb[c]);
+            q = JoinRows();
+        });
+        j.s_off[kb[nb]] = kb[nb];
+        j.r_off[kb[nb]] = rb[nb];
     }
+    clk.lap("read + inflate + parse");
     std::vector<int32_t> call((size_t)std::max<int32_t>(max_read + 1, 1), -1);
     if (!j.keys.empty()) {
         Gpu g;
@@ -1016,7 +1146,9 @@ int read_classifier(int argc, char **argv) {
             if (r >= 0 && r <= max_read && call[r] >= 0) out.append(buf, snprintf(buf, sizeof buf, "%d\t%d\n", r, call[r]));
         blocks.push_back({br.first, std::move(out)});
     }
+    clk.lap("classify (GPU) + format");
     write_text_blocks(a.get('o'), blocks);
+    clk.lap("deflate + write");
     return 0;
 }
 

@@ -39,10 +39,10 @@ common = ["-K", "31", "-k", "31", "-l", "6", "-t", "16"]
 res["make_ref_z5_s"] = run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("ref.db"), *common)
 res["make_reads_z5_s"] = run("Database.MakeDatabase", "-q", "-i", fq, "-o", p("reads.db"), "-r", p("map.gz"), *common)
 res["make_reads_unzipped_s"] = run("Database.MakeDatabase", "-q", "-i", fq, "-o", p("readsZ.db"), "-r", p("mapZ.gz"), "-Z", *common)
-res["matcher_s"] = run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("matches.gz"), "-t", "16")
+res["matcher_s"] = run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("matches.gz"), "-t", "16", "-v")
 res["taxacounts_s"] = run("Utils.TaxaCounts", "-d", p("ref.db"), "-o", p("counts.tsv"))
-res["collect_by_read_s"] = run("Utils.CollectByRead", "-i", p("matches.gz"), "-o", p("by_read"))
-res["read_classifier_s"] = run("Utils.ReadClassifier", "-i", p("by_read"), "-o", p("calls"), "-t", "16")
+res["collect_by_read_s"] = run("Utils.CollectByRead", "-i", p("matches.gz"), "-o", p("by_read"), "-v")
+res["read_classifier_s"] = run("Utils.ReadClassifier", "-i", p("by_read"), "-o", p("calls"), "-t", "16", "-v")
 # the same calls file from the reads and the reference database in one process, nothing in between on disk
 res["read_calls_fused_s"] = run("Pipeline.ReadCalls", "-q", fq, "-d", p("ref.db"), "-o", p("calls.fused"), "-t", "16", "-v")
 res["read_calls_fused_from_fasta_s"] = run("Pipeline.ReadCalls", "-q", fq, "-a", fa, "-o", p("calls.fused2"), "-K", "31", "-l", "6", "-t", "16")
