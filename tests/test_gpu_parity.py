@@ -243,6 +243,64 @@ def test_large_first_batch_then_more_batches(ctx):
         got.close()
 
 
+def test_concurrent_callers_on_one_context(ctx):
+    """The reference calls addKmers on ONE FileCreator from up to -t pool threads at once in -p mode
+    (MakeDatabase.java:220-236,259-265) and quickMatchCommonKey from `threads` pool threads (DB.java:191-207), so a
+    context has to take concurrent kmg_build_add / kmg_match / kmg_taxacounts calls (threading).  Eight
+    threads add eight slices of a reference in whatever order they get there -- a reference database does not depend
+    on it -- then eight threads join and count at once; everything equals the oracle's single-threaded answer."""
+    import threading
+    import kmers_amd as km
+    from kmers_amd import parse, synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(57, 24, 6000, shared_frac=0.3)
+    reads = synth.random_reads(58, genomes, 3000, 100, 0.01)
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    b = parse.parse(fa, parse.FASTA, 21).batch
+    fc = km.FileCreator(ctx, 5, 21, "ref", rc=True)
+    errors = []
+
+    def add(lo, hi):
+        try:
+            a0, a1 = int(b.seq_off[lo]), int(b.seq_off[hi])
+            fc.add_kmers(km.SequenceBatch(b.bases[a0:a1], b.seq_off[lo:hi + 1] - b.seq_off[lo], seq_id=b.seq_id[lo:hi]))
+        except Exception as e:                      # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    th = [threading.Thread(target=add, args=(3 * i, 3 * i + 3)) for i in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    ref = fc.create()
+    o_ref, o_reads = OracleDB(fa, 0, 21, 5, threads=4), OracleDB(fq, 1, 21, 5, threads=4)
+    _same_db(ref, o_ref)
+    rdb, _ = km.make_read_db(ctx, fq, 21, 5)
+    o_hit, o_nh = o_reads.match(o_ref)
+    o_t = o_ref.taxacounts()
+    results = [None] * 8
+
+    def query(i):
+        try:
+            hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
+            results[i] = (hit, nh, km.taxa_counts(ref))
+        except Exception as e:                      # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=query, args=(i,)) for i in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for hit, nh, (t_, m_, q_) in results:
+        assert nh == o_nh and np.array_equal(hit, o_hit)
+        assert np.array_equal(t_, o_t[0]) and np.array_equal(m_, o_t[1]) and np.array_equal(q_, o_t[2])
+    ref.close()
+    rdb.close()
+
+
 # ---------------------------------------------------------------------------- match + counts parity
 @pytest.mark.parametrize("k,key_len,seed", [(5, 2, 31), (9, 3, 32), (31, 6, 33)])
 def test_match_and_taxacounts_match_oracle(ctx, k, key_len, seed):
