@@ -243,6 +243,39 @@ def test_large_first_batch_then_more_batches(ctx):
         got.close()
 
 
+@pytest.mark.parametrize("k,l,shared", [(31, 6, 26), (32, 6, 29), (21, 4, 19)])
+def test_kmers_that_differ_only_in_their_last_bases(ctx, k, l, shared):
+    """Every other read starts with the same `shared` bases, so thousands of DIFFERENT k-mers agree on all leading
+    digits of the sort and only the lowest ones tell them apart (each of them twice: ties must keep their order) --
+    next to ordinary reads.  Both kinds of database, single batch (fused path) and two batches."""
+    import kmers_amd as km
+    from kmers_amd import parse, synth
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(1000 + k)
+    taxa, genomes = synth.random_genomes(61, 3, 4000)
+    head = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, shared)]
+    tails = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (2000, k + 6 - shared))]
+    tails[1000:] = tails[:1000]                                  # every such k-mer twice: ties must keep their order
+    same_start = np.concatenate([np.tile(head, (2000, 1)), tails], axis=1)
+    plain = synth.random_reads(62, genomes, 1500, k + 6, 0.01)
+    reads = np.concatenate([same_start, plain])[rng.permutation(3500)]
+    fq = synth.fastq_bytes(reads)
+    fa = b"".join(b">%d\n%s\n" % (70 + (i % 5), bytes(r)) for i, r in enumerate(reads))
+    for data, mode, kind, rc in ((fq, parse.FASTQ, "read", False), (fa, parse.FASTA, "ref", True)):
+        want = OracleDB(data, 0 if kind == "ref" else 1, k, l, threads=4)
+        b = parse.parse(data, mode, k).batch
+        for cuts in ([0, 3500], [0, 1700, 3500]):
+            fc = km.FileCreator(ctx, l, k, kind, rc=rc)
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                a0, a1 = int(b.seq_off[lo]), int(b.seq_off[hi])
+                fc.add_kmers(km.SequenceBatch(b.bases[a0:a1], b.seq_off[lo:hi + 1] - b.seq_off[lo],
+                                              seq_id=None if b.seq_id is None else b.seq_id[lo:hi],
+                                              seq_tok=None if b.seq_tok is None else b.seq_tok[lo:hi]))
+            got = fc.create()
+            _same_db(got, want)
+            got.close()
+
+
 def test_concurrent_callers_on_one_context(ctx):
     """The reference calls addKmers on ONE FileCreator from up to -t pool threads at once in -p mode
     (MakeDatabase.java:220-236,259-265) and quickMatchCommonKey from `threads` pool threads (DB.java:191-207), so a
