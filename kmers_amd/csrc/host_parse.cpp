@@ -10,16 +10,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <memory>
 #include <string>
-#include <string_view>
-#include <unordered_map>
 #include <vector>
 
 namespace {
 enum { S_ID = 0, S_KMER = 1, S_OTHER = 2 };
 
 struct Batch {
-    std::vector<uint8_t> bases;
+    std::unique_ptr<uint8_t[]> bases;   // not value-initialised: only what is written gets touched
+    uint64_t nbases = 0;
     std::vector<uint64_t> seq_off;   // nseq + 1
     std::vector<int32_t> seq_id;     // FASTA: Integer.parseInt(header id); 0 where unparsable
     std::vector<uint8_t> id_ok;      // FASTA: 1 if the header parsed as a Java int
@@ -28,6 +28,58 @@ struct Batch {
     std::string names;
     int eof_in_kmer = 0;             // file ended inside a sequence line whose last char was a base
     std::string err;
+};
+
+// Header strings -> tokens (equal <=> equal strings).  A flat open-addressing table over the names already stored in
+// the batch: one probe and one short memcmp per header (a node-based map spent three quarters of the parse here).
+struct NameTable {
+    struct Slot { uint64_t hash; int64_t tok; };       // tok < 0: empty
+    std::vector<Slot> slots;
+    size_t used = 0;
+    NameTable() : slots(1 << 16, Slot{0, -1}) {}
+    static uint64_t hash_of(const uint8_t *p, size_t n) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xD6E8FEB86659FD93ull);
+        while (n >= 8) {
+            uint64_t w;
+            memcpy(&w, p, 8);
+            h = (h ^ w) * 0xD6E8FEB86659FD93ull;
+            h ^= h >> 32;
+            p += 8; n -= 8;
+        }
+        uint64_t w = 0;
+        memcpy(&w, p, n);
+        h = (h ^ w) * 0xD6E8FEB86659FD93ull;
+        return h ^ (h >> 29);
+    }
+    void grow() {
+        std::vector<Slot> old(slots.size() * 2, Slot{0, -1});
+        old.swap(slots);
+        const size_t mask = slots.size() - 1;
+        for (const Slot &s : old)
+            if (s.tok >= 0) {
+                size_t i = s.hash & mask;
+                while (slots[i].tok >= 0) i = (i + 1) & mask;
+                slots[i] = s;
+            }
+    }
+    // token of the string, appended to names / name_off if it is new
+    int64_t intern(const uint8_t *p, size_t n, std::string &names, std::vector<uint64_t> &name_off) {
+        if (used * 2 >= slots.size()) grow();
+        const uint64_t h = hash_of(p, n);
+        const size_t mask = slots.size() - 1;
+        size_t i = h & mask;
+        for (; slots[i].tok >= 0; i = (i + 1) & mask) {
+            if (slots[i].hash != h) continue;
+            const uint64_t a = name_off[slots[i].tok], e = name_off[slots[i].tok + 1];
+            if (e - a == n && memcmp(names.data() + a, p, n) == 0) return slots[i].tok;
+        }
+        const int64_t tok = (int64_t)name_off.size() - 1;
+        names.append((const char *)p, n);
+        name_off.push_back(names.size());
+        slots[i] = Slot{h, tok};
+        used++;
+        return tok;
+    }
 };
 
 // Integer.parseInt: optional sign, at least one digit, fits in int32.
@@ -70,7 +122,7 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
         trans[S_OTHER]['@'] = S_ID; trans[S_KMER]['@'] = S_ID; trans[S_ID]['\n'] = S_KMER;
         trans[S_KMER]['+'] = S_OTHER;
     }
-    std::unordered_map<std::string_view, int64_t> intern;
+    NameTable intern;
     b->name_off.push_back(0);
     int state = S_OTHER;
     uint64_t id_start = 0, id_len = 0;
@@ -83,20 +135,13 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
             cur_ok = parse_java_int(data + id_start, id_len, &cur_id) ? 1 : 0;
             if (!cur_ok) cur_id = 0;
         } else {
-            std::string_view sv((const char *)data + id_start, id_len);
-            auto it = intern.find(sv);
-            if (it == intern.end()) {
-                cur_tok = (int64_t)intern.size();
-                intern.emplace(sv, cur_tok);
-                b->names.append(sv);
-                b->name_off.push_back(b->names.size());
-            } else cur_tok = it->second;
+            cur_tok = intern.intern(data + id_start, id_len, b->names, b->name_off);
         }
     };
     b->seq_off.push_back(0);   // seq_off = [0, end_0, end_1, ...]: a sequence is opened/closed in turn
     // bases are written through a raw pointer into a buffer sized for the whole input (it can only shrink)
-    b->bases.resize(n);
-    uint8_t *out = b->bases.data();
+    b->bases.reset(new uint8_t[n + (k > 0 ? (uint64_t)k : 0) + 1]);   // + room for the repeated last window (below)
+    uint8_t *out = b->bases.get();
     uint64_t nout = 0;
     auto close_seq_fast = [&]() {
         if (in_seq) { b->seq_off.push_back(nout); in_seq = false; }
@@ -105,6 +150,13 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
     bool special[3][256];
     for (int st = 0; st < 3; st++)
         for (int c = 0; c < 256; c++) special[st][c] = trans[st][c] >= 0;
+    // Whole lines at a time where nothing special happens (the bulk of any FASTA / FASTQ file): the characters of
+    // a state that have a transition, for the states that have one or two of them
+    int nsp[3] = {0, 0, 0};
+    uint8_t spc[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    for (int st = 0; st < 3; st++)
+        for (int c = 0; c < 256; c++)
+            if (special[st][c]) { if (nsp[st] < 2) spc[st][nsp[st]] = (uint8_t)c; nsp[st]++; }
     uint64_t i = 0;
     while (i < n) {
         const uint8_t c = data[i];
@@ -127,6 +179,28 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
         // a run of characters without a transition: handled in one go per state
         const bool *sp = special[state];
         uint64_t j = i + 1;
+        if (state == S_KMER && c > 32 && nsp[S_KMER] <= 2) {
+            // up to the end of the line: if it holds nothing but bases, copy it in one piece
+            const uint8_t *nl = (const uint8_t *)memchr(data + i, '\n', n - i);
+            const uint64_t end = nl ? (uint64_t)(nl - data) : n;
+            const uint8_t s1 = spc[S_KMER][0], s2 = nsp[S_KMER] == 2 ? spc[S_KMER][1] : spc[S_KMER][0];
+            unsigned odd = 0;
+            for (uint64_t q = i; q < end; q++) odd |= (unsigned)(data[q] <= 32) | (unsigned)(data[q] == s1) | (unsigned)(data[q] == s2);
+            if (!odd) {
+                memcpy(out + nout, data + i, end - i);
+                nout += end - i;
+                last_was_base = true;
+                i = end;
+                continue;
+            }
+        } else if (state != S_KMER && nsp[state] == 1) {
+            // header or quality text: straight to the one character that ends it
+            const uint8_t *at = (const uint8_t *)memchr(data + i, spc[state][0], n - i);
+            j = at ? (uint64_t)(at - data) : n;
+            if (state == S_ID) id_len += j - i;
+            i = j;
+            continue;
+        }
         if (state == S_KMER) {
             // sequence characters: everything > 32 is a base position (KmersFromFile.java:154-158)
             if (c > 32) { out[nout++] = c; last_was_base = true; } else last_was_base = false;
@@ -140,9 +214,9 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
         }
         i = j;
     }
-    b->bases.resize(nout);
+    b->nbases = nout;
     auto close_seq = [&]() {
-        if (in_seq) { b->seq_off.push_back(b->bases.size()); in_seq = false; }
+        if (in_seq) { b->seq_off.push_back(b->nbases); in_seq = false; }
     };
     const bool ended_in_kmer = state == S_KMER && in_seq && last_was_base;
     close_seq();
@@ -151,9 +225,10 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
         b->eof_in_kmer = 1;
         const uint64_t last_len = b->seq_off[nseq] - b->seq_off[nseq - 1];
         if (mode == 0 && k > 0 && last_len >= (uint64_t)k) {
-            size_t from = b->bases.size() - (size_t)k;
-            for (int j = 0; j < k; j++) b->bases.push_back(b->bases[from + j]);
-            b->seq_off.push_back(b->bases.size());
+            const uint64_t from = b->nbases - (uint64_t)k;
+            for (int j = 0; j < k; j++) out[b->nbases + j] = out[from + j];
+            b->nbases += (uint64_t)k;
+            b->seq_off.push_back(b->nbases);
             b->seq_id.push_back(b->seq_id.back());
             b->id_ok.push_back(b->id_ok.back());
         }
@@ -163,8 +238,8 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
 
 void kmh_free(kmh_batch *h) { delete (Batch *)h; }
 uint64_t kmh_nseq(const kmh_batch *h) { return ((const Batch *)h)->seq_off.size() - 1; }
-uint64_t kmh_nbases(const kmh_batch *h) { return ((const Batch *)h)->bases.size(); }
-const uint8_t *kmh_bases(const kmh_batch *h) { return ((const Batch *)h)->bases.data(); }
+uint64_t kmh_nbases(const kmh_batch *h) { return ((const Batch *)h)->nbases; }
+const uint8_t *kmh_bases(const kmh_batch *h) { return ((const Batch *)h)->bases.get(); }
 const uint64_t *kmh_seq_off(const kmh_batch *h) { return ((const Batch *)h)->seq_off.data(); }
 const int32_t *kmh_seq_id(const kmh_batch *h) { return ((const Batch *)h)->seq_id.data(); }
 const uint8_t *kmh_id_ok(const kmh_batch *h) { return ((const Batch *)h)->id_ok.data(); }
