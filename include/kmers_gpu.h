@@ -91,6 +91,15 @@ int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind);
  *                   (its RC goes with it); reads are numbered before the filters.  -1 = off.  Call
  *                   between kmg_build_begin and the first kmg_build_add. */
 int kmg_build_set_filters(kmg_ctx *ctx, int dust_threshold, int runofsame_length);
+/* kmg_build_set_key_range: build only the part of the database whose key buckets (Kmer.key(key_len), Kmer.java:47-55)
+ *   lie in [first_bucket, end_bucket) -- each record is judged by its own k-mer, so a reverse complement can be kept
+ *   where its forward k-mer is not.  Read numbering is not affected (as with the -D / -R filters: the mapper runs
+ *   first).  The reference builds its files key by key as well (FileCreator.MakeAndWriteKey, FileCreator.java:271-406),
+ *   so the blocks of several range builds over the same input, written in key order, are the file of one complete
+ *   build: inputs whose records do not fit one build (2^32-16) or the GPU's memory are built in passes, and ranks of
+ *   a multi-GPU build extract only what they own.  After kmg_build_begin, before the first add.  *n_windows of
+ *   kmg_build_finish then counts the forward windows kept. */
+int kmg_build_set_key_range(kmg_ctx *ctx, uint32_t first_bucket, uint32_t end_bucket);
 int kmg_build_add(kmg_ctx *ctx, const uint8_t *bases, uint64_t nbases, const uint64_t *seq_off,
                   const int32_t *seq_id, const int64_t *seq_tok, uint64_t nseq,
                   int32_t *read_index_out);

@@ -189,9 +189,10 @@ class FileCreator:
     """KmerFiles/FileCreator.java.  data_kind: 'ref' = DataCollector.getCountInstance (taxon payload,
     the reference passes rc=True, MakeDatabase.java:130), 'read' = getReadInstance (rc=False, :167)."""
 
-    def __init__(self, ctx, key_length, max_kmer_length, data_kind, rc, dust=None, runofsame=None):
+    def __init__(self, ctx, key_length, max_kmer_length, data_kind, rc, dust=None, runofsame=None, key_range=None):
         """dust / runofsame: the -D / -R stream filters of MakeDatabase.filterAndAdd (MakeDatabase.java:279-291),
-        fused into the extraction kernel."""
+        fused into the extraction kernel.  key_range = (first, end): only the k-mers of those key buckets are built
+        (kmg_build_set_key_range) -- one pass of a database built in key ranges, or one rank's share."""
         self.ctx = ctx
         self.key_length = key_length
         self.max_k = max_kmer_length
@@ -203,6 +204,8 @@ class FileCreator:
         if dust is not None or runofsame is not None:
             ctx.check(ctx.lib.kmg_build_set_filters(ctx.h, -1 if dust is None else dust,
                                                     -1 if runofsame is None else runofsame))
+        if key_range is not None:
+            ctx.check(ctx.lib.kmg_build_set_key_range(ctx.h, int(key_range[0]), int(key_range[1])))
 
     def add_kmers(self, batch, min_length=None, max_length=None):
         """addKmers (FileCreator.java:65-110).  Returns, for read DBs, the read index of every sequence

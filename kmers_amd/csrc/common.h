@@ -152,6 +152,8 @@ struct kmg_ctx {
     bool building = false;
     int k = 0, key_len = 0, rc = 0, kind = 0;
     int dust = -1, runofsame = -1;   // MakeDatabase -D / -R, -1 = off
+    bool ranged = false;             // kmg_build_set_key_range: keep the records of key buckets [range_lo, range_hi)
+    u32 range_lo = 0, range_hi = 0;
     u64 *rec_keys = nullptr;     // record keys (left-aligned 2-bit k-mers)
     void *rec_vals = nullptr;    // u32 taxon | u64 (read << 16 | pos16)
     u64 rec_cap = 0;             // capacity in records

@@ -100,6 +100,11 @@ struct ExtractArgs {
     int kind;
     int dust;                    // MakeDatabase -D threshold, -1 = off
     int runofsame;               // MakeDatabase -R length, -1 = off
+    // key-range builds (kmg_build_set_key_range): a record is kept iff its OWN key bucket -- the forward k-mer's
+    // for the forward record, the reverse complement's for the RC record -- lies in [range_lo, range_hi)
+    int ranged;
+    int range_shift;             // 64 - 2 * key_len
+    u32 range_lo, range_hi;
     // count pass outputs
     u32 *tile_count;
     u32 *tile_fwd;               // valid forward windows per tile
@@ -226,6 +231,14 @@ __global__ __launch_bounds__(EX_BLOCK) void extract_kernel(ExtractArgs a) {
             // Kmer.isOwnRC (Kmer.java:210-225) is a palindrome test on even lengths
             u64 rev = revpairs64(key >> (64 - 2 * k));
             emit_rc = !(((k & 1) == 0) && rev == key);
+            if (a.ranged && emit_rc) {
+                const u32 rb = (u32)((rev ^ (0xAAAAAAAAAAAAAAAAull & kmask)) >> a.range_shift);
+                emit_rc = rb >= a.range_lo && rb < a.range_hi;
+            }
+        }
+        if (a.ranged && ok) {
+            const u32 fb = (u32)(key >> a.range_shift);
+            ok = fb >= a.range_lo && fb < a.range_hi;
         }
         vmask |= (u32)ok << j;
         rmask |= (u32)emit_rc << j;
@@ -267,29 +280,27 @@ __global__ __launch_bounds__(EX_BLOCK) void extract_kernel(ExtractArgs a) {
     for (int j = 0; j < EX_ROUNDS; j++) {
         const bool ok = (vmask >> j) & 1, erc = (rmask >> j) & 1;
         u64 bal_v = __ballot(ok), bal_r = __ballot(erc);
-        if (ok) {
+        if (ok || erc) {
+        // (the RC record can be there without the forward one: key-range builds keep each by its own bucket)
         const u32 p = j * EX_BLOCK + tid;
         const u32 s = s_lo + seqrel[p];
-        u64 slot = out_base + wave_cnt[j][wave] + __popcll(bal_v & lt) + __popcll(bal_r & lt);
+        const u64 slot = out_base + wave_cnt[j][wave] + __popcll(bal_v & lt) + __popcll(bal_r & lt);
+        const u64 rslot = slot + (ok ? 1 : 0);
         const u64 key = fkey[j];
-        a.out_keys[slot] = key;
-        u64 rkey = 0;
-        if (erc) {
-            rkey = revpairs64(key >> (64 - 2 * k)) ^ (0xAAAAAAAAAAAAAAAAull & kmask);
-            a.out_keys[slot + 1] = rkey;
-        }
+        if (ok) a.out_keys[slot] = key;
+        if (erc) a.out_keys[rslot] = revpairs64(key >> (64 - 2 * k)) ^ (0xAAAAAAAAAAAAAAAAull & kmask);
         if (a.kind == KMG_PAYLOAD_TAXON) {
             u32 v = (u32)a.seq_id[s];
             u32 *ov = reinterpret_cast<u32 *>(a.out_vals);
-            ov[slot] = v;
-            if (erc) ov[slot + 1] = v;
+            if (ok) ov[slot] = v;
+            if (erc) ov[rslot] = v;
         } else {
             // ReadPos(read, (short)(pos - maxK)): offset of the window start within its sequence
             u64 pos16 = (u64)((t0 + p - a.seq_off[s]) & 0xFFFFu);
             u64 v = ((u64)(u32)a.read_index[s] << 16) | pos16;
             u64 *ov = reinterpret_cast<u64 *>(a.out_vals);
-            ov[slot] = v;
-            if (erc) ov[slot + 1] = v;
+            if (ok) ov[slot] = v;
+            if (erc) ov[rslot] = v;
         }
         }
     }

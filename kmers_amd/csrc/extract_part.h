@@ -235,6 +235,11 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
             emit_rc = !(((k & 1) == 0) && rev == key);
             rk = rev ^ rcx;
         }
+        if (a.ranged) {
+            const u32 fb = (u32)(key >> a.range_shift), rb = (u32)(rk >> a.range_shift);
+            emit_rc = emit_rc && rb >= a.range_lo && rb < a.range_hi;
+            ok = ok && fb >= a.range_lo && fb < a.range_hi;
+        }
         vmask |= (u32)ok << j;
         rmask |= (u32)emit_rc << j;
         if (!WRITE) {

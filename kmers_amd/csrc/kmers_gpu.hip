@@ -105,6 +105,7 @@ extern "C" int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int pay
     KMG_HIP(hipSetDevice(ctx->device));
     ctx->k = k; ctx->key_len = key_len; ctx->rc = rc ? 1 : 0; ctx->kind = payload_kind;
     ctx->dust = -1; ctx->runofsame = -1;
+    ctx->ranged = false; ctx->range_lo = 0; ctx->range_hi = 0;
     ctx->rec_upper = 0;
     ctx->n_adds = 0; ctx->prepart = false; ctx->plan_pbits = 0; ctx->compact_pb = 0; ctx->snap_valid = false;
     // stream-ordered, no host round trip
@@ -122,6 +123,19 @@ extern "C" int kmg_build_set_filters(kmg_ctx *ctx, int dust_threshold, int runof
     if (ctx->rec_upper) return fail(ctx, KMG_ESTATE, "filters must be set before the first kmg_build_add");
     ctx->dust = dust_threshold < 0 ? -1 : dust_threshold;
     ctx->runofsame = runofsame_length < 0 ? -1 : runofsame_length;
+    return KMG_OK;
+}
+
+extern "C" int kmg_build_set_key_range(kmg_ctx *ctx, uint32_t first_bucket, uint32_t end_bucket) {
+    if (!ctx) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!ctx->building) return fail(ctx, KMG_ESTATE, "kmg_build_set_key_range before kmg_build_begin");
+    if (ctx->n_adds) return fail(ctx, KMG_ESTATE, "the key range must be set before the first kmg_build_add");
+    const u32 nbuckets = 1u << (2 * ctx->key_len);
+    if (first_bucket >= end_bucket || end_bucket > nbuckets) return fail(ctx, KMG_EINVAL, "key range must be first < end <= 4^key_len");
+    ctx->ranged = !(first_bucket == 0 && end_bucket == nbuckets);
+    ctx->range_lo = first_bucket;
+    ctx->range_hi = end_bucket;
     return KMG_OK;
 }
 
@@ -174,8 +188,12 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         ctx->rec_vals = wide;
         ctx->compact_pb = 0;
     }
-    const u64 upper = ctx->rec_upper + nbases * (ctx->rc ? 2 : 1);
-    KMG_TRY(ensure_record_capacity(ctx, upper));
+    // Record buffers: sized for every window of the batch -- except in a key-range build, which keeps a fraction
+    // and exists for inputs whose full record set does not fit: there the count pass's total is fetched first
+    // (`exact` below) and the buffers hold exactly what the write pass will store.
+    const bool exact = ctx->ranged;
+    u64 upper = ctx->rec_upper + nbases * (ctx->rc ? 2 : 1);
+    if (!exact) KMG_TRY(ensure_record_capacity(ctx, upper));
 
     const u32 ntiles = div_up_u64(nbases, EX_TILE);
     PoolBuf tile_seq(ctx), tile_count(ctx), tile_fwd(ctx), tile_off(ctx), agg(ctx), has_kmer(ctx), read_index(ctx), tmp_a(ctx), tmp_b(ctx);
@@ -190,6 +208,7 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     a.bases = d_bases; a.nbases = nbases; a.seq_off = d_seq_off; a.nseq = nseq; a.seq_id = d_seq_id;
     a.tile_seq = tile_seq.as<u32>(); a.tile_end = tile_seq.as<u32>() + ntiles + 1; a.k = ctx->k; a.rc = ctx->rc; a.kind = ctx->kind;
     a.dust = ctx->dust; a.runofsame = ctx->runofsame;
+    a.ranged = ctx->ranged ? 1 : 0; a.range_shift = 64 - 2 * ctx->key_len; a.range_lo = ctx->range_lo; a.range_hi = ctx->range_hi;
     a.tile_count = tile_count.as<u32>(); a.tile_fwd = tile_fwd.as<u32>(); a.tile_off = tile_off.as<u64>();
     a.out_keys = ctx->rec_keys; a.out_vals = ctx->rec_vals; a.state = ctx->d_state;
     a.pos_bits = 16; a.pos_mask = 0xFFFFu;
@@ -295,6 +314,13 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         }
         KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, table.as<u32>(), table.as<u32>(), (u64)RS_DIGITS * pa.ncols, OpSum(),
                                                     0u, tagg.as<u32>(), nullptr, false, KP_SCAN)));
+        if (exact) {
+            u64 nrec = 0;
+            KMG_HIP(read_back(ctx, &nrec, ctx->d_state + ST_NREC, 8));
+            upper = std::max<u64>(nrec, 1);
+            KMG_TRY(ensure_record_capacity(ctx, upper));
+            a.out_keys = ctx->rec_keys; a.out_vals = ctx->rec_vals;
+        }
         if (len_pending) {
             u32 maxlen = 0;
             if (ctx->h_snap) {
@@ -318,6 +344,14 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     } else {
         KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, tile_count.as<u32>(), tile_off.as<u64>(), ntiles, OpSum(), 0ull,
                                                     agg.as<u64>(), nullptr, true, KP_SCAN)));
+        if (exact) {
+            u64 before = 0, added = 0;
+            KMG_HIP(read_back(ctx, &before, ctx->d_state + ST_NREC, 8));
+            KMG_HIP(read_back(ctx, &added, tile_off.as<u64>() + ntiles, 8));
+            upper = std::max<u64>(before + added, 1);
+            KMG_TRY(ensure_record_capacity(ctx, upper));
+            a.out_keys = ctx->rec_keys; a.out_vals = ctx->rec_vals;
+        }
         ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases /* + records * rec_b, added at finish when N is known */);
         hipLaunchKernelGGL((extract_kernel<true>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
         hipLaunchKernelGGL(extract_advance_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, tile_off.as<u64>(), ntiles);
@@ -632,7 +666,9 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     // prefix bits for the global passes: segments of ~1-2 K records on uniform data
     // (a single-batch build keeps the bits its extractor already partitioned the records by)
     const bool prepart = ctx->prepart && ctx->n_adds == 1;
-    const int pbits = prepart ? ctx->plan_pbits : choose_pbits(n, 2 * ctx->k);
+    // (a key-range build holds its records in a fraction of the prefixes: plan the segments for that density)
+    const u64 n_dense = ctx->ranged ? (u64)n * (1u << (2 * ctx->key_len)) / (ctx->range_hi - ctx->range_lo) : n;
+    const int pbits = prepart ? ctx->plan_pbits : choose_pbits(n_dense, 2 * ctx->k);
 
     PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx), seg(ctx), ucount(ctx);
     SortHeads heads;

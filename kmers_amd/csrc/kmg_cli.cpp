@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -347,12 +348,31 @@ DbInfo db_info(const kmg_db *db) {
 // the meta block written again, so every file of the set is a complete database over a contiguous key range.
 // The reference checks the limit per buffered write (it can cut inside a key's block); this writer cuts at key
 // boundaries only, so the split points are equivalent, not byte-identical.
-void write_database(const Gpu &g, const kmg_db *db, const std::string &path, int level, uint64_t max_size = 0, bool hr = false) {
+// FileCreator.create (FileCreator.java:117-217) on the output side: meta under key -1, then every key in ascending
+// order, each with a block.  add() appends the blocks of keys [key_lo, key_hi) of a database; a build done in
+// key-range passes calls it once per pass, in order.
+struct DatabaseWriter {
+    const Gpu &g;
+    std::string path;
+    int level;
+    uint64_t max_size;
+    bool hr;
+    std::unique_ptr<IndexedOutputFile> out;
+    std::string meta;
+    int nfiles = 1;
+    size_t keys_in_file = 0;
+    DatabaseWriter(const Gpu &g_, const std::string &path_, int level_, uint64_t max_size_, bool hr_)
+        : g(g_), path(path_), level(level_), max_size(max_size_), hr(hr_) {}
+    void add(const kmg_db *db, size_t key_lo, size_t key_hi);
+    void close() { if (out) out->close(); }
+};
+
+void DatabaseWriter::add(const kmg_db *db, size_t key_lo, size_t key_hi) {
     const DbInfo d = db_info(db);
     const size_t nkeys = (size_t)1 << (2 * d.key_len);
     std::vector<uint8_t> bytes;
     std::vector<uint64_t> off(nkeys + 1);
-    std::string meta;
+    meta.clear();
     if (!hr) {
         uint64_t nbytes = 0;
         g.check(kmg_db_encode(g.ctx, db, nullptr, 0, &nbytes, nullptr));
@@ -373,6 +393,7 @@ void write_database(const Gpu &g, const kmg_db *db, const std::string &path, int
         g.check(kmg_db_fetch(db, keys.data(), val_off.data(), va.data(), vb.data(), boff.data()));
         std::vector<std::string> text(nkeys);
         parallel_for(nkeys, [&](size_t key) {
+            if (key < key_lo || key >= key_hi) return;
             std::string &t = text[key];
             std::string last((size_t)d.k, ' '), nxt((size_t)d.k, ' ');
             char buf[48];
@@ -399,12 +420,14 @@ void write_database(const Gpu &g, const kmg_db *db, const std::string &path, int
     }
     std::vector<std::string> blobs(nkeys);
     if (level >= 0)
-        parallel_for(nkeys, [&](size_t key) { blobs[key] = gzip_member(bytes.data() + off[key], off[key + 1] - off[key], level); });
-    std::unique_ptr<IndexedOutputFile> out(new IndexedOutputFile(path, level, hr));
-    out->add_block(-1, out->pack(meta, level));
-    int nfiles = 1;
-    size_t keys_in_file = 0;
-    for (size_t key = 0; key < nkeys; key++) {
+        parallel_for(nkeys, [&](size_t key) {
+            if (key >= key_lo && key < key_hi) blobs[key] = gzip_member(bytes.data() + off[key], off[key + 1] - off[key], level);
+        });
+    if (!out) {
+        out.reset(new IndexedOutputFile(path, level, hr));
+        out->add_block(-1, out->pack(meta, level));
+    }
+    for (size_t key = key_lo; key < key_hi && key < nkeys; key++) {
         const std::string blob = level >= 0 ? std::move(blobs[key])
                                             : std::string((const char *)bytes.data() + off[key], off[key + 1] - off[key]);
         const uint64_t tail = 24 * (keys_in_file + 2) + 256;     // index + footer still to come
@@ -419,7 +442,12 @@ void write_database(const Gpu &g, const kmg_db *db, const std::string &path, int
         out->add_block((int)key, blob);
         keys_in_file++;
     }
-    out->close();
+}
+
+void write_database(const Gpu &g, const kmg_db *db, const std::string &path, int level, uint64_t max_size = 0, bool hr = false) {
+    DatabaseWriter w(g, path, level, max_size, hr);
+    w.add(db, 0, (size_t)1 << (2 * db_info(db).key_len));
+    w.close();
 }
 
 // jar Files.SizeConvertor.fromHuman: a byte count with an optional K / M / G / T suffix (powers of 1024)
@@ -672,8 +700,11 @@ int make_database_preprocessed(const Args &a, int k, int key_len, int level) {
 // FASTA (reference) or FASTQ (reads) text -> database on the GPU; for reads also the read-name map file
 // (ReadIDMapping.geNext prints a header each time a new index is handed out: gzip text, one per line) unless
 // read_map is empty, and the number of read indices.
+// passes > 1: the database is built in that many key ranges, one after the other over the same parsed input
+// (kmg_build_set_key_range), each handed to per_pass(db, first key, end key) and freed; returns NULL then.
 kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int key_len, bool filters, int dust, int runofsame,
-                        const std::string &read_map, uint64_t *n_reads, uint64_t *nwin, StageClock &clk) {
+                        const std::string &read_map, uint64_t *n_reads, uint64_t *nwin, StageClock &clk, int passes = 1,
+                        const std::function<void(kmg_db *, size_t, size_t)> &per_pass = nullptr) {
     const std::string data = read_input(path);
     clk.lap("read input");
     const std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch(kmh_parse((const uint8_t *)data.data(), data.size(), reads ? 1 : 0, k), kmh_free);
@@ -687,21 +718,36 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
                 throw std::runtime_error("NumberFormatException: FASTA header of sequence " + std::to_string(s) + " is not an int");
     }
     clk.lap("split records (host)");
-    g.check(kmg_build_begin(g.ctx, k, key_len, reads ? 0 : 1, reads ? KMG_PAYLOAD_READPOS : KMG_PAYLOAD_TAXON));
-    if (filters) g.check(kmg_build_set_filters(g.ctx, dust, runofsame));
     std::vector<int32_t> ridx(reads ? nseq : 0);
-    g.check(kmg_build_add(g.ctx, kmh_bases(b), kmh_nbases(b), off, reads ? nullptr : kmh_seq_id(b),
-                          reads ? kmh_seq_tok(b) : nullptr, nseq, reads ? ridx.data() : nullptr));
     kmg_db *db = nullptr;
-    g.check(kmg_build_finish(g.ctx, &db, nwin));
-    clk.lap("copy in + build (GPU)");
+    const size_t nkeys = (size_t)1 << (2 * key_len);
+    passes = (int)std::max<size_t>(1, std::min<size_t>((size_t)passes, nkeys));
+    uint64_t windows = 0;
+    for (int ps = 0; ps < passes; ps++) {
+        const size_t lo = nkeys * ps / passes, hi = nkeys * (ps + 1) / passes;
+        g.check(kmg_build_begin(g.ctx, k, key_len, reads ? 0 : 1, reads ? KMG_PAYLOAD_READPOS : KMG_PAYLOAD_TAXON));
+        if (filters) g.check(kmg_build_set_filters(g.ctx, dust, runofsame));
+        if (passes > 1) g.check(kmg_build_set_key_range(g.ctx, (uint32_t)lo, (uint32_t)hi));
+        g.check(kmg_build_add(g.ctx, kmh_bases(b), kmh_nbases(b), off, reads ? nullptr : kmh_seq_id(b),
+                              reads ? kmh_seq_tok(b) : nullptr, nseq, reads ? ridx.data() : nullptr));
+        uint64_t w = 0;
+        g.check(kmg_build_finish(g.ctx, &db, &w));
+        windows += w;
+        if (passes > 1) {
+            per_pass(db, lo, hi);
+            kmg_db_free(db);
+            db = nullptr;
+        }
+    }
+    if (nwin) *nwin = windows;
+    clk.lap(passes > 1 ? "copy in + build (GPU), encode + write, per pass" : "copy in + build (GPU)");
     if (reads) {
         int32_t top = -1;
         for (uint64_t s = 0; s < nseq; s++) top = std::max(top, ridx[s]);
         if (n_reads) *n_reads = (uint64_t)(top + 1);
         if (!read_map.empty()) {
             gzFile z = gzopen(read_map.c_str(), "wb");
-            if (!z) { kmg_db_free(db); throw std::runtime_error("cannot create " + read_map); }
+            if (!z) { if (db) kmg_db_free(db); throw std::runtime_error("cannot create " + read_map); }
             const int64_t *tok = kmh_seq_tok(b);
             const uint64_t *noff = kmh_name_off(b);
             const char *names = kmh_names(b);
@@ -720,7 +766,7 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
 }
 
 int make_database(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmN", "aqpZvh");
+    const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmNP", "aqpZvh");
     for (char c : std::string("mN")) if (a.has(c)) throw Unsupported(std::string("option -") + c + " is not on the GPU path");
     const int k = a.geti('K', 32), min_k = a.geti('k', 24), key_len = a.geti('l', 6);     // MakeDatabase.java:106-109
     const int level = a.has('Z') ? -1 : a.geti('z', 5);
@@ -736,16 +782,27 @@ int make_database(int argc, char **argv) {
     Gpu g;
     clk.lap("GPU context");
     uint64_t nwin = 0;
+    // -P n (no counterpart in the reference): build and write the database in n key ranges, one after the other --
+    // the same file, for inputs whose k-mers do not fit one build (2^32-16 records) or the GPU's memory
+    const int passes = std::max(1, a.geti('P', 1));
+    DatabaseWriter w(g, a.get('o'), level, a.has('S') ? size_from_human(a.get('S')) : 0, a.has('h'));
+    uint64_t U = 0, V = 0;
+    auto emit = [&](kmg_db *part, size_t lo, size_t hi) {
+        const DbInfo d = db_info(part);
+        U += d.U; V += d.V;
+        w.add(part, lo, hi);
+    };
     kmg_db *db = build_from_text(g, a.get('i'), reads, k, key_len, a.has('D') || a.has('R'), a.geti('D', -1), a.geti('R', -1),
-                                 reads ? a.get('r') : "", nullptr, &nwin, clk);
-    write_database(g, db, a.get('o'), level, a.has('S') ? size_from_human(a.get('S')) : 0, a.has('h'));
-    clk.lap("encode + deflate + write");
-    if (a.has('v')) {
-        const DbInfo d = db_info(db);
-        fprintf(stderr, "%llu k-mer windows, %llu distinct k-mers, %llu values\n", (unsigned long long)nwin,
-                (unsigned long long)d.U, (unsigned long long)d.V);
+                                 reads ? a.get('r') : "", nullptr, &nwin, clk, passes, emit);
+    if (db) {
+        emit(db, 0, (size_t)1 << (2 * key_len));
+        kmg_db_free(db);
     }
-    kmg_db_free(db);
+    w.close();
+    clk.lap("encode + deflate + write");
+    if (a.has('v'))
+        fprintf(stderr, "%llu k-mer windows, %llu distinct k-mers, %llu values\n", (unsigned long long)nwin,
+                (unsigned long long)U, (unsigned long long)V);
     return 0;
 }
 

@@ -6,24 +6,25 @@ from . import parse
 from .api import FileCreator
 
 
-def make_reference_db(ctx, fasta: bytes, k=32, key_length=6, dust=None, runofsame=None):
-    """MakeDatabase -a -K k -k k -l key_length [-D dust] [-R runofsame].  -> KmerDatabase"""
-    pf = parse.parse(fasta, parse.FASTA, k)
+def make_reference_db(ctx, fasta, k=32, key_length=6, dust=None, runofsame=None, key_range=None):
+    """MakeDatabase -a -K k -k k -l key_length [-D dust] [-R runofsame].  -> KmerDatabase
+    fasta: the file's bytes, or what parse.parse made of them (a build in key ranges parses once)."""
+    pf = fasta if isinstance(fasta, parse.ParsedFile) else parse.parse(fasta, parse.FASTA, k)
     lens = np.diff(pf.batch.seq_off.astype(np.int64))
     bad = np.nonzero((pf.id_ok == 0) & (lens >= k))[0]
     if bad.size:   # Integer.parseInt throws NumberFormatException at the sequence's first k-mer
         raise ValueError("NumberFormatException: FASTA header of sequence %d is not an int" % int(bad[0]))
-    fc = FileCreator(ctx, key_length, k, "ref", rc=True, dust=dust, runofsame=runofsame)
+    fc = FileCreator(ctx, key_length, k, "ref", rc=True, dust=dust, runofsame=runofsame, key_range=key_range)
     fc.add_kmers(pf.batch)
     db = fc.create()
     db.n_windows = fc.n_windows
     return db
 
 
-def make_read_db(ctx, fastq: bytes, k=32, key_length=6, dust=None, runofsame=None):
+def make_read_db(ctx, fastq, k=32, key_length=6, dust=None, runofsame=None, key_range=None):
     """MakeDatabase -q -r map [-D dust] [-R runofsame].  -> (KmerDatabase, read-name map lines in index order)"""
-    pf = parse.parse(fastq, parse.FASTQ, k)
-    fc = FileCreator(ctx, key_length, k, "read", rc=False, dust=dust, runofsame=runofsame)
+    pf = fastq if isinstance(fastq, parse.ParsedFile) else parse.parse(fastq, parse.FASTQ, k)
+    fc = FileCreator(ctx, key_length, k, "read", rc=False, dust=dust, runofsame=runofsame, key_range=key_range)
     ridx = fc.add_kmers(pf.batch)
     db = fc.create()
     db.n_windows = fc.n_windows

@@ -27,27 +27,35 @@ def _hr_values(kind, a, b):
     return " ".join("%d:%d" % x for x in zip(a, b))
 
 
-def write_database(db: KmerDatabase, path, zip_level=5, hr=False):
+def write_database(db: KmerDatabase, path, zip_level=5, hr=False, out=None, key_range=None):
     """FileCreator.create (FileCreator.java:117-217): meta under key -1, then every key 0..4^l-1 in order
     (each gets a block, empty ones included, quirk C.12).  hr = MakeDatabase -h: text meta, one text line per
     k-mer with the characters it shares with the previous k-mer of its key block dropped
-    (FileCreator.java:166-179, 234-242, 349-370), text index."""
-    out = container.IndexedOutputFile(path, hr=hr, zip_level=zip_level)
+    (FileCreator.java:166-179, 234-242, 349-370), text index.
+    out / key_range: append the blocks of keys [first, end) to an open file instead (a database built in key
+    ranges, one call per range in ascending order; the first call writes the meta block, the caller closes)."""
+    part = out is not None
+    first, end = key_range if key_range is not None else (0, 4 ** db.key_length)
+    if out is None:
+        out = container.IndexedOutputFile(path, hr=hr, zip_level=zip_level)
     if not hr:
         blocks, off = db.encode_blocks()
-        out.write_all(db.meta(), -1)
-        for key in range(4 ** db.key_length):
+        if not part or first == 0:
+            out.write_all(db.meta(), -1)
+        for key in range(first, end):
             out.set_current_key(key)
             out.write(blocks[int(off[key]):int(off[key + 1])])
-        out.close()
+        if not part:
+            out.close()
         return
     ids = " ".join(str(i) for i in db.data_id())                     # Compressor.getStringID
-    out.write_all(("%d\n%d\n%d\n%s\n%s\n" % (db.k, db.k, db.key_length, ids, "1" if db.rc else "0")).encode(), -1)
+    if not part or first == 0:
+        out.write_all(("%d\n%d\n%d\n%s\n%s\n" % (db.k, db.k, db.key_length, ids, "1" if db.rc else "0")).encode(), -1)
     h = db.fetch()
     names = kmer_strings(h["keys"], db.k)
     val_off, va, vb = h["val_off"].tolist(), h["val_a"].tolist(), h["val_b"].tolist()
     boff = h["bucket_off"].tolist()
-    for key in range(4 ** db.key_length):
+    for key in range(first, end):
         out.set_current_key(key)
         last = " " * db.k
         lines = []
@@ -59,7 +67,8 @@ def write_database(db: KmerDatabase, path, zip_level=5, hr=False):
             lines.append("%s\t%s\n" % (nxt[first:], _hr_values(db.kind, va[val_off[u]:val_off[u + 1]], vb[val_off[u]:val_off[u + 1]])))
             last = nxt
         out.write("".join(lines).encode())
-    out.close()
+    if not part:
+        out.close()
 
 
 def _read_hr_database(ctx, f: container.IndexedInputFile):
@@ -181,11 +190,35 @@ def read_preprocessed(path, packed=False):
 
 
 def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length=6, zip_level=5, read_map_path=None,
-                  dust=None, runofsame=None, hr=False):
+                  dust=None, runofsame=None, hr=False, passes=1):
     """MakeDatabase -a (mode 'a') / -q (mode 'q') / -p (mode 'p', preprocessed input).  Defaults as the reference's
-    (-K 32 -k 24 -l 6 -z 5, MakeDatabase.java:106-109); minK != maxK is refused (GPU path limit)."""
+    (-K 32 -k 24 -l 6 -z 5, MakeDatabase.java:106-109); minK != maxK is refused (GPU path limit).
+    passes > 1 (-P, no counterpart in the reference; modes 'a' and 'q'): the database is built and written in that many
+    key ranges, one after the other -- the same file, for inputs that do not fit one build; returns None then."""
     if min_k != k:
         raise KmersGpuError(KMG_EUNSUPPORTED, "minK != maxK is not supported on the GPU path")
+    if passes > 1 and mode in ("a", "q"):
+        from . import parse
+        if mode == "q" and read_map_path is None:
+            raise ValueError("-r <read map file> is required with -q")
+        pf = parse.parse(open(input_path, "rb").read(), parse.FASTA if mode == "a" else parse.FASTQ, k)
+        nkeys = 4 ** key_length
+        passes = min(passes, nkeys)
+        out = container.IndexedOutputFile(output_path, hr=hr, zip_level=zip_level)
+        for ps in range(passes):
+            rng = (nkeys * ps // passes, nkeys * (ps + 1) // passes)
+            if mode == "a":
+                db = make_reference_db(ctx, pf, k, key_length, dust, runofsame, key_range=rng)
+            else:
+                db, names = make_read_db(ctx, pf, k, key_length, dust, runofsame, key_range=rng)
+            write_database(db, output_path, zip_level, hr, out=out, key_range=rng)
+            db.close()
+        out.close()
+        if mode == "q":
+            with gzip.open(read_map_path, "wt") as g:
+                for nm in names:
+                    g.write(nm + "\n")
+        return None
     if mode == "p":
         # MakeDatabase.java:186-237: reference payload, reverse complements included, every index of the input
         from .api import FileCreator

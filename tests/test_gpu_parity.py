@@ -276,6 +276,61 @@ def test_kmers_that_differ_only_in_their_last_bases(ctx, k, l, shared):
             got.close()
 
 
+@pytest.mark.parametrize("k,l,cuts", [(21, 3, [0, 5, 6, 40, 64]), (32, 5, [0, 300, 1024]), (7, 2, [0, 1, 2, 15, 16])])
+def test_key_range_builds_are_slices_of_the_whole(ctx, k, l, cuts):
+    """kmg_build_set_key_range: a build restricted to key buckets [first, end) holds exactly the whole database's
+    k-mers of those buckets, values and all -- forward and reverse-complement records are judged one by one (an RC
+    usually lies in another range than its forward k-mer) -- and numbers its reads as the whole build does.  Laid end
+    to end the range builds are the oracle's database.  Reference and read databases, one batch (extraction fused
+    with the partition) and two batches (plain extraction), -D / -R filters on."""
+    import kmers_amd as km
+    from kmers_amd import parse, synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(200 + k, 4, 6000, shared_frac=0.3)
+    reads = synth.random_reads(201 + k, genomes, 1500, 90, 0.01, n_rate=0.004)
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    for data, mode, kind, rc, filt in ((fa, parse.FASTA, "ref", True, {}), (fq, parse.FASTQ, "read", False, {}),
+                                       (fa, parse.FASTA, "ref", True, dict(dust=3, runofsame=6))):
+        want = OracleDB(data, 0 if kind == "ref" else 1, k, l, threads=4, **filt)
+        b = parse.parse(data, mode, k).batch
+        for batches in (1, 2):
+            keys, offs, va, vb, windows, ridx_all = [], [np.zeros(1, np.uint64)], [], [], 0, []
+            for first, end in zip(cuts[:-1], cuts[1:]):
+                fc = km.FileCreator(ctx, l, k, kind, rc=rc, key_range=(first, end), **filt)
+                half = b.nseq // 2 if batches == 2 else b.nseq
+                ridx = []
+                for lo, hi in ((0, half), (half, b.nseq)):
+                    if hi > lo:
+                        a0, a1 = int(b.seq_off[lo]), int(b.seq_off[hi])
+                        ridx.append(fc.add_kmers(km.SequenceBatch(b.bases[a0:a1], b.seq_off[lo:hi + 1] - b.seq_off[lo],
+                                                                  seq_id=None if b.seq_id is None else b.seq_id[lo:hi],
+                                                                  seq_tok=None if b.seq_tok is None else b.seq_tok[lo:hi])))
+                part = fc.create()
+                windows += fc.n_windows
+                h = part.fetch()
+                bucket = (h["keys"] >> np.uint64(64 - 2 * l)).astype(np.int64)
+                assert np.all((bucket >= first) & (bucket < end))
+                keys.append(h["keys"])
+                offs.append(h["val_off"][1:] + offs[-1][-1])
+                va.append(h["val_a"]); vb.append(h["val_b"])
+                if kind == "read":
+                    ridx_all.append(np.concatenate(ridx))
+                part.close()
+            assert np.array_equal(np.concatenate(keys), want.keys)
+            assert np.array_equal(np.concatenate(offs), want.val_off)
+            assert np.array_equal(np.concatenate(va), want.val_a) and np.array_equal(np.concatenate(vb), want.val_b)
+            if not rc:
+                assert windows == want.n_windows
+            for r in ridx_all[1:]:
+                assert np.array_equal(r, ridx_all[0])
+    fc = km.FileCreator(ctx, l, k, "ref", rc=True)
+    with pytest.raises(km.InconsistentDataException):
+        ctx.check(ctx.lib.kmg_build_set_key_range(ctx.h, 3, 3))
+    with pytest.raises(km.InconsistentDataException):
+        ctx.check(ctx.lib.kmg_build_set_key_range(ctx.h, 0, 4 ** l + 1))
+    fc.create().close()
+
+
 def test_concurrent_callers_on_one_context(ctx):
     """The reference calls addKmers on ONE FileCreator from up to -t pool threads at once in -p mode
     (MakeDatabase.java:220-236,259-265) and quickMatchCommonKey from `threads` pool threads (DB.java:191-207), so a

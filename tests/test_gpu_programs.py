@@ -157,6 +157,22 @@ def test_native_cli_matches_python_drivers(tmp_path):
     assert R.read_indexed_file(p("by_read.empty")) == {}
     run("Utils.ReadClassifier", "-i", p("by_read.empty"), "-o", p("calls.empty"))
     assert R.read_indexed_file(p("calls.empty")) == {}
+    # -P: the database built and written in key ranges, one after the other -- the same file
+    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("ref.p5.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z", "-P", "5")
+    assert open(p("ref.p5.db"), "rb").read() == open(p("ref.want"), "rb").read()
+    run("Database.MakeDatabase", "-q", "-i", fq, "-o", p("reads.p3.db"), "-r", p("map.p3.gz"), "-K", str(k), "-k", str(k), "-l", str(l), "-P", "3")
+    assert R.read_indexed_file(p("reads.p3.db")) == R.read_indexed_file(p("reads.want"))
+    assert gzip.open(p("map.p3.gz"), "rt").read().splitlines() == o_reads.names
+    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("ref.p2h.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z", "-h", "-P", "2")
+    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("ref.h.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z", "-h")
+    assert open(p("ref.p2h.db"), "rb").read() == open(p("ref.h.db"), "rb").read()
+    ctx = km.Context(0)
+    assert programs.make_database(ctx, fa, p("ref.py.p4.db"), "a", k, k, l, zip_level=None, passes=4) is None
+    assert open(p("ref.py.p4.db"), "rb").read() == open(p("ref.want"), "rb").read()
+    programs.make_database(ctx, fq, p("reads.py.p2.db"), "q", k, k, l, zip_level=3, read_map_path=p("map.py.p2.gz"), passes=2)
+    assert R.read_indexed_file(p("reads.py.p2.db")) == R.read_indexed_file(p("reads.want"))
+    assert gzip.open(p("map.py.p2.gz"), "rt").read().splitlines() == o_reads.names
+    ctx.close()
     # -D / -R filters reach the kernel
     run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("f.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z", "-D", "2", "-R", "5")
     o_f = OracleDB(synth.fasta_bytes(taxa, genomes), 0, k, l, dust=2, runofsame=5)
