@@ -16,7 +16,7 @@ def main(argv=None):
     prog, rest = argv[0].split(".")[-1], argv[1:]
     ap = argparse.ArgumentParser(prog=prog, add_help=False)
     if prog == "MakeDatabase":
-        for f in "ioKklzrDRP":
+        for f in "ioKklzrDRPL":
             ap.add_argument("-" + f)
         for f in "aqpZvh":
             ap.add_argument("-" + f, action="store_true")
@@ -24,14 +24,14 @@ def main(argv=None):
         ctx = Context(0)
         programs.make_database(ctx, a.i, a.o, "a" if a.a else ("p" if a.p else "q"), int(a.K or 32), int(a.k or 24), int(a.l or 6),
                                None if a.Z else int(a.z or 5), a.r, None if a.D is None else int(a.D),
-                               None if a.R is None else int(a.R), hr=a.h, passes=int(a.P or 1))
+                               None if a.R is None else int(a.R), hr=a.h, passes=int(a.P or 1), limit=a.L)
     elif prog == "Matcher":
-        for f in "idozZn":
+        for f in "idozZnL":
             ap.add_argument("-" + f)
         a = ap.parse_args(rest)
         if int(a.n or 0) != 0:
             raise SystemExit("inexact search (-n > 0) stays on the Java path")
-        programs.matcher(Context(0), a.i, a.d, a.o, plain=a.Z is not None)
+        programs.matcher(Context(0), a.i, a.d, a.o, plain=a.Z is not None, limit=a.L)
     elif prog == "TaxaCounts":
         for f in "do":
             ap.add_argument("-" + f)

@@ -471,7 +471,7 @@ uint64_t size_from_human(const std::string &v) {
 // KmerFile over a human-readable file: text meta (KmerFile.java:279-283), UncompressedKmerSpliterator
 // (KmerFile.java:132-160): k-mer = previous k-mer with its tail replaced by the line's first field
 // (Kmer.java:26-44); values by CountDataType.fromString / SetDataType<ReadPos>.fromString
-kmg_db *open_hr_database(const Gpu &g, const IndexedInputFile &f, const std::string &path) {
+kmg_db *open_hr_database(const Gpu &g, const IndexedInputFile &f, const std::string &path, int key_lo, int key_hi) {
     const std::string m = f.read_key(-1);
     int min_k, max_k, key_len, rc;
     char ids[64];
@@ -486,7 +486,8 @@ kmg_db *open_hr_database(const Gpu &g, const IndexedInputFile &f, const std::str
     std::vector<int32_t> va, vb;
     std::string prev;
     for (auto &kv : f.index) {
-        if (kv.first < 0) continue;
+        if (kv.first < 0 || kv.first < key_lo || kv.first >= key_hi) continue;
+        prev.clear();                                   // (a key's first line is a whole k-mer)
         for (auto &b : kv.second) {
             const std::string text = f.block(b.first, b.second);
             size_t p0 = 0;
@@ -528,9 +529,10 @@ kmg_db *open_hr_database(const Gpu &g, const IndexedInputFile &f, const std::str
 }
 
 // new KmerFile(file, dataType) + its decoded content uploaded to the GPU
-kmg_db *open_database(const Gpu &g, const std::string &path) {
+// keys [key_lo, key_hi) only: Matcher -L
+kmg_db *open_database(const Gpu &g, const std::string &path, int key_lo = 0, int key_hi = INT32_MAX) {
     IndexedInputFile f(path);
-    if (f.hr) return open_hr_database(g, f, path);
+    if (f.hr) return open_hr_database(g, f, path, key_lo, key_hi);
     const std::string m = f.read_key(-1);                                   // KmerFile.getMetaData, KmerFile.java:284-288
     if (m.size() < 8) throw std::runtime_error("bad meta block: " + path);
     const int min_k = (uint8_t)m[0], max_k = (uint8_t)m[1], key_len = (uint8_t)m[2];
@@ -547,7 +549,7 @@ kmg_db *open_database(const Gpu &g, const std::string &path) {
     // Every key's block is a stream of its own (its first record shares nothing, FileCreator.java:315), so the keys
     // are inflated and decoded side by side and their arrays laid end to end in key order.
     std::vector<const std::vector<std::pair<uint64_t, uint64_t>> *> per_key;
-    for (auto &kv : f.index) if (kv.first >= 0) per_key.push_back(&kv.second);
+    for (auto &kv : f.index) if (kv.first >= 0 && kv.first >= key_lo && kv.first < key_hi) per_key.push_back(&kv.second);
     const size_t nk = per_key.size();
     std::vector<kmh_batch *> dec(nk, nullptr);
     std::atomic<bool> bad{false};
@@ -587,11 +589,11 @@ kmg_db *open_database(const Gpu &g, const std::string &path) {
 
 // a database given as one file or as name.1 .. name.N (Matcher.java:80-89): the files are merged on the GPU
 // (DB.kmers, DB.java:99-109)
-kmg_db *open_database_set(const Gpu &g, const std::string &path) {
+kmg_db *open_database_set(const Gpu &g, const std::string &path, int key_lo = 0, int key_hi = INT32_MAX) {
     const auto files = file_set(path);
     if (files.empty()) throw std::runtime_error("cannot open " + path);
     std::vector<kmg_db *> dbs;
-    for (auto &f : files) dbs.push_back(open_database(g, f));
+    for (auto &f : files) dbs.push_back(open_database(g, f, key_lo, key_hi));
     if (dbs.size() == 1) return dbs[0];
     kmg_db *out = nullptr;
     const int r = kmg_db_merge(g.ctx, dbs.data(), (int)dbs.size(), &out);
@@ -644,7 +646,16 @@ int make_database_preprocessed(const Args &a, int k, int key_len, int level) {
     std::string bases;                 // letters (human-readable input) or packed bytes (binary input)
     std::vector<uint64_t> off{0}, boff{0};
     std::vector<int32_t> ids;
+    // -L start[-end]: only the input indexes between the two names, both inclusive (MakeDatabase.java:207-227)
+    std::string l_start, l_end;
+    if (a.has('L')) {
+        const std::string L = a.get('L');
+        const size_t dash = L.find('-');
+        l_start = L.substr(0, dash);
+        l_end = dash == std::string::npos ? l_start : L.substr(dash + 1);
+    }
     for (auto &kv : in.sindex) {
+        if (a.has('L') && (kv.first.compare(l_start) < 0 || kv.first.compare(l_end) > 0)) continue;
         std::string data;
         for (auto &b : kv.second) data += in.block(b.first, b.second);
         if (in.hr) {
@@ -766,7 +777,8 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
 }
 
 int make_database(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmNP", "aqpZvh");
+    const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmNPL", "aqpZvh");
+    if (a.has('L') && !a.has('p')) throw std::runtime_error("-L limits the input indexes of a preprocessed file (-p)");
     for (char c : std::string("mN")) if (a.has(c)) throw Unsupported(std::string("option -") + c + " is not on the GPU path");
     const int k = a.geti('K', 32), min_k = a.geti('k', 24), key_len = a.geti('l', 6);     // MakeDatabase.java:106-109
     const int level = a.has('Z') ? -1 : a.geti('z', 5);
@@ -841,13 +853,22 @@ void append_values(std::string &s, const HostDb &h, uint64_t i) {
 }
 
 int matcher(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "idozZnt", "v");
+    const Args a = parse_args(argc, argv, 2, "idozZntL", "v");
     if (a.geti('n', 0) != 0) throw Unsupported("inexact search (-n > 0) stays on the Java path");
     StageClock clk(a.has('v'));
     if (!a.has('i') || !a.has('d') || !a.has('o')) throw std::runtime_error("-i, -d and -o are required");
     g_threads = std::max(1, a.geti('t', g_threads));
     Gpu g;
-    kmg_db *ref = open_database_set(g, a.get('d')), *search = open_database_set(g, a.get('i'));
+    // -L start[-end]: only the search k-mers of keys start .. end (Matcher.java:159-171: end inclusive); a k-mer and
+    // its match share their key, so the same slice of the reference is all that is needed
+    int key_lo = 0, key_hi = INT32_MAX;
+    if (a.has('L')) {
+        const std::string L = a.get('L');
+        const size_t dash = L.find('-');
+        key_lo = atoi(L.c_str());
+        key_hi = (dash == std::string::npos ? key_lo : atoi(L.c_str() + dash + 1)) + 1;
+    }
+    kmg_db *ref = open_database_set(g, a.get('d'), key_lo, key_hi), *search = open_database_set(g, a.get('i'), key_lo, key_hi);
     const DbInfo rd = db_info(ref), sd = db_info(search);
     if (!rd.rc)   // DB.java:57-64
         throw std::runtime_error("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included");

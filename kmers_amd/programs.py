@@ -71,7 +71,7 @@ def write_database(db: KmerDatabase, path, zip_level=5, hr=False, out=None, key_
         out.close()
 
 
-def _read_hr_database(ctx, f: container.IndexedInputFile):
+def _read_hr_database(ctx, f: container.IndexedInputFile, first=0, last=None):
     """KmerFile over a human-readable file: text meta (KmerFile.java:279-283) and UncompressedKmerSpliterator
     (KmerFile.java:132-160): k-mer = previous k-mer with its tail replaced by the line's first field
     (Kmer.java:26-44), values parsed by CountDataType.fromString / SetDataType<ReadPos>.fromString."""
@@ -90,7 +90,7 @@ def _read_hr_database(ctx, f: container.IndexedInputFile):
     code = {"A": 0, "C": 1, "T": 2, "G": 3}
     keys, val_off, va, vb = [], [0], [], []
     prev = None
-    for line in f.read_keys(0, f.max_index()).decode().splitlines():
+    for line in f.read_keys(first, f.max_index() if last is None else last).decode().splitlines():
         part, vals = line.split("\t")
         cur = part if prev is None or len(part) >= len(prev) else prev[:len(prev) - len(part)] + part
         prev = cur
@@ -120,11 +120,13 @@ def read_meta(f: container.IndexedInputFile):
     return min_k, max_k, key_len, ids, m[7 + 4 * n] == 1
 
 
-def open_database(ctx, path) -> KmerDatabase:
-    """new KmerFile(file, dataType) + its decoded content uploaded to the GPU."""
+def open_database(ctx, path, key_range=None) -> KmerDatabase:
+    """new KmerFile(file, dataType) + its decoded content uploaded to the GPU.  key_range = (first, last), both
+    inclusive: only those keys' blocks (KmerFile.kmers(minKey, maxKey); Matcher -L)."""
     f = container.IndexedInputFile(path)
+    first, last = (0, f.max_index()) if key_range is None else key_range
     if f.hr:
-        return _read_hr_database(ctx, f)
+        return _read_hr_database(ctx, f, first, last)
     min_k, max_k, key_len, ids, rc = read_meta(f)
     if min_k != max_k or max_k > 32:
         raise KmersGpuError(KMG_EUNSUPPORTED, "minK != maxK or k > 32: use the Java path")
@@ -134,14 +136,14 @@ def open_database(ctx, path) -> KmerDatabase:
         kind = PAYLOAD_READPOS
     else:
         raise ValueError("UnexpectedDataTypeException: %s" % path)       # KmerFile.java:30-33
-    keys, val_off, val_a, val_b = parse.decode_blocks(f.read_keys(0, f.max_index()), kind)
+    keys, val_off, val_a, val_b = parse.decode_blocks(f.read_keys(first, last), kind)
     return KmerDatabase.load(ctx, max_k, key_len, rc, kind, keys, val_off, val_a, val_b)
 
 
 _UNPACK = np.array([[65, 67, 84, 71][(b >> s) & 3] for b in range(256) for s in (6, 4, 2, 0)], np.uint8).reshape(256, 4)
 
 
-def read_preprocessed(path, packed=False):
+def read_preprocessed(path, packed=False, limit=None):
     """The input of MakeDatabase -p (written by OtherFiles.SeqToTaxID): an IndexedFile keyed by String whose blocks
     hold (taxid, Sequence) records -- binary [int taxid][int length][2 bits per base] (IntCompressor +
     SequenceDataType.java:21-34) or human-readable lines `taxid ~ SEQUENCE`.  -> SequenceBatch of every record
@@ -149,9 +151,13 @@ def read_preprocessed(path, packed=False):
     -> (packed bytes, seq_off, byte_off, seq_id) for FileCreator.add_packed, the bases left as they are."""
     from .api import SequenceBatch
     f = container.IndexedInputFile(path)
+    wanted = sorted(f.index)
+    if limit is not None:            # -L start[-end]: input indexes between the two names, inclusive (MakeDatabase.java:207-227)
+        start, _, end = str(limit).partition("-")
+        wanted = [x for x in wanted if start <= x <= (end or start)]
     if packed and not f.hr:
         chunks, ids, lens = [], [], []
-        for key in sorted(f.index):
+        for key in wanted:
             data = f.read_key(key)
             off = 0
             while off < len(data):
@@ -166,7 +172,7 @@ def read_preprocessed(path, packed=False):
         byte_off = np.concatenate([[0], np.cumsum((lens + np.uint64(3)) // np.uint64(4))]).astype(np.uint64)
         return np.frombuffer(b"".join(chunks), np.uint8), seq_off, byte_off, np.array(ids, np.int32)
     parts, ids, lens = [], [], []
-    for key in sorted(f.index):
+    for key in wanted:
         data = f.read_key(key)
         if f.hr:
             for line in data.decode().splitlines():
@@ -190,7 +196,7 @@ def read_preprocessed(path, packed=False):
 
 
 def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length=6, zip_level=5, read_map_path=None,
-                  dust=None, runofsame=None, hr=False, passes=1):
+                  dust=None, runofsame=None, hr=False, passes=1, limit=None):
     """MakeDatabase -a (mode 'a') / -q (mode 'q') / -p (mode 'p', preprocessed input).  Defaults as the reference's
     (-K 32 -k 24 -l 6 -z 5, MakeDatabase.java:106-109); minK != maxK is refused (GPU path limit).
     passes > 1 (-P, no counterpart in the reference; modes 'a' and 'q'): the database is built and written in that many
@@ -223,7 +229,7 @@ def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length
         # MakeDatabase.java:186-237: reference payload, reverse complements included, every index of the input
         from .api import FileCreator
         fc = FileCreator(ctx, key_length, k, "ref", rc=True, dust=dust, runofsame=runofsame)
-        got = read_preprocessed(input_path, packed=True)
+        got = read_preprocessed(input_path, packed=True, limit=limit)
         if isinstance(got, tuple):                       # binary file: the packed bases go to the device as they are
             if len(got[3]):
                 fc.add_packed(*got)
@@ -248,15 +254,21 @@ def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length
     return db
 
 
-def matcher(ctx, search_path, db_path, output_path, plain=False):
+def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None):
     """Matcher with -n 0: one line per matched search k-mer, ascending (Matcher.java:235-250); output is
-    gzip at the default level unless plain (-Z x)."""
+    gzip at the default level unless plain (-Z x).  limit = "start" or "start-end" (-L, Matcher.java:159-171): only
+    the search k-mers of keys start .. end; a k-mer and its match share their key, so the same slice of the
+    reference is all that is loaded."""
+    key_range = None
+    if limit is not None:
+        parts = str(limit).split("-")
+        key_range = (int(parts[0]), int(parts[1]) if len(parts) == 2 else int(parts[0]))
     dbfiles = container.file_set(db_path)
     sfiles = container.file_set(search_path)
     if not dbfiles or not sfiles:
         raise FileNotFoundError(db_path if not dbfiles else search_path)
-    db = DB([open_database(ctx, f) for f in dbfiles])          # name.1 .. name.N are merged (DB.java:99-109)
-    searches = [open_database(ctx, f) for f in sfiles]
+    db = DB([open_database(ctx, f, key_range) for f in dbfiles])          # name.1 .. name.N are merged (DB.java:99-109)
+    searches = [open_database(ctx, f, key_range) for f in sfiles]
     search = searches[0] if len(searches) == 1 else merge_databases(searches)   # Matcher.java:111-128 via KmerUtils
     hit, _ = db.get_nearest_kmers(search)
     lines = match_lines(search, db.merged, hit)

@@ -133,6 +133,19 @@ def test_native_cli_matches_python_drivers(tmp_path):
     assert open(p("m.txt"), "rb").read() == want
     run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("m.gz"))
     assert gzip.open(p("m.gz"), "rb").read() == want
+    # -L start-end: the lines of the search k-mers with those keys (end inclusive), -L start: of one key
+    code = {"A": 0, "C": 1, "T": 2, "G": 3}
+    key_of = lambda line: sum(code[c] * 4 ** (l - 1 - i) for i, c in enumerate(line[:l]))
+    all_lines = want.decode().splitlines()
+    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("m.L.txt"), "-Z", "x", "-L", "17-130")
+    assert open(p("m.L.txt")).read().splitlines() == [x for x in all_lines if 17 <= key_of(x) <= 130]
+    one = key_of(all_lines[len(all_lines) // 2])
+    run("Database.Matcher", "-i", p("reads.db"), "-d", p("refz.db"), "-o", p("m.L1.txt"), "-Z", "x", "-L", str(one))
+    assert open(p("m.L1.txt")).read().splitlines() == [x for x in all_lines if key_of(x) == one] != []
+    ctx = km.Context(0)
+    assert programs.matcher(ctx, p("reads.db"), p("ref.db"), p("m.L.py.txt"), plain=True, limit="17-130") == \
+        [x for x in all_lines if 17 <= key_of(x) <= 130]
+    ctx.close()
     run("Utils.TaxaCounts", "-d", p("refz.db"), "-o", p("c.tsv"))
     t, m, q = o_ref.taxacounts()
     assert open(p("c.tsv")).read().splitlines() == ["%d\t%d\t%d" % x for x in zip(t, m, q)]
@@ -255,9 +268,16 @@ def test_human_readable_databases(tmp_path):
     want = o_reads.match_lines(o_ref, hit)
     programs.matcher(ctx, p("reads.c.db"), p("ref.c.db"), p("m.py.txt"), plain=True)
     assert open(p("m.py.txt"), "rb").read() == want
+    # -L on human-readable files: the lines of keys 3 .. 9
+    code = {"A": 0, "C": 1, "T": 2, "G": 3}
+    key_of = lambda line: sum(code[c] * 4 ** (l - 1 - i) for i, c in enumerate(line[:l]))
+    some = [x for x in want.decode().splitlines() if 3 <= key_of(x) <= 9]
+    assert programs.matcher(ctx, p("reads.c.db"), p("ref.c.db"), p("m.L.py.txt"), plain=True, limit="3-9") == some != []
     ctx.close()
     run("Database.Matcher", "-i", p("reads.py.db"), "-d", p("ref.py.db"), "-o", p("m.c.txt"), "-Z", "x")
     assert open(p("m.c.txt"), "rb").read() == want
+    run("Database.Matcher", "-i", p("reads.py.db"), "-d", p("ref.py.db"), "-o", p("m.L.c.txt"), "-Z", "x", "-L", "3-9")
+    assert open(p("m.L.c.txt")).read().splitlines() == some
     run("Utils.TaxaCounts", "-d", p("ref.py.db"), "-o", p("c.tsv"))
     t, m, q = o_ref.taxacounts()
     assert open(p("c.tsv")).read().splitlines() == ["%d\t%d\t%d" % x for x in zip(t, m, q)]
@@ -301,3 +321,16 @@ def test_preprocessed_input(tmp_path):
     r = subprocess.run([kmg, "Database.MakeDatabase", "-p", "-i", str(tmp_path / "want.db"), "-o", str(tmp_path / "x.db"),
                         "-K", str(k), "-k", str(k), "-l", str(l)], capture_output=True, text=True, timeout=110)
     assert r.returncode == 1 and "not a preprocessed file" in r.stderr
+    # -L start-end: only the input indexes between the two names, both inclusive (MakeDatabase.java:207-227)
+    some = {name: recs for name, recs in groups.items() if "NC01" <= name <= "NC02"}
+    assert 0 < len(some) < len(groups)
+    R.write_indexed_file(str(tmp_path / "want.L.db"), _oracle_blocks(OracleDB(R.preprocessed_kmers_as_fasta(some), 0, k, l)), None)
+    for name in ("pp.bin", "pp.hr"):
+        path = str(tmp_path / name)
+        r = subprocess.run([kmg, "Database.MakeDatabase", "-p", "-i", path, "-o", path + ".L.db", "-K", str(k), "-k", str(k),
+                            "-l", str(l), "-Z", "-L", "NC01-NC02"], capture_output=True, text=True, timeout=110)
+        assert r.returncode == 0, r.stderr
+        assert open(path + ".L.db", "rb").read() == open(str(tmp_path / "want.L.db"), "rb").read()
+        assert cli(["Database.MakeDatabase", "-p", "-i", path, "-o", path + ".L.py.db", "-K", str(k), "-k", str(k), "-l", str(l),
+                    "-Z", "-L", "NC01-NC02"]) == 0
+        assert open(path + ".L.py.db", "rb").read() == open(str(tmp_path / "want.L.db"), "rb").read()
