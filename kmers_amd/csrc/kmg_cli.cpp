@@ -530,8 +530,7 @@ kmg_db *open_hr_database(const Gpu &g, const IndexedInputFile &f, const std::str
 
 // new KmerFile(file, dataType) + its decoded content uploaded to the GPU
 // keys [key_lo, key_hi) only: Matcher -L
-kmg_db *open_database(const Gpu &g, const std::string &path, int key_lo = 0, int key_hi = INT32_MAX) {
-    IndexedInputFile f(path);
+kmg_db *load_database(const Gpu &g, const IndexedInputFile &f, const std::string &path, int key_lo = 0, int key_hi = INT32_MAX) {
     if (f.hr) return open_hr_database(g, f, path, key_lo, key_hi);
     const std::string m = f.read_key(-1);                                   // KmerFile.getMetaData, KmerFile.java:284-288
     if (m.size() < 8) throw std::runtime_error("bad meta block: " + path);
@@ -587,13 +586,31 @@ kmg_db *open_database(const Gpu &g, const std::string &path, int key_lo = 0, int
     return db;
 }
 
-// a database given as one file or as name.1 .. name.N (Matcher.java:80-89): the files are merged on the GPU
-// (DB.kmers, DB.java:99-109)
+// a database given as one file or as name.1 .. name.N (Matcher.java:80-89), opened once; load() decodes the keys
+// [key_lo, key_hi) of every file and merges the files on the GPU (DB.kmers, DB.java:99-109)
+struct DatabaseSet {
+    std::vector<std::string> paths;
+    std::vector<std::unique_ptr<IndexedInputFile>> files;
+    uint64_t bytes = 0;
+    int end_key = 0;              // one past the largest key any file holds
+    explicit DatabaseSet(const std::string &path) : paths(file_set(path)) {
+        if (paths.empty()) throw std::runtime_error("cannot open " + path);
+        for (auto &p : paths) {
+            files.emplace_back(new IndexedInputFile(p));
+            bytes += files.back()->data.size();
+            if (!files.back()->index.empty()) end_key = std::max(end_key, files.back()->index.rbegin()->first + 1);
+        }
+    }
+    kmg_db *load(const Gpu &g, int key_lo = 0, int key_hi = INT32_MAX) const;
+};
+
 kmg_db *open_database_set(const Gpu &g, const std::string &path, int key_lo = 0, int key_hi = INT32_MAX) {
-    const auto files = file_set(path);
-    if (files.empty()) throw std::runtime_error("cannot open " + path);
+    return DatabaseSet(path).load(g, key_lo, key_hi);
+}
+
+kmg_db *DatabaseSet::load(const Gpu &g, int key_lo, int key_hi) const {
     std::vector<kmg_db *> dbs;
-    for (auto &f : files) dbs.push_back(open_database(g, f, key_lo, key_hi));
+    for (size_t i = 0; i < files.size(); i++) dbs.push_back(load_database(g, *files[i], paths[i], key_lo, key_hi));
     if (dbs.size() == 1) return dbs[0];
     kmg_db *out = nullptr;
     const int r = kmg_db_merge(g.ctx, dbs.data(), (int)dbs.size(), &out);
@@ -853,76 +870,85 @@ void append_values(std::string &s, const HostDb &h, uint64_t i) {
 }
 
 int matcher(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "idozZntL", "v");
+    const Args a = parse_args(argc, argv, 2, "idozZntLP", "v");
     if (a.geti('n', 0) != 0) throw Unsupported("inexact search (-n > 0) stays on the Java path");
     StageClock clk(a.has('v'));
     if (!a.has('i') || !a.has('d') || !a.has('o')) throw std::runtime_error("-i, -d and -o are required");
     g_threads = std::max(1, a.geti('t', g_threads));
     Gpu g;
+    const DatabaseSet ref_set(a.get('d')), search_set(a.get('i'));
     // -L start[-end]: only the search k-mers of keys start .. end (Matcher.java:159-171: end inclusive); a k-mer and
-    // its match share their key, so the same slice of the reference is all that is needed
-    int key_lo = 0, key_hi = INT32_MAX;
+    // its match share their key, so the same slice of the reference is all that is needed.
+    // Without -L the keys are walked in slices -- -P n (not in the reference), or as many as keep a slice's files
+    // around 4 GB -- so that databases beyond one GPU database's 2^32 values, or the host's memory, join too; the
+    // lines come out in the same order either way.
+    int key_lo = 0, key_hi = std::max(ref_set.end_key, search_set.end_key);
+    int slices = std::max<int>(std::max(1, a.geti('P', 1)), (int)((ref_set.bytes + search_set.bytes) >> 32) + 1);
     if (a.has('L')) {
         const std::string L = a.get('L');
         const size_t dash = L.find('-');
         key_lo = atoi(L.c_str());
         key_hi = (dash == std::string::npos ? key_lo : atoi(L.c_str() + dash + 1)) + 1;
+        slices = 1;
     }
-    kmg_db *ref = open_database_set(g, a.get('d'), key_lo, key_hi), *search = open_database_set(g, a.get('i'), key_lo, key_hi);
-    const DbInfo rd = db_info(ref), sd = db_info(search);
-    if (!rd.rc)   // DB.java:57-64
-        throw std::runtime_error("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included");
-    std::vector<int64_t> hit(sd.U + 1);
-    uint64_t nh = 0;
-    clk.lap("read + decode databases");
-    g.check(kmg_match(g.ctx, search, ref, hit.data(), &nh));
-    const HostDb hs = fetch(g, search), hr = fetch(g, ref);
-    clk.lap("match (GPU) + fetch");
-    // one line per matched search k-mer, ascending (Matcher.java:247-249, ResultsDataType.java:15-35):
-    //   KMER \t values of the search k-mer \t -|values of the reference k-mer       ("-" = empty KmerDiff)
-    std::vector<uint64_t> rows;
-    rows.reserve(nh);
-    for (uint64_t i = 0; i < sd.U; i++) if (hit[i] >= 0) rows.push_back(i);
-    const size_t nchunk = (rows.size() + 65535) / 65536;
-    std::vector<std::string> text(nchunk);
-    parallel_for(nchunk, [&](size_t c) {
-        std::string &s = text[c];
-        const size_t lo = c * 65536, hi = std::min(rows.size(), lo + 65536);
-        s.reserve((hi - lo) * (size_t)(sd.k + 48));
-        for (size_t r = lo; r < hi; r++) {
-            const uint64_t i = rows[r], key = hs.keys[i];
-            for (int p = 0; p < sd.k; p++) s.push_back("ACTG"[(key >> (62 - 2 * p)) & 3]);   // Sequence.java:117-134
-            s.push_back('\t');
-            append_values(s, hs, i);
-            s += "\t-|";
-            append_values(s, hr, (uint64_t)hit[i]);
-            s.push_back('\n');
-        }
-    });
-    clk.lap("format match lines");
-    if (a.has('Z')) {
-        FILE *f = fopen(a.get('o').c_str(), "wb");
-        if (!f) throw std::runtime_error("cannot create " + a.get('o'));
-        for (auto &s : text) fwrite(s.data(), 1, s.size(), f);
-        fclose(f);
-    } else {
-        // gzip at the default level (Matcher.java:138-139).  One member per 64 K lines, deflated on the pool:
-        // a multi-member file is what every gzip reader (java.util.zip.GZIPInputStream included) accepts, and
-        // single-threaded deflate of the match text would otherwise dominate the whole program.
-        std::vector<std::string> zipped(nchunk);
+    slices = std::max(1, std::min(slices, key_hi - key_lo));
+    FILE *f = fopen(a.get('o').c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot create " + a.get('o'));
+    bool wrote = false;
+    for (int sl = 0; sl < slices; sl++) {
+        const int lo = key_lo + (int)((int64_t)(key_hi - key_lo) * sl / slices);
+        const int hi = key_lo + (int)((int64_t)(key_hi - key_lo) * (sl + 1) / slices);
+        kmg_db *ref = ref_set.load(g, lo, hi), *search = search_set.load(g, lo, hi);
+        const DbInfo rd = db_info(ref), sd = db_info(search);
+        if (!rd.rc)   // DB.java:57-64
+            throw std::runtime_error("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included");
+        std::vector<int64_t> hit(sd.U + 1);
+        uint64_t nh = 0;
+        clk.lap("read + decode databases");
+        g.check(kmg_match(g.ctx, search, ref, hit.data(), &nh));
+        const HostDb hs = fetch(g, search), hr = fetch(g, ref);
+        kmg_db_free(ref);
+        kmg_db_free(search);
+        clk.lap("match (GPU) + fetch");
+        // one line per matched search k-mer, ascending (Matcher.java:247-249, ResultsDataType.java:15-35):
+        //   KMER \t values of the search k-mer \t -|values of the reference k-mer       ("-" = empty KmerDiff)
+        std::vector<uint64_t> rows;
+        rows.reserve(nh);
+        for (uint64_t i = 0; i < sd.U; i++) if (hit[i] >= 0) rows.push_back(i);
+        const size_t nchunk = (rows.size() + 65535) / 65536;
+        std::vector<std::string> text(nchunk);
         parallel_for(nchunk, [&](size_t c) {
-            zipped[c] = gzip_member((const uint8_t *)text[c].data(), text[c].size(), 6);
-            std::string().swap(text[c]);
+            std::string &s = text[c];
+            const size_t lo_r = c * 65536, hi_r = std::min(rows.size(), lo_r + 65536);
+            s.reserve((hi_r - lo_r) * (size_t)(sd.k + 48));
+            for (size_t r = lo_r; r < hi_r; r++) {
+                const uint64_t i = rows[r], key = hs.keys[i];
+                for (int p = 0; p < sd.k; p++) s.push_back("ACTG"[(key >> (62 - 2 * p)) & 3]);   // Sequence.java:117-134
+                s.push_back('\t');
+                append_values(s, hs, i);
+                s += "\t-|";
+                append_values(s, hr, (uint64_t)hit[i]);
+                s.push_back('\n');
+            }
         });
-        FILE *f = fopen(a.get('o').c_str(), "wb");
-        if (!f) throw std::runtime_error("cannot create " + a.get('o'));
-        if (nchunk == 0) { const std::string e = gzip_member(nullptr, 0, 6); fwrite(e.data(), 1, e.size(), f); }
-        for (auto &s : zipped) fwrite(s.data(), 1, s.size(), f);
-        fclose(f);
+        clk.lap("format match lines");
+        if (a.has('Z')) {
+            for (auto &s : text) fwrite(s.data(), 1, s.size(), f);
+        } else {
+            // gzip at the default level (Matcher.java:138-139).  One member per 64 K lines, deflated on the pool:
+            // a multi-member file is what every gzip reader (java.util.zip.GZIPInputStream included) accepts, and
+            // single-threaded deflate of the match text would otherwise dominate the whole program.
+            std::vector<std::string> zipped(nchunk);
+            parallel_for(nchunk, [&](size_t c) {
+                zipped[c] = gzip_member((const uint8_t *)text[c].data(), text[c].size(), 6);
+                std::string().swap(text[c]);
+            });
+            for (auto &s : zipped) { fwrite(s.data(), 1, s.size(), f); wrote = wrote || !s.empty(); }
+        }
+        clk.lap("deflate + write");
     }
-    clk.lap("deflate + write");
-    kmg_db_free(ref);
-    kmg_db_free(search);
+    if (!a.has('Z') && !wrote) { const std::string e = gzip_member(nullptr, 0, 6); fwrite(e.data(), 1, e.size(), f); }
+    fclose(f);
     return 0;
 }
 

@@ -142,6 +142,11 @@ def test_native_cli_matches_python_drivers(tmp_path):
     one = key_of(all_lines[len(all_lines) // 2])
     run("Database.Matcher", "-i", p("reads.db"), "-d", p("refz.db"), "-o", p("m.L1.txt"), "-Z", "x", "-L", str(one))
     assert open(p("m.L1.txt")).read().splitlines() == [x for x in all_lines if key_of(x) == one] != []
+    # the keys walked in slices (databases too large for one join): the same lines, plain and gzip
+    run("Database.Matcher", "-i", p("reads.db"), "-d", p("set.db") if os.path.exists(p("set.db.1")) else p("ref.db"), "-o", p("m.P7.txt"), "-Z", "x", "-P", "7")
+    assert open(p("m.P7.txt"), "rb").read() == want
+    run("Database.Matcher", "-i", p("reads.py.db"), "-d", p("refz.db"), "-o", p("m.P3.gz"), "-P", "3")
+    assert gzip.open(p("m.P3.gz"), "rb").read() == want
     ctx = km.Context(0)
     assert programs.matcher(ctx, p("reads.db"), p("ref.db"), p("m.L.py.txt"), plain=True, limit="17-130") == \
         [x for x in all_lines if 17 <= key_of(x) <= 130]
