@@ -953,20 +953,29 @@ int matcher(int argc, char **argv) {
 }
 
 int taxa_counts(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "dot", "");
+    const Args a = parse_args(argc, argv, 2, "dotP", "");
     if (!a.has('d') || !a.has('o')) throw std::runtime_error("-d and -o are required");
+    g_threads = std::max(1, a.geti('t', g_threads));
     Gpu g;
-    kmg_db *ref = open_database_set(g, a.get('d'));
-    const DbInfo d = db_info(ref);
-    uint64_t n = std::max<uint64_t>(d.V, 1);
-    std::vector<int32_t> t(n);
-    std::vector<int64_t> m(n), q(n);
-    g.check(kmg_taxacounts(g.ctx, ref, t.data(), m.data(), q.data(), &n));
+    // the keys in slices, as in Matcher (-P n, or by file size): a k-mer lives in one slice, so the counts add
+    const DatabaseSet set(a.get('d'));
+    const int slices = std::max(1, std::min(std::max<int>(std::max(1, a.geti('P', 1)), (int)(set.bytes >> 32) + 1), set.end_key));
+    std::map<int32_t, std::pair<int64_t, int64_t>> total;
+    for (int sl = 0; sl < slices; sl++) {
+        const int lo = (int)((int64_t)set.end_key * sl / slices), hi = (int)((int64_t)set.end_key * (sl + 1) / slices);
+        kmg_db *ref = set.load(g, lo, hi);
+        const DbInfo d = db_info(ref);
+        uint64_t n = std::max<uint64_t>(d.V, 1);
+        std::vector<int32_t> t(n);
+        std::vector<int64_t> m(n), q(n);
+        g.check(kmg_taxacounts(g.ctx, ref, t.data(), m.data(), q.data(), &n));
+        kmg_db_free(ref);
+        for (uint64_t i = 0; i < n; i++) { auto &e = total[t[i]]; e.first += m[i]; e.second += q[i]; }
+    }
     FILE *f = fopen(a.get('o').c_str(), "w");
     if (!f) throw std::runtime_error("cannot create " + a.get('o'));
-    for (uint64_t i = 0; i < n; i++) fprintf(f, "%d\t%lld\t%lld\n", t[i], (long long)m[i], (long long)q[i]);   // TaxaCounts.java:142-150
+    for (auto &kv : total) fprintf(f, "%d\t%lld\t%lld\n", kv.first, (long long)kv.second.first, (long long)kv.second.second);   // TaxaCounts.java:142-150
     fclose(f);
-    kmg_db_free(ref);
     return 0;
 }
 

@@ -154,6 +154,8 @@ def test_native_cli_matches_python_drivers(tmp_path):
     run("Utils.TaxaCounts", "-d", p("refz.db"), "-o", p("c.tsv"))
     t, m, q = o_ref.taxacounts()
     assert open(p("c.tsv")).read().splitlines() == ["%d\t%d\t%d" % x for x in zip(t, m, q)]
+    run("Utils.TaxaCounts", "-d", p("ref.db"), "-o", p("c.P5.tsv"), "-P", "5")        # keys in slices: the counts add
+    assert open(p("c.P5.tsv")).read() == open(p("c.tsv")).read()
     # per-read tools downstream of the match, native: same blocks as the restated CollectByRead / ReadClassifier
     want_cb = R.collect_by_read(want.decode().splitlines())
     run("Utils.CollectByRead", "-i", p("m.gz"), "-o", p("by_read"))
