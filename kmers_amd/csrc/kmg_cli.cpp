@@ -1270,7 +1270,7 @@ int read_classifier(int argc, char **argv) {
 // three files in between: both databases stay on the GPU, the join feeds kmg_classify_reads_hits and only the
 // `read \t call` lines leave.  No counterpart program in the reference.
 int read_calls(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "qdaoKlrt", "v");
+    const Args a = parse_args(argc, argv, 2, "qdaoKlrtC", "v");
     if (!a.has('q') || !a.has('o') || a.has('d') == a.has('a'))
         throw std::runtime_error("-q, -o and exactly one of -d (database) / -a (FASTA reference) are required");
     g_threads = std::max(1, a.geti('t', g_threads));
@@ -1287,14 +1287,81 @@ int read_calls(int argc, char **argv) {
     } else ref = build_from_text(g, a.get('a'), false, k, key_len, false, -1, -1, "", nullptr, nullptr, clk);
     if (!db_info(ref).rc)   // DB.java:57-64
         throw std::runtime_error("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included");
-    uint64_t n_reads = 0;
-    kmg_db *reads = build_from_text(g, a.get('q'), true, k, key_len, false, -1, -1, a.get('r'), &n_reads, nullptr, clk);
-    std::vector<int32_t> call(std::max<uint64_t>(n_reads, 1), -1);
-    std::vector<uint8_t> seen(std::max<uint64_t>(n_reads, 1), 0);
-    g.check(kmg_classify_reads_hits(g.ctx, reads, ref, n_reads, call.data(), seen.data()));
-    kmg_db_free(reads);
+    // The reads go through in chunks of sequences (-C n, default: what keeps a chunk's windows inside one build): a
+    // call depends on its own read only.  Reads number on across chunks as ReadIDMapping would: the sequences
+    // that share a chunk's LAST read index may have more of their kind behind the cut, so that index is left to the
+    // next chunk, which starts at its first sequence -- an emitting one, so the numbering there starts as it would
+    // have gone on.
+    const std::string data = read_input(a.get('q'));
+    clk.lap("read input");
+    const std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch(kmh_parse((const uint8_t *)data.data(), data.size(), 1, k), kmh_free);
+    const kmh_batch *b = batch.get();
+    const uint64_t nseq = kmh_nseq(b);
+    const uint64_t *off = kmh_seq_off(b);
+    const int64_t *tok = kmh_seq_tok(b);
+    clk.lap("split records (host)");
+    gzFile zmap = nullptr;
+    if (a.has('r')) {
+        zmap = gzopen(a.get('r').c_str(), "wb");
+        if (!zmap) throw std::runtime_error("cannot create " + a.get('r'));
+    }
+    std::vector<int32_t> call;
+    std::vector<uint8_t> seen;
+    uint64_t chunk_seqs = a.has('C') ? (uint64_t)std::max(1, a.geti('C', 1)) : 0;
+    uint64_t s0 = 0;
+    while (s0 < nseq) {
+        uint64_t s1;
+        if (chunk_seqs) s1 = std::min(nseq, s0 + chunk_seqs);
+        else {      // as many sequences as hold at most 3 G bases (every base can start a window)
+            s1 = std::upper_bound(off + s0, off + nseq + 1, off[s0] + 3000000000ull) - off - 1;
+            s1 = std::max(s1, s0 + 1);
+        }
+        std::vector<uint64_t> loff(s1 - s0 + 1);
+        for (uint64_t i = 0; i <= s1 - s0; i++) loff[i] = off[s0 + i] - off[s0];
+        std::vector<int32_t> ridx(s1 - s0, -1);
+        g.check(kmg_build_begin(g.ctx, k, key_len, 0, KMG_PAYLOAD_READPOS));
+        g.check(kmg_build_add(g.ctx, kmh_bases(b) + off[s0], loff.back(), loff.data(), nullptr, tok + s0, s1 - s0, ridx.data()));
+        kmg_db *reads = nullptr;
+        g.check(kmg_build_finish(g.ctx, &reads, nullptr));
+        int32_t top = -1;
+        for (int32_t r : ridx) top = std::max(top, r);
+        const uint64_t n_local = (uint64_t)(top + 1);
+        uint64_t keep = n_local, next = s1;
+        if (s1 < nseq && n_local > 0) {
+            keep = n_local - 1;
+            next = s0;
+            while (ridx[next - s0] != top) next++;
+            if (next == s0) {               // one read index fills the whole chunk: take a longer one
+                kmg_db_free(reads);
+                chunk_seqs = (s1 - s0) * 2;
+                continue;
+            }
+        }
+        std::vector<int32_t> c(std::max<uint64_t>(n_local, 1), -1);
+        std::vector<uint8_t> h(std::max<uint64_t>(n_local, 1), 0);
+        g.check(kmg_classify_reads_hits(g.ctx, reads, ref, n_local, c.data(), h.data()));
+        kmg_db_free(reads);
+        call.insert(call.end(), c.begin(), c.begin() + keep);
+        seen.insert(seen.end(), h.begin(), h.begin() + keep);
+        if (zmap) {
+            const uint64_t *noff = kmh_name_off(b);
+            const char *names = kmh_names(b);
+            int32_t last = -1;
+            for (uint64_t s = s0; s < s1; s++) {
+                const int32_t r = ridx[s - s0];
+                if (r >= 0 && r != last && (uint64_t)r < keep) {
+                    gzwrite(zmap, names + noff[tok[s]], (unsigned)(noff[tok[s] + 1] - noff[tok[s]]));
+                    gzwrite(zmap, "\n", 1);
+                }
+                if (r >= 0) last = r;
+            }
+        }
+        s0 = next;
+    }
+    if (zmap) gzclose(zmap);
     kmg_db_free(ref);
-    clk.lap("join + classify (GPU)");
+    const uint64_t n_reads = call.size();
+    clk.lap("build + join + classify (GPU)");
     // one block per (read / 1000) * 1000 that holds a read with a matched k-mer (CollectByRead.java:105-124 writes no
     // other); inside, the reads that have a call (ReadClassifier.java:140-160)
     std::vector<std::pair<int, std::string>> blocks;

@@ -169,6 +169,25 @@ def test_native_cli_matches_python_drivers(tmp_path):
     assert gzip.open(p("map2.gz"), "rt").read().splitlines() == o_reads.names
     run("Pipeline.ReadCalls", "-q", fq, "-a", fa, "-o", p("calls.fused2"), "-K", str(k), "-l", str(l))
     assert R.read_indexed_file(p("calls.fused2")) == want_calls
+    # reads in chunks (-C sequences per chunk): calls depend on their own read only and the numbering runs on across
+    # the cuts -- also where neighbouring records share a header (one read index for both mates, or for a whole run
+    # of records longer than a chunk) and where reads without any k-mer sit at the cuts
+    recs = synth.fastq_bytes(reads).split(b"@")[1:]
+    names = [b"r%d" % (i // 2) for i in range(len(recs))]
+    for i in range(300, 340):
+        names[i] = b"same"                                            # forty records, one read index
+    for i in range(0, len(recs), 11):
+        recs[i] = recs[i].split(b"\n", 1)[0] + b"\n" + b"N" * 110 + b"\n+\n" + b"I" * 110 + b"\n"      # no k-mer at all
+    open(p("paired.fq"), "wb").write(b"".join(b"@" + nm + b"\n" + r.split(b"\n", 1)[1] for nm, r in zip(names, recs)))
+    run("Pipeline.ReadCalls", "-q", p("paired.fq"), "-d", p("ref.db"), "-o", p("pc.whole"), "-r", p("pc.whole.map.gz"))
+    ctx = km.Context(0)
+    whole = programs.read_calls(ctx, p("paired.fq"), p("pc.py"), db_path=p("ref.db"))
+    ctx.close()
+    assert R.read_indexed_file(p("pc.whole")) == whole and sum(len(v) for v in whole.values()) > 200
+    for c in ("1", "2", "7", "64", "1000"):
+        run("Pipeline.ReadCalls", "-q", p("paired.fq"), "-d", p("ref.db"), "-o", p("pc." + c), "-r", p("pc.map.gz"), "-C", c)
+        assert open(p("pc." + c), "rb").read() == open(p("pc.whole"), "rb").read(), c
+        assert gzip.open(p("pc.map.gz"), "rb").read() == gzip.open(p("pc.whole.map.gz"), "rb").read(), c
     open(p("none.fq"), "wb").write(b"@r\nNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN\n+\n" + b"I" * 40 + b"\n")
     run("Pipeline.ReadCalls", "-q", p("none.fq"), "-d", p("ref.db"), "-o", p("calls.none"))
     assert R.read_indexed_file(p("calls.none")) == {}
