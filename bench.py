@@ -38,9 +38,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calib", action="store_true", help="also launch the known-traffic copy kernel (PMC calibration)")
     ap.add_argument("--exchange", action="store_true",
-                    help="key-range mode (SURVEY 8e) instead of the replicated reference: every rank builds the database of "
-                         "its share of the genomes, the shards are exchanged by key range (all-to-all of CSR slices + GPU "
-                         "merge), read k-mers are exchanged to the owners for the join.  Opt-in: not the headline line.")
+                    help="key-range mode (SURVEY 8e) instead of the replicated reference: the reference is range-partitioned by "
+                         "k-mer prefix -- every rank builds only the key range it owns (kmg_build_set_key_range) -- and the "
+                         "read k-mers are bucketed and exchanged to the owners for the join (RCCL all-to-all, hits come back "
+                         "the same way).  Opt-in: not the headline line.")
     args = ap.parse_args()
 
     # stdout carries the one JSON line and nothing else: RCCL prints a version banner on file descriptor 1 when the
@@ -72,8 +73,7 @@ def main():
     nreads = max(100, int(1_000_000 * args.scale))
     taxa, genomes = synth.random_genomes(1, 10, glen)
     reads = synth.random_reads(2 + rank, genomes, nreads, 150, 0.01)
-    my_genomes = genomes[rank::world] if args.exchange else genomes
-    my_taxa = taxa[rank::world] if args.exchange else taxa
+    my_genomes, my_taxa = genomes, taxa          # every rank holds the whole reference input
     ref_bases, ref_off = synth.batch_from_seqs(my_genomes)
     read_off = np.arange(nreads + 1, dtype=np.uint64) * np.uint64(150)
     d_ref_bases = torch.from_numpy(ref_bases).to(dev)
@@ -108,23 +108,33 @@ def main():
 
     stage_s = {"ref_build": 0.0, "read_build": 0.0, "match": 0.0}
 
-    def step_exchange():
-        """Key-range mode: local reference build -> ranges from the all-reduced bucket histogram -> exchange + merge
-        -> local read build -> sharded join (kmers_amd/dist.py; RCCL all-to-all under nccl)."""
+    ranges = None
+    if args.exchange:
+        # The partition of the key space is a property of the reference, planned once: balanced ranges from the bucket
+        # histogram of one complete build (every rank holds the whole input, so all ranks find the same ranges).
         from kmers_amd import dist as kd
         submit(ctx_ref, d_ref_bases, d_ref_off, d_ref_id, None, len(my_genomes), 0, 1)
+        whole = km.KmerDatabase(ctx_ref, finish(ctx_ref)[0])
+        ranges = kd.balanced_key_ranges(np.diff(whole.bucket_offsets().astype(np.int64)), world)
+        whole.close()
+
+    def step_exchange():
+        """Key-range mode: this rank's range of the reference is built from the whole input (no reference k-mer leaves
+        its GPU), the reads are built locally, their distinct k-mers are cut at the range bounds, exchanged, joined by
+        the owners and the hit indices exchanged back (kmers_amd/dist.py; RCCL all-to-all under nccl)."""
+        ctx_ref.check(lib.kmg_build_begin(h_ref, K, KEY_LEN, 1, 0))
+        ctx_ref.check(lib.kmg_build_set_key_range(h_ref, ranges[rank][0], ranges[rank][1]))
+        ctx_ref.check(lib.kmg_build_add_dev(h_ref, d_ref_bases.data_ptr(), d_ref_bases.numel(), d_ref_off.data_ptr(),
+                                            d_ref_id.data_ptr(), None, len(my_genomes), None))
         submit(ctx, d_read_bases, d_read_off, None, d_read_tok, nreads, 1, 0)
         ref_h, nw_ref = finish(ctx_ref)
-        local = km.KmerDatabase(ctx_ref, ref_h)
-        hist = kd.allreduce_sum(np.diff(local.bucket_offsets().astype(np.int64)), device=dev if use_dist else "cpu")
-        ranges = kd.balanced_key_ranges(hist, world)
-        shard = kd.build_key_range_shard(ctx_ref, local, ranges)
+        shard = km.KmerDatabase(ctx_ref, ref_h)
         rdb_h, nw_reads = finish(ctx)
         rdb = km.KmerDatabase(ctx, rdb_h)
-        owner, hit = kd.match_key_range_shard(ctx, rdb, shard, ranges)
+        _, hit = kd.match_key_range_shard(ctx, rdb, shard, ranges, want_owner=False)
         nw_all = int(kd.allreduce_sum(np.array([nw_ref]), device=dev if use_dist else "cpu")[0])
-        for d in {id(x): x for x in (rdb, shard, local)}.values():
-            d.close()
+        rdb.close()
+        shard.close()
         return nw_all, nw_reads
 
     def step(timed_stages=False):
@@ -235,8 +245,9 @@ def main():
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": ("BASELINE config 2 in key-range mode: 5 Mbp reference (10 taxa) built in shares and exchanged "
-                                    "by key range, 1M x 150 bp reads per GPU joined at the owners, k=31, key length 6"
+            "config": {"workload": ("BASELINE config 2 in key-range mode: 5 Mbp reference (10 taxa) range-partitioned by k-mer "
+                                    "prefix (every GPU builds the range it owns), 1M x 150 bp reads per GPU, their k-mers "
+                                    "exchanged to the owners and joined there, k=31, key length 6"
                                     if args.exchange else
                                     "BASELINE config 2: 5 Mbp reference (10 taxa) + 1M x 150 bp reads per GPU, k=31, "
                                     "key length 6; build both DBs + exact match; inputs resident in HBM"),
