@@ -32,6 +32,7 @@ $DRIVER Database.Matcher -i "$WORK/gpu/reads.db" -d "$WORK/gpu/ref.db" -o "$WORK
 $DRIVER Utils.TaxaCounts -d "$WORK/gpu/ref.db" -o "$WORK/gpu.counts.tsv"
 $DRIVER Utils.CollectByRead -i "$WORK/gpu.matches.txt" -o "$WORK/gpu.by_read"
 $DRIVER Utils.ReadClassifier -i "$WORK/gpu.by_read" -o "$WORK/gpu.calls"
+$DRIVER Pipeline.ReadCalls -q "$WORK/reads.fq" -d "$WORK/java_ref/ref.db" -o "$WORK/gpu.calls.fused"      # the Java-built reference, no files in between
 cmp "$WORK/java_ref/ref.db" "$WORK/gpu/ref.db" && echo "reference DB: byte-identical"
 diff <(zcat "$WORK/java_reads/reads.map.gz") <(zcat "$WORK/gpu/reads.map.gz") && echo "read map: identical"
 python3 - <<PY
@@ -50,4 +51,5 @@ assert lines("$WORK/java.matches.txt") == lines("$WORK/gpu.matches.txt"); print(
 assert open("$WORK/java.counts.tsv").read() == open("$WORK/gpu.counts.tsv").read(); print("TaxaCounts: identical")
 assert R.read_indexed_file("$WORK/java.by_read") == R.read_indexed_file("$WORK/gpu.by_read"); print("CollectByRead: identical blocks")
 assert R.read_indexed_file("$WORK/java.calls") == R.read_indexed_file("$WORK/gpu.calls"); print("ReadClassifier: identical blocks")
+assert R.read_indexed_file("$WORK/java.calls") == R.read_indexed_file("$WORK/gpu.calls.fused"); print("Pipeline.ReadCalls: the same blocks in one go")
 PY
