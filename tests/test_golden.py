@@ -83,6 +83,20 @@ def test_gpu_reproduces_golden(path):
                 rs.append(r)
         want_calls[key] = "".join("%d\t%d\n" % (r, int(call[r])) for r in rs if call[r] >= 0).encode()
     assert want_calls == g["read_classifier"]
+    # the same blocks without CollectByRead's records in between (kmg_classify_reads_hits)
+    call2, seen = km.classify_reads(reads, ref, len(names), with_hits=True)
+    assert km.read_call_blocks(call2, seen) == g["read_classifier"]
     for d in (ref, reads):
         d.close()
+    # the databases again, built in three key ranges (kmg_build_set_key_range): the frozen blocks, range by range
+    nkeys = 4 ** l
+    for lo, hi in ((0, nkeys // 3), (nkeys // 3, nkeys - 1), (nkeys - 1, nkeys)):
+        part_ref = km.make_reference_db(ctx, g["fasta"].encode(), k, l, dust=dust, runofsame=run, key_range=(lo, hi))
+        part_reads, part_names = km.make_read_db(ctx, g["fastq"].encode(), k, l, dust=dust, runofsame=run, key_range=(lo, hi))
+        assert part_names == g["read_names"]
+        for db, want in ((part_ref, g["ref_blocks"]), (part_reads, g["read_blocks"])):
+            blob, off = db.encode_blocks()
+            for key in range(nkeys):
+                assert blob[int(off[key]):int(off[key + 1])] == (want[key] if lo <= key < hi else b""), key
+            db.close()
     ctx.close()
