@@ -732,7 +732,7 @@ int make_database_preprocessed(const Args &a, int k, int key_len, int level) {
 // (kmg_build_set_key_range), each handed to per_pass(db, first key, end key) and freed; returns NULL then.
 kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int key_len, bool filters, int dust, int runofsame,
                         const std::string &read_map, uint64_t *n_reads, uint64_t *nwin, StageClock &clk, int passes = 1,
-                        const std::function<void(kmg_db *, size_t, size_t)> &per_pass = nullptr) {
+                        const std::function<void(kmg_db *, size_t, size_t)> &per_pass = nullptr, int share = 0, int shares = 1) {
     const std::string data = read_input(path);
     clk.lap("read input");
     const std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch(kmh_parse((const uint8_t *)data.data(), data.size(), reads ? 1 : 0, k), kmh_free);
@@ -749,26 +749,30 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
     std::vector<int32_t> ridx(reads ? nseq : 0);
     kmg_db *db = nullptr;
     const size_t nkeys = (size_t)1 << (2 * key_len);
-    passes = (int)std::max<size_t>(1, std::min<size_t>((size_t)passes, nkeys));
+    // share / shares (-G): this process builds the share-th of `shares` equal key ranges only
+    const size_t r_lo = nkeys * (size_t)share / (size_t)shares, r_hi = nkeys * ((size_t)share + 1) / (size_t)shares;
+    const bool ranged = passes > 1 || shares > 1;
+    passes = (int)std::max<size_t>(1, std::min<size_t>((size_t)passes, std::max<size_t>(r_hi - r_lo, 1)));
     uint64_t windows = 0;
     for (int ps = 0; ps < passes; ps++) {
-        const size_t lo = nkeys * ps / passes, hi = nkeys * (ps + 1) / passes;
+        const size_t lo = r_lo + (r_hi - r_lo) * ps / passes, hi = r_lo + (r_hi - r_lo) * (ps + 1) / passes;
+        if (hi <= lo) continue;
         g.check(kmg_build_begin(g.ctx, k, key_len, reads ? 0 : 1, reads ? KMG_PAYLOAD_READPOS : KMG_PAYLOAD_TAXON));
         if (filters) g.check(kmg_build_set_filters(g.ctx, dust, runofsame));
-        if (passes > 1) g.check(kmg_build_set_key_range(g.ctx, (uint32_t)lo, (uint32_t)hi));
+        if (ranged) g.check(kmg_build_set_key_range(g.ctx, (uint32_t)lo, (uint32_t)hi));
         g.check(kmg_build_add(g.ctx, kmh_bases(b), kmh_nbases(b), off, reads ? nullptr : kmh_seq_id(b),
                               reads ? kmh_seq_tok(b) : nullptr, nseq, reads ? ridx.data() : nullptr));
         uint64_t w = 0;
         g.check(kmg_build_finish(g.ctx, &db, &w));
         windows += w;
-        if (passes > 1) {
+        if (ranged) {
             per_pass(db, lo, hi);
             kmg_db_free(db);
             db = nullptr;
         }
     }
     if (nwin) *nwin = windows;
-    clk.lap(passes > 1 ? "copy in + build (GPU), encode + write, per pass" : "copy in + build (GPU)");
+    clk.lap(ranged ? "copy in + build (GPU), encode + write, per pass" : "copy in + build (GPU)");
     if (reads) {
         int32_t top = -1;
         for (uint64_t s = 0; s < nseq; s++) top = std::max(top, ridx[s]);
@@ -794,7 +798,7 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
 }
 
 int make_database(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmNPL", "aqpZvh");
+    const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmNPLG", "aqpZvh");
     if (a.has('L') && !a.has('p')) throw std::runtime_error("-L limits the input indexes of a preprocessed file (-p)");
     for (char c : std::string("mN")) if (a.has(c)) throw Unsupported(std::string("option -") + c + " is not on the GPU path");
     const int k = a.geti('K', 32), min_k = a.geti('k', 24), key_len = a.geti('l', 6);     // MakeDatabase.java:106-109
@@ -804,6 +808,7 @@ int make_database(int argc, char **argv) {
     if ((int)a.has('a') + (int)a.has('q') + (int)a.has('p') != 1)
         throw std::runtime_error("exactly one of -a (FASTA reference) / -q (FASTQ reads) / -p (preprocessed) is required");
     if (!a.has('i') || !a.has('o')) throw std::runtime_error("-i and -o are required");
+    if (a.has('p') && (a.has('P') || a.has('G'))) throw std::runtime_error("-P and -G go with -a / -q");
     if (a.has('p')) return make_database_preprocessed(a, k, key_len, level);
     const bool reads = a.has('q');
     if (reads && !a.has('r')) throw std::runtime_error("-r <read map file> is required with -q");   // MakeDatabase.java:172-173
@@ -814,7 +819,17 @@ int make_database(int argc, char **argv) {
     // -P n (no counterpart in the reference): build and write the database in n key ranges, one after the other --
     // the same file, for inputs whose k-mers do not fit one build (2^32-16 records) or the GPU's memory
     const int passes = std::max(1, a.geti('P', 1));
-    DatabaseWriter w(g, a.get('o'), level, a.has('S') ? size_from_human(a.get('S')) : 0, a.has('h'));
+    // -G r/n (no counterpart either): this process builds the r-th of n equal key ranges (r = 0 .. n-1) and writes it as
+    // <output>.<r+1> -- n processes, one per GPU, no communication, and the files are a database set as the reference
+    // reads it (name.1 .. name.N, Matcher.java:80-89).  The read map is written by share 0 only.
+    int share = 0, shares = 1;
+    if (a.has('G')) {
+        if (sscanf(a.get('G').c_str(), "%d/%d", &share, &shares) != 2 || shares < 1 || share < 0 || share >= shares)
+            throw std::runtime_error("-G wants r/n with 0 <= r < n");
+        if (a.has('S')) throw std::runtime_error("-G and -S both name the files of a set");
+    }
+    const std::string out_path = shares > 1 ? a.get('o') + "." + std::to_string(share + 1) : a.get('o');
+    DatabaseWriter w(g, out_path, level, a.has('S') ? size_from_human(a.get('S')) : 0, a.has('h'));
     uint64_t U = 0, V = 0;
     auto emit = [&](kmg_db *part, size_t lo, size_t hi) {
         const DbInfo d = db_info(part);
@@ -822,7 +837,7 @@ int make_database(int argc, char **argv) {
         w.add(part, lo, hi);
     };
     kmg_db *db = build_from_text(g, a.get('i'), reads, k, key_len, a.has('D') || a.has('R'), a.geti('D', -1), a.geti('R', -1),
-                                 reads ? a.get('r') : "", nullptr, &nwin, clk, passes, emit);
+                                 reads && share == 0 ? a.get('r') : "", nullptr, &nwin, clk, passes, emit, share, shares);
     if (db) {
         emit(db, 0, (size_t)1 << (2 * key_len));
         kmg_db_free(db);

@@ -27,7 +27,7 @@ def _hr_values(kind, a, b):
     return " ".join("%d:%d" % x for x in zip(a, b))
 
 
-def write_database(db: KmerDatabase, path, zip_level=5, hr=False, out=None, key_range=None):
+def write_database(db: KmerDatabase, path, zip_level=5, hr=False, out=None, key_range=None, with_meta=None):
     """FileCreator.create (FileCreator.java:117-217): meta under key -1, then every key 0..4^l-1 in order
     (each gets a block, empty ones included, quirk C.12).  hr = MakeDatabase -h: text meta, one text line per
     k-mer with the characters it shares with the previous k-mer of its key block dropped
@@ -36,11 +36,13 @@ def write_database(db: KmerDatabase, path, zip_level=5, hr=False, out=None, key_
     ranges, one call per range in ascending order; the first call writes the meta block, the caller closes)."""
     part = out is not None
     first, end = key_range if key_range is not None else (0, 4 ** db.key_length)
+    if with_meta is None:
+        with_meta = not part or first == 0
     if out is None:
         out = container.IndexedOutputFile(path, hr=hr, zip_level=zip_level)
     if not hr:
         blocks, off = db.encode_blocks()
-        if not part or first == 0:
+        if with_meta:
             out.write_all(db.meta(), -1)
         for key in range(first, end):
             out.set_current_key(key)
@@ -49,7 +51,7 @@ def write_database(db: KmerDatabase, path, zip_level=5, hr=False, out=None, key_
             out.close()
         return
     ids = " ".join(str(i) for i in db.data_id())                     # Compressor.getStringID
-    if not part or first == 0:
+    if with_meta:
         out.write_all(("%d\n%d\n%d\n%s\n%s\n" % (db.k, db.k, db.key_length, ids, "1" if db.rc else "0")).encode(), -1)
     h = db.fetch()
     names = kmer_strings(h["keys"], db.k)
@@ -196,31 +198,38 @@ def read_preprocessed(path, packed=False, limit=None):
 
 
 def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length=6, zip_level=5, read_map_path=None,
-                  dust=None, runofsame=None, hr=False, passes=1, limit=None):
+                  dust=None, runofsame=None, hr=False, passes=1, limit=None, share=None):
     """MakeDatabase -a (mode 'a') / -q (mode 'q') / -p (mode 'p', preprocessed input).  Defaults as the reference's
     (-K 32 -k 24 -l 6 -z 5, MakeDatabase.java:106-109); minK != maxK is refused (GPU path limit).
     passes > 1 (-P, no counterpart in the reference; modes 'a' and 'q'): the database is built and written in that many
-    key ranges, one after the other -- the same file, for inputs that do not fit one build; returns None then."""
+    key ranges, one after the other -- the same file, for inputs that do not fit one build; returns None then.
+    share = (r, n) (-G r/n, no counterpart either): this process builds the r-th of n equal key ranges and writes it as
+    <output>.<r+1>: n processes, one per GPU, no communication, and the files are a database set as the reference reads
+    it (name.1 .. name.N, Matcher.java:80-89); the read map is written by share 0."""
     if min_k != k:
         raise KmersGpuError(KMG_EUNSUPPORTED, "minK != maxK is not supported on the GPU path")
-    if passes > 1 and mode in ("a", "q"):
+    if (passes > 1 or share is not None) and mode in ("a", "q"):
         from . import parse
         if mode == "q" and read_map_path is None:
             raise ValueError("-r <read map file> is required with -q")
         pf = parse.parse(open(input_path, "rb").read(), parse.FASTA if mode == "a" else parse.FASTQ, k)
         nkeys = 4 ** key_length
-        passes = min(passes, nkeys)
+        r, n = share if share is not None else (0, 1)
+        r_lo, r_hi = nkeys * r // n, nkeys * (r + 1) // n
+        passes = max(1, min(passes, r_hi - r_lo))
+        if n > 1:
+            output_path = "%s.%d" % (output_path, r + 1)
         out = container.IndexedOutputFile(output_path, hr=hr, zip_level=zip_level)
         for ps in range(passes):
-            rng = (nkeys * ps // passes, nkeys * (ps + 1) // passes)
+            rng = (r_lo + (r_hi - r_lo) * ps // passes, r_lo + (r_hi - r_lo) * (ps + 1) // passes)
             if mode == "a":
                 db = make_reference_db(ctx, pf, k, key_length, dust, runofsame, key_range=rng)
             else:
                 db, names = make_read_db(ctx, pf, k, key_length, dust, runofsame, key_range=rng)
-            write_database(db, output_path, zip_level, hr, out=out, key_range=rng)
+            write_database(db, output_path, zip_level, hr, out=out, key_range=rng, with_meta=ps == 0)
             db.close()
         out.close()
-        if mode == "q":
+        if mode == "q" and r == 0:
             with gzip.open(read_map_path, "wt") as g:
                 for nm in names:
                     g.write(nm + "\n")

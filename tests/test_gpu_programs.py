@@ -212,6 +212,28 @@ def test_native_cli_matches_python_drivers(tmp_path):
     assert R.read_indexed_file(p("reads.py.p2.db")) == R.read_indexed_file(p("reads.want"))
     assert gzip.open(p("map.py.p2.gz"), "rt").read().splitlines() == o_reads.names
     ctx.close()
+    # -G r/n: every process builds one share of the key space into <output>.<r+1>; together the files are a database set
+    for r in range(3):
+        run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("g.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-G", "%d/3" % r,
+            *(["-P", "2"] if r == 1 else []))
+        run("Database.MakeDatabase", "-q", "-i", fq, "-o", p("gr.db"), "-r", p("gr.map.gz"), "-K", str(k), "-k", str(k), "-l", str(l),
+            "-Z", "-G", "%d/3" % r)
+    assert not os.path.exists(p("g.db")) and sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("g.db.")) == ["g.db.1", "g.db.2", "g.db.3"]
+    whole_ref, got_keys = R.read_indexed_file(p("ref.want")), []
+    for r in range(3):
+        blocks = R.read_indexed_file(p("g.db.%d" % (r + 1)))
+        assert blocks[-1] == whole_ref[-1]
+        assert all(blocks[kk] == whole_ref[kk] for kk in blocks)
+        got_keys += [kk for kk in sorted(blocks) if kk >= 0]
+    assert got_keys == list(range(4 ** l))
+    assert gzip.open(p("gr.map.gz"), "rt").read().splitlines() == o_reads.names
+    run("Database.Matcher", "-i", p("gr.db"), "-d", p("g.db"), "-o", p("g.m.txt"), "-Z", "x")
+    assert open(p("g.m.txt"), "rb").read() == want
+    ctx = km.Context(0)
+    for r in range(2):
+        programs.make_database(ctx, fa, p("gpy.db"), "a", k, k, l, zip_level=None, share=(r, 2))
+    assert programs.taxa_counts(ctx, p("gpy.db"), p("gpy.tsv")) == open(p("c.tsv")).read().splitlines()
+    ctx.close()
     # -D / -R filters reach the kernel
     run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("f.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z", "-D", "2", "-R", "5")
     o_f = OracleDB(synth.fasta_bytes(taxa, genomes), 0, k, l, dust=2, runofsame=5)
