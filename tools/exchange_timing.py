@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""Where the sharded join's time goes on one GPU (run ON the GPU box): the steps of dist.match_key_range_shard --
+copying the search k-mers out of the library, loading them back as a keys-only database, the join -- timed one by
+one on BASELINE config 2, then the whole call with and without the owner array.
+    python tools/exchange_timing.py"""
 import sys, time, numpy as np, torch, ctypes as C
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import kmers_amd as km
 from kmers_amd import synth, dist as kd
 dev = torch.device('cuda', 0)
