@@ -172,6 +172,18 @@ int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, kmg_db **out
 int kmg_match(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *hit_index, uint64_t *n_hits);
 int kmg_match_dev(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *d_hit_index);
 
+/* kmg_match_near: inexact search for k-mers of one length (replaces DB.getNearestKmers' other branch ->
+ *   processNearestCommonKey, DB.java:139-184, over Root.addKmers / closestKmers, Root.java:22-170, and
+ *   KmerUtils.getCloseKeys, KmerUtils.java:18-47; Matcher -n 1 | 2): for every search k-mer ALL reference k-mers
+ *   within Hamming distance max_diff (0 .. 2; more -> KMG_EUNSUPPORTED), as pairs (ref_index, dist) in ascending
+ *   reference order -- the order the reference's trie hands them to ClosestInfoCollector.add -- with
+ *   pair_off[i] .. pair_off[i + 1] the pairs of search k-mer i.  `-j` (only the best distance), the reverse-complement
+ *   rule of ClosestInfoCollector.add (:30-50) and the KmerDiff text (KmerDiff.java:54-67) are cheap per-k-mer steps
+ *   left to the caller.  Two calls: ref_index == dist == NULL -> *n_pairs (and pair_off[n_unique + 1] if given); then
+ *   with arrays of `capacity` >= *n_pairs. */
+int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int max_diff, uint64_t *pair_off,
+                   int64_t *ref_index, uint8_t *dist, uint64_t capacity, uint64_t *n_pairs);
+
 /* ---- TaxaCounts default mode (replaces TaxaCounts.java:119-130,355-360,386-395) --------------
  * Over every stored k-mer: match[t]++ for each taxon of its list, unique[t]++ if the list has
  * exactly one taxon.  Output ascending by taxon.  In: *n_taxa = capacity; out: taxa found

@@ -29,10 +29,11 @@ def main(argv=None):
     elif prog == "Matcher":
         for f in "idozZnL":
             ap.add_argument("-" + f)
+        ap.add_argument("-j", action="store_true")
         a = ap.parse_args(rest)
-        if int(a.n or 0) != 0:
-            raise SystemExit("inexact search (-n > 0) stays on the Java path")
-        programs.matcher(Context(0), a.i, a.d, a.o, plain=a.Z is not None, limit=a.L)
+        if int(a.n or 0) > 2:
+            raise SystemExit("inexact search with more than 2 differences stays on the Java path")
+        programs.matcher(Context(0), a.i, a.d, a.o, plain=a.Z is not None, limit=a.L, max_diff=int(a.n or 0), just=a.j)
     elif prog == "TaxaCounts":
         for f in "do":
             ap.add_argument("-" + f)

@@ -309,6 +309,21 @@ def match_into(ctx, search, ref, out):
     return out
 
 
+def match_near(search, ref, max_diff):
+    """Inexact search for k-mers of one length (kmg_match_near; DB.processNearestCommonKey, DB.java:139-184): every
+    reference k-mer within Hamming distance max_diff of every search k-mer.  -> (pair_off[n_unique + 1], ref_index[],
+    dist[]): the matches of search k-mer i are pair_off[i] .. pair_off[i + 1], ascending by reference k-mer."""
+    ref = ref.merged if isinstance(ref, DB) else ref
+    ctx = search.ctx
+    off = np.zeros(search.n_unique + 1, np.uint64)
+    n = C.c_uint64()
+    ctx.check(ctx.lib.kmg_match_near(ctx.h, search.h, ref.h, int(max_diff), _ptr(off), None, None, 0, C.byref(n)))
+    idx, dist = np.empty(max(n.value, 1), np.int64), np.empty(max(n.value, 1), np.uint8)
+    if n.value:
+        ctx.check(ctx.lib.kmg_match_near(ctx.h, search.h, ref.h, int(max_diff), None, _ptr(idx), _ptr(dist), n.value, C.byref(n)))
+    return off, idx[:n.value], dist[:n.value]
+
+
 def taxa_counts(db):
     """Utils/TaxaCounts.java default mode -> (taxon[], match[], unique[]) ascending by taxon."""
     f = db.merged if isinstance(db, DB) else db
@@ -419,4 +434,67 @@ def match_lines(search, ref, hit):
         c, d = int(r["val_off"][h]), int(r["val_off"][h + 1])
         right = "|".join("%dx%d" % (x, min(y, 255)) for x, y in zip(r["val_a"][c:d].tolist(), r["val_b"][c:d].tolist()))
         lines.append("%s\t%s\t-|%s" % (name, left, right))
+    return lines
+
+
+def _revcomp_key(key, k):
+    """Kmer.getRC on a left-aligned 2-bit k-mer: bases reversed, each complemented (code ^ 2)."""
+    v, out = int(key) >> (64 - 2 * k), 0
+    for _ in range(k):
+        out = (out << 2) | ((v & 3) ^ 2)
+        v >>= 2
+    return out << (64 - 2 * k)
+
+
+def near_match_lines(search, ref, max_diff, just=False):
+    """Matcher -n max_diff [-j] for k-mers of one length: one line per search k-mer that has a match within max_diff
+    differences, `KMER \\t values \\t DIFF|TxC|TxC DIFF|TxC ...` (ResultsDataType.java:15-35).  The GPU hands over
+    every reference k-mer within reach in ascending order (kmg_match_near); here, per search k-mer and on a handful
+    of matches: -j keeps the best distance only (Root.java:144-148, DB.java:164-171), of a k-mer and its reverse
+    complement the one met first stays unless the later one is closer (ClosestInfoCollector.add, :30-50), entries
+    are ordered by number of differences, then (position, base) (KmerDiffComparaotr, :119-147), and a difference
+    prints as position + new base, no difference as "-" (KmerDiff.java:54-67)."""
+    ref = ref.merged if isinstance(ref, DB) else ref
+    off, idx, dist = match_near(search, ref, max_diff)
+    s, r = search.fetch(), ref.fetch()
+    k = search.k
+    rows = np.nonzero(off[1:] > off[:-1])[0]
+    names = kmer_strings(s["keys"][rows], k)
+    letters = "ACTG"
+    lines = []
+    for name, i in zip(names, rows.tolist()):
+        lo, hi = int(off[i]), int(off[i + 1])
+        cand = list(zip(idx[lo:hi].tolist(), dist[lo:hi].tolist()))
+        if just:
+            best = min(d for _, d in cand)
+            cand = [c for c in cand if c[1] == best]
+        kept = {}                                           # reference k-mer (key) -> (hit, dist), in meeting order
+        for h, d in cand:
+            key = int(r["keys"][h])
+            rc = _revcomp_key(key, k)
+            if rc in kept:
+                if d < kept[rc][1]:
+                    del kept[rc]
+                    kept[key] = (h, d)
+            else:
+                kept[key] = (h, d)
+        skey = int(s["keys"][i])
+        entries = []
+        for key, (h, d) in kept.items():
+            x = (skey ^ key) >> (64 - 2 * k)
+            diffs = [(p, (key >> (62 - 2 * p)) & 3) for p in range(k) if (x >> (2 * (k - 1 - p))) & 3]
+            entries.append(((len(diffs), diffs), h))
+        entries.sort(key=lambda e: e[0])
+        a0, a1 = int(s["val_off"][i]), int(s["val_off"][i + 1])
+        if search.kind == PAYLOAD_READPOS:
+            left = "|".join("%d:%d" % (x, y) for x, y in zip(s["val_a"][a0:a1].tolist(), s["val_b"][a0:a1].tolist()))
+        else:
+            left = "|".join("%dx%d" % (x, min(y, 255)) for x, y in zip(s["val_a"][a0:a1].tolist(), s["val_b"][a0:a1].tolist()))
+        parts = []
+        for (_, diffs), h in entries:
+            c0, c1 = int(r["val_off"][h]), int(r["val_off"][h + 1])
+            text = "".join("%d%s" % (p, letters[b]) for p, b in diffs) if diffs else "-"
+            parts.append("%s|%s" % (text, "|".join("%dx%d" % (x, min(y, 255)) for x, y in
+                                                      zip(r["val_a"][c0:c1].tolist(), r["val_b"][c0:c1].tolist()))))
+        lines.append("%s\t%s\t%s" % (name, left, " ".join(parts)))
     return lines

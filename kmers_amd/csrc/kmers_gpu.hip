@@ -1074,6 +1074,56 @@ extern "C" int kmg_match(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, 
     return KMG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ inexact match
+extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int max_diff, uint64_t *pair_off,
+                              int64_t *ref_index, uint8_t *dist, uint64_t capacity, uint64_t *n_pairs) {
+    if (!ctx || !search || !ref || !n_pairs) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    *n_pairs = 0;
+    if (max_diff < 0) return fail(ctx, KMG_EINVAL, "max_diff must not be negative");
+    if (max_diff > 2) return fail(ctx, KMG_EUNSUPPORTED, "more than 2 differences are not supported on the GPU path");
+    if (search->ctx->device != ctx->device || ref->ctx->device != ctx->device)
+        return fail(ctx, KMG_EINVAL, "database belongs to another device");
+    if (search->k != ref->k || search->key_len != ref->key_len)      // DB.java:78-81
+        return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
+    if ((ref_index == nullptr) != (dist == nullptr)) return fail(ctx, KMG_EINVAL, "ref_index and dist go together");
+    const u64 U = search->U;
+    if (U == 0) { if (pair_off) pair_off[0] = 0; return KMG_OK; }
+    if (U * (u64)search->k >= 0xFFFFFFFFull * 256) return fail(ctx, KMG_EUNSUPPORTED, "too many search k-mers for one call");
+    PoolBuf cnt(ctx), off(ctx), agg(ctx), tot(ctx), d_ref(ctx), d_dist(ctx);
+    KMG_ALLOC(cnt, U * 4);
+    KMG_ALLOC(off, (U + 1) * 8);
+    KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
+    KMG_ALLOC(tot, 64);
+    KMG_HIP(hipMemsetAsync(cnt.p, 0, U * 4, ctx->stream));
+    const dim3 grid(div_up_u64(U * (u64)search->k, 256)), blk(256);
+    hipLaunchKernelGGL((near_kernel<false>), grid, blk, 0, ctx->stream, search->keys, U, search->k, max_diff, ref->keys,
+                       ref->bucket_off, ref->key_len, cnt.as<u32>(), (const u64 *)nullptr, (long long *)nullptr, (uint8_t *)nullptr);
+    KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt.as<u32>(), off.as<u64>(), U, OpSum(), 0ull, agg.as<u64>(),
+                                                tot.as<u64>(), true, KP_SCAN)));
+    u64 n = 0;
+    KMG_HIP(read_back(ctx, &n, tot.p, 8));
+    *n_pairs = n;
+    if (pair_off) KMG_HIP(hipMemcpyAsync(pair_off, off.p, (U + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (ref_index && n) {
+        if (capacity < n) return fail(ctx, KMG_EINVAL, "capacity below the number of matches");
+        KMG_ALLOC(d_ref, n * 8);
+        KMG_ALLOC(d_dist, n);
+        KMG_HIP(hipMemsetAsync(cnt.p, 0, U * 4, ctx->stream));
+        hipLaunchKernelGGL((near_kernel<true>), grid, blk, 0, ctx->stream, search->keys, U, search->k, max_diff, ref->keys,
+                           ref->bucket_off, ref->key_len, cnt.as<u32>(), off.as<u64>(), d_ref.as<long long>(), d_dist.as<uint8_t>());
+        hipLaunchKernelGGL(near_sort_kernel, dim3(div_up_u64(U, 256)), blk, 0, ctx->stream, off.as<u64>(), U, d_ref.as<long long>(),
+                           d_dist.as<uint8_t>());
+        KMG_HIP(hipGetLastError());
+        KMG_HIP(hipMemcpyAsync(ref_index, d_ref.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        KMG_HIP(hipMemcpyAsync(dist, d_dist.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    KMG_HIP(hipGetLastError());
+    return KMG_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ taxa counts
 // ------------------------------------------------------------------------------------------------ per read
 // the join both per-read entry points start from: hit index of every search k-mer, on the device

@@ -151,3 +151,71 @@ __global__ void taxa_compact_kernel(const u64 *__restrict__ keys, const u32 *__r
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < V && flag[i]) taxa[pos[i]] = (int32_t)((u32)keys[i] ^ 0x80000000u);
 }
+
+// ---- inexact search, fixed k (Matcher -n 1 | 2) ----------------------------------------------------------------
+// Replaces DB.processNearestCommonKey + Root.addKmers / closestKmers (Database/DB.java:139-184, Root.java:22-170) for
+// k-mers of one length: with minK == maxK no node of the reference's radix trie carries merged data (Root.java:94-102
+// clears it above depth minK), so closestKmers returns exactly the stored k-mers within Hamming distance maxDiff of
+// the search k-mer, and KmerUtils.getCloseKeys (KmerUtils.java:18-47) only names the key buckets they can lie in.
+// Here every neighbour of the search k-mer -- 3k of them at distance 1, 9 k (k-1) / 2 at distance 2 -- is looked up
+// by binary search inside its own key bucket.  Thread (s, j) owns the variants of search k-mer s whose FIRST changed
+// base is j (j == 0 also takes the unchanged k-mer).  `just`, the reverse-complement rule of ClosestInfoCollector.add
+// and the KmerDiff text are the caller's (a handful of matches per k-mer).
+__device__ __forceinline__ long long near_find(const u64 *__restrict__ rkeys, const u64 *__restrict__ rbucket, int key_len, u64 key) {
+    const u64 b = key >> (64 - 2 * key_len);
+    u64 lo = rbucket[b], hi = rbucket[b + 1];
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (rkeys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < rbucket[b + 1] && rkeys[lo] == key) ? (long long)lo : -1ll;
+}
+
+// FILL = false: cnt[s] += matches.  FILL = true: matches stored at off[s] + (cursor[s]++), unordered.
+template <bool FILL>
+__global__ __launch_bounds__(256) void near_kernel(const u64 *__restrict__ skeys, u64 ns, int k, int max_diff,
+                                                   const u64 *__restrict__ rkeys, const u64 *__restrict__ rbucket, int key_len,
+                                                   u32 *__restrict__ cnt, const u64 *__restrict__ off,
+                                                   long long *__restrict__ out_ref, uint8_t *__restrict__ out_dist) {
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 s = idx / (u32)k;
+    const int j = (int)(idx % (u32)k);
+    if (s >= ns) return;
+    const u64 key = skeys[s];
+    u32 found = 0;
+    auto probe = [&](u64 x, int d) {
+        const long long r = near_find(rkeys, rbucket, key_len, x);
+        if (r >= 0) {
+            if (FILL) {
+                const u64 at = off[s] + atomicAdd(&cnt[s], 1u);
+                out_ref[at] = r;
+                out_dist[at] = (uint8_t)d;
+            } else found++;
+        }
+    };
+    if (j == 0) probe(key, 0);
+    const int sj = 62 - 2 * j;
+    for (u64 b1 = 1; b1 < 4 && max_diff >= 1; b1++) {
+        const u64 x1 = key ^ (b1 << sj);
+        probe(x1, 1);
+        if (max_diff >= 2)
+            for (int j2 = j + 1; j2 < k; j2++)
+                for (u64 b2 = 1; b2 < 4; b2++) probe(x1 ^ (b2 << (62 - 2 * j2)), 2);
+    }
+    if (!FILL && found) atomicAdd(&cnt[s], found);
+}
+
+// every search k-mer's matches into ascending reference order (= ascending k-mer: the order the trie hands them out)
+__global__ void near_sort_kernel(const u64 *__restrict__ off, u64 ns, long long *__restrict__ ref, uint8_t *__restrict__ dist) {
+    const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns) return;
+    const u64 a = off[s], e = off[s + 1];
+    for (u64 i = a + 1; i < e; i++) {
+        const long long r = ref[i];
+        const uint8_t d = dist[i];
+        u64 p = i;
+        while (p > a && ref[p - 1] > r) { ref[p] = ref[p - 1]; dist[p] = dist[p - 1]; p--; }
+        ref[p] = r;
+        dist[p] = d;
+    }
+}

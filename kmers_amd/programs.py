@@ -263,7 +263,7 @@ def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length
     return db
 
 
-def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None):
+def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max_diff=0, just=False):
     """Matcher with -n 0: one line per matched search k-mer, ascending (Matcher.java:235-250); output is
     gzip at the default level unless plain (-Z x).  limit = "start" or "start-end" (-L, Matcher.java:159-171): only
     the search k-mers of keys start .. end; a k-mer and its match share their key, so the same slice of the
@@ -279,8 +279,14 @@ def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None):
     db = DB([open_database(ctx, f, key_range) for f in dbfiles])          # name.1 .. name.N are merged (DB.java:99-109)
     searches = [open_database(ctx, f, key_range) for f in sfiles]
     search = searches[0] if len(searches) == 1 else merge_databases(searches)   # Matcher.java:111-128 via KmerUtils
-    hit, _ = db.get_nearest_kmers(search)
-    lines = match_lines(search, db.merged, hit)
+    if max_diff > 0:        # -n [-j]: DB.getNearestKmers' other branch, k-mers of one length (kmg_match_near)
+        from .api import near_match_lines
+        if not db.merged.rc:
+            raise ValueError("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included")
+        lines = near_match_lines(search, db.merged, max_diff, just)
+    else:
+        hit, _ = db.get_nearest_kmers(search)
+        lines = match_lines(search, db.merged, hit)
     text = "".join(l + "\n" for l in lines).encode()
     with (open(output_path, "wb") if plain else gzip.open(output_path, "wb")) as f:
         f.write(text)

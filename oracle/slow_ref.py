@@ -566,6 +566,205 @@ def match_lines(search_blocks, db):
     return lines
 
 
+# ------------------------------------------------------------------- Database/Root.java, Node.java
+class _Node:                                     # Node.java:3-15
+    __slots__ = ("seq", "children", "data")
+
+    def __init__(self, seq):
+        self.seq = list(seq)
+        self.children = [None] * 4
+        self.data = None
+
+
+def _merge_counts(a, b):                         # CountDataType.getMerger: TreeCountMap.addAll, in place
+    if a is None or b is None:                   # (merge.accept on a cleared node would throw in Java; never reached
+        return                                   #  with k-mers of one length, which is all this restatement is used for)
+    for t, c in b.items():
+        a[t] = a.get(t, 0) + c
+
+
+class Root:
+    """Database/Root.java, literally: a radix trie over the k-mers of one key.  Data objects are shared between a
+    split node and its tail exactly as there (n1.data = n.data, Root.java:79-80)."""
+
+    def __init__(self, kmer_length, shortest):
+        self.root = None
+        self.kmer_length = kmer_length
+        self.shortest = shortest
+
+    def add_kmer(self, chars, data):             # Root.java:29-113
+        if self.root is None:
+            self.root = _Node(chars)
+            self.root.data = data
+            return
+        s, n, L = 0, self.root, len(chars)
+        while s != L:
+            d = 0                                # firstDiff (:200-211)
+            lim = min(len(n.seq), L - s)
+            while d < lim and chars[s + d] == n.seq[d]:
+                d += 1
+            if d == len(n.seq):
+                s += len(n.seq)
+                if s >= self.shortest:
+                    _merge_counts(n.data, data)
+                if s == L:
+                    pass                         # exact match: already there
+                elif n.children[chars[s]] is not None:
+                    n = n.children[chars[s]]
+                else:
+                    nn = _Node(chars[s:])
+                    nn.data = data
+                    n.children[chars[s]] = nn
+                    s = L
+            else:
+                b1 = n.seq[d]
+                n1 = _Node(n.seq[d:])
+                n1.children = n.children
+                n1.data = n.data
+                n.children = [None] * 4
+                n.children[b1] = n1
+                if s + d < L:
+                    n2 = _Node(chars[s + d:])
+                    n2.data = data
+                    n.children[chars[s + d]] = n2
+                n.seq = n.seq[:d]
+                if s + d < self.shortest:
+                    n.data = None
+                else:
+                    _merge_counts(n.data, data)
+                s = L
+
+    def closest_kmers(self, target, maxdiff, just):      # Root.java:115-170
+        best = ClosestInfoCollector()
+        test_dist = maxdiff
+        process = []
+        if self.root is not None:
+            process.append((self.root, 0, []))
+        while process:
+            n, prevdist, prevseq = process.pop(0)        # pollFirst
+            lim = min(len(n.seq), len(target) - len(prevseq))
+            curdist = prevdist + sum(1 for i in range(lim) if target[i + len(prevseq)] != n.seq[i])   # numDiff
+            if curdist <= test_dist:
+                newseq = (prevseq + n.seq)[:len(target)]
+                if len(prevseq) + len(n.seq) >= len(target):
+                    if curdist < test_dist and just:
+                        test_dist = curdist
+                        best = ClosestInfoCollector()
+                    best.add(newseq, n.data, curdist)
+                else:
+                    front = [(n.children[i], curdist, list(newseq)) for i in range(4) if n.children[i] is not None]
+                    process[0:0] = front                 # addFirst from 3 down to 0: child 0 is polled first
+        return best
+
+
+def _rc_chars(chars):                            # Kmer.rc (Kmer.java:57-88)
+    return [c ^ 2 for c in reversed(chars)]
+
+
+class ClosestInfoCollector:                      # Database/ClosestInfoCollector.java
+    def __init__(self):
+        self.matched = {}                        # TreeMap<Kmer, CI>: tuple(chars) -> (data, dist); iterated ascending
+        self.mindist = 255
+
+    def add(self, chars, data, dist):            # :30-50
+        k, rc = tuple(chars), tuple(_rc_chars(chars))
+        if rc in self.matched:
+            if dist < self.matched[rc][1]:
+                del self.matched[rc]
+                self.matched[k] = (data, dist)
+        else:
+            self.matched[k] = (data, dist)
+        self.mindist = min(dist, self.mindist)
+
+    def add_all(self, other):                    # :52-59
+        for k in sorted(other.matched):
+            self.add(list(k), *other.matched[k])
+        self.mindist = min(self.mindist, other.mindist)
+
+    def result(self, search):                    # getResult (:82-92) + KmerDiffComparaotr (:119-147)
+        out = []
+        for k in sorted(self.matched):
+            diffs = [(i, k[i]) for i in range(len(search)) if search[i] != k[i]]        # KmerDiff (KmerDiff.java:11-32)
+            out.append(((len(diffs), diffs), self.matched[k][0]))
+        out.sort(key=lambda x: x[0])             # TreeSet: size first, then (position, base) pairs in turn
+        dedup = []
+        for key, data in out:                    # equal under the comparator = the same k-mer: cannot happen twice
+            if not dedup or dedup[-1][0] != key:
+                dedup.append((key, data))
+        return [(diffs, data) for (_, diffs), data in dedup]
+
+
+def get_close_keys(keychars, max_diff):          # KmerUtils.getCloseKeys (KmerUtils.java:18-47)
+    def key(chars):
+        v = 0
+        for c in chars:
+            v = v * 4 + c
+        return v
+    closest, cur = {key(keychars)}, [list(keychars)]
+    for _ in range(max_diff):
+        nxt = []
+        for ck in cur:
+            for j in range(len(ck)):
+                for b in range(4):
+                    nb = list(ck)
+                    nb[j] = b
+                    nxt.append(nb)
+                    closest.add(key(nb))
+        cur = nxt
+    return sorted(closest)
+
+
+def kmer_diff_text(diffs):                       # KmerDiff.toString (KmerDiff.java:54-67)
+    return "".join("%d%s" % (p, _CODE2CHAR[b]) for p, b in diffs) if diffs else "-"
+
+
+def near_match_lines(search_blocks, db, max_diff, just):
+    """Matcher.doMatching with -n max_diff [-j] for k-mers of one length: DB.getNearestKmers' non-quick branch
+    (DB.java:83-90) -> processNearestCommonKey per group of search k-mers with a common key (DB.java:139-184): for
+    every close key a Root over that key's k-mers of every file, closestKmers per search k-mer, the collectors
+    combined as there; lines as match_lines, the diff text in place of "-"."""
+    min_k, max_k, key_len, ids, rc = parse_meta(search_blocks[-1])
+    kind = "read" if ids == READ_ID else "ref"
+    lines = []
+    roots = {}
+
+    def root_for(key):
+        if key not in roots:
+            r = Root(max_k, min_k)
+            for f in db.files:                                           # DB.java:155-158: file by file, unmerged
+                for k, data in decode_block(f.get(key, b""), "ref"):
+                    r.add_kmer(list(k.chars), dict(data))
+            roots[key] = r
+        return roots[key]
+
+    for key in range(4 ** key_len):
+        group = decode_block(search_blocks.get(key, b""), kind)
+        if not group:
+            continue
+        close = get_close_keys(group[0][0].chars[:key_len], max_diff)
+        best = [ClosestInfoCollector() for _ in group]
+        for ck in close:
+            r = root_for(ck)
+            for i, (kmer, _) in enumerate(group):
+                newci = r.closest_kmers(list(kmer.chars), max_diff, just)
+                old = best[i]
+                if newci.mindist == old.mindist or not just:             # DB.java:164-171
+                    old.add_all(newci)
+                if newci.mindist < old.mindist and just:
+                    best[i] = newci
+        for (kmer, sdata), ci in zip(group, best):
+            res = ci.result(kmer.chars)
+            if not res:
+                continue
+            if kind == "read":
+                s = "|".join("%d:%d" % (r_, p) for r_, p in sorted(sdata))
+            else:
+                s = "|".join("%dx%d" % (t, sdata[t]) for t in sorted(sdata))
+            lines.append("%s\t%s\t%s" % (kmer, s, " ".join(
+                "%s|%s" % (kmer_diff_text(diffs), "|".join("%dx%d" % (t, data[t]) for t in sorted(data))) for diffs, data in res)))
+    return lines
+
+
 # --------------------------------------------------------------------- Utils/TaxaCounts.java
 def taxa_counts(db):
     """TaxaCounts default mode (TaxaCounts.java:119-150, 355-360, 386-395, 427-436)."""

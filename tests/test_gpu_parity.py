@@ -331,6 +331,43 @@ def test_key_range_builds_are_slices_of_the_whole(ctx, k, l, cuts):
     fc.create().close()
 
 
+@pytest.mark.parametrize("k,l,seed", [(9, 2, 5), (8, 2, 6), (31, 6, 8)])
+def test_inexact_search_matches_trie_restatement(ctx, k, l, seed):
+    """Matcher -n 1 | 2 [-j] for k-mers of one length: kmg_match_near + the per-k-mer steps of api.near_match_lines
+    against the reference's radix trie restated in oracle/slow_ref.py (Root, ClosestInfoCollector,
+    processNearestCommonKey) -- itself checked against an all-pairs search in tests/test_oracle_kat.py.  Three taxa a
+    few bases apart, reads with errors, one database file and a set of two (merged on the GPU / inserted file by
+    file into the trie), even k with palindromes."""
+    import kmers_amd as km
+    from oracle import slow_ref as R
+    from test_oracle_kat import _near_inputs
+    fa1, fa2, fq = _near_inputs(seed, min(k, 12))
+    if k == 31:                                                       # long k-mers: same genomes, longer reads
+        fq = b"".join(b"@q%d\n%s\n+\n%s\n" % (i, fa1.split(b"\n")[1][o:o + 60], b"I" * 60) for i, o in enumerate(range(0, 200, 7)))
+        fq = fq.replace(b"ACG", b"ACT", 3)
+    o_reads, _ = R.build_read_db(fq, k, l)
+    o_files = [R.build_ref_db(fa1, k, l), R.build_ref_db(fa2, k, l)]
+    reads, _ = km.make_read_db(ctx, fq, k, l)
+    refs = [km.make_reference_db(ctx, fa1, k, l), km.make_reference_db(ctx, fa2, k, l)]
+    for nfiles in (1, 2):
+        db = km.DB(refs[:nfiles])
+        for max_diff in (1, 2):
+            for just in (False, True):
+                want = R.near_match_lines(o_reads, R.DB(o_files[:nfiles]), max_diff, just)
+                assert km.near_match_lines(reads, db, max_diff, just) == want, (nfiles, max_diff, just)
+                assert len(want) > 5
+        off, idx, dist = km.match_near(reads, db, 0)                  # no difference allowed = the exact join
+        hit, nh = db.get_nearest_kmers(reads)
+        assert len(idx) == nh and np.array_equal(idx, hit[hit >= 0]) and not dist.any()
+        assert np.array_equal(np.diff(off.astype(np.int64)), (hit >= 0).astype(np.int64))
+        if nfiles == 2:
+            db.merged.close()
+    with pytest.raises(km.KmersGpuError):
+        km.match_near(reads, refs[0], 3)
+    for d in refs + [reads]:
+        d.close()
+
+
 def test_concurrent_callers_on_one_context(ctx):
     """The reference calls addKmers on ONE FileCreator from up to -t pool threads at once in -p mode
     (MakeDatabase.java:220-236,259-265) and quickMatchCommonKey from `threads` pool threads (DB.java:191-207), so a

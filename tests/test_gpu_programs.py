@@ -77,6 +77,19 @@ def test_programs_end_to_end(tmp_path):
     assert cli(["Utils.ReadClassifier", "-i", str(tmp_path / "cli.collected"), "-o", str(tmp_path / "cli.calls")]) == 0
     assert R.read_indexed_file(str(tmp_path / "cli.calls")) == rcb
 
+    # Matcher -n 1 [-j]: inexact search, file to file, against the restated trie (slow: a slice of the reads)
+    few = str(tmp_path / "few.fq")
+    open(few, "wb").write(b"@" + b"@".join(synth.fastq_bytes(reads).split(b"@")[1:41]))          # the first 40 reads
+    assert cli(["Database.MakeDatabase", "-q", "-i", few, "-o", str(tmp_path / "few.db"), "-r", str(tmp_path / "few.map.gz"),
+                "-K", str(k), "-k", str(k), "-l", str(l), "-Z"]) == 0
+    o_few, _ = R.build_read_db(open(few, "rb").read(), k, l)
+    o_db = R.DB([R.read_indexed_file(refdb)])
+    for extra, just in (([], False), (["-j"], True)):
+        assert cli(["Database.Matcher", "-i", str(tmp_path / "few.db"), "-d", refdb, "-o", str(tmp_path / "near.txt"), "-Z", "x",
+                    "-n", "1"] + extra) == 0
+        got = open(str(tmp_path / "near.txt")).read().splitlines()
+        assert got == R.near_match_lines(o_few, o_db, 1, just) and len(got) > 100
+
     # the same through the reference's command lines
     assert cli(["Database.MakeDatabase", "-a", "-i", fa, "-o", str(tmp_path / "cli.db"), "-K", str(k), "-k", str(k),
                 "-l", str(l), "-Z"]) == 0

@@ -178,3 +178,83 @@ def test_collect_by_read_and_read_classifier_hand_example():
     # a single-taxon hit that another hit's set does not contain
     assert R.read_classifier({0: b"4:0\t0:5x1\n4:1\t0:6x1|7x1"}) == {0: b""}
     assert R.read_classifier({0: b"4:0\t0:5x1\n4:1\t0:5x3|7x1\n5:0\t0:8x1"}) == {0: b"4\t5\n5\t8\n"}
+
+
+def _brute_near_lines(R, reads, ref_files, max_diff, just, k):
+    """Independent of the trie: every reference k-mer within max_diff differences, by comparing all pairs."""
+    db = R.DB(ref_files)
+    l = db.key_length
+    refs = [(km, data) for key in range(4 ** l) for km, data in db.kmers(key)]
+    lines = []
+    for key in range(4 ** l):
+        for kmer, sdata in R.decode_block(reads.get(key, b""), "read"):
+            cand = []
+            for rk, data in refs:                                    # ascending reference k-mer
+                d = sum(1 for a, b in zip(kmer.chars, rk.chars) if a != b)
+                if d <= max_diff:
+                    cand.append((rk, data, d))
+            if just and cand:
+                best = min(c[2] for c in cand)
+                cand = [c for c in cand if c[2] == best]
+            kept = {}
+            for rk, data, d in cand:
+                me, rc = tuple(rk.chars), tuple(c ^ 2 for c in reversed(rk.chars))
+                if rc in kept:
+                    if d < kept[rc][1]:
+                        del kept[rc]
+                        kept[me] = (data, d)
+                else:
+                    kept[me] = (data, d)
+            ents = []
+            for me, (data, d) in kept.items():
+                diffs = [(i, me[i]) for i in range(k) if me[i] != kmer.chars[i]]
+                ents.append(((len(diffs), diffs), data))
+            ents.sort(key=lambda e: e[0])
+            if ents:
+                lines.append("%s\t%s\t%s" % (kmer, "|".join("%d:%d" % rp for rp in sorted(sdata)), " ".join(
+                    "%s|%s" % (R.kmer_diff_text(df), "|".join("%dx%d" % (t, data[t]) for t in sorted(data))) for (_, df), data in ents)))
+    return lines
+
+
+def _near_inputs(seed, k):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    al = np.frombuffer(b"ACGT", np.uint8)
+    base = rng.choice(al, size=260)
+    genomes = []
+    for g in range(3):                                   # three taxa that differ in a few bases: near matches abound
+        x = base.copy()
+        for j in rng.choice(260, size=12, replace=False).tolist():
+            x[j] = int(rng.choice(al))
+        genomes.append(bytes(x.tolist()))
+    pal = b"ACGTTGCAACGT"[:k] if k <= 12 else b""
+    fa1 = b">11\n%s\n>12\n%s\n" % (genomes[0], genomes[1] + pal)
+    fa2 = b">13\n%s\n>11\n%s\n" % (genomes[2], genomes[0][:80])
+    recs = []
+    for i in range(30):
+        o = int(rng.integers(0, 260 - 40))
+        s_ = bytearray(genomes[int(rng.integers(3))][o:o + 40])
+        for j in np.nonzero(rng.random(40) < 0.04)[0].tolist():
+            s_[j] = int(rng.choice(al))
+        recs.append(b"@q%d\n%s\n+\n%s\n" % (i, bytes(s_), b"I" * 40))
+    return fa1, fa2, b"".join(recs)
+
+
+def test_trie_restatement_equals_all_pairs_search():
+    """Root / ClosestInfoCollector restated (oracle/slow_ref.py) against a search that knows nothing of tries: for
+    k-mers of one length the trie returns the stored k-mers within maxDiff differences, no more and no fewer --
+    one database file and two (unmerged insertion, DB.java:155-158), -j on and off, one and two differences, even
+    k (where a k-mer can be its own reverse complement's neighbour)."""
+    from oracle import slow_ref as R
+    for k, l, seed in ((9, 2, 5), (8, 2, 6), (11, 3, 7)):
+        fa1, fa2, fq = _near_inputs(seed, k)
+        reads, _ = R.build_read_db(fq, k, l)
+        files = [R.build_ref_db(fa1, k, l), R.build_ref_db(fa2, k, l)]
+        for ref_files in (files[:1], files):
+            for max_diff in (1, 2):
+                for just in (False, True):
+                    got = R.near_match_lines(reads, R.DB(ref_files), max_diff, just)
+                    assert got == _brute_near_lines(R, reads, ref_files, max_diff, just, k), (k, len(ref_files), max_diff, just)
+                    assert any(" " in ln.split("\t")[2] for ln in got) or just
+        exact = R.match_lines(reads, R.DB(files))
+        assert [ln for ln in R.near_match_lines(reads, R.DB(files), 1, True) if ln.split("\t")[2].startswith("-|")] == exact
