@@ -884,9 +884,69 @@ void append_values(std::string &s, const HostDb &h, uint64_t i) {
     }
 }
 
+// Kmer.getRC on a left-aligned 2-bit k-mer
+uint64_t revcomp_key(uint64_t key, int k) {
+    uint64_t v = key >> (64 - 2 * k), out = 0;
+    for (int i = 0; i < k; i++) { out = (out << 2) | ((v & 3) ^ 2); v >>= 2; }
+    return out << (64 - 2 * k);
+}
+
+// The third field of an inexact match line: `DIFF|TxC|TxC DIFF|TxC ...` from the matches of search k-mer i, which
+// arrive in ascending reference order.  -j keeps the best distance only (Root.java:144-148, DB.java:164-171); of a
+// k-mer and its reverse complement the one met first stays unless the later one is closer
+// (ClosestInfoCollector.add, ClosestInfoCollector.java:30-50); entries are ordered by number of differences, then by
+// (position, base) in turn (KmerDiffComparaotr, :119-147); a difference prints as position + new base, none as "-"
+// (KmerDiff.java:54-67).
+void append_near(std::string &s, const HostDb &hs, const HostDb &hr, uint64_t i, int k, const std::vector<uint64_t> &off,
+                 const std::vector<int64_t> &ref, const std::vector<uint8_t> &dist, bool just) {
+    struct Kept { uint64_t key; int64_t h; int d; bool alive; };
+    std::vector<Kept> kept;
+    int best = 255;
+    for (uint64_t p = off[i]; p < off[i + 1]; p++) best = std::min<int>(best, dist[p]);
+    for (uint64_t p = off[i]; p < off[i + 1]; p++) {
+        if (just && dist[p] != best) continue;
+        const uint64_t key = hr.keys[ref[p]], rc = revcomp_key(key, k);
+        bool placed = false;
+        for (auto &e : kept)
+            if (e.alive && e.key == rc) {
+                if ((int)dist[p] < e.d) e.alive = false; else placed = true;
+                break;
+            }
+        if (!placed) kept.push_back({key, ref[p], (int)dist[p], true});
+    }
+    struct Entry { std::vector<std::pair<int, int>> diffs; int64_t h; };
+    std::vector<Entry> ents;
+    const uint64_t skey = hs.keys[i];
+    for (auto &e : kept) {
+        if (!e.alive) continue;
+        Entry en;
+        en.h = e.h;
+        for (int p = 0; p < k; p++) {
+            const int a = (int)((skey >> (62 - 2 * p)) & 3), b = (int)((e.key >> (62 - 2 * p)) & 3);
+            if (a != b) en.diffs.push_back({p, b});
+        }
+        ents.push_back(std::move(en));
+    }
+    std::stable_sort(ents.begin(), ents.end(), [](const Entry &x, const Entry &y) {
+        if (x.diffs.size() != y.diffs.size()) return x.diffs.size() < y.diffs.size();
+        return x.diffs < y.diffs;
+    });
+    bool first = true;
+    for (auto &en : ents) {
+        if (!first) s.push_back(' ');
+        first = false;
+        if (en.diffs.empty()) s.push_back('-');
+        for (auto &d : en.diffs) { append_int(s, d.first); s.push_back("ACTG"[d.second]); }
+        s.push_back('|');
+        append_values(s, hr, (uint64_t)en.h);
+    }
+}
+
 int matcher(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "idozZntLP", "v");
-    if (a.geti('n', 0) != 0) throw Unsupported("inexact search (-n > 0) stays on the Java path");
+    const Args a = parse_args(argc, argv, 2, "idozZntLP", "vj");
+    const int max_diff = a.geti('n', 0);
+    const bool just = a.has('j');
+    if (max_diff < 0 || max_diff > 2) throw Unsupported("inexact search with more than 2 differences stays on the Java path");
     StageClock clk(a.has('v'));
     if (!a.has('i') || !a.has('d') || !a.has('o')) throw std::runtime_error("-i, -d and -o are required");
     g_threads = std::max(1, a.geti('t', g_threads));
@@ -910,19 +970,35 @@ int matcher(int argc, char **argv) {
     FILE *f = fopen(a.get('o').c_str(), "wb");
     if (!f) throw std::runtime_error("cannot create " + a.get('o'));
     bool wrote = false;
+    kmg_db *ref_whole = nullptr;
     for (int sl = 0; sl < slices; sl++) {
         const int lo = key_lo + (int)((int64_t)(key_hi - key_lo) * sl / slices);
         const int hi = key_lo + (int)((int64_t)(key_hi - key_lo) * (sl + 1) / slices);
-        kmg_db *ref = ref_set.load(g, lo, hi), *search = search_set.load(g, lo, hi);
+        // (an inexact match can sit under any key close to the search k-mer's, KmerUtils.getCloseKeys: the whole
+        // reference stays loaded then and only the search side is walked in slices)
+        if (max_diff > 0 && !ref_whole) ref_whole = ref_set.load(g);
+        kmg_db *ref = max_diff > 0 ? ref_whole : ref_set.load(g, lo, hi), *search = search_set.load(g, lo, hi);
         const DbInfo rd = db_info(ref), sd = db_info(search);
         if (!rd.rc)   // DB.java:57-64
             throw std::runtime_error("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included");
         std::vector<int64_t> hit(sd.U + 1);
         uint64_t nh = 0;
         clk.lap("read + decode databases");
-        g.check(kmg_match(g.ctx, search, ref, hit.data(), &nh));
+        // -n 1 | 2 [-j]: every reference k-mer within reach of every search k-mer (kmg_match_near), else the exact join
+        std::vector<uint64_t> pair_off;
+        std::vector<int64_t> pair_ref;
+        std::vector<uint8_t> pair_dist;
+        if (max_diff > 0) {
+            uint64_t np = 0;
+            pair_off.resize(sd.U + 1);
+            g.check(kmg_match_near(g.ctx, search, ref, max_diff, pair_off.data(), nullptr, nullptr, 0, &np));
+            pair_ref.resize(np + 1);
+            pair_dist.resize(np + 1);
+            if (np) g.check(kmg_match_near(g.ctx, search, ref, max_diff, nullptr, pair_ref.data(), pair_dist.data(), np, &np));
+            for (uint64_t i = 0; i < sd.U; i++) { hit[i] = pair_off[i + 1] > pair_off[i] ? 0 : -1; nh += hit[i] >= 0; }
+        } else g.check(kmg_match(g.ctx, search, ref, hit.data(), &nh));
         const HostDb hs = fetch(g, search), hr = fetch(g, ref);
-        kmg_db_free(ref);
+        if (ref != ref_whole) kmg_db_free(ref);
         kmg_db_free(search);
         clk.lap("match (GPU) + fetch");
         // one line per matched search k-mer, ascending (Matcher.java:247-249, ResultsDataType.java:15-35):
@@ -941,8 +1017,13 @@ int matcher(int argc, char **argv) {
                 for (int p = 0; p < sd.k; p++) s.push_back("ACTG"[(key >> (62 - 2 * p)) & 3]);   // Sequence.java:117-134
                 s.push_back('\t');
                 append_values(s, hs, i);
-                s += "\t-|";
-                append_values(s, hr, (uint64_t)hit[i]);
+                if (max_diff == 0) {
+                    s += "\t-|";
+                    append_values(s, hr, (uint64_t)hit[i]);
+                } else {
+                    s.push_back('\t');
+                    append_near(s, hs, hr, i, sd.k, pair_off, pair_ref, pair_dist, just);
+                }
                 s.push_back('\n');
             }
         });
@@ -962,6 +1043,7 @@ int matcher(int argc, char **argv) {
         }
         clk.lap("deflate + write");
     }
+    if (ref_whole) kmg_db_free(ref_whole);
     if (!a.has('Z') && !wrote) { const std::string e = gzip_member(nullptr, 0, 6); fwrite(e.data(), 1, e.size(), f); }
     fclose(f);
     return 0;

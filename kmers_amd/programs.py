@@ -276,7 +276,9 @@ def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max
     sfiles = container.file_set(search_path)
     if not dbfiles or not sfiles:
         raise FileNotFoundError(db_path if not dbfiles else search_path)
-    db = DB([open_database(ctx, f, key_range) for f in dbfiles])          # name.1 .. name.N are merged (DB.java:99-109)
+    # name.1 .. name.N are merged (DB.java:99-109); an inexact match can sit under any key close to the search
+    # k-mer's (KmerUtils.getCloseKeys), so -L then limits the search side only
+    db = DB([open_database(ctx, f, key_range if max_diff == 0 else None) for f in dbfiles])
     searches = [open_database(ctx, f, key_range) for f in sfiles]
     search = searches[0] if len(searches) == 1 else merge_databases(searches)   # Matcher.java:111-128 via KmerUtils
     if max_diff > 0:        # -n [-j]: DB.getNearestKmers' other branch, k-mers of one length (kmg_match_near)

@@ -254,7 +254,7 @@ def test_native_cli_matches_python_drivers(tmp_path):
     assert open(p("f.db"), "rb").read() == open(p("f.want"), "rb").read()
     # what is not on the GPU path exits with status 3 (wrapper falls back to Java)
     run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("x.db"), "-K", "32", "-k", "24", rc=3)
-    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-n", "2", rc=3)
+    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-n", "3", rc=3)
     # a reference given as name.1 .. name.N is merged (DB.java:99-109): same results as the single file
     half = len(taxa) // 2
     open(p("h1.fa"), "wb").write(synth.fasta_bytes(taxa[:half], genomes[:half]))
@@ -270,6 +270,20 @@ def test_native_cli_matches_python_drivers(tmp_path):
     programs.matcher(ctx, p("reads.db"), p("set.db"), p("set.py.txt"), plain=True)
     assert open(p("set.py.txt"), "rb").read() == want
     ctx.close()
+    # -n 1 | 2 [-j]: inexact search; the native lines are the Python driver's, and on a slice of the reads the restated trie's
+    ctx = km.Context(0)
+    for n_, flags in ((1, []), (2, []), (2, ["-j"])):
+        run("Database.Matcher", "-i", p("reads.db"), "-d", p("set.db"), "-o", p("near.txt"), "-Z", "x", "-n", str(n_), "-P", "3", *flags)
+        py = programs.matcher(ctx, p("reads.db"), p("set.db"), p("near.py.txt"), plain=True, max_diff=n_, just=bool(flags))
+        assert open(p("near.txt")).read().splitlines() == py and len(py) > len(all_lines)
+    ctx.close()
+    open(p("few.fq"), "wb").write(b"@" + b"@".join(synth.fastq_bytes(reads).split(b"@")[1:31]))
+    run("Database.MakeDatabase", "-q", "-i", p("few.fq"), "-o", p("few.db"), "-r", p("few.map.gz"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z")
+    o_few, _ = R.build_read_db(open(p("few.fq"), "rb").read(), k, l)
+    o_set = R.DB([R.read_indexed_file(p("set.db.1")), R.read_indexed_file(p("set.db.2"))])
+    for n_, just in ((1, False), (2, True)):
+        run("Database.Matcher", "-i", p("few.db"), "-d", p("set.db"), "-o", p("few.near.gz"), "-n", str(n_), *(["-j"] if just else []))
+        assert gzip.open(p("few.near.gz"), "rt").read().splitlines() == R.near_match_lines(o_few, o_set, n_, just)
     # -S: the database split into name.1 .. name.N at key boundaries, every file complete; the set reads back whole
     run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("split.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z", "-S", "200K")
     parts = sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("split.db."))
