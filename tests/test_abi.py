@@ -54,6 +54,6 @@ def test_native_cli_builds_and_refuses_what_is_off_the_gpu_path():
     assert run().returncode == 1
     assert run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y").returncode == 3          # default -k 24 != -K 32
     assert run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y", "-K", "31", "-k", "31", "-m", "5").returncode == 3
-    assert run("Database.Matcher", "-i", "a", "-d", "b", "-o", "c", "-n", "1").returncode == 3
+    assert run("Database.Matcher", "-i", "a", "-d", "b", "-o", "c", "-n", "3").returncode == 3          # -n 1, 2 run on the GPU
     r = run("Database.MakeDatabase", "-a", "-q", "-i", "x", "-o", "y", "-K", "31", "-k", "31")
     assert r.returncode == 1 and "exactly one of" in r.stderr
