@@ -180,7 +180,8 @@ int kmg_match_dev(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t
  *   pair_off[i] .. pair_off[i + 1] the pairs of search k-mer i.  `-j` (only the best distance), the reverse-complement
  *   rule of ClosestInfoCollector.add (:30-50) and the KmerDiff text (KmerDiff.java:54-67) are cheap per-k-mer steps
  *   left to the caller.  Two calls: ref_index == dist == NULL -> *n_pairs (and pair_off[n_unique + 1] if given); then
- *   with arrays of `capacity` >= *n_pairs. */
+ *   with arrays of `capacity` >= *n_pairs (the sizing call leaves its offsets with the search database, which must
+ *   belong to ctx, so the second call only fills). */
 int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int max_diff, uint64_t *pair_off,
                    int64_t *ref_index, uint8_t *dist, uint64_t capacity, uint64_t *n_pairs);
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <atomic>
 
 #include <map>
 #include <mutex>
@@ -183,8 +184,14 @@ struct kmg_ctx {
     std::vector<hipEvent_t> event_pool;
 };
 
+static inline u64 next_db_id() {
+    static std::atomic<u64> n{1};
+    return n.fetch_add(1);
+}
+
 struct kmg_db {
     kmg_ctx *ctx = nullptr;
+    const u64 id = next_db_id();   // never reused: names a database where a pointer could be a later one's
     int k = 0, key_len = 0, rc = 0, kind = 0;
     u64 U = 0, V = 0;
     u64 *keys = nullptr;        // U
@@ -195,6 +202,11 @@ struct kmg_db {
     u32 *vals_packed32 = nullptr; // ... or V x (read << pos_bits | pos) when the build ran compact
     int pos_bits = 16;
     u64 *bucket_off = nullptr;  // 4^key_len + 1
+    // kmg_match_near's sizing call leaves its offsets here for the filling call that follows (same reference, same
+    // max_diff): the neighbour look-ups of the count are not repeated
+    u64 *near_off = nullptr;    // U + 1
+    u64 near_ref_id = 0, near_pairs = 0;
+    int near_diff = -1;
 };
 
 #define PIN_BYTES 256

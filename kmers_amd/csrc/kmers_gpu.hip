@@ -457,6 +457,7 @@ static void db_release(kmg_db *db) {
     ctx->pool.release(db->vals_packed);
     ctx->pool.release(db->vals_packed32);
     ctx->pool.release(db->bucket_off);
+    ctx->pool.release(db->near_off);
     delete db;
 }
 
@@ -1091,29 +1092,41 @@ extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     const u64 U = search->U;
     if (U == 0) { if (pair_off) pair_off[0] = 0; return KMG_OK; }
     if (U * (u64)search->k >= 0xFFFFFFFFull * 256) return fail(ctx, KMG_EUNSUPPORTED, "too many search k-mers for one call");
-    PoolBuf cnt(ctx), off(ctx), agg(ctx), tot(ctx), d_ref(ctx), d_dist(ctx);
+    PoolBuf cnt(ctx), agg(ctx), tot(ctx), d_ref(ctx), d_dist(ctx);
     KMG_ALLOC(cnt, U * 4);
-    KMG_ALLOC(off, (U + 1) * 8);
-    KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
-    KMG_ALLOC(tot, 64);
-    KMG_HIP(hipMemsetAsync(cnt.p, 0, U * 4, ctx->stream));
     const dim3 grid(div_up_u64(U * (u64)search->k, 256)), blk(256);
-    hipLaunchKernelGGL((near_kernel<false>), grid, blk, 0, ctx->stream, search->keys, U, search->k, max_diff, ref->keys,
-                       ref->bucket_off, ref->key_len, cnt.as<u32>(), (const u64 *)nullptr, (long long *)nullptr, (uint8_t *)nullptr);
-    KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt.as<u32>(), off.as<u64>(), U, OpSum(), 0ull, agg.as<u64>(),
-                                                tot.as<u64>(), true, KP_SCAN)));
+    kmg_db *sdb = const_cast<kmg_db *>(search);          // (the cached offsets are bookkeeping, not content)
+    if (sdb->ctx != ctx) return fail(ctx, KMG_EINVAL, "the search database belongs to another context");
     u64 n = 0;
-    KMG_HIP(read_back(ctx, &n, tot.p, 8));
+    if (sdb->near_off && sdb->near_ref_id == ref->id && sdb->near_diff == max_diff) n = sdb->near_pairs;
+    else {
+        if (!sdb->near_off) {
+            void *p = nullptr;
+            if (ctx->pool.alloc(&p, (U + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "allocation failed");
+            sdb->near_off = (u64 *)p;
+        }
+        sdb->near_diff = -1;
+        KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
+        KMG_ALLOC(tot, 64);
+        KMG_HIP(hipMemsetAsync(cnt.p, 0, U * 4, ctx->stream));
+        hipLaunchKernelGGL((near_kernel<false>), grid, blk, 0, ctx->stream, search->keys, U, search->k, max_diff, ref->keys,
+                           ref->bucket_off, ref->key_len, cnt.as<u32>(), (const u64 *)nullptr, (long long *)nullptr, (uint8_t *)nullptr);
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt.as<u32>(), sdb->near_off, U, OpSum(), 0ull, agg.as<u64>(),
+                                                    tot.as<u64>(), true, KP_SCAN)));
+        KMG_HIP(read_back(ctx, &n, tot.p, 8));
+        sdb->near_ref_id = ref->id; sdb->near_diff = max_diff; sdb->near_pairs = n;
+    }
+    u64 *off_p = sdb->near_off;
     *n_pairs = n;
-    if (pair_off) KMG_HIP(hipMemcpyAsync(pair_off, off.p, (U + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (pair_off) KMG_HIP(hipMemcpyAsync(pair_off, off_p, (U + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (ref_index && n) {
         if (capacity < n) return fail(ctx, KMG_EINVAL, "capacity below the number of matches");
         KMG_ALLOC(d_ref, n * 8);
         KMG_ALLOC(d_dist, n);
         KMG_HIP(hipMemsetAsync(cnt.p, 0, U * 4, ctx->stream));
         hipLaunchKernelGGL((near_kernel<true>), grid, blk, 0, ctx->stream, search->keys, U, search->k, max_diff, ref->keys,
-                           ref->bucket_off, ref->key_len, cnt.as<u32>(), off.as<u64>(), d_ref.as<long long>(), d_dist.as<uint8_t>());
-        hipLaunchKernelGGL(near_sort_kernel, dim3(div_up_u64(U, 256)), blk, 0, ctx->stream, off.as<u64>(), U, d_ref.as<long long>(),
+                           ref->bucket_off, ref->key_len, cnt.as<u32>(), off_p, d_ref.as<long long>(), d_dist.as<uint8_t>());
+        hipLaunchKernelGGL(near_sort_kernel, dim3(div_up_u64(U, 256)), blk, 0, ctx->stream, off_p, U, d_ref.as<long long>(),
                            d_dist.as<uint8_t>());
         KMG_HIP(hipGetLastError());
         KMG_HIP(hipMemcpyAsync(ref_index, d_ref.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
