@@ -27,6 +27,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/kmers_gpu.h"
@@ -1094,6 +1095,7 @@ struct JoinRows {
     std::vector<uint64_t> keys, s_off{0}, r_off{0};
     std::vector<int32_t> s_read, s_pos, r_tax, r_cnt;
     void load(Gpu &g, int k, int key_len, kmg_db **search, kmg_db **ref) {
+        s_read.push_back(0); s_pos.push_back(0); r_tax.push_back(0); r_cnt.push_back(0);     // (never an empty array)
         g.check(kmg_db_load(g.ctx, k, key_len, 0, KMG_PAYLOAD_READPOS, keys.data(), keys.size(), s_off.data(), s_read.data(),
                             s_pos.data(), search));
         g.check(kmg_db_load(g.ctx, k, key_len, 1, KMG_PAYLOAD_TAXON, keys.data(), keys.size(), r_off.data(), r_tax.data(),
@@ -1115,6 +1117,47 @@ void parse_counts(const char *q, const char *end, JoinRows &j) {
     j.r_off.push_back(j.r_tax.size());
 }
 
+// The third field of a match line with inexact entries, `DIFF|TxC|TxC DIFF|TxC ...`, as CollectByRead.processKmer
+// (CollectByRead.java:165-173) files it: the taxa of all entries with the same number of differences added up
+// (KmerDiff.dist = number of position + base pairs, "-" = none), printed `dist:TxC|TxC` per distance, ascending, joined
+// by " " (jar MapCompressor text form), counts capped at 255 on the way through the temp file (CountDataType.java:40).
+std::string dist_taxa_text(const char *q, const char *end) {
+    std::map<int, std::map<int32_t, int64_t>> by_dist;
+    while (q < end) {
+        const char *sp = (const char *)memchr(q, ' ', end - q);
+        const char *ee = sp ? sp : end;
+        const char *bar = (const char *)memchr(q, '|', ee - q);
+        if (!bar) throw std::runtime_error("bad match entry");
+        int dist = 0;
+        for (const char *c = q; c < bar; c++) dist += (*c >= 'A' && *c <= 'Z');
+        auto &m = by_dist[dist];
+        for (const char *t = bar + 1; t < ee;) {
+            char *e;
+            const long taxon = strtol(t, &e, 10);
+            if (e >= ee || *e != 'x') throw std::runtime_error("bad taxon count list");
+            const long cnt = strtol(e + 1, &e, 10);
+            m[(int32_t)taxon] += cnt;
+            t = (e < ee && *e == '|') ? e + 1 : ee;
+        }
+        q = sp ? sp + 1 : end;
+    }
+    std::string out;
+    for (auto &d : by_dist) {
+        if (!out.empty()) out += ' ';
+        append_int(out, d.first);
+        out += ':';
+        bool first = true;
+        for (auto &tc : d.second) {
+            if (!first) out += '|';
+            first = false;
+            append_int(out, tc.first);
+            out += 'x';
+            append_int(out, (int32_t)std::min<int64_t>(tc.second, 255));
+        }
+    }
+    return out;
+}
+
 // Utils.CollectByRead -i <Matcher output> -o <file> (CollectByRead.java:28-90): the match lines are loaded back as
 // a read database and a reference database over the same k-mers (every k-mer hits itself) and transposed on the GPU.
 int collect_by_read(int argc, char **argv) {
@@ -1134,6 +1177,7 @@ int collect_by_read(int argc, char **argv) {
     std::vector<JoinRows> part(nslice);
     std::vector<int> part_k(nslice, -1);
     std::vector<std::string> unsupported(nslice);
+    std::vector<std::vector<std::pair<uint64_t, std::string>>> special(nslice);
     parallel_for(nslice, [&](size_t c) {
         JoinRows &j = part[c];
         int &k = part_k[c];
@@ -1167,17 +1211,19 @@ int collect_by_read(int argc, char **argv) {
                     q = (*en == '|') ? en + 1 : t2;
                 }
                 j.s_off.push_back(j.s_read.size());
-                // exact matches only: one entry, diff "-"
-                if (t2 + 2 >= lend || t2[1] != '-' || t2[2] != '|' || memchr(t2 + 1, ' ', lend - t2 - 1)) {
-                    unsupported[c] = "inexact matches stay on the Java path";
-                    return;
+                // one entry with diff "-" (an exact match): its taxa go into the arrays; anything else (Matcher -n > 0)
+                // is turned into the record's text right here and the line keeps an empty taxon list as its mark
+                if (t2 + 2 < lend && t2[1] == '-' && t2[2] == '|' && !memchr(t2 + 1, ' ', lend - t2 - 1)) parse_counts(t2 + 3, lend, j);
+                else {
+                    j.r_off.push_back(j.r_tax.size());
+                    special[c].push_back({j.keys.size() - 1, dist_taxa_text(t2 + 1, lend)});
                 }
-                parse_counts(t2 + 3, lend, j);
             }
             p0 = e + 1;
         }
     });
     JoinRows j;
+    std::unordered_map<uint64_t, std::string> special_text;      // line -> `dist:TxC|TxC dist:...` where it is not one exact match
     int k = -1;
     for (size_t c = 0; c < nslice; c++) {
         if (!unsupported[c].empty()) throw Unsupported(unsupported[c]);
@@ -1209,6 +1255,8 @@ int collect_by_read(int argc, char **argv) {
         });
         j.s_off[kb[nslice]] = sb[nslice];
         j.r_off[kb[nslice]] = rb[nslice];
+        for (size_t c = 0; c < nslice; c++)
+            for (auto &sp : special[c]) special_text.emplace(kb[c] + sp.first, std::move(sp.second));
     }
     clk.lap("parse match lines");
     std::vector<std::pair<int, std::string>> blocks;
@@ -1242,6 +1290,11 @@ int collect_by_read(int argc, char **argv) {
                 append_int(out, read[i]);
                 out += ':';
                 append_int(out, pos[i]);
+                if (j.r_off[idx[i]] == j.r_off[idx[i] + 1]) {          // (an exact match always names a taxon)
+                    out += '\t';
+                    out += special_text.at((uint64_t)idx[i]);
+                    continue;
+                }
                 out += "\t0:";
                 for (uint64_t t = j.r_off[idx[i]]; t < j.r_off[idx[i] + 1]; t++) {
                     if (t > j.r_off[idx[i]]) out += '|';

@@ -338,6 +338,7 @@ def collect_by_read(ctx, input_path, output_path):
     """Utils.CollectByRead -i <Matcher output> -o <file>.  The match lines are loaded back as a read database and
     a reference database over the same k-mers (every k-mer hits itself) and transposed on the GPU."""
     keys, s_off, s_read, s_pos, r_off, r_tax, r_cnt = [], [0], [], [], [0], [], []
+    special = {}
     k = None
     with _open_text(input_path) as f:
         for line in f:
@@ -346,8 +347,6 @@ def collect_by_read(ctx, input_path, output_path):
                 continue
             kmer, reads_s, matches_s = line.split("\t", 2)
             ents = matches_s.split(" ")
-            if len(ents) != 1 or not ents[0].startswith("-|"):
-                raise SystemExit("inexact matches stay on the Java path")
             k = len(kmer) if k is None else k
             keys.append(_kmer_key(kmer))
             for rp in reads_s.split("|"):
@@ -355,10 +354,23 @@ def collect_by_read(ctx, input_path, output_path):
                 s_read.append(int(r))
                 s_pos.append(int(p))
             s_off.append(len(s_read))
-            for tc in ents[0][2:].split("|"):
-                t, c = tc.split("x")
-                r_tax.append(int(t))
-                r_cnt.append(int(c))
+            if len(ents) == 1 and ents[0].startswith("-|"):          # one exact match: its taxa go to the GPU database
+                for tc in ents[0][2:].split("|"):
+                    t, c = tc.split("x")
+                    r_tax.append(int(t))
+                    r_cnt.append(int(c))
+            else:
+                # Matcher -n > 0: the taxa of all entries with the same number of differences added up, one map per
+                # distance (CollectByRead.java:165-173); the line keeps an empty taxon list as its mark
+                by_dist = {}
+                for ent in ents:
+                    diff_s, counts_s = ent.split("|", 1)
+                    m = by_dist.setdefault(sum(1 for ch in diff_s if ch.isalpha()), {})
+                    for tc in counts_s.split("|"):
+                        t, c = tc.split("x")
+                        m[int(t)] = m.get(int(t), 0) + int(c)
+                special[len(keys) - 1] = " ".join("%d:%s" % (d, "|".join("%dx%d" % (t, min(c, 255)) for t, c in sorted(by_dist[d].items())))
+                                                  for d in sorted(by_dist))
             r_off.append(len(r_tax))
     if k is None:
         _write_text_blocks(output_path, {})
@@ -367,8 +379,28 @@ def collect_by_read(ctx, input_path, output_path):
     search = KmerDatabase.load(ctx, k, kl, False, PAYLOAD_READPOS, np.array(keys, np.uint64), np.array(s_off, np.uint64),
                                np.array(s_read, np.int32), np.array(s_pos, np.int32))
     ref = KmerDatabase.load(ctx, k, kl, True, PAYLOAD_TAXON, np.array(keys, np.uint64), np.array(r_off, np.uint64),
-                            np.array(r_tax, np.int32), np.array(r_cnt, np.int32))
-    blocks = collect_by_read_blocks(search, ref)
+                            np.array(r_tax + [0], np.int32), np.array(r_cnt + [0], np.int32))     # (+ a sentinel: never an empty array)
+    if not special:
+        blocks = collect_by_read_blocks(search, ref)
+    else:
+        from .api import collect_by_read as transpose
+        read, pos, idx = transpose(search, ref)
+        blocks, lines, cur, last = {}, [], None, None
+        for rd, ps, h in zip(read.tolist(), pos.tolist(), idx.tolist()):
+            if (rd, ps) == last:                                     # TreeSet.add keeps the element already present
+                continue
+            last = (rd, ps)
+            key = (rd // 1000) * 1000
+            if key != cur:
+                if cur is not None:
+                    blocks[cur] = "\n".join(lines).encode()
+                cur, lines = key, []
+            text = special.get(h)
+            if text is None:
+                text = "0:" + "|".join("%dx%d" % (r_tax[t], min(r_cnt[t], 255)) for t in range(r_off[h], r_off[h + 1]))
+            lines.append("%d:%d\t%s" % (rd, ps, text))
+        if cur is not None:
+            blocks[cur] = "\n".join(lines).encode()
     search.close()
     ref.close()
     _write_text_blocks(output_path, blocks)

@@ -809,9 +809,8 @@ def collect_by_read(match_lines_):
         dist_taxa = {}
         for ent in matches_s.split(" "):                       # SetDataType " "
             diff_s, counts_s = ent.split("|", 1)               # DataPairDataType "|", limit 2
-            if diff_s != "-":
-                raise NotImplementedError("inexact matches (KmerDiff with diffs) are outside the exact path")
-            d = dist_taxa.setdefault(0, {})                    # KmerDiff.dist() of "-" = 0
+            # KmerDiff.dist() = number of (position, base) pairs of the text `3G17A`; "-" holds none (KmerDiff.java:54-72)
+            d = dist_taxa.setdefault(sum(1 for ch in diff_s if ch.isalpha()), {})
             for t, c in _counts_from_string(counts_s).items():
                 d[t] = d.get(t, 0) + c                         # TreeCountMap.addAll
         capped = {dist: {t: min(c, 255) for t, c in m.items()} for dist, m in dist_taxa.items()}

@@ -283,7 +283,19 @@ def test_native_cli_matches_python_drivers(tmp_path):
     o_set = R.DB([R.read_indexed_file(p("set.db.1")), R.read_indexed_file(p("set.db.2"))])
     for n_, just in ((1, False), (2, True)):
         run("Database.Matcher", "-i", p("few.db"), "-d", p("set.db"), "-o", p("few.near.gz"), "-n", str(n_), *(["-j"] if just else []))
-        assert gzip.open(p("few.near.gz"), "rt").read().splitlines() == R.near_match_lines(o_few, o_set, n_, just)
+        near = R.near_match_lines(o_few, o_set, n_, just)
+        assert gzip.open(p("few.near.gz"), "rt").read().splitlines() == near
+        # ... and on through CollectByRead (one taxa map per number of differences) and ReadClassifier (distance 0 only)
+        want_near_cb = R.collect_by_read(near)
+        run("Utils.CollectByRead", "-i", p("few.near.gz"), "-o", p("few.by_read"))
+        assert R.read_indexed_file(p("few.by_read")) == want_near_cb
+        assert any(b" 1:" in v or b"\t1:" in v for v in want_near_cb.values())
+        run("Utils.ReadClassifier", "-i", p("few.by_read"), "-o", p("few.calls"))
+        assert R.read_indexed_file(p("few.calls")) == R.read_classifier(want_near_cb)
+        ctx = km.Context(0)
+        assert programs.collect_by_read(ctx, p("few.near.gz"), p("few.by_read.py")) == want_near_cb
+        assert programs.read_classifier(ctx, p("few.by_read.py"), p("few.calls.py")) == R.read_classifier(want_near_cb)
+        ctx.close()
     # -S: the database split into name.1 .. name.N at key boundaries, every file complete; the set reads back whole
     run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("split.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z", "-S", "200K")
     parts = sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("split.db."))
