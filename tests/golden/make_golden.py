@@ -58,6 +58,8 @@ def main():
         counts = R.taxa_counts(db)
         collected = R.collect_by_read(lines)
         calls = R.read_classifier(collected)
+        near1 = R.near_match_lines(reads, db, 1, False)              # Matcher -n 1 / -n 2 -j: the restated trie
+        near2j = R.near_match_lines(reads, db, 2, True)
         # the independent C restatement must agree before anything is frozen
         c_ref = OracleDB(fa, 0, k, l, dust=-1 if dust is None else dust, runofsame=-1 if run is None else run)
         c_reads = OracleDB(fq, 1, k, l, dust=-1 if dust is None else dust, runofsame=-1 if run is None else run)
@@ -74,6 +76,8 @@ def main():
             "read_names": names, "match_lines": lines, "taxa_counts": counts,
             "collect_by_read": {str(key): collected[key].decode() for key in sorted(collected)},
             "read_classifier": {str(key): calls[key].decode() for key in sorted(calls)},
+            "near_match_lines_n1": near1, "near_match_lines_n2_just": near2j,
+            "collect_by_read_near_n1": {str(key): v.decode() for key, v in sorted(R.collect_by_read(near1).items())},
         }
         path = os.path.join(ROOT, "tests", "golden", "case_%s.json" % name)
         with open(path, "w") as f:

@@ -17,6 +17,7 @@ def _load(path):
     g["read_blocks"] = {int(k): bytes.fromhex(v) for k, v in g["read_blocks"].items()}
     g["collect_by_read"] = {int(k): v.encode() for k, v in g["collect_by_read"].items()}
     g["read_classifier"] = {int(k): v.encode() for k, v in g["read_classifier"].items()}
+    g["collect_by_read_near_n1"] = {int(k): v.encode() for k, v in g["collect_by_read_near_n1"].items()}
     return g
 
 
@@ -39,6 +40,9 @@ def test_restatements_reproduce_golden(path):
     assert lines == g["match_lines"] and R.taxa_counts(db) == g["taxa_counts"]
     collected = R.collect_by_read(lines)
     assert collected == g["collect_by_read"] and R.read_classifier(collected) == g["read_classifier"]
+    near1 = R.near_match_lines(reads, db, 1, False)                  # Matcher -n 1 / -n 2 -j through the restated trie
+    assert near1 == g["near_match_lines_n1"] and R.near_match_lines(reads, db, 2, True) == g["near_match_lines_n2_just"]
+    assert R.collect_by_read(near1) == g["collect_by_read_near_n1"]
     cd, cr = (-1 if dust is None else dust), (-1 if run is None else run)
     c_ref, c_reads = OracleDB(fa, 0, k, l, dust=cd, runofsame=cr), OracleDB(fq, 1, k, l, dust=cd, runofsame=cr)
     blob, off = c_ref.encode_blocks()
@@ -83,6 +87,9 @@ def test_gpu_reproduces_golden(path):
                 rs.append(r)
         want_calls[key] = "".join("%d\t%d\n" % (r, int(call[r])) for r in rs if call[r] >= 0).encode()
     assert want_calls == g["read_classifier"]
+    # inexact search (kmg_match_near + the per-k-mer host steps)
+    assert km.near_match_lines(reads, ref, 1, False) == g["near_match_lines_n1"]
+    assert km.near_match_lines(reads, ref, 2, True) == g["near_match_lines_n2_just"]
     # the same blocks without CollectByRead's records in between (kmg_classify_reads_hits)
     call2, seen = km.classify_reads(reads, ref, len(names), with_hits=True)
     assert km.read_call_blocks(call2, seen) == g["read_classifier"]
