@@ -207,6 +207,8 @@ struct kmg_db {
     u64 *near_off = nullptr;    // U + 1
     u64 near_ref_id = 0, near_pairs = 0;
     int near_diff = -1;
+    u32 *near_log_s = nullptr, *near_log_ref = nullptr;   // ... and the matches themselves, unordered (freed by the filling call)
+    uint8_t *near_log_dist = nullptr;
 };
 
 #define PIN_BYTES 256

@@ -458,6 +458,9 @@ static void db_release(kmg_db *db) {
     ctx->pool.release(db->vals_packed32);
     ctx->pool.release(db->bucket_off);
     ctx->pool.release(db->near_off);
+    ctx->pool.release(db->near_log_s);
+    ctx->pool.release(db->near_log_ref);
+    ctx->pool.release(db->near_log_dist);
     delete db;
 }
 
@@ -1076,6 +1079,12 @@ extern "C" int kmg_match(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, 
 }
 
 // ------------------------------------------------------------------------------------------------ inexact match
+static void near_log_release(kmg_ctx *ctx, kmg_db *db) {
+    ctx->pool.release(db->near_log_s); ctx->pool.release(db->near_log_ref); ctx->pool.release(db->near_log_dist);
+    db->near_log_s = db->near_log_ref = nullptr;
+    db->near_log_dist = nullptr;
+}
+
 extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int max_diff, uint64_t *pair_off,
                               int64_t *ref_index, uint8_t *dist, uint64_t capacity, uint64_t *n_pairs) {
     if (!ctx || !search || !ref || !n_pairs) return KMG_EINVAL;
@@ -1106,14 +1115,31 @@ extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
             sdb->near_off = (u64 *)p;
         }
         sdb->near_diff = -1;
+        near_log_release(ctx, sdb);
         KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
         KMG_ALLOC(tot, 64);
         KMG_HIP(hipMemsetAsync(cnt.p, 0, U * 4, ctx->stream));
+        KMG_HIP(hipMemsetAsync(tot.p, 0, 64, ctx->stream));
+        // The matches are noted down as they are found (two per search k-mer's worth of room: typical data holds about
+        // one), so that the filling call places them instead of looking every neighbour up again; if the room does not
+        // suffice, or cannot be had, that call falls back to the look-ups.
+        NearLog log = {nullptr, nullptr, nullptr, 0, nullptr};
+        if (ref->U < 0xFFFFFFF0ull && U < 0xFFFFFFF0ull) {
+            const u64 cap = std::max<u64>(2 * U, 1024);
+            void *a = nullptr, *b = nullptr, *c = nullptr;
+            if (ctx->pool.alloc(&a, cap * 4) == KMG_OK && ctx->pool.alloc(&b, cap * 4) == KMG_OK && ctx->pool.alloc(&c, cap) == KMG_OK) {
+                sdb->near_log_s = (u32 *)a; sdb->near_log_ref = (u32 *)b; sdb->near_log_dist = (uint8_t *)c;
+                log = {sdb->near_log_s, sdb->near_log_ref, sdb->near_log_dist, cap, reinterpret_cast<unsigned long long *>(tot.as<u64>() + 1)};
+            } else { ctx->pool.release(a); ctx->pool.release(b); ctx->pool.release(c); }
+        }
         hipLaunchKernelGGL((near_kernel<false>), grid, blk, 0, ctx->stream, search->keys, U, search->k, max_diff, ref->keys,
-                           ref->bucket_off, ref->key_len, cnt.as<u32>(), (const u64 *)nullptr, (long long *)nullptr, (uint8_t *)nullptr);
+                           ref->bucket_off, ref->key_len, cnt.as<u32>(), (const u64 *)nullptr, (long long *)nullptr, (uint8_t *)nullptr, log);
         KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt.as<u32>(), sdb->near_off, U, OpSum(), 0ull, agg.as<u64>(),
                                                     tot.as<u64>(), true, KP_SCAN)));
-        KMG_HIP(read_back(ctx, &n, tot.p, 8));
+        u64 t2[2] = {0, 0};
+        KMG_HIP(read_back(ctx, t2, tot.p, 16));
+        n = t2[0];
+        if (log.n && t2[1] > log.cap) near_log_release(ctx, sdb);          // did not fit: the filling call looks up again
         sdb->near_ref_id = ref->id; sdb->near_diff = max_diff; sdb->near_pairs = n;
     }
     u64 *off_p = sdb->near_off;
@@ -1124,8 +1150,16 @@ extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
         KMG_ALLOC(d_ref, n * 8);
         KMG_ALLOC(d_dist, n);
         KMG_HIP(hipMemsetAsync(cnt.p, 0, U * 4, ctx->stream));
-        hipLaunchKernelGGL((near_kernel<true>), grid, blk, 0, ctx->stream, search->keys, U, search->k, max_diff, ref->keys,
-                           ref->bucket_off, ref->key_len, cnt.as<u32>(), off_p, d_ref.as<long long>(), d_dist.as<uint8_t>());
+        if (sdb->near_log_s) {
+            const NearLog log = {sdb->near_log_s, sdb->near_log_ref, sdb->near_log_dist, n, nullptr};
+            hipLaunchKernelGGL(near_place_kernel, dim3(div_up_u64(n, 256)), blk, 0, ctx->stream, log, n, cnt.as<u32>(), off_p,
+                               d_ref.as<long long>(), d_dist.as<uint8_t>());
+        } else {
+            const NearLog none = {nullptr, nullptr, nullptr, 0, nullptr};
+            hipLaunchKernelGGL((near_kernel<true>), grid, blk, 0, ctx->stream, search->keys, U, search->k, max_diff, ref->keys,
+                               ref->bucket_off, ref->key_len, cnt.as<u32>(), off_p, d_ref.as<long long>(), d_dist.as<uint8_t>(), none);
+        }
+        near_log_release(ctx, sdb);                   // (stream-ordered: whoever gets the memory next runs after the kernel)
         hipLaunchKernelGGL(near_sort_kernel, dim3(div_up_u64(U, 256)), blk, 0, ctx->stream, off_p, U, d_ref.as<long long>(),
                            d_dist.as<uint8_t>());
         KMG_HIP(hipGetLastError());
