@@ -40,6 +40,7 @@ res["make_ref_z5_s"] = run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("ref
 res["make_reads_z5_s"] = run("Database.MakeDatabase", "-q", "-i", fq, "-o", p("reads.db"), "-r", p("map.gz"), *common)
 res["make_reads_unzipped_s"] = run("Database.MakeDatabase", "-q", "-i", fq, "-o", p("readsZ.db"), "-r", p("mapZ.gz"), "-Z", *common)
 res["matcher_s"] = run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("matches.gz"), "-t", "16", "-v")
+res["matcher_n1_s"] = run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("matches.n1.gz"), "-t", "16", "-n", "1", "-v")
 res["taxacounts_s"] = run("Utils.TaxaCounts", "-d", p("ref.db"), "-o", p("counts.tsv"))
 res["collect_by_read_s"] = run("Utils.CollectByRead", "-i", p("matches.gz"), "-o", p("by_read"), "-v")
 res["read_classifier_s"] = run("Utils.ReadClassifier", "-i", p("by_read"), "-o", p("calls"), "-t", "16", "-v")
