@@ -146,6 +146,11 @@ def test_native_cli_matches_python_drivers(tmp_path):
     assert open(p("m.txt"), "rb").read() == want
     run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("m.gz"))
     assert gzip.open(p("m.gz"), "rb").read() == want
+    # a reference database as the search side (ResultsDataType.getReferenceReferenceInstance, Matcher.java:182-209):
+    # every k-mer finds itself, and with one difference allowed its neighbours across taxa
+    ref_blocks = R.read_indexed_file(p("ref.want"))
+    run("Database.Matcher", "-i", p("ref.db"), "-d", p("refz.db"), "-o", p("rr.txt"), "-Z", "x")
+    assert open(p("rr.txt")).read().splitlines() == R.match_lines(ref_blocks, R.DB([ref_blocks]))
     # -L start-end: the lines of the search k-mers with those keys (end inclusive), -L start: of one key
     code = {"A": 0, "C": 1, "T": 2, "G": 3}
     key_of = lambda line: sum(code[c] * 4 ** (l - 1 - i) for i, c in enumerate(line[:l]))
