@@ -944,7 +944,7 @@ void append_near(std::string &s, const HostDb &hs, const HostDb &hr, uint64_t i,
 }
 
 int matcher(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "idozZntLP", "vj");
+    const Args a = parse_args(argc, argv, 2, "idozZntLPkK", "vj");
     const int max_diff = a.geti('n', 0);
     const bool just = a.has('j');
     if (max_diff < 0 || max_diff > 2) throw Unsupported("inexact search with more than 2 differences stays on the Java path");
@@ -980,6 +980,9 @@ int matcher(int argc, char **argv) {
         if (max_diff > 0 && !ref_whole) ref_whole = ref_set.load(g);
         kmg_db *ref = max_diff > 0 ? ref_whole : ref_set.load(g, lo, hi), *search = search_set.load(g, lo, hi);
         const DbInfo rd = db_info(ref), sd = db_info(search);
+        // -k / -K default to the search file's lengths (Matcher.java:147-148); anything else restricts the k-mers to
+        // other lengths (KmerUtils.restrictedStream), which is the variable-length path
+        if (a.geti('k', sd.k) != sd.k || a.geti('K', sd.k) != sd.k) throw Unsupported("-k / -K other than the files' k-mer length");
         if (!rd.rc)   // DB.java:57-64
             throw std::runtime_error("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included");
         std::vector<int64_t> hit(sd.U + 1);

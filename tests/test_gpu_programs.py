@@ -260,6 +260,9 @@ def test_native_cli_matches_python_drivers(tmp_path):
     # what is not on the GPU path exits with status 3 (wrapper falls back to Java)
     run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("x.db"), "-K", "32", "-k", "24", rc=3)
     run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-n", "3", rc=3)
+    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-k", str(k - 2), "-K", str(k - 2), rc=3)
+    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("mk.txt"), "-Z", "x", "-k", str(k), "-K", str(k))
+    assert open(p("mk.txt"), "rb").read() == want
     # a reference given as name.1 .. name.N is merged (DB.java:99-109): same results as the single file
     half = len(taxa) // 2
     open(p("h1.fa"), "wb").write(synth.fasta_bytes(taxa[:half], genomes[:half]))
