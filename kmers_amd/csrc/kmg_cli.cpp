@@ -1164,8 +1164,9 @@ std::string dist_taxa_text(const char *q, const char *end) {
 // Utils.CollectByRead -i <Matcher output> -o <file> (CollectByRead.java:28-90): the match lines are loaded back as
 // a read database and a reference database over the same k-mers (every k-mer hits itself) and transposed on the GPU.
 int collect_by_read(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "iof", "v");
+    const Args a = parse_args(argc, argv, 2, "ioft", "v");
     if (!a.has('i') || !a.has('o')) throw std::runtime_error("-i and -o are required");
+    g_threads = std::max(1, a.geti('t', g_threads));
     StageClock clk(a.has('v'));
     const std::string text = read_input(a.get('i'));
     clk.lap("read + inflate match text");
