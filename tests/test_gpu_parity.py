@@ -852,6 +852,26 @@ def test_fuzz_against_oracle(ctx, seed):
         want = OracleDB(data, 0 if kind == "ref" else 1, k, l, threads=4, dust=-1 if dust is None else dust,
                         runofsame=-1 if run is None else run)
         _same_db(got, want)
+        if seed % 3 == 0:
+            # the same database once more, in two key ranges cut at a random bucket (kmg_build_set_key_range)
+            cut_at = int(rng.integers(0, 4 ** l + 1))
+            pk, pa, pb, nvals = [], [], [], 0
+            for first, end in ((0, cut_at), (cut_at, 4 ** l)):
+                if first == end:
+                    continue
+                fc = km.FileCreator(ctx, l, k, kind, rc=rc, dust=dust, runofsame=run, key_range=(first, end))
+                for lo, hi in zip(cuts[:-1], cuts[1:]):
+                    a0, a1 = int(b.seq_off[lo]), int(b.seq_off[hi])
+                    fc.add_kmers(km.SequenceBatch(b.bases[a0:a1], b.seq_off[lo:hi + 1] - b.seq_off[lo],
+                                                  seq_id=None if b.seq_id is None else b.seq_id[lo:hi],
+                                                  seq_tok=None if b.seq_tok is None else b.seq_tok[lo:hi]))
+                part = fc.create()
+                h = part.fetch()
+                pk.append(h["keys"]); pa.append(h["val_a"]); pb.append(h["val_b"])
+                nvals += part.n_values
+                part.close()
+            assert np.array_equal(np.concatenate(pk), want.keys) and nvals == want.V
+            assert np.array_equal(np.concatenate(pa), want.val_a) and np.array_equal(np.concatenate(pb), want.val_b)
         if kind == "ref":
             ref, o_ref = got, want
         else:
