@@ -368,6 +368,38 @@ def test_inexact_search_matches_trie_restatement(ctx, k, l, seed):
         d.close()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_inexact_search_pairs_against_all_pairs_distances(ctx, seed):
+    """kmg_match_near's raw output -- every (search k-mer, reference k-mer) pair within max_diff differences, ascending
+    per search k-mer, with its distance -- against Hamming distances computed for ALL pairs (numpy, on the packed
+    k-mers): random k and key length, related genomes, low-complexity stretches, reads with errors."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    rng = np.random.default_rng(7000 + seed)
+    k = int(rng.integers(6, 33))
+    l = int(rng.integers(1, min(k, 6) + 1))
+    taxa, genomes = synth.random_genomes(300 + seed, 3, int(rng.integers(300, 2500)), shared_frac=0.5)
+    if seed % 3 == 0:
+        genomes[0][:200] = ord("A")                                   # poly-A: many neighbours of one another
+        genomes[1][100:300] = np.frombuffer(b"AC" * 100, np.uint8)
+    reads = synth.random_reads(400 + seed, genomes, int(rng.integers(20, 120)), max(k + 5, 60), 0.03)
+    ref = km.make_reference_db(ctx, synth.fasta_bytes(taxa, genomes), k, l)
+    rdb, _ = km.make_read_db(ctx, synth.fastq_bytes(reads), k, l)
+    sk, rk = rdb.fetch()["keys"], ref.fetch()["keys"]
+    x = sk[:, None] ^ rk[None, :]
+    nz = (x | (x >> np.uint64(1))) & np.uint64(0x5555555555555555)    # one bit per differing base
+    ham = np.zeros(nz.shape, np.int32)
+    for sh in range(0, 64, 2):
+        ham += ((nz >> np.uint64(sh)) & np.uint64(1)).astype(np.int32)
+    for max_diff in (0, 1, 2):
+        off, idx, dist = km.match_near(rdb, ref, max_diff)
+        rows, cols = np.nonzero(ham <= max_diff)                      # row-major: ascending reference index per row
+        assert np.array_equal(np.diff(off.astype(np.int64)), np.bincount(rows, minlength=len(sk)))
+        assert np.array_equal(idx, cols) and np.array_equal(dist, ham[rows, cols])
+    ref.close()
+    rdb.close()
+
+
 def test_concurrent_callers_on_one_context(ctx):
     """The reference calls addKmers on ONE FileCreator from up to -t pool threads at once in -p mode
     (MakeDatabase.java:220-236,259-265) and quickMatchCommonKey from `threads` pool threads (DB.java:191-207), so a
