@@ -57,3 +57,15 @@ def test_native_cli_builds_and_refuses_what_is_off_the_gpu_path():
     assert run("Database.Matcher", "-i", "a", "-d", "b", "-o", "c", "-n", "3").returncode == 3          # -n 1, 2 run on the GPU
     r = run("Database.MakeDatabase", "-a", "-q", "-i", "x", "-o", "y", "-K", "31", "-k", "31")
     assert r.returncode == 1 and "exactly one of" in r.stderr
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/kmers_gpu.h is what a cgo / JNI / FFM binding generator reads: it has to stand as C99 on its own."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "h.c"
+    src.write_text('#include "kmers_gpu.h"\nint main(void) { return 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
