@@ -168,9 +168,22 @@ int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, kmg_db **out
  * Sorted inner join of the search database's distinct k-mers against the reference database:
  * hit_index[i] = index (into the reference CSR) of the k-mer equal to search k-mer i, else -1.
  * Same k and key_len required (DB.java:78-81 -> KMG_EINVAL).  n_hits may be NULL.
- * kmg_match_dev writes hit_index to a device pointer and does not synchronise. */
+ * kmg_match_dev writes hit_index to a device pointer and does not synchronise.  The databases may belong to
+ * another context of the same GPU (a caller may build the reference and the reads side by side on two contexts);
+ * lifetime rule: they must stay alive until the call returns -- after that kmg_db_free is safe at once, the library
+ * orders the release of a foreign database's memory behind the join that still reads it. */
 int kmg_match(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *hit_index, uint64_t *n_hits);
 int kmg_match_dev(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *d_hit_index);
+
+/* kmg_match_keys_dev: the same join for search k-mers that are not a database of this library: d_keys (device)
+ *   holds n_runs (1 .. 64) ascending runs back to back, run i = elements [run_off[i], run_off[i+1]) (run_off: HOST
+ *   array of n_runs + 1, non-decreasing).  That is what the owner of a key range holds after the key-range exchange
+ *   of a multi-GPU search (the reference opens such a sharded reference as the file set name.1 .. name.N,
+ *   Matcher.java:80-89, and walks its k-mers in ascending order, DB.java:99-109): one ascending slice of read
+ *   k-mers from every GPU, all inside the owner's range -- joined in ONE launch, hit_index[i] for element i, written
+ *   to a device pointer without synchronising.  k = length of the search k-mers (DB.java:78-81 -> KMG_EINVAL). */
+int kmg_match_keys_dev(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run_off, int n_runs, int k,
+                       const kmg_db *ref, int64_t *d_hit_index);
 
 /* kmg_match_near: inexact search for k-mers of one length (replaces DB.getNearestKmers' other branch ->
  *   processNearestCommonKey, DB.java:139-184, over Root.addKmers / closestKmers, Root.java:22-170, and

@@ -209,6 +209,12 @@ struct kmg_db {
     int near_diff = -1;
     u32 *near_log_s = nullptr, *near_log_ref = nullptr;   // ... and the matches themselves, unordered (freed by the filling call)
     uint8_t *near_log_dist = nullptr;
+    // Work another context queued on ITS stream that reads this database's arrays (kmg_match_dev with a database
+    // of another context of the same GPU): one event per such context, recorded after its last launch.  The
+    // owner's stream waits for them before the arrays go back to the owner's pool (db_release), so a later build
+    // on the owner's stream cannot overwrite what the foreign kernel is still reading.
+    std::mutex foreign_mu;
+    std::map<kmg_ctx *, hipEvent_t> foreign_use;
 };
 
 #define PIN_BYTES 256

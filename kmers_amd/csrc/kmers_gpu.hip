@@ -447,9 +447,31 @@ extern "C" int kmg_build_add_packed(kmg_ctx *ctx, const uint8_t *packed, uint64_
     return KMG_OK;
 }
 
+// `user` has just queued work on its stream that reads `db`, a database of another context: note it down
+// (see kmg_db::foreign_use).  Re-recording the context's event is enough -- its stream runs in order.
+static int note_foreign_use(kmg_ctx *user, const kmg_db *cdb) {
+    kmg_db *db = const_cast<kmg_db *>(cdb);
+    if (db->ctx == user) return KMG_OK;
+    kmg_ctx *ctx = user;
+    std::lock_guard<std::mutex> g(db->foreign_mu);
+    hipEvent_t &ev = db->foreign_use[user];
+    if (!ev) KMG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    KMG_HIP(hipEventRecord(ev, user->stream));
+    return KMG_OK;
+}
+
 static void db_release(kmg_db *db) {
     if (!db) return;
     kmg_ctx *ctx = db->ctx;
+    {
+        // every reuse of the arrays happens on the owner's stream (or after a hipFree, which waits for the device)
+        std::lock_guard<std::mutex> g(db->foreign_mu);
+        for (auto &kv : db->foreign_use) {
+            if (hipStreamWaitEvent(ctx->stream, kv.second, 0) != hipSuccess) (void)hipEventSynchronize(kv.second);
+            (void)hipEventDestroy(kv.second);     // (released by the runtime once the wait has been served)
+        }
+        db->foreign_use.clear();
+    }
     ctx->pool.release(db->keys);
     ctx->pool.release(db->val_off);
     ctx->pool.release(db->val_a);
@@ -608,7 +630,10 @@ static int reduce_read_heads(kmg_ctx *ctx, const SortHeads &h, u32 n, kmg_db *db
 }
 
 // val_a / val_b of a read DB are materialised from the packed payloads the first time they are needed.
+// ctx must be the database's own context (its pool holds the arrays, its lock guards the handle): every caller
+// either takes db->ctx or has rejected foreign databases.
 static int ensure_vals(kmg_ctx *ctx, kmg_db *db) {
+    if (db->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
     if (db->val_a || (!db->vals_packed && !db->vals_packed32)) return KMG_OK;
     void *a = nullptr, *b = nullptr;
     if (ctx->pool.alloc(&a, (db->V + 1) * 4) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
@@ -889,6 +914,7 @@ extern "C" int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint6
                              uint64_t *block_off) {
     if (!ctx || !db || !n_bytes) return KMG_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
+    if (db->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
     KMG_HIP(hipSetDevice(ctx->device));
     const u64 U = db->U;
     const u32 nbuckets = 1u << (2 * db->key_len);
@@ -1051,6 +1077,8 @@ static int match_locked(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, l
     hipLaunchKernelGGL(match_kernel, dim3(ntiles), dim3(MT_BLOCK), 0, ctx->stream, search->keys, search->U, ref->keys,
                        bounds.as<u64>(), d_hit, d_nhits);
     KMG_HIP(hipGetLastError());
+    KMG_TRY(note_foreign_use(ctx, search));
+    KMG_TRY(note_foreign_use(ctx, ref));
     return KMG_OK;
 }
 
@@ -1059,6 +1087,44 @@ extern "C" int kmg_match_dev(kmg_ctx *ctx, const kmg_db *search, const kmg_db *r
     std::lock_guard<std::mutex> g(ctx->mu);
     KMG_HIP(hipSetDevice(ctx->device));
     return match_locked(ctx, search, ref, (long long *)d_hit_index, nullptr);
+}
+
+extern "C" int kmg_match_keys_dev(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run_off, int n_runs, int k,
+                                  const kmg_db *ref, int64_t *d_hit_index) {
+    if (!ctx || !ref || !run_off) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    if (ref->ctx->device != ctx->device) return fail(ctx, KMG_EINVAL, "database belongs to another device");
+    if (k != ref->k)                                                                             // DB.java:78-81
+        return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
+    if (n_runs < 1 || n_runs > MT_MAX_RUNS) return fail(ctx, KMG_EINVAL, "between 1 and 64 runs");
+    MatchRuns runs;
+    memset(&runs, 0, sizeof runs);
+    runs.n_runs = (u32)n_runs;
+    u64 tiles = 0;
+    for (int r = 0; r < n_runs; r++) {
+        if (run_off[r] > run_off[r + 1]) return fail(ctx, KMG_EINVAL, "run_off must be non-decreasing");
+        runs.tile0[r] = (u32)tiles;
+        runs.off[r] = run_off[r];
+        tiles += (run_off[r + 1] - run_off[r] + MT_TILE - 1) / MT_TILE;
+        if (tiles >= 0x7FFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "too many search k-mers for one call");
+    }
+    runs.tile0[n_runs] = (u32)tiles;
+    runs.off[n_runs] = run_off[n_runs];
+    const u64 n = run_off[n_runs] - run_off[0];
+    if (n == 0) return KMG_OK;
+    if (!d_keys || !d_hit_index) return fail(ctx, KMG_EINVAL, "null keys / hit_index");
+    const u32 ntiles = (u32)tiles;
+    ProfScope ps(ctx, KP_MATCH, 8 * (n + ref->U) + 8 * n);
+    PoolBuf tb(ctx);
+    KMG_ALLOC(tb, (size_t)ntiles * sizeof(MatchTile));
+    hipLaunchKernelGGL(match_runs_bounds_kernel, dim3(div_up_u64(ntiles, 256)), dim3(256), 0, ctx->stream, (const u64 *)d_keys, runs,
+                       ref->keys, ref->bucket_off, ref->key_len, ntiles, tb.as<MatchTile>());
+    hipLaunchKernelGGL(match_runs_kernel, dim3(ntiles), dim3(MT_BLOCK), 0, ctx->stream, (const u64 *)d_keys, ref->keys,
+                       tb.as<MatchTile>(), (long long *)d_hit_index);
+    KMG_HIP(hipGetLastError());
+    KMG_TRY(note_foreign_use(ctx, ref));
+    return KMG_OK;
 }
 
 extern "C" int kmg_match(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *hit_index, uint64_t *n_hits) {
@@ -1179,6 +1245,8 @@ static int join_for_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref,
         return fail(ctx, KMG_EINVAL, "per-read aggregation joins a read database against a reference database");
     if (ref->U >= 0xFFFFFFF0ull || search->V >= 0xFFFFFFF0ull)
         return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 reference k-mers or read occurrences");
+    // (its values are unpacked into the owner's pool, under the owner's lock: ensure_vals)
+    if (search->ctx != ctx) return fail(ctx, KMG_EINVAL, "the search database belongs to another context");
     KMG_ALLOC(d_hit, (search->U + 1) * 8);
     KMG_TRY(match_locked(ctx, search, ref, d_hit.as<long long>(), nullptr));
     KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(search)));

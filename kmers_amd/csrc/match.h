@@ -36,15 +36,10 @@ __global__ void match_bounds_kernel(const u64 *__restrict__ skeys, u64 ns, const
 // few hundred k-mers when the two sets are of similar density) and every search k-mer is then binary-searched
 // in LDS instead of through L2.  Ranges that do not fit are searched in place.  hit[i] = index of the k-mer
 // in the reference, or -1.
-__global__ __launch_bounds__(MT_BLOCK) void match_kernel(const u64 *__restrict__ skeys, u64 ns,
-                                                          const u64 *__restrict__ rkeys,
-                                                          const u64 *__restrict__ bounds,
-                                                          long long *__restrict__ hit, u64 *__restrict__ nhits) {
+__device__ __forceinline__ void match_tile(const u64 *__restrict__ skeys, u64 q0, u64 q1, const u64 *__restrict__ rkeys,
+                                           u64 r_lo, u64 r_hi, long long *__restrict__ hit, u64 *__restrict__ nhits) {
     __shared__ u64 sref[MT_RMAX];
     __shared__ u32 smem[4];
-    const u64 q0 = (u64)blockIdx.x * MT_TILE;
-    const u64 q1 = q0 + MT_TILE < ns ? q0 + MT_TILE : ns;
-    const u64 r_lo = bounds[blockIdx.x], r_hi = bounds[blockIdx.x + 1];
     const u32 cnt = (u32)(r_hi - r_lo < MT_RMAX ? r_hi - r_lo : MT_RMAX);
     const bool staged = r_hi - r_lo <= MT_RMAX;
     if (staged)
@@ -86,6 +81,62 @@ __global__ __launch_bounds__(MT_BLOCK) void match_kernel(const u64 *__restrict__
             if (total) atomicAdd(nhits, (u64)total);
         }
     }
+}
+
+__global__ __launch_bounds__(MT_BLOCK) void match_kernel(const u64 *__restrict__ skeys, u64 ns,
+                                                          const u64 *__restrict__ rkeys,
+                                                          const u64 *__restrict__ bounds,
+                                                          long long *__restrict__ hit, u64 *__restrict__ nhits) {
+    const u64 q0 = (u64)blockIdx.x * MT_TILE;
+    const u64 q1 = q0 + MT_TILE < ns ? q0 + MT_TILE : ns;
+    match_tile(skeys, q0, q1, rkeys, bounds[blockIdx.x], bounds[blockIdx.x + 1], hit, nhits);
+}
+
+// ---- the same join for search k-mers that arrive as several ascending runs back to back (what the owner of a key
+// range receives from the other GPUs in the key-range exchange: one ascending slice per source, all inside the owner's
+// range, so the concatenation is not ascending).  Tiles never straddle a run boundary; every tile carries its own
+// search range and reference range, so one launch joins all runs.
+#define MT_MAX_RUNS 64
+struct MatchRuns {
+    u32 n_runs;
+    u32 tile0[MT_MAX_RUNS + 1];   // first tile of every run (runs without k-mers have no tile)
+    u64 off[MT_MAX_RUNS + 1];     // first search k-mer of every run
+};
+struct MatchTile { u64 q0, q1, r_lo, r_hi; };
+
+__global__ void match_runs_bounds_kernel(const u64 *__restrict__ skeys, MatchRuns runs, const u64 *__restrict__ rkeys,
+                                         const u64 *__restrict__ rbucket, int key_len, u32 ntiles,
+                                         MatchTile *__restrict__ tiles) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    u32 r = 0;
+    while (r + 1 < runs.n_runs && t >= runs.tile0[r + 1]) r++;
+    const u64 q0 = runs.off[r] + (u64)(t - runs.tile0[r]) * MT_TILE;
+    const u64 q1 = q0 + MT_TILE < runs.off[r + 1] ? q0 + MT_TILE : runs.off[r + 1];
+    const u64 first = skeys[q0], last = skeys[q1 - 1];
+    u64 b = first >> (64 - 2 * key_len);
+    u64 lo = rbucket[b], hi = rbucket[b + 1];
+    while (lo < hi) {                         // first reference k-mer >= the tile's first search k-mer
+        const u64 mid = (lo + hi) >> 1;
+        if (rkeys[mid] < first) lo = mid + 1; else hi = mid;
+    }
+    const u64 r_lo = lo;
+    b = last >> (64 - 2 * key_len);
+    lo = rbucket[b]; hi = rbucket[b + 1];
+    while (lo < hi) {                         // first reference k-mer > the tile's last search k-mer
+        const u64 mid = (lo + hi) >> 1;
+        if (rkeys[mid] <= last) lo = mid + 1; else hi = mid;
+    }
+    MatchTile mt;
+    mt.q0 = q0; mt.q1 = q1; mt.r_lo = r_lo; mt.r_hi = lo < r_lo ? r_lo : lo;      // (a run that is not ascending finds nothing)
+    tiles[t] = mt;
+}
+
+__global__ __launch_bounds__(MT_BLOCK) void match_runs_kernel(const u64 *__restrict__ skeys, const u64 *__restrict__ rkeys,
+                                                               const MatchTile *__restrict__ tiles,
+                                                               long long *__restrict__ hit) {
+    const MatchTile mt = tiles[blockIdx.x];
+    match_tile(skeys, mt.q0, mt.q1, rkeys, mt.r_lo, mt.r_hi, hit, nullptr);
 }
 
 // ---- TaxaCounts ----------------------------------------------------------------------------------------

@@ -210,18 +210,14 @@ def build_key_range_shard(ctx, local_db, ranges, device=None, group=None):
 
 def match_by_key_range_tensors(keys, cuts, local_match, group=None, want_owner=True):
     """Join ascending search k-mers (int64 tensor holding the u64 bits, on the CPU or on this rank's GPU) against a
-    key-range-sharded reference: keys[cuts[g] : cuts[g+1]] go to rank g, every owner joins what it received --
-    local_match(tensor of ascending keys from ONE source rank) -> int64 hit indices into its shard, -1 = miss --
-    and the reverse all-to-all brings the hits back in the order of `keys`.  -> (owner int32[n], hit int64[n])."""
+    key-range-sharded reference: keys[cuts[g] : cuts[g+1]] go to rank g, every owner joins what it received in ONE
+    call -- local_match(tensor of everything received, counts per source rank: one ascending run per source, all of
+    them inside the owner's range) -> int64 hit indices into its shard, -1 = miss -- and the reverse all-to-all
+    brings the hits back in the order of `keys`.  -> (owner int32[n], hit int64[n])."""
     world = len(cuts) - 1
     kc = [int(cuts[g + 1] - cuts[g]) for g in range(world)]
     recv, rc = all_to_all_tensor(keys[int(cuts[0]):int(cuts[-1])], kc, group)
-    hits = torch.empty(recv.numel(), dtype=torch.int64, device=keys.device)
-    o = 0
-    for n in rc:
-        if n:
-            hits[o:o + n] = local_match(recv[o:o + n])
-        o += n
+    hits = local_match(recv, rc)
     back, _ = all_to_all_tensor(hits, rc, group)
     if not want_owner:          # (the owner of k-mer i is the range i falls in: cuts says it all)
         return None, back
@@ -236,34 +232,42 @@ def match_by_key_range_tensors(keys, cuts, local_match, group=None, want_owner=T
 
 def match_by_key_range(search_keys, ranges, key_len, local_match, device="cpu", group=None):
     """numpy front of match_by_key_range_tensors.  local_match(keys) -> int64 hit index into THIS rank's reference
-    shard (-1 = miss) for an ascending u64 array.  Returns (owner, hit): for every search k-mer the rank that owns
-    its range and the hit index inside that rank's shard (-1 = miss)."""
+    shard (-1 = miss) for an ascending u64 array (called once per source rank's run).  Returns (owner, hit): for
+    every search k-mer the rank that owns its range and the hit index inside that rank's shard (-1 = miss)."""
     keys = np.ascontiguousarray(search_keys, np.uint64)
     c = cut_points(keys, ranges, key_len)
 
-    def lm(t):
-        h = np.asarray(local_match(t.cpu().numpy().view(np.uint64)), np.int64)
-        return torch.from_numpy(np.ascontiguousarray(h)).to(t.device)
+    def lm(t, counts):
+        a = t.cpu().numpy().view(np.uint64)
+        h = np.empty(len(a), np.int64)
+        o = 0
+        for n in counts:
+            if n:
+                h[o:o + n] = np.asarray(local_match(a[o:o + n]), np.int64)
+            o += n
+        return torch.from_numpy(h).to(t.device)
 
     owner, hit = match_by_key_range_tensors(torch.from_numpy(keys.view(np.int64).copy()).to(device), c, lm, group)
     return owner.cpu().numpy(), hit.cpu().numpy()
 
 
 def shard_matcher(ctx, like_db, ref_shard):
-    """-> local_match for match_by_key_range_tensors on the GPU: ascending key tensor -> hit indices into
-    ref_shard (kmg_db_load_dev of a keys-only database shaped like `like_db`, then kmg_match_dev)."""
-    from .api import KmerDatabase, match_into
+    """-> local_match for match_by_key_range_tensors on the GPU: everything the owner received (one ascending run
+    per source rank) is joined against ref_shard in one launch (kmg_match_keys_dev), straight from the receive
+    buffer."""
+    import ctypes as C
     dev = torch.device("cuda", ctx.device)
-    no_vals = torch.empty(0, dtype=torch.int32, device=dev)
 
-    def local_match(part):
-        part = part.contiguous()
-        torch.cuda.synchronize(dev)
-        q = KmerDatabase.load_tensors(ctx, like_db.k, like_db.key_length, like_db.rc, like_db.kind, part,
-                                      torch.zeros(part.numel() + 1, dtype=torch.int64, device=dev), no_vals, no_vals)
-        out = torch.empty(part.numel(), dtype=torch.int64, device=dev)
-        match_into(ctx, q, ref_shard, out)
-        q.close()
+    def local_match(recv, counts):
+        recv = recv.contiguous()
+        out = torch.empty(recv.numel(), dtype=torch.int64, device=dev)
+        if recv.numel() == 0:
+            return out
+        off = np.concatenate([[0], np.cumsum(np.asarray(counts, np.uint64))]).astype(np.uint64)
+        torch.cuda.current_stream(dev).synchronize()         # the collective that filled `recv` ran on torch's stream
+        ctx.check(ctx.lib.kmg_match_keys_dev(ctx.h, recv.data_ptr(), off.ctypes.data_as(C.c_void_p), len(counts), like_db.k,
+                                             ref_shard.h, out.data_ptr()))
+        torch.cuda.ExternalStream(ctx.stream, device=dev).synchronize()
         return out
 
     return local_match
@@ -276,7 +280,7 @@ def match_key_range_shard(ctx, search_db, ref_shard, ranges, group=None, want_ow
     of search_db."""
     dev = torch.device("cuda", ctx.device)
     keys = torch.empty(search_db.n_unique, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize(dev)
+    torch.cuda.current_stream(dev).synchronize()
     ctx.check(ctx.lib.kmg_db_copy_dev(search_db.h, 0, keys.data_ptr() if keys.numel() else None, 0, keys.numel()))
     boff = search_db.bucket_offsets()
     cuts = [int(boff[r[0]]) for r in ranges] + [int(boff[ranges[-1][1]])]

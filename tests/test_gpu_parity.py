@@ -650,6 +650,55 @@ def test_key_range_sharded_match_on_the_gpu(ctx):
     rdb.close()
 
 
+def test_match_keys_in_runs(ctx):
+    """kmg_match_keys_dev: the owner's side of the key-range exchange -- several ascending runs of search k-mers back
+    to back (one per source GPU, all inside one key range, an empty one among them, run lengths on both sides of a
+    tile) joined in one launch; every element's hit index equals the oracle's for that k-mer.  Also the one-run
+    form against a whole database, and the argument checks."""
+    import ctypes as C
+    import kmers_amd as km
+    from kmers_amd import _lib, synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(61, 3, 40000, shared_frac=0.2)
+    reads = synth.random_reads(62, genomes, 3000, 120, 0.01)
+    k, l = 23, 5
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    ref = km.make_reference_db(ctx, fa, k, l)
+    o_ref, o_reads = OracleDB(fa, 0, k, l), OracleDB(fq, 1, k, l)
+    o_hit, _ = o_reads.match(o_ref)
+    rng = np.random.default_rng(5)
+    n = o_reads.U
+    assert n > 5 * 2048
+    # deal the (ascending) search k-mers to 5 "sources": each source's share stays ascending
+    src = rng.integers(0, 5, size=n)
+    src[src == 3] = 4                                  # source 3 sends nothing
+    src[:3] = [0, 1, 2]
+    order = np.concatenate([np.nonzero(src == g)[0] for g in range(5)])
+    counts = [int((src == g).sum()) for g in range(5)]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    dev = torch.device("cuda", 0)
+    d_keys = torch.from_numpy(o_reads.keys[order].view(np.int64).copy()).to(dev)
+    d_hit = torch.full((n + 1,), -7, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.kmg_match_keys_dev(ctx.h, d_keys.data_ptr(), off.ctypes.data_as(C.c_void_p), 5, k, ref.h, d_hit.data_ptr()))
+    torch.cuda.ExternalStream(ctx.stream, device=dev).synchronize()
+    got = d_hit.cpu().numpy()
+    assert got[n] == -7 and np.array_equal(got[:n], o_hit[order])
+    # one run = the plain join
+    one = np.array([0, n], np.uint64)
+    d_keys = torch.from_numpy(o_reads.keys.view(np.int64).copy()).to(dev)
+    d_hit.fill_(-7)
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.kmg_match_keys_dev(ctx.h, d_keys.data_ptr(), one.ctypes.data_as(C.c_void_p), 1, k, ref.h, d_hit.data_ptr()))
+    torch.cuda.ExternalStream(ctx.stream, device=dev).synchronize()
+    assert np.array_equal(d_hit.cpu().numpy()[:n], o_hit)
+    bad = np.array([5, 0], np.uint64)
+    assert ctx.lib.kmg_match_keys_dev(ctx.h, d_keys.data_ptr(), bad.ctypes.data_as(C.c_void_p), 1, k, ref.h, d_hit.data_ptr()) == _lib.KMG_EINVAL
+    assert ctx.lib.kmg_match_keys_dev(ctx.h, d_keys.data_ptr(), one.ctypes.data_as(C.c_void_p), 1, k - 1, ref.h, d_hit.data_ptr()) == _lib.KMG_EINVAL
+    assert ctx.lib.kmg_match_keys_dev(ctx.h, d_keys.data_ptr(), one.ctypes.data_as(C.c_void_p), 65, k, ref.h, d_hit.data_ptr()) == _lib.KMG_EINVAL
+    ref.close()
+
+
 def test_device_resident_copy_and_load(ctx):
     """kmg_db_copy_dev / kmg_db_load_dev: a database copied into torch tensors and loaded back is the same
     database; slices are bounds-checked; the device-side checks reject what kmg_db_load rejects on the host."""
@@ -1126,3 +1175,73 @@ def test_packed_input_equals_letters(ctx):
     with pytest.raises(km.InconsistentDataException):
         fc.add_packed(np.frombuffer(packed, np.uint8), seq_off, byte_off, np.array(ids, np.int32))
     fc.create().close()
+
+
+# ---------------------------------------------------------------------------- the bench step's shape
+def test_bench_step_shape_two_contexts(ctx):
+    """What bench.py times, at small scale and checked: kmg_build_add_dev from device tensors without a stream sync,
+    the reference on a second context (a second stream) underneath the reads' extraction, kmg_match_dev across the two
+    contexts into a device tensor, and kmg_db_free right behind it -- for several steps in a row, so the pools hand the
+    just-freed arrays of one step to the next while the join of the step before may still be reading them (the library
+    orders that: kmg_db::foreign_use).  Both databases and every hit index against the oracle, every step."""
+    import ctypes as C
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    K, L = 31, 6
+    dev = torch.device("cuda", 0)
+    ctx_ref = km.Context(0)
+    lib = ctx.lib
+    try:
+        steps = []
+        for seed in (1, 2, 3):
+            taxa, genomes = synth.random_genomes(seed, 4, 30000, shared_frac=0.1)
+            reads = synth.random_reads(seed + 10, genomes, 6000, 150, 0.01)
+            ref_bases, ref_off = synth.batch_from_seqs(genomes)
+            t = dict(
+                ref_bases=torch.from_numpy(ref_bases).to(dev), ref_off=torch.from_numpy(ref_off.view(np.int64)).to(dev),
+                ref_id=torch.tensor(taxa, dtype=torch.int32, device=dev), nref=len(genomes),
+                read_bases=torch.from_numpy(np.ascontiguousarray(reads).reshape(-1)).to(dev),
+                read_off=torch.from_numpy((np.arange(len(reads) + 1, dtype=np.uint64) * np.uint64(150)).view(np.int64)).to(dev),
+                read_tok=torch.arange(len(reads), dtype=torch.int64, device=dev), nreads=len(reads),
+                o_ref=OracleDB(synth.fasta_bytes(taxa, genomes), 0, K, L), o_reads=OracleDB(synth.fastq_bytes(reads), 1, K, L))
+            t["o_hit"], t["o_nh"] = t["o_reads"].match(t["o_ref"])
+            t["hit"] = torch.full((t["o_reads"].U + 1,), -7, dtype=torch.int64, device=dev)
+            steps.append(t)
+        torch.cuda.synchronize()
+
+        def finish(c):
+            db, nw = C.c_void_p(), C.c_uint64()
+            c.check(lib.kmg_build_finish(c.h, C.byref(db), C.byref(nw)))
+            return db, nw.value
+
+        for rep in range(2):
+            for i, t in enumerate(steps):
+                ctx_ref.check(lib.kmg_build_begin(ctx_ref.h, K, L, 1, 0))
+                ctx_ref.check(lib.kmg_build_add_dev(ctx_ref.h, t["ref_bases"].data_ptr(), t["ref_bases"].numel(),
+                                                    t["ref_off"].data_ptr(), t["ref_id"].data_ptr(), None, t["nref"], None))
+                ctx.check(lib.kmg_build_begin(ctx.h, K, L, 0, 1))
+                ctx.check(lib.kmg_build_add_dev(ctx.h, t["read_bases"].data_ptr(), t["read_bases"].numel(),
+                                                t["read_off"].data_ptr(), None, t["read_tok"].data_ptr(), t["nreads"], None))
+                ref, nw_ref = finish(ctx_ref)
+                rdb, nw_reads = finish(ctx)
+                assert nw_ref == t["o_ref"].n_windows and nw_reads == t["o_reads"].n_windows
+                ctx.check(lib.kmg_match_dev(ctx.h, rdb, ref, t["hit"].data_ptr()))
+                if rep == 0:
+                    # first round: look at the databases too (fetch synchronises their contexts)
+                    _same_db(km.KmerDatabase(ctx_ref, ref), t["o_ref"])
+                    _same_db(km.KmerDatabase(ctx, rdb), t["o_reads"])
+                # second round: free right behind the asynchronous join, then go straight on to the next step
+                lib.kmg_db_free(rdb)
+                lib.kmg_db_free(ref)
+            torch.cuda.ExternalStream(ctx.stream, device=dev).synchronize()
+            torch.cuda.ExternalStream(ctx_ref.stream, device=dev).synchronize()
+            for t in steps:
+                n = t["o_reads"].U
+                got = t["hit"].cpu().numpy()
+                assert got[n] == -7
+                assert np.array_equal(got[:n], t["o_hit"]) and int((got[:n] >= 0).sum()) == t["o_nh"]
+                t["hit"].fill_(-7)
+            torch.cuda.synchronize()
+    finally:
+        ctx_ref.close()

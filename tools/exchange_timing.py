@@ -22,7 +22,7 @@ keys = torch.empty(rdb.n_unique, dtype=torch.int64, device=dev)
 T('copy keys', lambda: ctx.check(ctx.lib.kmg_db_copy_dev(rdb.h, 0, keys.data_ptr(), 0, keys.numel())))
 T('bucket_offsets', lambda: rdb.bucket_offsets())
 lm = kd.shard_matcher(ctx, rdb, ref)
-T('local_match', lambda: lm(keys))
+T('local_match', lambda: lm(keys, [keys.numel()]))
 no_vals = torch.empty(0, dtype=torch.int32, device=dev)
 z = T('zeros', lambda: torch.zeros(keys.numel() + 1, dtype=torch.int64, device=dev))
 q = T('load_tensors', lambda: km.KmerDatabase.load_tensors(ctx, 31, 6, False, 1, keys, z, no_vals, no_vals))
