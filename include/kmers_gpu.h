@@ -185,6 +185,16 @@ int kmg_match_dev(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t
 int kmg_match_keys_dev(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run_off, int n_runs, int k,
                        const kmg_db *ref, int64_t *d_hit_index);
 
+/* kmg_match_dev_noalloc: kmg_match_dev for callers that cannot allocate.  No counterpart in the reference: it is
+ *   for code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same result as
+ *   kmg_match_dev, to the bit; calls no hipMalloc / hipFree / allocating routine and does not synchronise.  Its only
+ *   scratch, the per-tile bounds of the join, lives in a file-scope device array of 1 MiB that every GPU the library
+ *   runs on holds until the process ends; hence the limit: at most KMG_MATCH_NOALLOC_MAX_SEARCH distinct search
+ *   k-mers per call (KMG_EINVAL beyond).  Both databases must belong to ctx.  Every call on a GPU shares that GPU's
+ *   array: calls that overlap on one GPU (two contexts = two streams) race -- serialise them. */
+#define KMG_MATCH_NOALLOC_MAX_SEARCH 268433408ull   /* 131071 tiles x 2048 k-mers */
+int kmg_match_dev_noalloc(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *d_hit_index);
+
 /* kmg_match_near: inexact search for k-mers of one length (replaces DB.getNearestKmers' other branch ->
  *   processNearestCommonKey, DB.java:139-184, over Root.addKmers / closestKmers, Root.java:22-170, and
  *   KmerUtils.getCloseKeys, KmerUtils.java:18-47; Matcher -n 1 | 2): for every search k-mer ALL reference k-mers

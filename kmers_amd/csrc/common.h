@@ -176,6 +176,7 @@ struct kmg_ctx {
     hipEvent_t ev_len = nullptr, ev_snap = nullptr;
     bool snap_valid = false;     // h_snap holds the state finish() needs (single fused batch)
     std::vector<void *> staged;  // device copies of host batches, released at finish
+    u64 *match_scratch = nullptr; // this device's copy of the file-scope bounds array (kmg_match_dev_noalloc)
 
     // profiling
     bool prof_on = false;

@@ -44,6 +44,8 @@ static int fail(kmg_ctx *ctx, int code, const char *msg) {
     } while (0)
 
 // ------------------------------------------------------------------------------------------------ context
+static int resolve_match_scratch(kmg_ctx *ctx);
+
 extern "C" int kmg_create(int device, kmg_ctx **out) {
     if (!out) return KMG_EINVAL;
     *out = nullptr;
@@ -64,6 +66,12 @@ extern "C" int kmg_create(int device, kmg_ctx **out) {
         return KMG_ENOMEM;
     }
     ctx->d_state = (u64 *)st;
+    if (resolve_match_scratch(ctx) != KMG_OK) {
+        ctx->pool.destroy();
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return KMG_EDEVICE;
+    }
     if (hipHostMalloc(&ctx->h_pin, PIN_BYTES, hipHostMallocDefault) != hipSuccess) ctx->h_pin = nullptr;   // optional
     if (hipHostMalloc(&ctx->h_snap, PIN_BYTES, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_len, hipEventDisableTiming) != hipSuccess ||
@@ -1126,6 +1134,54 @@ extern "C" int kmg_match_keys_dev(kmg_ctx *ctx, const uint64_t *d_keys, const ui
     KMG_TRY(note_foreign_use(ctx, ref));
     return KMG_OK;
 }
+
+// ---- the join for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid it) ----
+// kmg_match_dev's only scratch is the per-tile bounds array (one u64 per MT_TILE search k-mers + 1).  Here it lives
+// in a file-scope device array: every GPU the library runs on holds its own copy (1 MiB) until the process ends.
+// In host code the array's name is a stand-in, not a device address -- kmg_create resolves the address once per
+// device (hipGetSymbolAddress, that device current) and only that pointer is ever handed to a kernel.
+#define KMG_NOALLOC_TILES 131071u
+static __device__ __align__(256) u64 kmg_match_scratch[KMG_NOALLOC_TILES + 1];
+#define KMG_MAX_DEVICES 64
+static u64 *g_match_scratch[KMG_MAX_DEVICES];          // per device: address of ITS copy of kmg_match_scratch
+static std::mutex g_match_scratch_mu;
+
+// called by kmg_create with ctx->device current
+static int resolve_match_scratch(kmg_ctx *ctx) {
+    if (ctx->device < 0 || ctx->device >= KMG_MAX_DEVICES) return KMG_OK;       // no-alloc join not offered there
+    std::lock_guard<std::mutex> g(g_match_scratch_mu);
+    if (!g_match_scratch[ctx->device]) {
+        void *p = nullptr;
+        KMG_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(kmg_match_scratch)));
+        if (!p) return fail(ctx, KMG_EDEVICE, "hipGetSymbolAddress returned no address");
+        g_match_scratch[ctx->device] = (u64 *)p;
+    }
+    ctx->match_scratch = g_match_scratch[ctx->device];
+    return KMG_OK;
+}
+
+extern "C" int kmg_match_dev_noalloc(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *d_hit_index) {
+    if (!ctx || !search || !ref || !d_hit_index) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    if (!ctx->match_scratch) return fail(ctx, KMG_EDEVICE, "no scratch array on this device");
+    // (a foreign database would need an event of its own to order its release: that is an allocation)
+    if (search->ctx != ctx || ref->ctx != ctx) return fail(ctx, KMG_EINVAL, "both databases must belong to this context");
+    if (search->k != ref->k || search->key_len != ref->key_len)                                  // DB.java:78-81
+        return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
+    if (search->U > (u64)KMG_MATCH_NOALLOC_MAX_SEARCH)
+        return fail(ctx, KMG_EINVAL, "more search k-mers than the no-allocation join holds bounds for (KMG_MATCH_NOALLOC_MAX_SEARCH)");
+    if (search->U == 0) return KMG_OK;
+    const u32 ntiles = div_up_u64(search->U, MT_TILE);          // <= KMG_NOALLOC_TILES by the check above
+    u64 *bounds = ctx->match_scratch;                            // every word [0, ntiles] is written before it is read
+    hipLaunchKernelGGL(match_bounds_kernel, dim3(div_up_u64(ntiles + 1, 256)), dim3(256), 0, ctx->stream, search->keys, search->U,
+                       ref->keys, ref->U, ref->bucket_off, ref->key_len, ntiles, bounds);
+    hipLaunchKernelGGL(match_kernel, dim3(ntiles), dim3(MT_BLOCK), 0, ctx->stream, search->keys, search->U, ref->keys,
+                       bounds, (long long *)d_hit_index, (u64 *)nullptr);
+    KMG_HIP(hipGetLastError());
+    return KMG_OK;
+}
+static_assert((u64)KMG_NOALLOC_TILES * MT_TILE == KMG_MATCH_NOALLOC_MAX_SEARCH, "header limit and scratch size disagree");
 
 extern "C" int kmg_match(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *hit_index, uint64_t *n_hits) {
     if (!ctx || !search || !ref || !hit_index) return KMG_EINVAL;
