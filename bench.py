@@ -8,41 +8,109 @@ One step = BASELINE config 2 on one GPU, inputs already resident in HBM:
 at k = 31, key length 6.  value = (reference windows + read windows) / step time, whole job.
 The two builds are independent and are submitted on two contexts (two HIP streams): the small reference build
 runs underneath the reads' extraction; the match starts when both databases are complete.
-N > 1: one process per GPU, every rank builds the (small) reference and its own shard of 1M reads
-(weak scaling, no data-path collective -- see DESIGN.md "Multi-GPU"); value sums over ranks.
 
-Adds "roofline" (dominant kernel, algorithmic bytes / HIP-event time measured live on the library's
-stream) and, on rank 0 at N = 1, "cpu_baseline" (the C restatement of the reference's algorithm timed
-on a bounded sample on this box's host cores).
+N > 1 (`--gpus N`; one process per GPU, started here when no launcher has set WORLD_SIZE, else taken from the
+launcher's RANK / LOCAL_RANK / WORLD_SIZE): the north-star split is the headline -- the reference database is
+range-partitioned by k-mer prefix (every GPU builds only the key range it owns, kmg_build_set_key_range), every GPU
+builds the read database of its own 1M reads, and the distinct read k-mers are bucketed by owner and exchanged with an
+RCCL all-to-all; owners join what they received in one launch (kmg_match_keys_dev) and the hit indices travel back.
+The replicated-reference mode (every GPU builds the whole small reference, no data-path collective) is timed beside
+it and reported under "replicated".  After the timed loops one checked step asserts that the hits summed over ranks
+are the same in both modes.
+
+`--config 3` is the secondary line: BASELINE config 3 at full size on one GPU (1 Gbp / 10 k taxa reference, 100 M
+reads streamed in chunks against the resident reference, TaxaCounts) -- see bench_config3().
+
+Adds "roofline" (dominant kernel, algorithmic bytes / HIP-event time measured live on the library's stream) and, on
+rank 0 at N = 1, "cpu_baseline" (the C restatement of the reference's algorithm timed on this box's host cores).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~5 TB/s is the measured copy ceiling
 K, KEY_LEN = 31, 6
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scale", type=float, default=1.0, help="scale factor on config sizes (1.0 = BASELINE config 2)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="BASELINE config: 2 = headline, 3 = 1 Gbp + 100 M reads + TaxaCounts (one GPU)")
+    ap.add_argument("--scale", type=float, default=1.0, help="scale factor on config sizes (1.0 = the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calib", action="store_true", help="also launch the known-traffic copy kernel (PMC calibration)")
-    ap.add_argument("--exchange", action="store_true",
-                    help="key-range mode (SURVEY 8e) instead of the replicated reference: the reference is range-partitioned by "
-                         "k-mer prefix -- every rank builds only the key range it owns (kmg_build_set_key_range) -- and the "
-                         "read k-mers are bucketed and exchanged to the owners for the join (RCCL all-to-all, hits come back "
-                         "the same way).  Opt-in: not the headline line.")
-    args = ap.parse_args()
+    ap.add_argument("--mode", choices=("auto", "key-range", "replicated"), default="auto",
+                    help="N > 1: which split is the headline (auto = key-range, the north-star split; the other is "
+                         "reported beside it).  KMERS_BENCH_FORCE_DIST=1 runs the key-range code path on one GPU too.")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(n, script=None, argv=None, need_gpus=True, grace=20):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes BEFORE this process makes any GPU
+    call (it never does), one per GPU, with the launch contract's environment (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT); they inherit stdout, and only rank 0 writes the JSON line.  Fails loudly
+    when the box has fewer than N GPUs.  -> exit status (0 = every rank succeeded)."""
+    if need_gpus:
+        import torch
+        have = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this box -- not running\n" % (n, have))
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] +
+                                      (sys.argv[1:] if argv is None else list(argv)), env=env))
+    rc, deadline = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0):
+                rc = rc or p.returncode
+                deadline = deadline or time.time() + grace          # a rank died: the others would wait in a collective
+        if deadline and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    for p in procs:
+        rc = rc or p.returncode
+    return rc
+
+
+def source_hash():
+    """Hash of the kernel sources the loaded library was built from (kmers_amd/csrc/*): committed PMC measurements
+    carry it, and a measurement of other sources is not reported as this build's traffic."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "kmers_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
 
     # stdout carries the one JSON line and nothing else: RCCL prints a version banner on file descriptor 1 when the
     # communicator comes up, so everything but the result is sent to stderr at the descriptor level
@@ -53,32 +121,49 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d\n" % (args.gpus, world, world))
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d wants GPU %d, %d visible\n" % (rank, local_rank, torch.cuda.device_count()))
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.config == 3:
+        if world != 1:
+            sys.stderr.write("bench.py: --config 3 is a one-GPU line\n")
+            sys.exit(2)
+        out = bench_config3(args, dev)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        return
     # KMERS_BENCH_FORCE_DIST=1: run the collective code path with a single rank too (rehearsal on a 1-GPU box)
     use_dist = world > 1 or os.environ.get("KMERS_BENCH_FORCE_DIST") == "1"
     if use_dist:
+        if "RANK" not in os.environ:           # the one-rank rehearsal without a launcher
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]))
+            sk.close()
         dist.init_process_group("nccl", device_id=dev)
+    headline = "single" if not use_dist else ("replicated" if args.mode == "replicated" else "key-range")
 
     import kmers_amd as km
-    from kmers_amd import synth
+    from kmers_amd import dist as kd, synth
 
     # ---- synthetic inputs, resident in HBM before anything is timed ------------------------------
     glen = max(1000, int(500_000 * args.scale))
     nreads = max(100, int(1_000_000 * args.scale))
     taxa, genomes = synth.random_genomes(1, 10, glen)
     reads = synth.random_reads(2 + rank, genomes, nreads, 150, 0.01)
-    my_genomes, my_taxa = genomes, taxa          # every rank holds the whole reference input
-    ref_bases, ref_off = synth.batch_from_seqs(my_genomes)
+    ref_bases, ref_off = synth.batch_from_seqs(genomes)          # every rank holds the whole reference input
     read_off = np.arange(nreads + 1, dtype=np.uint64) * np.uint64(150)
     d_ref_bases = torch.from_numpy(ref_bases).to(dev)
     d_ref_off = torch.from_numpy(ref_off.view(np.int64)).to(dev)
-    d_ref_id = torch.tensor(my_taxa, dtype=torch.int32, device=dev)
+    d_ref_id = torch.tensor(taxa, dtype=torch.int32, device=dev)
     d_read_bases = torch.from_numpy(np.ascontiguousarray(reads).reshape(-1)).to(dev)
     d_read_off = torch.from_numpy(read_off.view(np.int64)).to(dev)
     d_read_tok = torch.arange(nreads, dtype=torch.int64, device=dev)
@@ -94,8 +179,10 @@ def main():
     ctx_ref = km.Context(local_rank)
     lib, h, h_ref = ctx.lib, ctx.h, ctx_ref.h
 
-    def submit(c, bases, off, ids, toks, nseq, kind, rc):
+    def submit(c, bases, off, ids, toks, nseq, kind, rc, key_range=None):
         c.check(lib.kmg_build_begin(c.h, K, KEY_LEN, rc, kind))
+        if key_range is not None:
+            c.check(lib.kmg_build_set_key_range(c.h, key_range[0], key_range[1]))
         c.check(lib.kmg_build_add_dev(c.h, bases.data_ptr(), bases.numel(), off.data_ptr(),
                                       ids.data_ptr() if ids is not None else None,
                                       toks.data_ptr() if toks is not None else None, nseq, None))
@@ -106,40 +193,39 @@ def main():
         c.check(lib.kmg_build_finish(c.h, C.byref(db), C.byref(nw)))
         return db, nw.value
 
+    def n_unique(db):
+        u = C.c_uint64()
+        lib.kmg_db_info(db, None, None, None, None, C.byref(u), None)
+        return u.value
+
     stage_s = {"ref_build": 0.0, "read_build": 0.0, "match": 0.0}
 
     ranges = None
-    if args.exchange:
+    if use_dist:
         # The partition of the key space is a property of the reference, planned once: balanced ranges from the bucket
         # histogram of one complete build (every rank holds the whole input, so all ranks find the same ranges).
-        from kmers_amd import dist as kd
-        submit(ctx_ref, d_ref_bases, d_ref_off, d_ref_id, None, len(my_genomes), 0, 1)
+        submit(ctx_ref, d_ref_bases, d_ref_off, d_ref_id, None, len(genomes), 0, 1)
         whole = km.KmerDatabase(ctx_ref, finish(ctx_ref)[0])
         ranges = kd.balanced_key_ranges(np.diff(whole.bucket_offsets().astype(np.int64)), world)
         whole.close()
 
-    def step_exchange():
+    def step_key_range(keep_hits=False):
         """Key-range mode: this rank's range of the reference is built from the whole input (no reference k-mer leaves
         its GPU), the reads are built locally, their distinct k-mers are cut at the range bounds, exchanged, joined by
-        the owners and the hit indices exchanged back (kmers_amd/dist.py; RCCL all-to-all under nccl)."""
-        ctx_ref.check(lib.kmg_build_begin(h_ref, K, KEY_LEN, 1, 0))
-        ctx_ref.check(lib.kmg_build_set_key_range(h_ref, ranges[rank][0], ranges[rank][1]))
-        ctx_ref.check(lib.kmg_build_add_dev(h_ref, d_ref_bases.data_ptr(), d_ref_bases.numel(), d_ref_off.data_ptr(),
-                                            d_ref_id.data_ptr(), None, len(my_genomes), None))
+        the owners in one launch and the hit indices exchanged back (kmers_amd/dist.py; RCCL all-to-all under nccl)."""
+        submit(ctx_ref, d_ref_bases, d_ref_off, d_ref_id, None, len(genomes), 0, 1, key_range=ranges[rank])
         submit(ctx, d_read_bases, d_read_off, None, d_read_tok, nreads, 1, 0)
         ref_h, nw_ref = finish(ctx_ref)
         shard = km.KmerDatabase(ctx_ref, ref_h)
         rdb_h, nw_reads = finish(ctx)
         rdb = km.KmerDatabase(ctx, rdb_h)
         _, hit = kd.match_key_range_shard(ctx, rdb, shard, ranges, want_owner=False)
-        nw_all = int(kd.allreduce_sum(np.array([nw_ref]), device=dev if use_dist else "cpu")[0])
+        u = rdb.n_unique
         rdb.close()
         shard.close()
-        return nw_all, nw_reads
+        return (nw_ref, nw_reads, u), (hit if keep_hits else None)
 
-    def step(timed_stages=False):
-        if args.exchange:
-            return step_exchange()
+    def step_local(timed_stages=False):
         t0 = time.perf_counter()
         submit(ctx_ref, d_ref_bases, d_ref_off, d_ref_id, None, len(genomes), 0, 1)
         if timed_stages:                      # stage-by-stage wall clock: one stage at a time
@@ -160,42 +246,75 @@ def main():
             stage_s["ref_build"] += t1 - t0
             stage_s["read_build"] += t2 - t1
             stage_s["match"] += t3 - t2
-        info = (nw_ref, nw_reads)
-        lib.kmg_db_free(rdb)
+        info = (nw_ref, nw_reads, n_unique(rdb))
+        lib.kmg_db_free(rdb)      # (right behind the asynchronous join: the library orders the release behind it)
         lib.kmg_db_free(ref)
         return info
 
+    def sync_all():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn):
+        for _ in range(args.warmup):
+            info = fn()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            info = fn()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, info
+
     if args.calib:
         ctx.check(lib.kmg_calib_copy(h, 1 << 27))   # 1 GiB read + 1 GiB written, known exactly
-    for _ in range(args.warmup):
-        info = step()
+    runs = {}
+    if headline == "single":
+        runs["single"] = timed(step_local)
+    else:
+        runs["key-range"] = timed(lambda: step_key_range()[0])
+        runs["replicated"] = timed(step_local)
+    elapsed, info = runs[headline]
+    for mode, (_, inf) in runs.items():
+        want_ref = n_ref_win if mode != "key-range" else inf[0]     # (a range build counts the windows it keeps)
+        assert inf[:2] == (want_ref, n_read_win), (mode, inf, n_ref_win, n_read_win)
+
+    # ---- one checked step (untimed): the hits behind the headline figure ---------------------------------------
+    info = step_local()
     torch.cuda.synchronize()
+    u_reads = info[2]
+    hits_local = int((d_hit[:u_reads] >= 0).sum().item())
+    verified = {"distinct_read_kmers": u_reads, "hits": hits_local}
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        info = step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    assert info == (n_ref_win, n_read_win), (info, n_ref_win, n_read_win)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        (nw_ref_kept, _, u_kr), hit_kr = step_key_range(keep_hits=True)
+        assert u_kr == u_reads and hit_kr.numel() == u_reads
+        hits_kr = int((hit_kr >= 0).sum().item())
+        # the same k-mers must be found (as a mask; the indices differ: one is into the shard, one into the whole)
+        assert bool(((hit_kr >= 0) == (d_hit[:u_reads] >= 0)).all().item()), "key-range and whole-reference joins differ"
+        tot = torch.tensor([hits_local, hits_kr, nw_ref_kept], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        tot = [int(x) for x in tot.tolist()]
+        assert tot[0] == tot[1], "sum of hits over ranks: whole-reference join %d, key-range join %d" % (tot[0], tot[1])
+        assert tot[2] == n_ref_win, "the ranges' reference windows must add up to the whole: %d vs %d" % (tot[2], n_ref_win)
+        verified.update(hits_all_ranks_whole_reference=tot[0], hits_all_ranks_key_range=tot[1])
 
     # ---- per-stage rates and the roofline of the dominant kernel (extra, untimed steps) -----------
-    prof_steps = 3
-    for _ in range(prof_steps):
-        step(timed_stages=True)
+    headline_step = (lambda: step_key_range()[0]) if headline == "key-range" else step_local
+    prof_steps = 10
+    if not use_dist:
+        for _ in range(3):
+            step_local(timed_stages=True)
     for c in (ctx, ctx_ref):
         c.prof_enable(True)
         c.prof_reset()
     for _ in range(prof_steps):
-        step()
+        headline_step()
     torch.cuda.synchronize()
     # the read build + match ran on `ctx`, the reference build on `ctx_ref`: kept apart ("<kernel>_ref")
     prof = {k: v for k, v in ctx.prof().items() if v["launches"]}
@@ -210,8 +329,75 @@ def main():
     avg_ms = d["ms"] / d["launches"]
     bytes_per_launch = d["bytes"] / d["launches"]
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    traffic = pmc_traffic(dom)
-    # measured device-copy ceiling of this box (report the fraction of it next to the spec peak)
+    traffic, traffic_src = pmc_traffic(dom)
+    copy_gbs = measured_copy_gbs(torch, dev)
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": int(bytes_per_launch),
+                "launches_per_step": d["launches"] // prof_steps,
+                "measured_copy_GBps": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
+    kernels = {k: {"ms_per_step": round(v["ms"] / prof_steps, 4), "launches_per_step": v["launches"] // prof_steps,
+                   "algo_GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) if v["bytes"] else None}
+               for k, v in prof.items() if v["launches"]}
+    # matched rate = k-mers presented to the join (the DISTINCT read k-mers) / time of stage 3, with HIP
+    # events on the library's stream, over prof_steps repetitions
+    match_ms = prof["match"]["ms"] / max(prof["match"]["launches"], 1)
+    stages = {"distinct_read_kmers_matched_per_s": u_reads / (match_ms * 1e-3), "match_ms": round(match_ms, 4),
+              "match_timing": "HIP events around the join's launches, mean of %d" % prof["match"]["launches"]}
+    if not use_dist:
+        stages.update(ref_kmers_built_per_s=n_ref_win * 3 / stage_s["ref_build"],
+                      read_kmers_built_per_s=n_read_win * 3 / stage_s["read_build"],
+                      build_timing="wall clock, one stage at a time, mean of 3")
+
+    if rank == 0:
+        # key-range mode builds the reference once across the node; the replicated mode builds it on every GPU
+        def line(mode, el):
+            total = n_ref_win + n_read_win * world if mode == "key-range" else (n_ref_win + n_read_win) * world
+            return total * args.steps / el, el / args.steps * 1e3
+        value, ms_per_step = line(headline, elapsed)
+        workload = {
+            "single": "BASELINE config 2: 5 Mbp reference (10 taxa) + 1M x 150 bp reads, k=31, key length 6; build both DBs + "
+                      "exact match; inputs resident in HBM",
+            "replicated": "BASELINE config 2, replicated reference: every GPU builds the 5 Mbp reference and the DB of its own 1M x "
+                          "150 bp reads and joins locally (no data-path collective), k=31, key length 6",
+            "key-range": "BASELINE config 2 in key-range mode (the config-4 split): 5 Mbp reference (10 taxa) range-partitioned by "
+                         "k-mer prefix (every GPU builds the range it owns), 1M x 150 bp reads per GPU, their distinct k-mers "
+                         "exchanged to the owners by RCCL all-to-all, joined there in one launch, hit indices sent back; k=31, "
+                         "key length 6"}[headline]
+        out = {
+            "metric": "k-mers/sec built + matched (reference build + read build + match, node)",
+            "value": value,
+            "unit": "k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": workload, "mode": headline, "k": K, "key_len": KEY_LEN, "scale": args.scale,
+                       "ref_windows": n_ref_win, "read_windows_per_gpu": n_read_win},
+            "stages": stages,
+            "verified": verified,
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        for mode, (el, _) in runs.items():
+            if mode != headline:
+                v, ms = line(mode, el)
+                out[mode.replace("-", "_")] = {"value": v, "ms_per_step": ms, "unit": "k-mers/s"}
+        if world == 1 and not use_dist and not args.no_cpu_baseline:
+            out["cpu_baseline"], o_u, o_nh = cpu_baseline(synth, taxa, genomes, reads)
+            if o_u is not None:      # the whole config went through the oracle: the step's results are pinned by it
+                assert (u_reads, hits_local) == (o_u, o_nh), ("GPU step vs oracle", u_reads, hits_local, o_u, o_nh)
+                out["verified"]["against"] = "oracle (cpu_baseline leg): distinct read k-mers and hit count equal"
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    ctx.close()
+    ctx_ref.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measured_copy_gbs(torch, dev):
+    """Device-copy ceiling of this box (report the fraction of it next to the spec peak)."""
     ca = torch.empty(1 << 27, dtype=torch.int64, device=dev)
     cb = torch.ones(1 << 27, dtype=torch.int64, device=dev)
     ca.copy_(cb)
@@ -222,50 +408,7 @@ def main():
         ca.copy_(cb)
     e1.record()
     torch.cuda.synchronize()
-    copy_gbs = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del ca, cb
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": int(bytes_per_launch),
-                "launches_per_step": d["launches"] // prof_steps,
-                "measured_copy_GBps": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
-    kernels = {k: {"ms_per_step": round(v["ms"] / prof_steps, 4), "launches_per_step": v["launches"] // prof_steps,
-                   "algo_GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) if v["bytes"] else None}
-               for k, v in prof.items() if v["launches"]}
-
-    if rank == 0:
-        # key-range mode builds the reference once across the node; the replicated mode builds it on every GPU
-        total_windows = n_ref_win + n_read_win * world if args.exchange else (n_ref_win + n_read_win) * world
-        ms_per_step = elapsed / args.steps * 1e3
-        out = {
-            "metric": "k-mers/sec built + matched (reference build + read build + match, node)",
-            "value": total_windows * args.steps / elapsed,
-            "unit": "k-mers/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
-            "config": {"workload": ("BASELINE config 2 in key-range mode: 5 Mbp reference (10 taxa) range-partitioned by k-mer "
-                                    "prefix (every GPU builds the range it owns), 1M x 150 bp reads per GPU, their k-mers "
-                                    "exchanged to the owners and joined there, k=31, key length 6"
-                                    if args.exchange else
-                                    "BASELINE config 2: 5 Mbp reference (10 taxa) + 1M x 150 bp reads per GPU, k=31, "
-                                    "key length 6; build both DBs + exact match; inputs resident in HBM"),
-                       "k": K, "key_len": KEY_LEN, "scale": args.scale,
-                       "ref_windows": n_ref_win, "read_windows_per_gpu": n_read_win},
-            "stages": None if args.exchange else {"ref_kmers_built_per_s": n_ref_win * prof_steps / stage_s["ref_build"],
-                       "read_kmers_built_per_s": n_read_win * prof_steps / stage_s["read_build"],
-                       "read_kmers_matched_per_s": n_read_win * prof_steps / stage_s["match"]},
-            "roofline": roofline,
-            "kernels": kernels,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(synth, taxa, genomes, reads)
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
-    ctx.close()
-    ctx_ref.close()
-    if use_dist:
-        dist.destroy_process_group()
+    return 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 # kernel id of the measurement hook -> kernel symbol in the rocprofv3 traces
@@ -283,43 +426,58 @@ KERNEL_SYMBOL = {
 
 
 def pmc_traffic(kernel_id):
-    """HBM bytes per launch of the dominant kernel from the committed PMC measurement
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC measurement
     (profiles/*_pmc_traffic.json, produced by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE
-    passes, calibrated on a copy of known size).  None when no measurement covers the kernel."""
+    passes, calibrated on a copy of known size).  -> (bytes, file name), or (None, reason) when no measurement covers
+    the kernel or the measurement was taken on other kernel sources than the ones this library was built from."""
     import glob
     sym = KERNEL_SYMBOL.get(kernel_id)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
     if not sym or not files:
-        return None
+        return None, "no measurement"
     try:
         data = json.load(open(files[-1]))
+        if data.get("source_hash") != source_hash():
+            return None, "%s was measured on other kernel sources" % os.path.basename(files[-1])
         hits = [int(v["traffic_bytes_per_launch"]) for name, v in data["kernels"].items() if sym in name]
         if hits:
-            return min(hits) if kernel_id.endswith("_ref") else max(hits)
+            return (min(hits) if kernel_id.endswith("_ref") else max(hits)), os.path.basename(files[-1])
     except Exception:
-        return None
-    return None
+        pass
+    return None, "no measurement"
 
 
 def cpu_baseline(synth, taxa, genomes, reads):
     """The C restatement of the reference's algorithm (oracle/kmers_oracle.c: char-at-a-time extractor,
-    per-key-bucket sort + reduce on a thread pool, two-pointer join) on a bounded sample of the same
-    workload (the full reference + the first 400k reads, a few seconds to a few tens of seconds of CPU
-    work depending on the host).  kind = "port": Kmers.jar needs a JVM, which neither box has."""
+    per-key-bucket sort + reduce on a thread pool, two-pointer join) on the WHOLE of config 2 (125 M windows, a few
+    seconds to a few tens of seconds of CPU work depending on the host; a host slower than ~3 M windows/s gets the first
+    400 k reads only).  kind = "port": Kmers.jar needs a JVM, which neither box has.
+    -> (record, distinct read k-mers, hits) -- the last two None unless the whole config was run."""
     from oracle.c_oracle import OracleDB
     threads = min(16, os.cpu_count() or 1)
-    sample_reads = min(400_000, reads.shape[0])
     fa = synth.fasta_bytes(taxa, genomes)
-    fq = synth.fastq_bytes(reads[:sample_reads])
     t0 = time.perf_counter()
     ref = OracleDB(fa, 0, K, KEY_LEN, threads=threads)
+    t_ref = time.perf_counter() - t0
+    whole = ref.n_windows / max(t_ref, 1e-9) > 3e6
+    sample_reads = reads.shape[0] if whole else min(400_000, reads.shape[0])
+    fq = synth.fastq_bytes(reads[:sample_reads])
+    t0 = time.perf_counter()
     rdb = OracleDB(fq, 1, K, KEY_LEN, threads=threads)
-    rdb.match(ref, threads=threads)
-    dt = time.perf_counter() - t0
+    _, nh = rdb.match(ref, threads=threads)
+    dt = t_ref + time.perf_counter() - t0
     windows = ref.n_windows + rdb.n_windows
-    return {"value": windows / dt, "unit": "k-mers/s", "cores": threads, "kind": "port",
-            "sample": "full 5 Mbp reference + first %d of the reads (%d windows) in %.1f s; extraction is "
-                      "single-threaded as in the reference, sort/join use %d threads" % (sample_reads, windows, dt, threads)}
+    rec = {"value": windows / dt, "unit": "k-mers/s", "cores": threads, "kind": "port",
+           "sample": "%s: full 5 Mbp reference + %d reads (%d windows) in %.1f s; extraction is "
+                     "single-threaded as in the reference, sort/join use %d threads"
+                     % ("the whole config" if sample_reads == reads.shape[0] else "bounded sample", sample_reads, windows, dt, threads)}
+    if sample_reads == reads.shape[0]:
+        return rec, int(rdb.U), int(nh)
+    return rec, None, None
+
+
+def bench_config3(args, dev):
+    raise SystemExit("bench.py --config 3: not in this build")
 
 
 if __name__ == "__main__":

@@ -97,7 +97,8 @@ int kmg_build_set_filters(kmg_ctx *ctx, int dust_threshold, int runofsame_length
  *   first).  The reference builds its files key by key as well (FileCreator.MakeAndWriteKey, FileCreator.java:271-406),
  *   so the blocks of several range builds over the same input, written in key order, are the file of one complete
  *   build: inputs whose records do not fit one build (2^32-16) or the GPU's memory are built in passes, and ranks of
- *   a multi-GPU build extract only what they own.  After kmg_build_begin, before the first add.  *n_windows of
+ *   a multi-GPU build extract only what they own (first == end: an empty share, an empty database).  After
+ *   kmg_build_begin, before the first add.  *n_windows of
  *   kmg_build_finish then counts the forward windows kept. */
 int kmg_build_set_key_range(kmg_ctx *ctx, uint32_t first_bucket, uint32_t end_bucket);
 int kmg_build_add(kmg_ctx *ctx, const uint8_t *bases, uint64_t nbases, const uint64_t *seq_off,

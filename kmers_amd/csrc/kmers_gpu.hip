@@ -140,7 +140,9 @@ extern "C" int kmg_build_set_key_range(kmg_ctx *ctx, uint32_t first_bucket, uint
     if (!ctx->building) return fail(ctx, KMG_ESTATE, "kmg_build_set_key_range before kmg_build_begin");
     if (ctx->n_adds) return fail(ctx, KMG_ESTATE, "the key range must be set before the first kmg_build_add");
     const u32 nbuckets = 1u << (2 * ctx->key_len);
-    if (first_bucket >= end_bucket || end_bucket > nbuckets) return fail(ctx, KMG_EINVAL, "key range must be first < end <= 4^key_len");
+    // (first == end is an empty range: the build keeps nothing and finishes with an empty database -- what a rank
+    // gets when there are more ranks than populated buckets; failing there would leave the other ranks waiting)
+    if (first_bucket > end_bucket || end_bucket > nbuckets) return fail(ctx, KMG_EINVAL, "key range must be first <= end <= 4^key_len");
     ctx->ranged = !(first_bucket == 0 && end_bucket == nbuckets);
     ctx->range_lo = first_bucket;
     ctx->range_hi = end_bucket;
@@ -704,7 +706,7 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     // (a single-batch build keeps the bits its extractor already partitioned the records by)
     const bool prepart = ctx->prepart && ctx->n_adds == 1;
     // (a key-range build holds its records in a fraction of the prefixes: plan the segments for that density)
-    const u64 n_dense = ctx->ranged ? (u64)n * (1u << (2 * ctx->key_len)) / (ctx->range_hi - ctx->range_lo) : n;
+    const u64 n_dense = ctx->ranged ? (u64)n * (1u << (2 * ctx->key_len)) / std::max<u32>(ctx->range_hi - ctx->range_lo, 1u) : n;
     const int pbits = prepart ? ctx->plan_pbits : choose_pbits(n_dense, 2 * ctx->k);
 
     PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx), seg(ctx), ucount(ctx);

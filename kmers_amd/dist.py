@@ -89,7 +89,9 @@ def taxa_counts_sharded(taxon, match, unique, device="cpu", group=None):
 def balanced_key_ranges(bucket_hist, world):
     """Split the 4^l key buckets into `world` contiguous ranges of near-equal record counts (skew-aware:
     poly-A piles into bucket 0).  -> list of (first_key, end_key).  Every rank computes the same answer
-    from the all-reduced histogram, so no further communication is needed."""
+    from the all-reduced histogram, so no further communication is needed.  A range can come out empty
+    (first == end) when one bucket holds more than a rank's share or the world is larger than the populated
+    buckets: kmg_build_set_key_range takes it (an empty database), the exchange sends that rank nothing."""
     h = np.asarray(bucket_hist, dtype=np.int64)
     csum = np.concatenate([[0], np.cumsum(h)])
     total = int(csum[-1])

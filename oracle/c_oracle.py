@@ -23,6 +23,8 @@ def _load():
     lib.ko_free.argtypes = [vp]
     lib.ko_set_filters.argtypes = [C.c_int, C.c_int]
     lib.ko_set_filters.restype = None
+    lib.ko_set_key_range.argtypes = [C.c_uint32, C.c_uint32]
+    lib.ko_set_key_range.restype = None
     for n in ("U", "V", "n_windows", "n_records", "n_reads"):
         f = getattr(lib, "ko_" + n)
         f.restype, f.argtypes = u64, [vp]
@@ -61,13 +63,17 @@ class OracleDB:
     """Result of MakeDatabase (-a: mode 0, -q: mode 1) as CSR arrays."""
 
     def __init__(self, data: bytes, mode: int, k: int, key_len: int, threads: int = 1, dust: int = -1,
-                 runofsame: int = -1):
+                 runofsame: int = -1, key_range=None):
+        """key_range = (first, end): only the slice of the database in those key buckets (ko_set_key_range)."""
         L = lib()
         L.ko_set_filters(dust, runofsame)          # MakeDatabase -D / -R
+        if key_range is not None:
+            L.ko_set_key_range(int(key_range[0]), int(key_range[1]))
         try:
             self._h = L.ko_build(data, len(data), mode, k, key_len, threads)
         finally:
             L.ko_set_filters(-1, -1)
+            L.ko_set_key_range(0, 0)
         if not self._h:
             raise ValueError("ko_build rejected the parameters")
         h = self._h

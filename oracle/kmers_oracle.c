@@ -133,6 +133,19 @@ static int g_dust = -1, g_runofsame = -1;
  * NEXT ko_build call(s); -1 = off.  (Test infrastructure: a process-wide setting is good enough.) */
 void ko_set_filters(int dust_threshold, int runofsame_length) { g_dust = dust_threshold; g_runofsame = runofsame_length; }
 
+/* Key slice: keep only the records whose key bucket (Kmer.key(keyLength), Kmer.java:47-55) lies in [lo, hi) -- the
+ * part of the database MakeAndWriteKey writes for those keys (FileCreator.java:271-406 works key by key; every
+ * record is bucketed by its own k-mer, FileCreator.java:82-87, so a reverse complement can be kept where its forward
+ * k-mer is not).  Lets a test check a slice of a database too large to restate whole.  hi == 0: everything.
+ * n_windows then counts the forward windows kept.  Applies to the NEXT ko_build call(s). */
+static uint32_t g_range_lo = 0, g_range_hi = 0;
+void ko_set_key_range(uint32_t lo, uint32_t hi) { g_range_lo = lo; g_range_hi = hi; }
+static int in_range(uint64_t kmer, int key_len) {
+    if (!g_range_hi) return 1;
+    uint32_t b = (uint32_t)(kmer >> (64 - 2 * key_len));
+    return b >= g_range_lo && b < g_range_hi;
+}
+
 /* mode 0 = FASTA -> reference DB (MakeDatabase -a), 1 = FASTQ -> read DB (MakeDatabase -q). */
 ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, int threads) {
     if (k < 1 || k > 32 || key_len < 1 || key_len > k || key_len > 12) return NULL;
@@ -174,9 +187,10 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
         if (ip == n) {                            /* in.read() == -1 */
             if (have_last && (g_dust < 0 || dust_keep(last.kmer, k, g_dust)) &&
                 (g_runofsame < 0 || runofsame_keep(last.kmer, k, g_runofsame))) { /* last k-mer emitted a second time */
-                rv_push(&recs, last); d->n_windows++;
+                if (in_range(last.kmer, key_len)) { rv_push(&recs, last); d->n_windows++; }
                 if (d->rc && !is_palindrome(last.kmer, k)) {
-                    ko_rec r = last; r.kmer = rc_packed(last.kmer, k); rv_push(&recs, r);
+                    ko_rec r = last; r.kmer = rc_packed(last.kmer, k);
+                    if (in_range(r.kmer, key_len)) rv_push(&recs, r);
                 }
             }
             break;
@@ -229,9 +243,10 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
         /* kstream.filter(Dust).filter(RunOfSame) sits between the extractor and addKmers */
         if (g_dust >= 0 && !dust_keep(packed, k, g_dust)) continue;
         if (g_runofsame >= 0 && !runofsame_keep(packed, k, g_runofsame)) continue;
-        rv_push(&recs, r); d->n_windows++;
+        if (in_range(packed, key_len)) { rv_push(&recs, r); d->n_windows++; }
         if (d->rc && !is_palindrome(packed, k)) { /* FileCreator.java:83-87 */
-            ko_rec q = r; q.kmer = rc_packed(packed, k); rv_push(&recs, q);
+            ko_rec q = r; q.kmer = rc_packed(packed, k);
+            if (in_range(q.kmer, key_len)) rv_push(&recs, q);
         }
     }
     d->n_reads = (uint64_t)(cur_read + 1);

@@ -276,10 +276,11 @@ def test_kmers_that_differ_only_in_their_last_bases(ctx, k, l, shared):
             got.close()
 
 
-@pytest.mark.parametrize("k,l,cuts", [(21, 3, [0, 5, 6, 40, 64]), (32, 5, [0, 300, 1024]), (7, 2, [0, 1, 2, 15, 16])])
+@pytest.mark.parametrize("k,l,cuts", [(21, 3, [0, 5, 6, 40, 64]), (32, 5, [0, 300, 1024]), (7, 2, [0, 1, 2, 2, 15, 16])])
 def test_key_range_builds_are_slices_of_the_whole(ctx, k, l, cuts):
     """kmg_build_set_key_range: a build restricted to key buckets [first, end) holds exactly the whole database's
-    k-mers of those buckets, values and all -- forward and reverse-complement records are judged one by one (an RC
+    k-mers of those buckets, values and all (an empty range, first == end, builds an empty database: a rank of a world
+    larger than the populated buckets) -- forward and reverse-complement records are judged one by one (an RC
     usually lies in another range than its forward k-mer) -- and numbers its reads as the whole build does.  Laid end
     to end the range builds are the oracle's database.  Reference and read databases, one batch (extraction fused
     with the partition) and two batches (plain extraction), -D / -R filters on."""
@@ -294,7 +295,7 @@ def test_key_range_builds_are_slices_of_the_whole(ctx, k, l, cuts):
         want = OracleDB(data, 0 if kind == "ref" else 1, k, l, threads=4, **filt)
         b = parse.parse(data, mode, k).batch
         for batches in (1, 2):
-            keys, offs, va, vb, windows, ridx_all = [], [np.zeros(1, np.uint64)], [], [], 0, []
+            keys, offs, va, vb, windows, ridx_all, vbase = [], [np.zeros(1, np.uint64)], [], [], 0, [], np.uint64(0)
             for first, end in zip(cuts[:-1], cuts[1:]):
                 fc = km.FileCreator(ctx, l, k, kind, rc=rc, key_range=(first, end), **filt)
                 half = b.nseq // 2 if batches == 2 else b.nseq
@@ -311,7 +312,8 @@ def test_key_range_builds_are_slices_of_the_whole(ctx, k, l, cuts):
                 bucket = (h["keys"] >> np.uint64(64 - 2 * l)).astype(np.int64)
                 assert np.all((bucket >= first) & (bucket < end))
                 keys.append(h["keys"])
-                offs.append(h["val_off"][1:] + offs[-1][-1])
+                offs.append(h["val_off"][1:] + vbase)
+                vbase += h["val_off"][-1]
                 va.append(h["val_a"]); vb.append(h["val_b"])
                 if kind == "read":
                     ridx_all.append(np.concatenate(ridx))
@@ -325,7 +327,7 @@ def test_key_range_builds_are_slices_of_the_whole(ctx, k, l, cuts):
                 assert np.array_equal(r, ridx_all[0])
     fc = km.FileCreator(ctx, l, k, "ref", rc=True)
     with pytest.raises(km.InconsistentDataException):
-        ctx.check(ctx.lib.kmg_build_set_key_range(ctx.h, 3, 3))
+        ctx.check(ctx.lib.kmg_build_set_key_range(ctx.h, 4, 3))
     with pytest.raises(km.InconsistentDataException):
         ctx.check(ctx.lib.kmg_build_set_key_range(ctx.h, 0, 4 ** l + 1))
     fc.create().close()

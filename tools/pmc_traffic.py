@@ -50,7 +50,10 @@ def main():
     # counters are reported in KiB
     f_fac = CALIB_BYTES / (fetch[cal][0] / fetch[cal][1] * 1024.0)
     w_fac = CALIB_BYTES / (write[cal][0] / write[cal][1] * 1024.0)
-    res = {"calibration": {"kernel": cal, "known_bytes_each_way": CALIB_BYTES, "fetch_factor": f_fac, "write_factor": w_fac,
+    sys.path.insert(0, ROOT)
+    from bench import source_hash
+    res = {"source_hash": source_hash(),        # bench.py reports this measurement only for the same kernel sources
+           "calibration": {"kernel": cal, "known_bytes_each_way": CALIB_BYTES, "fetch_factor": f_fac, "write_factor": w_fac,
                            "note": "traffic = FETCH_SIZE*1024*fetch_factor + WRITE_SIZE*1024*write_factor, averaged per launch"},
            "kernels": {}}
     for k in sorted(fetch):
