@@ -327,13 +327,16 @@ def match_near(search, ref, max_diff):
 def taxa_counts(db):
     """Utils/TaxaCounts.java default mode -> (taxon[], match[], unique[]) ascending by taxon."""
     f = db.merged if isinstance(db, DB) else db
-    cap = max(f.n_values, 1)
-    t = np.empty(cap, np.int32)
-    m = np.empty(cap, np.int64)
-    q = np.empty(cap, np.int64)
-    n = C.c_uint64(cap)
-    f.ctx.check(f.ctx.lib.kmg_taxacounts(f.ctx.h, f.h, _ptr(t), _ptr(m), _ptr(q), C.byref(n)))
-    return t[:n.value], m[:n.value], q[:n.value]
+    cap = min(max(f.n_values, 1), 1 << 16)
+    while True:
+        t = np.empty(cap, np.int32)
+        m = np.empty(cap, np.int64)
+        q = np.empty(cap, np.int64)
+        n = C.c_uint64(cap)
+        f.ctx.check(f.ctx.lib.kmg_taxacounts(f.ctx.h, f.h, _ptr(t), _ptr(m), _ptr(q), C.byref(n)))
+        if n.value <= cap:
+            return t[:n.value], m[:n.value], q[:n.value]
+        cap = n.value                      # more taxa than rows offered: once more with room for all of them
 
 
 def taxa_count_lines(db):

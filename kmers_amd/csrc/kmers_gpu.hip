@@ -1451,42 +1451,47 @@ extern "C" int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, in
     *n_taxa = 0;
     const u64 V = db->V;
     if (V == 0 || db->U == 0) return KMG_OK;
-    if (V >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 values");
     ProfScope ps(ctx, KP_TAXA, 8 * (db->U + 1) + 4 * V);
 
-    // distinct taxa: sort a copy of val_a (sign-flipped so that int order == unsigned order), keep run heads
-    PoolBuf k0(ctx), v0(ctx), k1(ctx), v1(ctx), table(ctx), agg(ctx), flag(ctx), total(ctx), taxa(ctx), cm(ctx), cu(ctx);
-    const u32 n = (u32)V;
-    const u32 ntiles = div_up_u64(n, RS_TILE);
-    KMG_ALLOC(k0, (size_t)n * 8); KMG_ALLOC(v0, (size_t)n * 4); KMG_ALLOC(k1, (size_t)n * 8); KMG_ALLOC(v1, (size_t)n * 4);
-    KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
-    // scan scratch: shared by the sort's table scans and the head-flag scan over all n values
-    KMG_ALLOC(agg, (size_t)(div_up_u64(std::max<u64>((u64)RS_DIGITS * ntiles, n), SCAN_TILE) + 1) * 8);
-    KMG_ALLOC(flag, (size_t)n * 4);
+    // distinct taxa from a presence bitmap over [min, max] (match.h), then one counting pass over the CSR
+    PoolBuf mm(ctx), bits(ctx), cnt(ctx), prefix(ctx), agg(ctx), total(ctx), taxa(ctx), cm(ctx), cu(ctx);
+    KMG_ALLOC(mm, 64);
     KMG_ALLOC(total, 64);
-    hipLaunchKernelGGL(taxa_expand_kernel, dim3(div_up_u64(n, 256)), dim3(256), 0, ctx->stream, db->val_a, V, k0.as<u64>(), v0.as<u32>());
-    std::vector<SortPass> passes;
-    for (int b = 0; b < 4; b++) passes.push_back({8 * b, 8, RS_SRC_KEY});
-    bool in1 = false;
-    KMG_TRY(radix_sort_records<u32>(ctx, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), n, passes, table.as<u32>(), agg.as<u32>(), &in1));
-    const u64 *sk = in1 ? k1.as<u64>() : k0.as<u64>();
-    u32 *pos = in1 ? v0.as<u32>() : v1.as<u32>();   // the idle value buffer holds the scan output
-    hipLaunchKernelGGL(taxa_headflag_kernel, dim3(div_up_u64(n, 256)), dim3(256), 0, ctx->stream, sk, V, flag.as<u32>());
-    KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, flag.as<u32>(), pos, V, OpSum(), 0u, agg.as<u32>(), total.as<u32>(), false, KP_SCAN)));
+    hipLaunchKernelGGL(taxa_minmax_init_kernel, dim3(1), dim3(64), 0, ctx->stream, mm.as<int32_t>());
+    const u32 vgrid = std::min<u32>(div_up_u64(V, 1024), 4096);
+    hipLaunchKernelGGL(taxa_minmax_kernel, dim3(vgrid), dim3(256), 0, ctx->stream, db->val_a, V, mm.as<int32_t>());
+    int32_t h_mm[2] = {0, 0};
+    KMG_HIP(read_back(ctx, h_mm, mm.p, 8));
+    const int32_t tmin = h_mm[0];
+    const u64 range = (u64)((long long)h_mm[1] - (long long)tmin) + 1;      // <= 2^32
+    const u64 nwords = (range + 31) / 32;
+    KMG_ALLOC(bits, nwords * 4);
+    KMG_ALLOC(cnt, nwords * 4);
+    KMG_ALLOC(prefix, (nwords + 1) * 4);
+    KMG_ALLOC(agg, (size_t)(div_up_u64(nwords, SCAN_TILE) + 1) * 8);
+    KMG_HIP(hipMemsetAsync(bits.p, 0, nwords * 4, ctx->stream));
+    hipLaunchKernelGGL(taxa_present_kernel, dim3(vgrid), dim3(256), 0, ctx->stream, db->val_a, V, tmin, bits.as<u32>());
+    hipLaunchKernelGGL(taxa_popc_kernel, dim3(div_up_u64(nwords, 256)), dim3(256), 0, ctx->stream, bits.as<u32>(), nwords, cnt.as<u32>());
+    KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, cnt.as<u32>(), prefix.as<u32>(), nwords, OpSum(), 0u, agg.as<u32>(),
+                                                total.as<u32>(), false, KP_SCAN)));
     u32 nt = 0;
-    KMG_HIP(hipMemcpyAsync(&nt, total.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    KMG_HIP(read_back(ctx, &nt, total.p, 4));
     KMG_ALLOC(taxa, (size_t)nt * 4);
     KMG_ALLOC(cm, (size_t)nt * 8);
     KMG_ALLOC(cu, (size_t)nt * 8);
     KMG_HIP(hipMemsetAsync(cm.p, 0, (size_t)nt * 8, ctx->stream));
     KMG_HIP(hipMemsetAsync(cu.p, 0, (size_t)nt * 8, ctx->stream));
-    hipLaunchKernelGGL(taxa_compact_kernel, dim3(div_up_u64(n, 256)), dim3(256), 0, ctx->stream, sk, flag.as<u32>(), pos, V, taxa.as<int32_t>());
-    const u32 grid = std::min<u32>(div_up_u64(db->U, 256), 2048);
-    if (nt <= TX_LDS_MAX)
-        hipLaunchKernelGGL((taxa_count_kernel<true>), dim3(grid), dim3(256), 0, ctx->stream, db->val_off, db->val_a, db->U, taxa.as<int32_t>(), nt, cm.as<u64>(), cu.as<u64>());
+    hipLaunchKernelGGL(taxa_list_kernel, dim3(div_up_u64(nwords, 256)), dim3(256), 0, ctx->stream, bits.as<u32>(), prefix.as<u32>(),
+                       nwords, tmin, taxa.as<int32_t>());
+    if (nt <= TX_LDS_SMALL)
+        hipLaunchKernelGGL((taxa_count_kernel<0>), dim3(std::min<u32>(div_up_u64(db->U, 256), 2048)), dim3(256), 0, ctx->stream,
+                           db->val_off, db->val_a, db->U, bits.as<u32>(), prefix.as<u32>(), tmin, nt, cm.as<u64>(), cu.as<u64>());
+    else if (nt <= TX_LDS_BIG)
+        hipLaunchKernelGGL((taxa_count_kernel<1>), dim3(std::min<u32>(div_up_u64(db->U, 1024), 256)), dim3(1024), 0, ctx->stream,
+                           db->val_off, db->val_a, db->U, bits.as<u32>(), prefix.as<u32>(), tmin, nt, cm.as<u64>(), cu.as<u64>());
     else
-        hipLaunchKernelGGL((taxa_count_kernel<false>), dim3(grid), dim3(256), 0, ctx->stream, db->val_off, db->val_a, db->U, taxa.as<int32_t>(), nt, cm.as<u64>(), cu.as<u64>());
+        hipLaunchKernelGGL((taxa_count_kernel<2>), dim3(std::min<u32>(div_up_u64(db->U, 256), 4096)), dim3(256), 0, ctx->stream,
+                           db->val_off, db->val_a, db->U, bits.as<u32>(), prefix.as<u32>(), tmin, nt, cm.as<u64>(), cu.as<u64>());
     KMG_HIP(hipGetLastError());
     const u64 w = std::min<u64>(nt, cap);
     if (w) {

@@ -140,67 +140,93 @@ __global__ __launch_bounds__(MT_BLOCK) void match_runs_kernel(const u64 *__restr
 }
 
 // ---- TaxaCounts ----------------------------------------------------------------------------------------
-// taxa[] = ascending distinct taxa of the DB (built by sorting val_a once).  Thread per k-mer.
-#define TX_LDS_MAX 2048
+// The distinct taxa of a database come from a presence bitmap over [min taxon, max taxon] (at most 2^32 bits =
+// 512 MB; BASELINE's taxon ids span a few thousand): one pass marks, a popcount scan ranks the words, and the rank
+// of a taxon -- its row in the ascending output, TaxaCounts.java:132-150 -- is prefix[word] + popcount of the lower
+// bits: two cached loads instead of a binary search, and no sort of the value array.  Counting is one pass over
+// the CSR, thread per k-mer: match[t]++ for every taxon of the k-mer, unique[t]++ if it is the only one
+// (CountDataAll.add, TaxaCounts.java:386-395), into an LDS histogram (<= 2048 taxa: 256-thread blocks; <= 16384
+// taxa: one 1024-thread block per CU with 128 KB of counters) or straight into global memory beyond that.
+#define TX_LDS_SMALL 2048
+#define TX_LDS_BIG 16384
 
-__device__ __forceinline__ u32 taxa_find(const int32_t *taxa, u32 nt, int32_t t) {
-    u32 lo = 0, hi = nt;
-    while (lo < hi) {
-        u32 mid = (lo + hi) >> 1;
-        if (taxa[mid] < t) lo = mid + 1; else hi = mid;
+__global__ void taxa_minmax_init_kernel(int32_t *mm) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { mm[0] = 0x7FFFFFFF; mm[1] = (int32_t)0x80000000; }
+}
+__global__ __launch_bounds__(256) void taxa_minmax_kernel(const int32_t *__restrict__ val_a, u64 V, int32_t *__restrict__ mm) {
+    int32_t lo = 0x7FFFFFFF, hi = (int32_t)0x80000000;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (u64)gridDim.x * blockDim.x) {
+        const int32_t t = val_a[i];
+        lo = t < lo ? t : lo;
+        hi = t > hi ? t : hi;
     }
-    return lo;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int32_t ol = __shfl_xor(lo, d, 64), oh = __shfl_xor(hi, d, 64);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
+}
+__global__ __launch_bounds__(256) void taxa_present_kernel(const int32_t *__restrict__ val_a, u64 V, int32_t tmin, u32 *__restrict__ bits) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (u64)gridDim.x * blockDim.x) {
+        const u32 r = (u32)val_a[i] - (u32)tmin;
+        const u32 bit = 1u << (r & 31);
+        if (!(bits[r >> 5] & bit)) atomicOr(&bits[r >> 5], bit);     // (a stale read only costs a redundant atomic)
+    }
+}
+__global__ void taxa_popc_kernel(const u32 *__restrict__ bits, u64 nwords, u32 *__restrict__ cnt) {
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nwords) cnt[w] = __popc(bits[w]);
+}
+__global__ void taxa_list_kernel(const u32 *__restrict__ bits, const u32 *__restrict__ prefix, u64 nwords, int32_t tmin,
+                                 int32_t *__restrict__ taxa) {
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    u32 b = bits[w], o = prefix[w];
+    while (b) {
+        const int j = __ffs(b) - 1;
+        b &= b - 1;
+        taxa[o++] = (int32_t)((u32)tmin + (u32)(w * 32 + j));
+    }
 }
 
-template <bool USE_LDS>
-__global__ __launch_bounds__(256) void taxa_count_kernel(const u64 *__restrict__ val_off,
-                                                          const int32_t *__restrict__ val_a, u64 U,
-                                                          const int32_t *__restrict__ taxa, u32 nt,
-                                                          u64 *__restrict__ match, u64 *__restrict__ unique) {
-    __shared__ int32_t s_taxa[USE_LDS ? TX_LDS_MAX : 1];
-    __shared__ u32 s_match[USE_LDS ? TX_LDS_MAX : 1];
-    __shared__ u32 s_unique[USE_LDS ? TX_LDS_MAX : 1];
-    if (USE_LDS) {
-        for (u32 i = threadIdx.x; i < nt; i += blockDim.x) { s_taxa[i] = taxa[i]; s_match[i] = 0; s_unique[i] = 0; }
+// MODE 0: LDS histogram of TX_LDS_SMALL rows, 1: of TX_LDS_BIG rows (1024 threads, one block per CU), 2: global
+template <int MODE>
+__global__ __launch_bounds__(MODE == 1 ? 1024 : 256) void taxa_count_kernel(const u64 *__restrict__ val_off,
+                                                                            const int32_t *__restrict__ val_a, u64 U,
+                                                                            const u32 *__restrict__ bits,
+                                                                            const u32 *__restrict__ prefix, int32_t tmin, u32 nt,
+                                                                            u64 *__restrict__ match, u64 *__restrict__ unique) {
+    constexpr u32 ROWS = MODE == 0 ? TX_LDS_SMALL : (MODE == 1 ? TX_LDS_BIG : 1);
+    __shared__ u32 s_match[ROWS];
+    __shared__ u32 s_unique[ROWS];
+    if (MODE != 2) {
+        for (u32 i = threadIdx.x; i < nt; i += blockDim.x) { s_match[i] = 0; s_unique[i] = 0; }
         __syncthreads();
     }
     for (u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (u64)gridDim.x * blockDim.x) {
         const u64 a = val_off[u], b = val_off[u + 1];
         for (u64 v = a; v < b; v++) {
-            const int32_t t = val_a[v];
-            if (USE_LDS) {
-                u32 idx = taxa_find(s_taxa, nt, t);
+            const u32 r = (u32)val_a[v] - (u32)tmin;
+            const u32 idx = prefix[r >> 5] + __popc(bits[r >> 5] & ((1u << (r & 31)) - 1u));
+            if (MODE != 2) {
                 atomicAdd(&s_match[idx], 1u);
                 if (b - a == 1) atomicAdd(&s_unique[idx], 1u);
             } else {
-                u32 idx = taxa_find(taxa, nt, t);
                 atomicAdd(&match[idx], 1ull);
                 if (b - a == 1) atomicAdd(&unique[idx], 1ull);
             }
         }
     }
-    if (USE_LDS) {
+    if (MODE != 2) {
+        // (a block's share of the values is far below 2^32: the u32 rows cannot wrap)
         __syncthreads();
         for (u32 i = threadIdx.x; i < nt; i += blockDim.x) {
             if (s_match[i]) atomicAdd(&match[i], (u64)s_match[i]);
             if (s_unique[i]) atomicAdd(&unique[i], (u64)s_unique[i]);
         }
     }
-}
-
-// helpers to derive the distinct taxa: expand val_a to sortable keys, then flag run heads
-__global__ void taxa_expand_kernel(const int32_t *__restrict__ val_a, u64 V, u64 *__restrict__ keys, u32 *__restrict__ vals) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < V) { keys[i] = (u64)((u32)val_a[i] ^ 0x80000000u); vals[i] = 0; }
-}
-__global__ void taxa_headflag_kernel(const u64 *__restrict__ keys, u64 V, u32 *__restrict__ flag) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < V) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
-}
-__global__ void taxa_compact_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ flag,
-                                    const u32 *__restrict__ pos, u64 V, int32_t *__restrict__ taxa) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < V && flag[i]) taxa[pos[i]] = (int32_t)((u32)keys[i] ^ 0x80000000u);
 }
 
 // ---- inexact search, fixed k (Matcher -n 1 | 2) ----------------------------------------------------------------

@@ -25,6 +25,11 @@ def _load():
     lib.ko_set_filters.restype = None
     lib.ko_set_key_range.argtypes = [C.c_uint32, C.c_uint32]
     lib.ko_set_key_range.restype = None
+    lib.ko_set_min_k.argtypes = [C.c_int]
+    lib.ko_set_min_k.restype = None
+    lib.ko_min_k.argtypes = [vp]
+    lib.ko_lens.restype, lib.ko_lens.argtypes = vp, [vp]
+    lib.ko_restrict.restype, lib.ko_restrict.argtypes = vp, [vp, C.c_int]
     for n in ("U", "V", "n_windows", "n_records", "n_reads"):
         f = getattr(lib, "ko_" + n)
         f.restype, f.argtypes = u64, [vp]
@@ -63,22 +68,30 @@ class OracleDB:
     """Result of MakeDatabase (-a: mode 0, -q: mode 1) as CSR arrays."""
 
     def __init__(self, data: bytes, mode: int, k: int, key_len: int, threads: int = 1, dust: int = -1,
-                 runofsame: int = -1, key_range=None):
-        """key_range = (first, end): only the slice of the database in those key buckets (ko_set_key_range)."""
+                 runofsame: int = -1, key_range=None, min_k=None, _handle=None):
+        """k = maxK (MakeDatabase -K), min_k = minK (-k; default: the same).
+        key_range = (first, end): only the slice of the database in those key buckets (ko_set_key_range)."""
         L = lib()
-        L.ko_set_filters(dust, runofsame)          # MakeDatabase -D / -R
-        if key_range is not None:
-            L.ko_set_key_range(int(key_range[0]), int(key_range[1]))
-        try:
-            self._h = L.ko_build(data, len(data), mode, k, key_len, threads)
-        finally:
-            L.ko_set_filters(-1, -1)
-            L.ko_set_key_range(0, 0)
+        if _handle is not None:
+            self._h = _handle
+        else:
+            L.ko_set_filters(dust, runofsame)          # MakeDatabase -D / -R
+            L.ko_set_min_k(0 if min_k is None else int(min_k))
+            if key_range is not None:
+                L.ko_set_key_range(int(key_range[0]), int(key_range[1]))
+            try:
+                self._h = L.ko_build(data, len(data), mode, k, key_len, threads)
+            finally:
+                L.ko_set_filters(-1, -1)
+                L.ko_set_key_range(0, 0)
+                L.ko_set_min_k(0)
         if not self._h:
             raise ValueError("ko_build rejected the parameters")
         h = self._h
         self.k, self.key_len, self.kind = k, key_len, mode
+        self.min_k = L.ko_min_k(h)
         self.U, self.V = L.ko_U(h), L.ko_V(h)
+        self.lens = _arr(L.ko_lens(h), self.U, np.uint8)
         self.n_windows, self.n_records = L.ko_n_windows(h), L.ko_n_records(h)
         self.keys = _arr(L.ko_keys(h), self.U, np.uint64)
         self.val_off = _arr(L.ko_val_off(h), self.U + 1, np.uint64)
@@ -86,7 +99,7 @@ class OracleDB:
         self.val_b = _arr(L.ko_val_b(h), self.V, np.int32)
         self.bucket_off = _arr(L.ko_bucket_off(h), 4 ** key_len + 1, np.uint64)
         self.names = []
-        if mode == 1:
+        if mode == 1 and _handle is None:
             nr = L.ko_n_reads(h)
             off = _arr(L.ko_name_off(h), nr + 1, np.uint64)
             raw = _arr(L.ko_names(h), int(off[-1]) if nr else 0, np.uint8).tobytes()
@@ -99,6 +112,13 @@ class OracleDB:
 
     def __del__(self):
         self.close()
+
+    def restrict(self, length):
+        """KmerUtils.restrictedStream(.., length, length, ..) over the whole database (ko_restrict)."""
+        h = lib().ko_restrict(self._h, int(length))
+        if not h:
+            raise ValueError("length outside the database's k-mer lengths")
+        return OracleDB(b"", self.kind, int(length), self.key_len, _handle=h)
 
     def encode_blocks(self):
         """-> (bytes of all 4^l blocks back to back, block_off[4^l+1])."""

@@ -19,7 +19,11 @@
  *   - per-key two-pointer inner join                     Database/DB.java:76-90,129-137, jar StreamUtils
  *   - match line text                                    DataTypes/ResultsDataType.java:15-35
  *   - TaxaCounts default mode                            Utils/TaxaCounts.java:119-150,386-395
- * Restrictions (documented): minK == maxK, k <= 32, input bytes < 128.
+ *   - variable-length k-mers (minK < maxK): the `ending` branch of tryAdvance (suffixes of length maxK-1 .. minK at
+ *     a sequence's end and behind an invalid base), (k-mer, length) order, KmerUtils.restrictedStream
+ *                                                        KmersFromFile.java:90-133,167-176, Sequence.java:165-187,
+ *                                                        KmerUtils.java:59-74
+ * Restrictions (documented): k <= 32, input bytes < 128.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -32,11 +36,14 @@
 typedef struct {
     uint64_t kmer;  /* cBytes() zero-padded to 8 bytes, read big-endian == left-aligned 2-bit */
     int32_t a;      /* taxon | read index */
-    int32_t b;      /* (unused) | pos (Java short) */
+    int32_t b;      /* bits 15..0: (unused) | pos (Java short); bits 23..16: k-mer length */
 } ko_rec;
+#define REC_LEN(r) (((r).b >> 16) & 0xFF)
+#define REC_POS(r) ((int16_t)((r).b & 0xFFFF))
 
 typedef struct {
-    int k, key_len, kind /*0 ref, 1 read*/, rc;
+    int k, min_k, key_len, kind /*0 ref, 1 read*/, rc;   /* k = maxK */
+    uint8_t *lens;        /* U: length of every k-mer (all k when min_k == k) */
     uint64_t n_windows;   /* valid forward windows emitted by the extractor */
     uint64_t n_records;   /* temp-bucket records (fwd + rc) */
     uint64_t U, V;
@@ -92,15 +99,18 @@ static int is_palindrome(uint64_t x, int k) { /* Kmer.isOwnRC */
 
 static int cmp_rec(const void *pa, const void *pb) {
     const ko_rec *a = (const ko_rec *)pa, *b = (const ko_rec *)pb;
-    if (a->kmer != b->kmer) return a->kmer < b->kmer ? -1 : 1;   /* Sequence.compareTo, fixed k */
+    /* Sequence.compareTo (Sequence.java:165-187): base by base, a proper prefix first == zero-padded value, then
+     * length (the pad symbol A = 0 is the smallest base) */
+    if (a->kmer != b->kmer) return a->kmer < b->kmer ? -1 : 1;
+    if (REC_LEN(*a) != REC_LEN(*b)) return REC_LEN(*a) < REC_LEN(*b) ? -1 : 1;
     if (a->a != b->a) return a->a < b->a ? -1 : 1;               /* TreeCountMap key order / canonical */
-    if (a->b != b->b) return a->b < b->b ? -1 : 1;
+    if (REC_POS(*a) != REC_POS(*b)) return REC_POS(*a) < REC_POS(*b) ? -1 : 1;
     return 0;
 }
 
 void ko_free(ko_db *d) {
     if (!d) return;
-    free(d->keys); free(d->val_off); free(d->val_a); free(d->val_b); free(d->bucket_off);
+    free(d->keys); free(d->val_off); free(d->val_a); free(d->val_b); free(d->bucket_off); free(d->lens);
     free(d->name_off); free(d->names); free(d);
 }
 
@@ -146,12 +156,17 @@ static int in_range(uint64_t kmer, int key_len) {
     return b >= g_range_lo && b < g_range_hi;
 }
 
-/* mode 0 = FASTA -> reference DB (MakeDatabase -a), 1 = FASTQ -> read DB (MakeDatabase -q). */
+/* MakeDatabase -k: the shortest k-mer (minK) of the NEXT ko_build call(s); 0 = the same as k (maxK). */
+static int g_min_k = 0;
+void ko_set_min_k(int min_k) { g_min_k = min_k; }
+
+/* mode 0 = FASTA -> reference DB (MakeDatabase -a), 1 = FASTQ -> read DB (MakeDatabase -q).  k = maxK. */
 ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, int threads) {
-    if (k < 1 || k > 32 || key_len < 1 || key_len > k || key_len > 12) return NULL;
+    const int min_k = g_min_k > 0 ? g_min_k : k;
+    if (k < 1 || k > 32 || min_k < 1 || min_k > k || key_len < 1 || key_len > min_k || key_len > 12) return NULL;
     const int8_t *code = code_table();
     ko_db *d = (ko_db *)calloc(1, sizeof(ko_db));
-    d->k = k; d->key_len = key_len; d->kind = mode; d->rc = (mode == 0);
+    d->k = k; d->min_k = min_k; d->key_len = key_len; d->kind = mode; d->rc = (mode == 0);
     uint32_t nkeys = 1u << (2 * key_len);
 
     /* ---- transition tables: KmersFromFileStateChanger.java:46-68 */
@@ -165,87 +180,108 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
         trans[ST_KMER]['+'] = ST_OTHER;
     }
 
-    /* ---- HOT LOOP 1: tryAdvance + FileCreator.addKmers, single thread like the reference */
+    /* ---- HOT LOOP 1: tryAdvance + FileCreator.addKmers, single thread like the reference.
+     * The outer loop is one tryAdvance call, the inner one its do { } while (kwd == null) (KmersFromFile.java:84-208). */
     recvec recs = {0, 0, 0};
     uint8_t window[32];
     memset(window, 0, sizeof window);
     int state = ST_OTHER;
     long pos = 0;
     uint64_t id_start = 0, id_len = 0;           /* current header id = file[id_start .. +id_len) */
-    int32_t taxon = 0; int taxon_valid = 0;
-    /* ReadIDMapping state */
-    uint64_t cur_name_start = 0, cur_name_len = 0; int have_cur = 0; int32_t cur_read = -1;
+    uint64_t old_start = 0, old_len = 0;         /* oldid */
+    uint64_t tax_of = (uint64_t)-1; int32_t taxon = 0;   /* Integer.parseInt(id), cached per header */
+    /* ReadIDMapping state: curReadS = "" and curReadI = -1 to begin with (ReadIDMapping.java:10-12) */
+    uint64_t cur_name_start = 0, cur_name_len = 0; int32_t cur_read = -1;
     size_t names_cap = 1 << 16, names_len = 0, noff_cap = 1 << 12;
     if (mode == 1) {
         d->names = (char *)malloc(names_cap);
         d->name_off = (uint64_t *)malloc(noff_cap * sizeof(uint64_t));
         d->name_off[0] = 0;
     }
-    int have_last = 0; ko_rec last = {0, 0, 0};    /* `kwd` field surviving to EOF (quirk C.7) */
-
-    for (uint64_t ip = 0; ip <= n; ip++) {
-        if (ip == n) {                            /* in.read() == -1 */
-            if (have_last && (g_dust < 0 || dust_keep(last.kmer, k, g_dust)) &&
-                (g_runofsame < 0 || runofsame_keep(last.kmer, k, g_runofsame))) { /* last k-mer emitted a second time */
-                if (in_range(last.kmer, key_len)) { rv_push(&recs, last); d->n_windows++; }
-                if (d->rc && !is_palindrome(last.kmer, k)) {
-                    ko_rec r = last; r.kmer = rc_packed(last.kmer, k);
-                    if (in_range(r.kmer, key_len)) rv_push(&recs, r);
+    int have_kwd = 0; ko_rec kwd = {0, 0, 0};     /* the `kwd` FIELD: it survives from one call to the next (quirk C.7) */
+    int ending = 0; long cur_k = 0;
+    uint64_t ip = 0;
+    for (;;) {                                    /* tryAdvance */
+        for (;;) {                                /* do { ... } while (kwd == null) */
+            int at_eof = 0, try_len = 0; uint64_t ms = 0, ml = 0; long mpos = 0;
+            if (ending) {                         /* :90-111 */
+                if (cur_k < min_k) { ending = 0; have_kwd = 0; }
+                else { try_len = (int)cur_k; ms = old_start; ml = old_len; mpos = pos - cur_k; cur_k--; }
+            } else if (ip >= n) {                 /* in.read() == -1, :116-123 */
+                ending = 1; old_start = id_start; old_len = id_len;
+                cur_k = (pos - 1 < k - 1) ? pos - 1 : k - 1;
+                at_eof = 1;
+            } else {
+                uint8_t c = file[ip++];
+                int ns = trans[state][c];
+                if (ns >= 0) {                    /* :126-148 */
+                    if (state == ST_KMER && pos >= min_k) {
+                        old_start = id_start; old_len = id_len; ending = 1;
+                        cur_k = pos < k - 1 ? pos : k - 1;
+                    }
+                    state = ns;
+                    if (state == ST_KMER) pos = 0;                  /* kwd NOT cleared here (:137-139) */
+                    else if (state == ST_ID) { id_start = ip; id_len = 0; have_kwd = 0; }
+                    else have_kwd = 0;
+                } else if (state == ST_ID) id_len++;
+                else if (state == ST_KMER) {
+                    if (c > 32) {
+                        pos++;
+                        memmove(window, window + 1, (size_t)k - 1);   /* System.arraycopy shift, :157 */
+                        window[k - 1] = c;
+                        if (pos >= k) { try_len = k; ms = id_start; ml = id_len; mpos = pos - k; }
+                    } else have_kwd = 0;
                 }
             }
-            break;
-        }
-        uint8_t c = file[ip];
-        int ns = trans[state][c];
-        if (ns >= 0) {
-            state = ns;
-            if (state == ST_KMER) pos = 0;        /* kwd NOT cleared here (KmersFromFile.java:137-139) */
-            else if (state == ST_ID) { id_start = ip + 1; id_len = 0; taxon_valid = 0; have_last = 0; }
-            else have_last = 0;
-            continue;
-        }
-        if (state == ST_ID) { id_len++; continue; }
-        if (state != ST_KMER) continue;
-        if (c <= 32) { have_last = 0; continue; }
-        pos++;
-        memmove(window, window + 1, (size_t)k - 1); /* System.arraycopy shift, :157 */
-        window[k - 1] = c;
-        if (pos < k) continue;
-        /* new Kmer(newbytes): per-window re-encode, InvalidBaseException => skip window */
-        uint64_t packed = 0; int ok = 1;
-        for (int i = 0; i < k; i++) {
-            int v = window[i] < 128 ? code[window[i]] : -1;
-            if (v < 0) { ok = 0; break; }
-            packed |= (uint64_t)v << (62 - 2 * i);
-        }
-        if (!ok) { have_last = 0; continue; }
-        ko_rec r; r.kmer = packed; r.b = 0;
-        if (mode == 0) {
-            if (!taxon_valid) {                   /* Integer.parseInt(id) */
-                char buf[32]; size_t l = id_len < 31 ? id_len : 31;
-                memcpy(buf, file + id_start, l); buf[l] = 0;
-                taxon = (int32_t)strtol(buf, NULL, 10); taxon_valid = 1;
+            if (try_len) {
+                /* new Kmer(newbytes) on the last try_len bytes of the window: per-window re-encode,
+                 * InvalidBaseException => no k-mer; the mapper runs only after the k-mer was built */
+                uint64_t packed = 0; int ok = 1;
+                for (int i = 0; i < try_len; i++) {
+                    uint8_t w = window[k - try_len + i];
+                    int v = w < 128 ? code[w] : -1;
+                    if (v < 0) { ok = 0; break; }
+                    packed |= (uint64_t)v << (62 - 2 * i);
+                }
+                if (ok) {
+                    kwd.kmer = packed;
+                    if (mode == 0) {
+                        if (tax_of != ms) {       /* Integer.parseInt(id) */
+                            char buf[32]; size_t l = ml < 31 ? ml : 31;
+                            memcpy(buf, file + ms, l); buf[l] = 0;
+                            taxon = (int32_t)strtol(buf, NULL, 10); tax_of = ms;
+                        }
+                        kwd.a = taxon; kwd.b = try_len << 16;
+                    } else {                      /* ReadIDMapping.geNext: compares with the last *emitting* id */
+                        if (cur_name_len != ml || memcmp(file + cur_name_start, file + ms, ml) != 0) {
+                            cur_name_start = ms; cur_name_len = ml; cur_read++;
+                            while (names_len + ml + 1 > names_cap) { names_cap *= 2; d->names = (char *)realloc(d->names, names_cap); }
+                            memcpy(d->names + names_len, file + ms, ml); names_len += ml;
+                            if ((uint64_t)cur_read + 2 > noff_cap) { noff_cap *= 2; d->name_off = (uint64_t *)realloc(d->name_off, noff_cap * sizeof(uint64_t)); }
+                            d->name_off[cur_read + 1] = names_len;
+                        }
+                        kwd.a = cur_read;
+                        kwd.b = (try_len << 16) | (int32_t)((uint16_t)(int16_t)mpos);   /* (short)(pos - length) */
+                    }
+                    have_kwd = 1;
+                } else if (try_len == k) {        /* :167-176 (in the ending branch the exception changes nothing) */
+                    have_kwd = 0;
+                    if (pos > min_k) {
+                        ending = 1; old_start = id_start; old_len = id_len;
+                        cur_k = (pos - 1 < k - 1) ? pos - 1 : k - 1;
+                    }
+                }
             }
-            r.a = taxon;
-        } else {                                  /* ReadIDMapping.geNext: compares with last *emitting* id */
-            if (!have_cur || cur_name_len != id_len ||
-                memcmp(file + cur_name_start, file + id_start, id_len) != 0) {
-                cur_name_start = id_start; cur_name_len = id_len; have_cur = 1; cur_read++;
-                while (names_len + id_len + 1 > names_cap) { names_cap *= 2; d->names = (char *)realloc(d->names, names_cap); }
-                memcpy(d->names + names_len, file + id_start, id_len); names_len += id_len;
-                if ((uint64_t)cur_read + 2 > noff_cap) { noff_cap *= 2; d->name_off = (uint64_t *)realloc(d->name_off, noff_cap * sizeof(uint64_t)); }
-                d->name_off[cur_read + 1] = names_len;
-            }
-            r.a = cur_read;
-            r.b = (int16_t)(pos - k);             /* (short)(pos - maxK) */
+            if (at_eof || have_kwd) break;
         }
-        last = r; have_last = 1;
-        /* kstream.filter(Dust).filter(RunOfSame) sits between the extractor and addKmers */
-        if (g_dust >= 0 && !dust_keep(packed, k, g_dust)) continue;
-        if (g_runofsame >= 0 && !runofsame_keep(packed, k, g_runofsame)) continue;
-        if (in_range(packed, key_len)) { rv_push(&recs, r); d->n_windows++; }
-        if (d->rc && !is_palindrome(packed, k)) { /* FileCreator.java:83-87 */
-            ko_rec q = r; q.kmer = rc_packed(packed, k);
+        if (!have_kwd) break;                     /* return false */
+        /* consumer.accept(kwd): kstream.filter(Dust).filter(RunOfSame), then FileCreator.addKmers (:77-95) */
+        const int len = REC_LEN(kwd);
+        if (g_dust >= 0 && !dust_keep(kwd.kmer, len, g_dust)) continue;
+        if (g_runofsame >= 0 && !runofsame_keep(kwd.kmer, len, g_runofsame)) continue;
+        if (in_range(kwd.kmer, key_len)) { rv_push(&recs, kwd); d->n_windows++; }
+        if (d->rc && !is_palindrome(kwd.kmer, len)) {
+            ko_rec q = kwd; q.kmer = rc_packed(kwd.kmer, len);
             if (in_range(q.kmer, key_len)) rv_push(&recs, q);
         }
     }
@@ -278,7 +314,7 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
         qsort(p, m, sizeof(ko_rec), cmp_rec);     /* TreeMap<Kmer,..> + TreeCountMap ordering */
         uint64_t u = 0, v = 0;
         for (size_t i = 0; i < m; i++) {
-            int newk = (i == 0) || p[i].kmer != p[i - 1].kmer;
+            int newk = (i == 0) || p[i].kmer != p[i - 1].kmer || REC_LEN(p[i]) != REC_LEN(p[i - 1]);
             if (newk) u++;
             if (d->kind == 1 || newk || p[i].a != p[i - 1].a) v++;
         }
@@ -290,15 +326,16 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
     d->val_off = (uint64_t *)malloc((d->U + 1) * sizeof(uint64_t));
     d->val_a = (int32_t *)malloc((d->V + 1) * sizeof(int32_t));
     d->val_b = (int32_t *)malloc((d->V + 1) * sizeof(int32_t));
+    d->lens = (uint8_t *)malloc(d->U + 1);
     d->bucket_off = ucount;
 #pragma omp parallel for schedule(dynamic, 16)
     for (int64_t key = 0; key < (int64_t)nkeys; key++) {
         ko_rec *p = sorted + boff[key]; size_t m = boff[key + 1] - boff[key];
         uint64_t u = ucount[key], v = vcount[key];
         for (size_t i = 0; i < m; i++) {
-            int newk = (i == 0) || p[i].kmer != p[i - 1].kmer;
-            if (newk) { d->keys[u] = p[i].kmer; d->val_off[u] = v; u++; }
-            if (d->kind == 1) { d->val_a[v] = p[i].a; d->val_b[v] = p[i].b; v++; }
+            int newk = (i == 0) || p[i].kmer != p[i - 1].kmer || REC_LEN(p[i]) != REC_LEN(p[i - 1]);
+            if (newk) { d->keys[u] = p[i].kmer; d->lens[u] = (uint8_t)REC_LEN(p[i]); d->val_off[u] = v; u++; }
+            if (d->kind == 1) { d->val_a[v] = p[i].a; d->val_b[v] = REC_POS(p[i]); v++; }
             else if (newk || p[i].a != p[i - 1].a) { d->val_a[v] = p[i].a; d->val_b[v] = 1; v++; }
             else if (d->val_b[v - 1] < INT32_MAX) d->val_b[v - 1]++;   /* TreeCountMap.add */
         }
@@ -314,6 +351,8 @@ uint64_t ko_V(const ko_db *d) { return d->V; }
 uint64_t ko_n_windows(const ko_db *d) { return d->n_windows; }
 uint64_t ko_n_records(const ko_db *d) { return d->n_records; }
 uint64_t ko_n_reads(const ko_db *d) { return d->n_reads; }
+int ko_min_k(const ko_db *d) { return d->min_k; }
+const uint8_t *ko_lens(const ko_db *d) { return d->lens; }
 const uint64_t *ko_keys(const ko_db *d) { return d->keys; }
 const uint64_t *ko_val_off(const ko_db *d) { return d->val_off; }
 const int32_t *ko_val_a(const ko_db *d) { return d->val_a; }
@@ -329,18 +368,22 @@ static void be16(uint8_t *p, uint16_t v) { p[0] = v >> 8; p[1] = v; }
 
 uint64_t ko_encode_blocks(const ko_db *d, uint8_t *out, uint64_t cap, uint64_t *block_off) {
     uint32_t nkeys = 1u << (2 * d->key_len);
-    int l = (d->k - 1) / 4 + 1;                   /* packed bytes per k-mer */
     uint64_t w = 0;
     uint8_t kc[9], prev[9];
     for (uint32_t key = 0; key < nkeys; key++) {
         if (block_off) block_off[key] = w;
         memset(prev, 0, sizeof prev);             /* byte[] prev = new byte[1] */
+        int prev_n = 1;
         for (uint64_t u = d->bucket_off[key]; u < d->bucket_off[key + 1]; u++) {
-            kc[0] = (uint8_t)d->k;
+            const int l = (d->lens[u] - 1) / 4 + 1;   /* packed bytes of this k-mer */
+            kc[0] = d->lens[u];                       /* Kmer.compressedBytes: [length byte][packed] */
             for (int i = 0; i < 8; i++) kc[1 + i] = (uint8_t)(d->keys[u] >> (56 - 8 * i));
+            /* shared(): leading bytes in common with the previous record's compressedBytes, within both lengths
+             * (FileCreator.java:244-252); prev = new byte[1] at the start of a key, and a record that shares
+             * nothing is written whole (:318-330) */
             int s = 0;
-            if (u > d->bucket_off[key]) while (s < l + 1 && prev[s] == kc[s]) s++;
-            memcpy(prev, kc, 9);
+            while (s < prev_n && s < l + 1 && prev[s] == kc[s]) s++;
+            memcpy(prev, kc, 9); prev_n = l + 1;
             uint64_t nv = d->val_off[u + 1] - d->val_off[u];
             uint64_t need = 1 + (uint64_t)(l + 1 - s) + (d->kind == 0 ? 2 + 5 * nv : 4 + 6 * nv);
             if (out && w + need <= cap) {
@@ -368,10 +411,66 @@ uint64_t ko_encode_blocks(const ko_db *d, uint8_t *out, uint64_t cap, uint64_t *
     return w;
 }
 
+/* ---- KmerUtils.restrictedStream(stream, L, L, dataType) (KmerUtils.java:59-74) over a whole database: drop the
+ * k-mers shorter than L, cut the rest to L (Kmer.limitTo, Kmer.java:277-289), fold runs of equal neighbours with the
+ * data type's reducer -- counts add per taxon (CountDataType.getMerger: TreeCountMap.addAll), read-position sets
+ * unite (every ReadPos is its own object: nothing is ever dropped; canonical order ascending).  What
+ * quickMatchCommonKey does to the database side (DB.java:134) and KmerFile.allRestrictedKmers to the search side
+ * (KmerFile.java:80-83, Matcher.java:241) under Matcher -k L -K L. */
+typedef struct { int32_t a, b; } ko_val;
+static int cmp_val(const void *pa, const void *pb) {
+    const ko_val *x = (const ko_val *)pa, *y = (const ko_val *)pb;
+    if (x->a != y->a) return x->a < y->a ? -1 : 1;
+    if (x->b != y->b) return x->b < y->b ? -1 : 1;
+    return 0;
+}
+ko_db *ko_restrict(const ko_db *s, int L) {
+    if (L < s->min_k || L > s->k) return NULL;     /* DB.java:78-81 */
+    ko_db *d = (ko_db *)calloc(1, sizeof(ko_db));
+    d->k = L; d->min_k = L; d->key_len = s->key_len; d->kind = s->kind; d->rc = s->rc;
+    d->n_windows = s->n_windows; d->n_records = s->n_records;
+    const uint32_t nkeys = 1u << (2 * s->key_len);
+    const uint64_t mask = L == 32 ? ~0ull : ~(~0ull >> (2 * L));
+    d->keys = (uint64_t *)malloc((s->U + 1) * sizeof(uint64_t));
+    d->val_off = (uint64_t *)malloc((s->U + 1) * sizeof(uint64_t));
+    d->val_a = (int32_t *)malloc((s->V + 1) * sizeof(int32_t));
+    d->val_b = (int32_t *)malloc((s->V + 1) * sizeof(int32_t));
+    d->lens = (uint8_t *)malloc(s->U + 1);
+    d->bucket_off = (uint64_t *)calloc((size_t)nkeys + 1, sizeof(uint64_t));
+    ko_val *tmp = (ko_val *)malloc((s->V + 1) * sizeof(ko_val));
+    uint64_t U = 0, V = 0;
+    for (uint64_t u = 0; u < s->U;) {
+        if (s->lens[u] < L) { u++; continue; }
+        const uint64_t key = s->keys[u] & mask;
+        uint64_t nt = 0;
+        /* the run of neighbours with the same cut k-mer (shorter ones in between are filtered out first) */
+        while (u < s->U && (s->lens[u] < L || (s->keys[u] & mask) == key)) {
+            if (s->lens[u] >= L)
+                for (uint64_t v = s->val_off[u]; v < s->val_off[u + 1]; v++) { tmp[nt].a = s->val_a[v]; tmp[nt].b = s->val_b[v]; nt++; }
+            u++;
+        }
+        qsort(tmp, nt, sizeof(ko_val), cmp_val);
+        d->keys[U] = key; d->lens[U] = (uint8_t)L; d->val_off[U] = V;
+        d->bucket_off[(key >> (64 - 2 * s->key_len)) + 1]++;
+        U++;
+        for (uint64_t i = 0; i < nt; i++) {
+            if (s->kind == 0 && i > 0 && tmp[i].a == tmp[i - 1].a) {         /* TreeCountMap.addAll */
+                int64_t c = (int64_t)d->val_b[V - 1] + tmp[i].b;
+                d->val_b[V - 1] = c > INT32_MAX ? INT32_MAX : (int32_t)c;
+            } else { d->val_a[V] = tmp[i].a; d->val_b[V] = tmp[i].b; V++; }
+        }
+    }
+    free(tmp);
+    for (uint32_t i = 0; i < nkeys; i++) d->bucket_off[i + 1] += d->bucket_off[i];
+    d->U = U; d->V = V; d->val_off[U] = V;
+    return d;
+}
+
 /* ---- HOT LOOP 3: per-key two-pointer inner join (DB.quickMatchCommonKey + matchTwoStreams).
  * hit[i] = index of the reference k-mer equal to search k-mer i, or -1.  Returns #hits. */
 uint64_t ko_match(const ko_db *s, const ko_db *r, int64_t *hit, int threads) {
-    if (s->k != r->k || s->key_len != r->key_len) return (uint64_t)-1;
+    /* the quick branch: search k-mers of one length (DB.java:83), the database restricted to it (:134) */
+    if (s->k != r->k || s->key_len != r->key_len || s->min_k != s->k || r->min_k != r->k) return (uint64_t)-1;
     uint32_t nkeys = 1u << (2 * s->key_len);
     uint64_t hits = 0;
 #ifdef _OPENMP

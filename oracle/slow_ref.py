@@ -529,7 +529,8 @@ class DB:
             j = i
             while j < n and search[j][0].key(self.key_length) == key:
                 j += 1
-            ref = self.kmers(key)
+            length = search[i][0].length()        # DB.java:132
+            ref = restricted_stream(self.kmers(key), self.min_k, self.max_k, length, length, "ref")   # :134
             a, b = i, 0
             while a < j and b < len(ref):
                 c = search[a][0].compare_to(ref[b][0])
@@ -545,16 +546,51 @@ class DB:
         return res
 
 
-def match_lines(search_blocks, db):
-    """Matcher.doMatching (Matcher.java:235-250), read-vs-reference, maxDiff 0, one search file.
+def restricted_stream(entries, stream_min, stream_max, min_length, max_length, kind):
+    """KmerUtils.restrictedStream (KmerUtils.java:59-74): the stream itself when its lengths are the wanted ones; else
+    the k-mers shorter than min_length dropped, the rest cut to max_length (Kmer.limitTo, Kmer.java:277-289), and runs
+    of equal neighbours folded with the data type's reducer (MergeableDataType.getKmerReducer: the merger applied to
+    the first k-mer's data -- TreeCountMap.addAll for a reference database, Set.addAll of ReadPos objects, which are
+    never equal to one another, for a read database)."""
+    if stream_min == min_length and stream_max == max_length:
+        return entries
+    out = []
+    for k, data in entries:
+        if k.length() < min_length:
+            continue
+        if max_length < k.length():
+            k = Kmer(list(k.chars[:max_length]))
+        if out and out[-1][0].chars == k.chars:    # groupAndReduceStream: equal to the previous raw element
+            if kind == "ref":
+                for t, c in data.items():
+                    out[-1][1][t] = out[-1][1].get(t, 0) + c
+            else:
+                out[-1][1].extend(data)
+        else:
+            out.append((k, dict(data) if kind == "ref" else list(data)))
+    return out
+
+
+def match_lines(search_blocks, db, min_k=None, max_k=None):
+    """Matcher.doMatching (Matcher.java:235-250), read-vs-reference, maxDiff 0, one search file; min_k / max_k =
+    Matcher -k / -K (default: the search file's own, Matcher.java:147-148).  Only the quick branch (search k-mers of
+    one length, DB.java:83): the search stream is KmerFile.allRestrictedKmers(minK, maxK) (Matcher.java:241) and the
+    database side of every key is restricted to that length (DB.java:134).
     Line text: ResultsDataType.java:15-35 -> KMER \\t r:p|r:p \\t -|TxC|TxC
     (KmerWithDataDataType.java:74-82, DataPairDataType.java:43-50, KmerDiff.java:54-67,
     ReadPosDataType.java:46-49, CountDataType.java:109-113 with separators "x" and "|")."""
-    min_k, max_k, key_len, ids, rc = parse_meta(search_blocks[-1])
+    f_min, f_max, key_len, ids, rc = parse_meta(search_blocks[-1])
+    min_k = f_min if min_k is None else min_k
+    max_k = f_max if max_k is None else max_k
     kind = "read" if ids == READ_ID else "ref"
+    if min_k < db.min_k or max_k > db.max_k:      # DB.java:78-81
+        raise InconsistentDataException("Search kmers contain kmers of a length inconsistent with the database")
+    if min_k != max_k:
+        raise NotImplementedError("search k-mers of several lengths take the trie branch (near_match_lines)")
     search = []
     for key in range(4 ** key_len):
         search.extend(decode_block(search_blocks.get(key, b""), kind))
+    search = restricted_stream(search, f_min, f_max, min_k, max_k, kind)
     lines = []
     for kmer, sdata, rdata in db.quick_match(search):
         if kind == "read":

@@ -1111,6 +1111,28 @@ def test_cfg3_flavour_many_taxa(ctx):
     rdb.close()
 
 
+def test_taxacounts_many_taxa_and_the_whole_int32_range(ctx):
+    """TaxaCounts beyond the LDS histograms (20 000 taxa: global counters) and with taxon ids from one end of int32
+    to the other, negative ones included (the presence bitmap then spans 2^32 bits) -- rows ascending by taxon as
+    TaxaCounts.java:132-150 prints them, against the oracle."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(77)
+    _, genomes = synth.random_genomes(78, 20000, 120, shared_frac=0.3)
+    for ids in (np.arange(20000) * 3 + 7,
+                np.concatenate([[-2 ** 31, -5, 0, 2 ** 31 - 1], rng.integers(-2 ** 31, 2 ** 31, size=19996)])):
+        taxa = [int(x) for x in ids]
+        fa = synth.fasta_bytes(taxa, genomes)
+        ref = km.make_reference_db(ctx, fa, 31, 6)
+        o_ref = OracleDB(fa, 0, 31, 6, threads=8)
+        t, m, q = km.taxa_counts(ref)
+        ot, om, oq = o_ref.taxacounts()
+        assert len(t) == len(set(taxa)) and np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
+        assert int(m.sum()) == ref.n_values and (q <= m).all() and (q < m).any()
+        ref.close()
+
+
 @pytest.mark.parametrize("k", [21, 25, 31])
 def test_cfg5_flavour_long_noisy_reads(ctx, k):
     """Config 5 in small: 10 kbp reads with 15 % substitutions and 0.5 % N, genome sizes spread over two orders of

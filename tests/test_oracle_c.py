@@ -107,3 +107,63 @@ def test_dust_and_runofsame_filters_agree(k, dust, run):
     cr = OracleDB(fq, 1, k, 3, dust=-1 if dust is None else dust, runofsame=-1 if run is None else run)
     assert cr.encode_blocks()[0] == _py_blocks_concat(pyr, 3)
     assert cr.names == names                        # reads are numbered before the filter sees their k-mers
+
+
+# ---------------------------------------------------------------------------- variable-length k-mers (minK < maxK)
+def _lens_from_py(py, key_len, kind):
+    out = []
+    for key in range(4 ** key_len):
+        out.extend(k.length() for k, _ in R.decode_block(py[key], kind))
+    return out
+
+
+@pytest.mark.parametrize("min_k,k,key_len,seed", [(3, 5, 2, 31), (4, 8, 2, 32), (24, 32, 3, 33), (20, 31, 3, 34), (6, 7, 3, 35)])
+def test_variable_length_builds_agree(min_k, k, key_len, seed):
+    """MakeDatabase -k min_k -K k (the reference's default is -k 24 -K 32): suffixes of length k-1 .. min_k at the
+    end of every sequence and behind every invalid base (KmersFromFile.java:90-133,167-176), records ordered by
+    (k-mer, length) (Sequence.java:165-187), every record with its own length byte (FileCreator.java:312-347)."""
+    rng = np.random.default_rng(seed)
+    small = k <= 8
+    fa = _rand_fasta(rng, 14, 160 if not small else 60, alphabet=b"AACCGTN" if small else b"ACGTacgtACGTACGTN")
+    fq = _rand_fastq(rng, 40, 100 if not small else 30, alphabet=b"AACGTN" if small else b"ACGTACGTACGTACGTN")
+    py = R.build_ref_db(fa, k, key_len, min_k=min_k)
+    c = OracleDB(fa, 0, k, key_len, min_k=min_k)
+    assert c.encode_blocks()[0] == _py_blocks_concat(py, key_len)
+    assert c.lens.tolist() == _lens_from_py(py, key_len, "ref") and min(c.lens) >= min_k and max(c.lens) <= k
+    assert len(set(c.lens.tolist())) > 1
+    pyr, names = R.build_read_db(fq, k, key_len, min_k=min_k)
+    cr = OracleDB(fq, 1, k, key_len, min_k=min_k)
+    assert cr.encode_blocks()[0] == _py_blocks_concat(pyr, key_len)
+    assert cr.names == names and cr.lens.tolist() == _lens_from_py(pyr, key_len, "read")
+
+
+def test_variable_length_without_trailing_newline_agrees():
+    for fa in (b">9\nACGTACGTTGCA", b">9\nACGTACGTTGCA\n>4\nACNTACGTTG", b">9\nACGTANGTTGCATT"):
+        py = R.build_ref_db(fa, 6, 2, min_k=3)
+        c = OracleDB(fa, 0, 6, 2, min_k=3)
+        assert c.encode_blocks()[0] == _py_blocks_concat(py, 2)
+
+
+@pytest.mark.parametrize("min_k,k,L,key_len,seed", [(3, 6, 4, 2, 41), (3, 6, 3, 2, 42), (3, 6, 6, 2, 43), (20, 31, 25, 3, 44)])
+def test_restricted_match_agrees(min_k, k, L, key_len, seed):
+    """Matcher -k L -K L over variable-length databases: both sides through KmerUtils.restrictedStream
+    (KmerUtils.java:59-74), then the quick branch's join (DB.java:129-137)."""
+    rng = np.random.default_rng(seed)
+    small = k <= 8
+    fa = _rand_fasta(rng, 10, 200 if not small else 80, alphabet=b"ACGT" * 12 + b"N" if not small else b"AACCGTN")
+    # reads cut from the reference text so that long k-mers match too
+    body = b"".join(l for l in fa.split(b"\n") if not l.startswith(b">"))
+    recs = []
+    for i in range(40):
+        a = int(rng.integers(0, max(len(body) - 60, 1)))
+        sq = body[a:a + int(rng.integers(min_k, 60))]
+        recs.append(b"@q%d\n%s\n+\n%s\n" % (i, sq, b"I" * len(sq)))
+    fq = b"".join(recs)
+    pyref = R.build_ref_db(fa, k, key_len, min_k=min_k)
+    pyreads, _ = R.build_read_db(fq, k, key_len, min_k=min_k)
+    want = R.match_lines(pyreads, R.DB([pyref]), min_k=L, max_k=L)
+    cref = OracleDB(fa, 0, k, key_len, min_k=min_k).restrict(L)
+    creads = OracleDB(fq, 1, k, key_len, min_k=min_k).restrict(L)
+    hit, nh = creads.match(cref)
+    assert creads.match_lines(cref, hit).decode().splitlines() == want
+    assert nh == len(want) and nh > 0
