@@ -13,7 +13,8 @@
  * nonzero return on that context.  The caller allocates and frees every host buffer; the library
  * copies inputs before returning and retains no host pointer.  A context is bound to one GPU and is
  * internally serialised (safe to call from several threads; calls do not overlap on the device).
- * Supported: 1 <= k <= 32 with minK == maxK, 1 <= key_len <= min(k, 12).  Anything else returns
+ * Supported: 1 <= minK <= maxK = k <= 32, 1 <= key_len <= min(minK, 12); the exact join takes k-mers of one
+ * length (restrict variable-length databases first, kmg_db_restrict).  Anything else returns
  * KMG_EUNSUPPORTED so a shim can fall back to the Java path.
  *
  * K-mer representation everywhere: uint64, 2 bits per base, code order A=0 C=1 T=2 G=3
@@ -34,7 +35,7 @@ extern "C" {
 #define KMG_EINVAL       (-1)   /* bad argument / inconsistent parameters (InconsistentDataException) */
 #define KMG_ENOMEM       (-2)   /* host or device allocation failed */
 #define KMG_EDEVICE      (-3)   /* HIP runtime error */
-#define KMG_EUNSUPPORTED (-4)   /* k > 32, minK != maxK, > 2^32-1 records in one build ... */
+#define KMG_EUNSUPPORTED (-4)   /* k > 32, a join over several k-mer lengths, > 2^32-16 records in one build ... */
 #define KMG_ESTATE       (-5)   /* call out of order (add before begin, ...) */
 
 #define KMG_PAYLOAD_TAXON   0   /* reference DB: int32 taxon per sequence  (DataCollector.getCountInstance) */
@@ -91,6 +92,16 @@ int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind);
  *                   (its RC goes with it); reads are numbered before the filters.  -1 = off.  Call
  *                   between kmg_build_begin and the first kmg_build_add. */
 int kmg_build_set_filters(kmg_ctx *ctx, int dust_threshold, int runofsame_length);
+/* kmg_build_set_min_k: MakeDatabase -k <minK> below -K <maxK> = the k of kmg_build_begin (the reference's defaults are
+ *   -k 24 -K 32, MakeDatabase.java:106-107).  Replaces the `ending` branch of KmersFromFileSpliterator.tryAdvance
+ *   (OtherFiles/KmersFromFile.java:90-111): besides every full window the build then holds the suffixes of length
+ *   min(pos, maxK - 1) .. minK that end at a sequence's last base (:128-133) and those that end at the last base of a
+ *   full window with an invalid base in it (:167-176), each skipped on its own if it holds an invalid base; when the
+ *   last full window of a sequence is invalid both rules fire and those suffixes are recorded twice, as there.  A read
+ *   is numbered at its first k-mer of any length.  The database is ordered as Sequence.compareTo orders k-mers
+ *   (Kmers/Sequence.java:165-187): zero-padded value first, length second (kmg_db_fetch_lens).  key_len <= min_k
+ *   (Kmer.key of a shorter k-mer throws in the reference).  After kmg_build_begin, before the first add. */
+int kmg_build_set_min_k(kmg_ctx *ctx, int min_k);
 /* kmg_build_set_key_range: build only the part of the database whose key buckets (Kmer.key(key_len), Kmer.java:47-55)
  *   lie in [first_bucket, end_bucket) -- each record is judged by its own k-mer, so a reverse complement can be kept
  *   where its forward k-mer is not.  Read numbering is not affected (as with the -D / -R filters: the mapper runs
@@ -130,6 +141,22 @@ int kmg_db_payload_bits(const kmg_db *db);
  *   Kmer.key(key_len) bucket (Kmer.java:47-55) -- the per-key blocks of the DB file. */
 int kmg_db_fetch(const kmg_db *db, uint64_t *keys, uint64_t *val_off, int32_t *val_a, int32_t *val_b,
                  uint64_t *bucket_off);
+/* Variable-length databases (minK < maxK).  kmg_db_min_k: the shortest k-mer length (== k of kmg_db_info for a
+ *   database of one length).  kmg_db_fetch_lens: lens[n_unique] = number of bases of every k-mer (the length byte of
+ *   Kmer.compressedBytes, Kmer.java:90-97); keys are zero-padded behind it.  kmg_db_load_var: kmg_db_load with lens
+ *   (what KmerFile's decoder, KmerFile.java:200-250, yields for such a file); (keys, lens) strictly ascending. */
+int kmg_db_min_k(const kmg_db *db);
+int kmg_db_fetch_lens(const kmg_db *db, uint8_t *lens);
+int kmg_db_load_var(kmg_ctx *ctx, int k, int min_k, int key_len, int rc, int payload_kind, const uint64_t *keys,
+                    const uint8_t *lens, uint64_t n_unique, const uint64_t *val_off, const int32_t *val_a,
+                    const int32_t *val_b, kmg_db **out);
+/* kmg_db_restrict: KmerUtils.restrictedStream(stream, length, length, dataType) (Kmers/KmerUtils.java:59-74) over a whole
+ *   database: k-mers shorter than `length` are dropped, the others cut to `length` bases (Kmer.limitTo, Kmer.java:277-289)
+ *   and equal neighbours folded with the data type's reducer (counts add per taxon, read-position sets unite).  That is
+ *   what Matcher -k L -K L does to the search side (KmerFile.allRestrictedKmers, Matcher.java:241) and to the database
+ *   side (DB.java:134) before the exact join.  min_k <= length <= k of the source (DB.java:78-81 -> KMG_EINVAL); the
+ *   result is a database of one length; the source stays valid. */
+int kmg_db_restrict(kmg_ctx *ctx, const kmg_db *db, int length, kmg_db **out);
 /* kmg_db_load : upload a decoded database (KmerFile.java:200-250 output) from host CSR arrays. */
 int kmg_db_load(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *keys,
                 uint64_t n_unique, const uint64_t *val_off, const int32_t *val_a, const int32_t *val_b,

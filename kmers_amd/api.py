@@ -93,19 +93,38 @@ class KmerDatabase:
         ctx.check(ctx.lib.kmg_db_info(handle, C.byref(k), C.byref(kl), C.byref(rc), C.byref(kind), C.byref(u), C.byref(v)))
         self.k, self.key_length, self.rc, self.kind = k.value, kl.value, bool(rc.value), kind.value
         self.n_unique, self.n_values = u.value, v.value
-        self.min_length = self.max_length = self.k
+        self.max_length = self.k
+        self.min_length = ctx.lib.kmg_db_min_k(handle)
         self._host = None
 
     @classmethod
-    def load(cls, ctx, k, key_length, rc, kind, keys, val_off, val_a, val_b):
+    def load(cls, ctx, k, key_length, rc, kind, keys, val_off, val_a, val_b, lens=None, min_length=None):
+        """lens / min_length: a database of k-mers of several lengths (kmg_db_load_var)."""
         keys = np.ascontiguousarray(keys, np.uint64)
         val_off = np.ascontiguousarray(val_off, np.uint64)
         val_a = np.ascontiguousarray(val_a, np.int32)
         val_b = np.ascontiguousarray(val_b, np.int32)
         h = C.c_void_p()
-        ctx.check(ctx.lib.kmg_db_load(ctx.h, k, key_length, 1 if rc else 0, kind, _ptr(keys), len(keys), _ptr(val_off),
-                                      _ptr(val_a), _ptr(val_b), C.byref(h)))
+        if min_length is not None and min_length != k:
+            lens = np.ascontiguousarray(lens, np.uint8)
+            ctx.check(ctx.lib.kmg_db_load_var(ctx.h, k, min_length, key_length, 1 if rc else 0, kind, _ptr(keys), _ptr(lens),
+                                              len(keys), _ptr(val_off), _ptr(val_a), _ptr(val_b), C.byref(h)))
+        else:
+            ctx.check(ctx.lib.kmg_db_load(ctx.h, k, key_length, 1 if rc else 0, kind, _ptr(keys), len(keys), _ptr(val_off),
+                                          _ptr(val_a), _ptr(val_b), C.byref(h)))
         return cls(ctx, h)
+
+    def lens(self):
+        """Number of bases of every k-mer (kmg_db_fetch_lens)."""
+        out = np.empty(max(self.n_unique, 1), np.uint8)
+        self.ctx.check(self.ctx.lib.kmg_db_fetch_lens(self.h, _ptr(out)))
+        return out[:self.n_unique]
+
+    def restrict(self, length):
+        """KmerUtils.restrictedStream(.., length, length, ..) over the whole database (kmg_db_restrict)."""
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.kmg_db_restrict(self.ctx.h, self.h, int(length), C.byref(h)))
+        return KmerDatabase(self.ctx, h)
 
     @classmethod
     def load_tensors(cls, ctx, k, key_length, rc, kind, keys, val_off, val_a, val_b):
@@ -152,7 +171,7 @@ class KmerDatabase:
     def meta(self):
         """The key -1 block, FileCreator.java:153-164."""
         ids = self.data_id()
-        b = bytes([self.k, self.k, self.key_length]) + len(ids).to_bytes(4, "big")
+        b = bytes([self.min_length, self.k, self.key_length]) + len(ids).to_bytes(4, "big")
         for i in ids:
             b += i.to_bytes(4, "big")
         return b + bytes([1 if self.rc else 0])
@@ -199,6 +218,7 @@ class FileCreator:
         self.kind = PAYLOAD_TAXON if data_kind == "ref" else PAYLOAD_READPOS
         self.rc = rc
         self.min_k = -1
+        self._min_set = False
         self.n_windows = 0
         ctx.check(ctx.lib.kmg_build_begin(ctx.h, max_kmer_length, key_length, 1 if rc else 0, self.kind))
         if dust is not None or runofsame is not None:
@@ -217,8 +237,9 @@ class FileCreator:
         if self.min_k != min_length or self.max_k != max_length:
             raise InconsistentDataException(
                 _lib.KMG_EINVAL, "New stream does not have the same min or max kmer length as a previous stream")
-        if min_length != max_length:
-            raise KmersGpuError(_lib.KMG_EUNSUPPORTED, "minK != maxK is not supported on the GPU path")
+        if min_length != max_length and not self._min_set:
+            self.ctx.check(self.ctx.lib.kmg_build_set_min_k(self.ctx.h, int(min_length)))
+            self._min_set = True
         ridx = None
         if self.kind == PAYLOAD_READPOS:
             ridx = np.empty(batch.nseq, np.int32)

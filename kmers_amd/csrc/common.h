@@ -176,6 +176,12 @@ struct kmg_ctx {
     hipEvent_t ev_len = nullptr, ev_snap = nullptr;
     bool snap_valid = false;     // h_snap holds the state finish() needs (single fused batch)
     std::vector<void *> staged;  // device copies of host batches, released at finish
+    // variable-length builds (kmg_build_set_min_k): the k-mers shorter than k, in emission order, every batch appended
+    int min_k = 0;               // == k unless set
+    u64 *sh_keys = nullptr;      // left-aligned, zero-padded
+    void *sh_vals = nullptr;     // u32 taxon | u64 (read << 16 | pos16)
+    uint8_t *sh_len = nullptr;
+    u64 sh_n = 0, sh_cap = 0;
     u64 *match_scratch = nullptr; // this device's copy of the file-scope bounds array (kmg_match_dev_noalloc)
 
     // profiling
@@ -194,8 +200,10 @@ struct kmg_db {
     kmg_ctx *ctx = nullptr;
     const u64 id = next_db_id();   // never reused: names a database where a pointer could be a later one's
     int k = 0, key_len = 0, rc = 0, kind = 0;
+    int min_k = 0;              // shortest k-mer (== k: every k-mer has k bases and lens is null)
+    uint8_t *lens = nullptr;    // U: length of every k-mer of a variable-length database, ascending inside equal keys
     u64 U = 0, V = 0;
-    u64 *keys = nullptr;        // U
+    u64 *keys = nullptr;        // U; zero-padded to k bases: (keys, lens) ascending == Sequence.compareTo order
     u64 *val_off = nullptr;     // U + 1
     int32_t *val_a = nullptr;   // V
     int32_t *val_b = nullptr;   // V

@@ -118,20 +118,14 @@ struct ExtractArgs {
     u32 pos_mask;
 };
 
-template <bool WRITE>
-__global__ __launch_bounds__(EX_BLOCK) void extract_kernel(ExtractArgs a) {
-    __shared__ u32 pk[EX_TILE / 16 + 4];          // 2-bit packed bases, base 16w at bits 31:30 of word w
-    __shared__ u32 inv[EX_TILE / 32 + 2];         // 1 = base is not one of ACGTacgt (or past the end)
-    __shared__ u32 stb[EX_TILE / 32 + 2];         // 1 = some sequence starts at this position
-    __shared__ u32 seqrel[EX_TILE + EX_EXT];      // #sequences (beyond the tile's first) starting at or before p
-    __shared__ u32 wave_cnt[EX_ROUNDS][EX_BLOCK / 64];
-    __shared__ u32 scan_smem[4];
-    __shared__ u32 blk_total;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 t0 = (u64)blockIdx.x * EX_TILE;
-    const int k = a.k;
-
+// Steps 1 and 2 of a tile (shared by extract_kernel and the short-k-mer kernels of extract_short.h): the tile's bytes
+// packed into LDS (pk: 2 bits per base, inv: "not ACGTacgt" bits, both with EX_EXT positions past the tile), the
+// "some sequence starts here" bitmap stb, and seqrel[p] = number of sequences beyond the tile's first one that start
+// at or before position p.  -> index of the tile's first sequence.  Ends behind a __syncthreads().
+__device__ __forceinline__ u32 ex_load_tile(const ExtractArgs &a, const u32 tile, u32 *pk, u32 *inv, u32 *stb, u32 *seqrel,
+                                            u32 *scan_smem) {
+    const int tid = threadIdx.x;
+    const u64 t0 = (u64)tile * EX_TILE;
     // ---- 1. load + pack ---------------------------------------------------------------------------
     const bool aligned = (((uintptr_t)a.bases) & 15) == 0;
     for (int chunk = tid; chunk < (EX_TILE + EX_EXT) / 16; chunk += EX_BLOCK) {
@@ -169,7 +163,7 @@ __global__ __launch_bounds__(EX_BLOCK) void extract_kernel(ExtractArgs a) {
     __syncthreads();
 
     // ---- 2. sequence starts -> per-position sequence index ------------------------------------------
-    const u32 s_lo = a.tile_seq[blockIdx.x];
+    const u32 s_lo = a.tile_seq[tile];
     for (u64 s = (u64)s_lo + 1 + tid; s <= a.nseq; s += EX_BLOCK) {
         u64 o = a.seq_off[s];
         if (o >= t0 + EX_TILE + EX_EXT) break;
@@ -203,6 +197,26 @@ __global__ __launch_bounds__(EX_BLOCK) void extract_kernel(ExtractArgs a) {
         }
     }
     __syncthreads();
+
+    return s_lo;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(EX_BLOCK) void extract_kernel(ExtractArgs a) {
+    __shared__ u32 pk[EX_TILE / 16 + 4];          // 2-bit packed bases, base 16w at bits 31:30 of word w
+    __shared__ u32 inv[EX_TILE / 32 + 2];         // 1 = base is not one of ACGTacgt (or past the end)
+    __shared__ u32 stb[EX_TILE / 32 + 2];         // 1 = some sequence starts at this position
+    __shared__ u32 seqrel[EX_TILE + EX_EXT];      // #sequences (beyond the tile's first) starting at or before p
+    __shared__ u32 wave_cnt[EX_ROUNDS][EX_BLOCK / 64];
+    __shared__ u32 scan_smem[4];
+    __shared__ u32 blk_total;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 t0 = (u64)blockIdx.x * EX_TILE;
+    const int k = a.k;
+
+    // ---- 1 + 2. load + pack, sequence starts -> per-position sequence index -------------------------
+    const u32 s_lo = ex_load_tile(a, blockIdx.x, pk, inv, stb, seqrel, scan_smem);
 
     // ---- 3. windows -----------------------------------------------------------------------------------
     const u64 kmask = k == 32 ? ~0ull : ~(~0ull >> (2 * k));

@@ -1,0 +1,257 @@
+// extract_short.h -- the k-mers SHORTER than maxK of a variable-length build (MakeDatabase -k minK -K maxK with
+// minK < maxK; the reference's own default is -k 24 -K 32, MakeDatabase.java:106-107).
+//
+// Replaces the `ending` branch of KmersFromFileSpliterator.tryAdvance (OtherFiles/KmersFromFile.java:90-111), which
+// hands out suffixes of the sliding window, longest first, from min(pos, maxK - 1) down to minK, each one skipped on
+// its own if it holds an invalid base, in two situations:
+//   (C) the sequence line ends with pos >= minK (:128-133): the suffixes that end at the sequence's last base;
+//   (B) a full window turned out invalid (:167-176; pos > minK always holds there): the suffixes that end at the
+//       window's last base -- valid ones exist once the bad base lies at least minK bases back.
+// When the LAST full window of a sequence is invalid both fire, one after the other, and every suffix comes out
+// twice (two records: the counts double, a read k-mer holds the position twice).
+// With W = maxK, m = minK and d(e) = number of valid bases in a row that end at base e (inside the sequence):
+//   (B) at every end e of an invalid full window: lengths m .. d(e)                (d(e) < W there)
+//   (C) at the last base of a sequence of n >= m bases: lengths m .. min(d, n, W - 1)
+// Position of a suffix of length L that ends behind base e: (e + 1 - L) - sequence start, as a Java short.
+//
+// Thread p of a tile owns the full window [p, p + W) -- both situations for that window -- and, if a sequence of
+// fewer than W bases starts at p, that sequence's (C).  Everything it needs lies in [p, p + W), i.e. in the tile's
+// LDS image (extract.h).  Records leave in window order with their length beside them; kmg_build_finish sorts the
+// records of every length on their own (a fixed-length build each) and interleaves the databases by rank.
+#pragma once
+#include "extract.h"
+
+struct ShortArgs {
+    ExtractArgs e;        // k = maxK; out_keys / out_vals = the short-record buffers; tile_count / tile_off as usual
+    int min_k;
+    uint8_t *out_len;     // length of every short record
+    u64 out_base;         // records already in the buffers (earlier batches)
+};
+
+// Calls emit(key, len, pos_in_sequence, is_rc) for every short record of thread position p, in the order the reference
+// hands them out (situation B before C, longest first, forward before reverse complement).  Returns the number of
+// forward k-mers the mapper saw (before the -D / -R filters and the key range): > 0 numbers the read.
+template <typename Emit>
+__device__ __forceinline__ u32 short_records(const ShortArgs &sa, const u32 *pk, const u32 *inv, const u32 *stb,
+                                             const u32 *seqrel, u32 s_lo, u64 t0, u32 p, Emit emit) {
+    const ExtractArgs &a = sa.e;
+    const int W = a.k, m = sa.min_k;
+    const u64 gp = t0 + p;
+    if (gp >= a.nbases) return 0;
+    const u32 w = p >> 4, r = p & 15;
+    const u64 hi = ((u64)pk[w] << 32) | pk[w + 1];
+    const u64 win = (hi << (2 * r)) | ((u64)pk[w + 2] >> (32 - 2 * r));     // 32 bases from p, first in the top bits
+    const u32 w2 = p >> 5, r2 = p & 31;
+    const u64 bad = (((u64)inv[w2] << 32) | inv[w2 + 1]) << r2;             // bit 63 - i: base p + i is invalid
+    const u64 st = (((u64)stb[w2] << 32) | stb[w2 + 1]) << r2;              // bit 63 - i: a sequence starts at p + i
+    const u32 s = s_lo + seqrel[p];
+    u32 seen = 0;
+
+    // one suffix of length L of the n bases that start at p (n = W for a full window)
+    auto one = [&](int n, int L) {
+        const u64 maskn = n == 32 ? ~0ull : ~(~0ull >> (2 * n));
+        const u64 key = (win & maskn) << (2 * (n - L));
+        seen++;
+        if (a.runofsame >= 0 && !runofsame_keep(key, L, a.runofsame)) return;
+        if (a.dust >= 0 && !dust_keep(key, L, a.dust)) return;
+        const u32 pos = (u32)(gp + (u64)(n - L) - a.seq_off[s]);
+        bool ok = true;
+        if (a.ranged) {
+            const u32 fb = (u32)(key >> a.range_shift);
+            ok = fb >= a.range_lo && fb < a.range_hi;
+        }
+        if (ok) emit(key, L, pos, false);
+        if (a.rc) {
+            const u64 maskL = ~(~0ull >> (2 * L));                          // L < 32 here
+            const u64 rev = revpairs64(key >> (64 - 2 * L));
+            if (((L & 1) == 0) && rev == key) return;                        // Kmer.isOwnRC: a palindrome of even length
+            const u64 rk = rev ^ (0xAAAAAAAAAAAAAAAAull & maskL);
+            if (a.ranged) {
+                const u32 rb = (u32)(rk >> a.range_shift);
+                if (rb < a.range_lo || rb >= a.range_hi) return;
+            }
+            emit(rk, L, pos, true);
+        }
+    };
+
+    const bool inside = (W == 1 || ((st << 1) >> (65 - W)) == 0) && gp + (u64)W <= a.nbases;
+    if (inside) {
+        const u64 badW = bad >> (64 - W);
+        const int d = badW ? __ffsll((long long)badW) - 1 : W;               // valid bases in a row at the window's end
+        if (badW && d >= m)                                                  // (B): lengths d .. m
+            for (int L = d; L >= m; L--) one(W, L);
+        const bool last = gp + (u64)W == a.nbases || ((st >> (63 - W)) & 1);
+        if (last) {                                                          // (C), sequence of n >= W bases
+            const int top = d < W - 1 ? d : W - 1;
+            for (int L = top; L >= m; L--) one(W, L);
+        }
+    } else if (a.seq_off[s] == gp) {
+        // a sequence of fewer than W bases starts here: its (C), if it has at least m bases
+        const u64 n64 = a.seq_off[s + 1] - gp;
+        if (n64 >= (u64)m && n64 < (u64)W) {
+            const int n = (int)n64;
+            const u64 badn = bad >> (64 - n);
+            const int d = badn ? __ffsll((long long)badn) - 1 : n;
+            for (int L = d; L >= m; L--) one(n, L);
+        }
+    }
+    return seen;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(EX_BLOCK) void extract_short_kernel(ShortArgs sa) {
+    __shared__ u32 pk[EX_TILE / 16 + 4];
+    __shared__ u32 inv[EX_TILE / 32 + 2];
+    __shared__ u32 stb[EX_TILE / 32 + 2];
+    __shared__ u32 seqrel[EX_TILE + EX_EXT];
+    __shared__ u32 wave_cnt[EX_ROUNDS][EX_BLOCK / 64];
+    __shared__ u32 scan_smem[4];
+    __shared__ u32 blk_total;
+    const ExtractArgs &a = sa.e;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 t0 = (u64)blockIdx.x * EX_TILE;
+    const u32 s_lo = ex_load_tile(a, blockIdx.x, pk, inv, stb, seqrel, scan_smem);
+
+    // records per thread and round, exclusive over the lanes of the wave
+    u32 cnt[EX_ROUNDS], before[EX_ROUNDS];
+    u32 nfwd = 0;
+#pragma unroll
+    for (int j = 0; j < EX_ROUNDS; j++) {
+        const u32 p = j * EX_BLOCK + tid;
+        u32 c = 0, f = 0;
+        const u32 seen = short_records(sa, pk, inv, stb, seqrel, s_lo, t0, p,
+                                       [&](u64, int, u32, bool is_rc) { c++; f += is_rc ? 0u : 1u; });
+        // reads are numbered by the mapper, which runs when the k-mer is built: before the filters
+        if (!WRITE && seen && a.has_kmer) a.has_kmer[s_lo + seqrel[p]] = 1;
+        cnt[j] = c;
+        nfwd += f;
+        u32 inc = c;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const u32 o = __shfl_up(inc, dd, 64);
+            if (lane >= dd) inc += o;
+        }
+        before[j] = inc - c;
+        if (lane == 63) wave_cnt[j][wave] = inc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const u32 v = wave_cnt[tid >> 2][tid & 3];
+        u32 inc = v;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const u32 o = __shfl_up(inc, dd, 64);
+            if (lane >= dd) inc += o;
+        }
+        wave_cnt[tid >> 2][tid & 3] = inc - v;
+        if (tid == 63) blk_total = inc;
+    }
+    __syncthreads();
+    if (!WRITE) {
+        u32 tot;
+        block_scan_inclusive(nfwd, OpSum(), scan_smem, &tot);
+        if (tid == 0) {
+            a.tile_count[blockIdx.x] = blk_total;
+            a.tile_fwd[blockIdx.x] = tot;
+        }
+        return;
+    }
+    const u64 tile_base = sa.out_base + a.tile_off[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < EX_ROUNDS; j++) {
+        if (cnt[j] == 0) continue;
+        const u32 p = j * EX_BLOCK + tid;
+        const u32 s = s_lo + seqrel[p];
+        u64 slot = tile_base + wave_cnt[j][wave] + before[j];
+        short_records(sa, pk, inv, stb, seqrel, s_lo, t0, p, [&](u64 key, int L, u32 pos, bool) {
+            a.out_keys[slot] = key;
+            sa.out_len[slot] = (uint8_t)L;
+            if (a.kind == KMG_PAYLOAD_TAXON) reinterpret_cast<u32 *>(a.out_vals)[slot] = (u32)a.seq_id[s];
+            else reinterpret_cast<u64 *>(a.out_vals)[slot] = ((u64)(u32)a.read_index[s] << 16) | (u64)(pos & 0xFFFFu);
+            slot++;
+        });
+    }
+}
+
+// ---- per-length classes -----------------------------------------------------------------------------------------
+// hist[L] += number of short records of length L
+__global__ __launch_bounds__(256) void short_hist_kernel(const uint8_t *__restrict__ len, u64 n, u32 *__restrict__ hist) {
+    __shared__ u32 h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) atomicAdd(&h[len[i] & 63], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// flag[i] = record i has length L (input of the exclusive scan that places the class, in record order: stable)
+__global__ void short_flag_kernel(const uint8_t *__restrict__ len, u64 n, int L, u32 *__restrict__ flag) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = len[i] == L;
+}
+template <typename V>
+__global__ void short_gather_kernel(const uint8_t *__restrict__ len, const u32 *__restrict__ dst, u64 n, int L,
+                                    const u64 *__restrict__ keys, const V *__restrict__ vals, u64 *__restrict__ out_keys,
+                                    V *__restrict__ out_vals) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && len[i] == L) { out_keys[dst[i]] = keys[i]; out_vals[dst[i]] = vals[i]; }
+}
+
+// ---- interleaving two databases by rank ---------------------------------------------------------------------------
+// Sequence.compareTo (Kmers/Sequence.java:165-187) orders k-mers base by base, a proper prefix first: that is the
+// zero-padded packed value first (the pad symbol A = 0 is the smallest base) and the length second.  X holds shorter
+// k-mers than Y throughout, both ascending: X_i goes before Y_j iff key(X_i) <= key(Y_j).  Hence
+//   place(X_i) = i + #{ j : key(Y_j) <  key(X_i) }          place(Y_j) = j + #{ i : key(X_i) <= key(Y_j) }.
+// FROM_X: the entries of X are placed (lower bound in Y's keys), else those of Y (upper bound in X's keys).
+template <bool FROM_X>
+__global__ void il_place_kernel(const u64 *__restrict__ keys, const uint8_t *__restrict__ lens, int len_all,
+                                const u64 *__restrict__ val_off, u64 n, const u64 *__restrict__ other, u64 n_other,
+                                u64 *__restrict__ out_keys, uint8_t *__restrict__ out_lens, u32 *__restrict__ out_cnt,
+                                u64 *__restrict__ place) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 key = keys[i];
+    u64 lo = 0, hi = n_other;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        const u64 o = other[mid];
+        if (FROM_X ? o < key : o <= key) lo = mid + 1; else hi = mid;
+    }
+    const u64 at = i + lo;
+    place[i] = at;
+    out_keys[at] = key;
+    out_lens[at] = lens ? lens[i] : (uint8_t)len_all;
+    out_cnt[at] = (u32)(val_off[i + 1] - val_off[i]);
+}
+// the values of every entry to their place in the interleaved value arrays
+__global__ void il_values_kernel(const u64 *__restrict__ val_off, const int32_t *__restrict__ val_a,
+                                 const int32_t *__restrict__ val_b, u64 n, const u64 *__restrict__ place,
+                                 const u64 *__restrict__ out_off, int32_t *__restrict__ out_a, int32_t *__restrict__ out_b) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 o = out_off[place[i]];
+    for (u64 v = val_off[i]; v < val_off[i + 1]; v++, o++) { out_a[o] = val_a[v]; out_b[o] = val_b[v]; }
+}
+
+// ---- KmerUtils.restrictedStream (Kmers/KmerUtils.java:59-74) ---------------------------------------------------------
+// keep[i] = number of values of entry i if its k-mer has at least L bases, else 0
+// (lens == null: every k-mer has len_all bases)
+__global__ void rs_keep_kernel(const uint8_t *__restrict__ lens, int len_all, const u64 *__restrict__ val_off, u64 n, int L,
+                               u32 *__restrict__ keep) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keep[i] = (lens ? (int)lens[i] : len_all) >= L ? (u32)(val_off[i + 1] - val_off[i]) : 0u;
+}
+// the kept entries' values as (k-mer cut to L bases, payload) records for the merge pipeline (reduce.h, mg_*)
+__global__ void rs_expand_kernel(const u64 *__restrict__ keys, const uint8_t *__restrict__ lens, int len_all,
+                                 const u64 *__restrict__ val_off, const int32_t *__restrict__ val_a,
+                                 const int32_t *__restrict__ val_b, u64 n, int L, const u64 *__restrict__ dst, int kind,
+                                 u64 *__restrict__ out_keys, u64 *__restrict__ out_vals) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (lens ? (int)lens[i] : len_all) < L) return;
+    const u64 key = keys[i] & (L == 32 ? ~0ull : ~(~0ull >> (2 * L)));       // Kmer.limitTo (Kmer.java:277-289)
+    u64 o = dst[i];
+    for (u64 v = val_off[i]; v < val_off[i + 1]; v++, o++) {
+        out_keys[o] = key;
+        out_vals[o] = kind == KMG_PAYLOAD_TAXON ? (((u64)((u32)val_a[v] ^ 0x80000000u) << 32) | (u32)val_b[v])
+                                                : (((u64)(u32)val_a[v] << 16) | (u64)((u32)val_b[v] & 0xFFFFu));
+    }
+}

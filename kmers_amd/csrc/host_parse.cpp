@@ -259,6 +259,7 @@ int kmh_eof_in_kmer(const kmh_batch *h) { return ((const Batch *)h)->eof_in_kmer
 struct Decoded {
     std::vector<uint64_t> keys, val_off;
     std::vector<int32_t> val_a, val_b;
+    std::vector<uint8_t> lens;          // length byte of every k-mer (Kmer.compressedBytes, Kmer.java:90-97)
 };
 
 kmh_batch *kmh_decode_blocks(const uint8_t *data, uint64_t n, int kind) {
@@ -291,6 +292,7 @@ kmh_batch *kmh_decode_blocks(const uint8_t *data, uint64_t n, int kind) {
         uint64_t key = 0;
         for (int i = 0; i < l; i++) key |= (uint64_t)kb[1 + i] << (56 - 8 * i);
         d->keys.push_back(key);
+        d->lens.push_back((uint8_t)len);
         if (kind == 0) {
             if (off + 2 > n) return fail();
             const int cnt = (int16_t)((data[off] << 8) | data[off + 1]);
@@ -321,6 +323,7 @@ kmh_batch *kmh_decode_blocks(const uint8_t *data, uint64_t n, int kind) {
 void kmh_decoded_free(kmh_batch *h) { delete (Decoded *)h; }
 uint64_t kmh_decoded_nkeys(const kmh_batch *h) { return ((const Decoded *)h)->keys.size(); }
 uint64_t kmh_decoded_nvals(const kmh_batch *h) { return ((const Decoded *)h)->val_a.size(); }
+const uint8_t *kmh_decoded_lens(const kmh_batch *h) { return ((const Decoded *)h)->lens.data(); }
 const uint64_t *kmh_decoded_keys(const kmh_batch *h) { return ((const Decoded *)h)->keys.data(); }
 const uint64_t *kmh_decoded_val_off(const kmh_batch *h) { return ((const Decoded *)h)->val_off.data(); }
 const int32_t *kmh_decoded_val_a(const kmh_batch *h) { return ((const Decoded *)h)->val_a.data(); }

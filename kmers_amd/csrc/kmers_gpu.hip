@@ -5,6 +5,7 @@
 #include "scan.h"
 #include "extract.h"
 #include "extract_part.h"
+#include "extract_short.h"
 #include "radix.h"
 #include "reduce.h"
 #include "match.h"
@@ -112,6 +113,7 @@ extern "C" int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int pay
         return fail(ctx, KMG_EINVAL, "unknown payload kind");
     KMG_HIP(hipSetDevice(ctx->device));
     ctx->k = k; ctx->key_len = key_len; ctx->rc = rc ? 1 : 0; ctx->kind = payload_kind;
+    ctx->min_k = k; ctx->sh_n = 0;
     ctx->dust = -1; ctx->runofsame = -1;
     ctx->ranged = false; ctx->range_lo = 0; ctx->range_hi = 0;
     ctx->rec_upper = 0;
@@ -131,6 +133,17 @@ extern "C" int kmg_build_set_filters(kmg_ctx *ctx, int dust_threshold, int runof
     if (ctx->rec_upper) return fail(ctx, KMG_ESTATE, "filters must be set before the first kmg_build_add");
     ctx->dust = dust_threshold < 0 ? -1 : dust_threshold;
     ctx->runofsame = runofsame_length < 0 ? -1 : runofsame_length;
+    return KMG_OK;
+}
+
+extern "C" int kmg_build_set_min_k(kmg_ctx *ctx, int min_k) {
+    if (!ctx) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!ctx->building) return fail(ctx, KMG_ESTATE, "kmg_build_set_min_k before kmg_build_begin");
+    if (ctx->n_adds) return fail(ctx, KMG_ESTATE, "the shortest k-mer length must be set before the first kmg_build_add");
+    if (min_k < 1 || min_k > ctx->k) return fail(ctx, KMG_EINVAL, "min_k must lie in 1 .. k");
+    if (min_k < ctx->key_len) return fail(ctx, KMG_EUNSUPPORTED, "key_len must be <= min_k");      // Kmer.key(keyLength) of a shorter k-mer throws
+    ctx->min_k = min_k;
     return KMG_OK;
 }
 
@@ -243,7 +256,10 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     // from the upper bound: any plan is correct, a tight one fills the local sort's segments)
     const u64 short_by = std::min<u64>(nbases, nseq * (u64)(ctx->k - 1));
     const u64 expect = std::max<u64>(nbases - short_by, nbases / 16) * (ctx->rc ? 2 : 1);
-    const int plan = ctx->n_adds == 0 ? choose_pbits(expect, 2 * ctx->k) : 0;
+    // (a variable-length build takes the window-order extractor: its short k-mers add to the build state after the
+    // full windows, so the state snapshot of the fused path would be stale)
+    const bool var = ctx->min_k < ctx->k;
+    const int plan = (ctx->n_adds == 0 && !var) ? choose_pbits(expect, 2 * ctx->k) : 0;
     const bool part = plan > 0 && nbases < 0xFFFFFFF0ull / 2;
     ctx->prepart = part;
     ctx->plan_pbits = plan;
@@ -289,6 +305,23 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
             hipLaunchKernelGGL((extract_part_kernel<false, u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
         } else hipLaunchKernelGGL((extract_kernel<false>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
         hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_fwd.as<u32>(),
+                           ntiles, ctx->d_state + ST_NWIN);
+    }
+    // variable-length build: count the k-mers shorter than k (extract_short.h) -- before the reads are numbered,
+    // because a read gets its index at its first k-mer of ANY length
+    PoolBuf sh_count(ctx), sh_fwd(ctx), sh_off(ctx);
+    ShortArgs sa;
+    memset(&sa, 0, sizeof sa);
+    if (var) {
+        KMG_ALLOC(sh_count, (size_t)ntiles * 4);
+        KMG_ALLOC(sh_fwd, (size_t)ntiles * 4);
+        KMG_ALLOC(sh_off, (size_t)(ntiles + 1) * 8);
+        sa.e = a;
+        sa.min_k = ctx->min_k;
+        sa.e.tile_count = sh_count.as<u32>(); sa.e.tile_fwd = sh_fwd.as<u32>(); sa.e.tile_off = sh_off.as<u64>();
+        ProfScope ps(ctx, KP_EXTRACT_COUNT, nbases);
+        hipLaunchKernelGGL((extract_short_kernel<false>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, sa);
+        hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, sh_fwd.as<u32>(),
                            ntiles, ctx->d_state + ST_NWIN);
     }
     if (reads) {
@@ -365,6 +398,36 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases /* + records * rec_b, added at finish when N is known */);
         hipLaunchKernelGGL((extract_kernel<true>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
         hipLaunchKernelGGL(extract_advance_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, tile_off.as<u64>(), ntiles);
+    }
+    if (var) {
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, sh_count.as<u32>(), sh_off.as<u64>(), ntiles, OpSum(), 0ull,
+                                                    agg.as<u64>(), nullptr, true, KP_SCAN)));
+        u64 added = 0;
+        KMG_HIP(read_back(ctx, &added, sh_off.as<u64>() + ntiles, 8));
+        if (added) {
+            const size_t vb = val_bytes(ctx->kind);
+            if (ctx->sh_n + added > ctx->sh_cap || !ctx->sh_keys) {
+                const u64 ncap = std::max<u64>(ctx->sh_n + added, ctx->sh_cap + ctx->sh_cap / 2);
+                void *nk = nullptr, *nv = nullptr, *nl = nullptr;
+                if (ctx->pool.alloc(&nk, ncap * 8) != KMG_OK || ctx->pool.alloc(&nv, ncap * vb) != KMG_OK ||
+                    ctx->pool.alloc(&nl, ncap) != KMG_OK) {
+                    ctx->pool.release(nk); ctx->pool.release(nv); ctx->pool.release(nl);
+                    return fail(ctx, KMG_ENOMEM, "record buffer allocation failed");
+                }
+                if (ctx->sh_n) {
+                    KMG_HIP(hipMemcpyAsync(nk, ctx->sh_keys, ctx->sh_n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                    KMG_HIP(hipMemcpyAsync(nv, ctx->sh_vals, ctx->sh_n * vb, hipMemcpyDeviceToDevice, ctx->stream));
+                    KMG_HIP(hipMemcpyAsync(nl, ctx->sh_len, ctx->sh_n, hipMemcpyDeviceToDevice, ctx->stream));
+                }
+                ctx->pool.release(ctx->sh_keys); ctx->pool.release(ctx->sh_vals); ctx->pool.release(ctx->sh_len);
+                ctx->sh_keys = (u64 *)nk; ctx->sh_vals = nv; ctx->sh_len = (uint8_t *)nl; ctx->sh_cap = ncap;
+            }
+            sa.e.read_index = ridx;
+            sa.e.out_keys = ctx->sh_keys; sa.e.out_vals = ctx->sh_vals; sa.out_len = ctx->sh_len; sa.out_base = ctx->sh_n;
+            ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases + added * (9 + vb));
+            hipLaunchKernelGGL((extract_short_kernel<true>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, sa);
+            ctx->sh_n += added;
+        }
     }
     KMG_HIP(hipGetLastError());
     ctx->rec_upper = upper;
@@ -483,6 +546,7 @@ static void db_release(kmg_db *db) {
         db->foreign_use.clear();
     }
     ctx->pool.release(db->keys);
+    ctx->pool.release(db->lens);
     ctx->pool.release(db->val_off);
     ctx->pool.release(db->val_a);
     ctx->pool.release(db->val_b);
@@ -660,6 +724,204 @@ static int ensure_vals(kmg_ctx *ctx, kmg_db *db) {
     return KMG_OK;
 }
 
+// Sort + dedup the n records (keys, vals) of k-mers of db->k bases into db's CSR arrays (db->k / key_len / kind set by
+// the caller).  When the sorted payloads become a read database's value array, `vals` changes owner and is nulled.
+static int sort_reduce_class(kmg_ctx *ctx, u64 *keys, void *&vals, u32 n, bool compact, int pos_bits,
+                             const std::vector<SortPass> &payload, int pbits, bool prepart, kmg_db *db, bool *heads_done) {
+    const bool reads = db->kind == KMG_PAYLOAD_READPOS;
+    const size_t vb = compact ? 4 : val_bytes(db->kind);
+    PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx), seg(ctx), ucount(ctx);
+    SortHeads heads;
+    memset(&heads, 0, sizeof heads);
+    const u32 ntiles = n ? div_up_u64(n, RS_TILE) : 1;
+    KMG_ALLOC(totals, 64);
+    int r = KMG_OK;
+    bool in1 = false;
+    if (n > 0) {
+        if (!keys || !vals) return fail(ctx, KMG_ESTATE, "no record buffer");
+        KMG_ALLOC(k1, (size_t)n * 8);
+        KMG_ALLOC(v1, (size_t)n * vb);
+        KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
+        KMG_ALLOC(agg, (size_t)(div_up_u64((u64)RS_DIGITS * ntiles, SCAN_TILE) + 1) * 8);
+        KMG_ALLOC(seg, (((size_t)1 << pbits) + 4) * 4);
+        const int low_bit = 64 - 2 * db->k;
+        if (reads) {
+            KMG_ALLOC(ucount, (((size_t)1 << pbits) + 1) * 4);
+            heads.ucount = ucount.as<u32>();
+            if (compact) {
+                ctx->sort_as_reads = true;
+                r = hybrid_sort_records<u32>(ctx, keys, (u32 *)vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1, &heads);
+                ctx->sort_as_reads = false;
+            } else
+                r = hybrid_sort_records<u64>(ctx, keys, (u64 *)vals, k1.as<u64>(), v1.as<u64>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1, &heads);
+        }
+        else r = hybrid_sort_records<u32>(ctx, keys, (u32 *)vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1);
+    }
+    if (r == KMG_OK) {
+        const u64 *sk = in1 ? k1.as<u64>() : keys;
+        const void *sv = in1 ? v1.p : vals;
+        if (reads) {
+            r = heads.done ? reduce_read_heads(ctx, heads, n, db, totals.as<u64>())
+                           : reduce_read_keys(ctx, sk, n, db, totals.as<u64>());
+            // the sorted payload buffer changes owner: it is the DB's value array now
+            void *sorted_vals = nullptr;
+            if (in1) sorted_vals = v1.detach();
+            else if (n > 0) { sorted_vals = vals; vals = nullptr; }
+            if (compact) { db->vals_packed32 = (u32 *)sorted_vals; db->pos_bits = pos_bits; }
+            else db->vals_packed = (u64 *)sorted_vals;
+        } else r = reduce_records<u32, true>(ctx, sk, (const u32 *)sv, n, db, totals.as<u64>());
+    }
+    u64 tot[2] = {0, 0};
+    if (r == KMG_OK) {
+        hipError_t e = read_back(ctx, tot, totals.p, 16);
+        if (e != hipSuccess) { ctx->err = hipGetErrorString(e); r = KMG_EDEVICE; }
+    }
+    if (r != KMG_OK) return r;
+    db->U = tot[0];
+    db->V = tot[1];
+    if (heads_done) *heads_done = heads.done;
+    return KMG_OK;
+}
+
+// X and Y ascending, every k-mer of X shorter than every k-mer of Y (extract_short.h: interleaving by rank) -> out
+static int interleave_dbs(kmg_ctx *ctx, kmg_db *X, kmg_db *Y, kmg_db *out) {
+    KMG_TRY(ensure_vals(ctx, X));
+    KMG_TRY(ensure_vals(ctx, Y));
+    const u64 U = X->U + Y->U, V = X->V + Y->V;
+    void *p;
+    if (ctx->pool.alloc(&p, (U + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    out->keys = (u64 *)p;
+    if (ctx->pool.alloc(&p, (U + 2) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    out->val_off = (u64 *)p;
+    if (ctx->pool.alloc(&p, (V + 1) * 4) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    out->val_a = (int32_t *)p;
+    if (ctx->pool.alloc(&p, (V + 1) * 4) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    out->val_b = (int32_t *)p;
+    if (ctx->pool.alloc(&p, U + 1) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    out->lens = (uint8_t *)p;
+    PoolBuf cnt(ctx), px(ctx), py(ctx), agg(ctx);
+    KMG_ALLOC(cnt, (U + 1) * 4);
+    KMG_ALLOC(px, (X->U + 1) * 8);
+    KMG_ALLOC(py, (Y->U + 1) * 8);
+    KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
+    if (X->U)
+        hipLaunchKernelGGL((il_place_kernel<true>), dim3(div_up_u64(X->U, 256)), dim3(256), 0, ctx->stream, X->keys, X->lens, X->k,
+                           X->val_off, X->U, Y->keys, Y->U, out->keys, out->lens, cnt.as<u32>(), px.as<u64>());
+    if (Y->U)
+        hipLaunchKernelGGL((il_place_kernel<false>), dim3(div_up_u64(Y->U, 256)), dim3(256), 0, ctx->stream, Y->keys, Y->lens, Y->k,
+                           Y->val_off, Y->U, X->keys, X->U, out->keys, out->lens, cnt.as<u32>(), py.as<u64>());
+    KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt.as<u32>(), out->val_off, U, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
+                                                KP_SCAN)));
+    if (X->U)
+        hipLaunchKernelGGL(il_values_kernel, dim3(div_up_u64(X->U, 256)), dim3(256), 0, ctx->stream, X->val_off, X->val_a, X->val_b,
+                           X->U, px.as<u64>(), out->val_off, out->val_a, out->val_b);
+    if (Y->U)
+        hipLaunchKernelGGL(il_values_kernel, dim3(div_up_u64(Y->U, 256)), dim3(256), 0, ctx->stream, Y->val_off, Y->val_a, Y->val_b,
+                           Y->U, py.as<u64>(), out->val_off, out->val_a, out->val_b);
+    KMG_HIP(hipGetLastError());
+    out->U = U;
+    out->V = V;
+    return KMG_OK;
+}
+
+// bucket_off (and val_off[U]) of a database whose U and V the host knows
+static int db_make_buckets(kmg_ctx *ctx, kmg_db *db) {
+    const u32 nbuckets = 1u << (2 * db->key_len);
+    if (!db->bucket_off) {
+        void *p;
+        if (ctx->pool.alloc(&p, ((size_t)nbuckets + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+        db->bucket_off = (u64 *)p;
+    }
+    PoolBuf totals(ctx);
+    KMG_ALLOC(totals, 64);
+    hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, totals.as<u64>() + 0, (u64)db->U);
+    hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, totals.as<u64>() + 1, (u64)db->V);
+    hipLaunchKernelGGL(rd_buckets_kernel, dim3(div_up_u64(nbuckets + 1, 256)), dim3(256), 0, ctx->stream, db->keys,
+                       totals.as<u64>(), db->val_off, db->bucket_off, nbuckets, db->key_len);
+    KMG_HIP(hipGetLastError());
+    return KMG_OK;
+}
+
+// The k-mers shorter than k of a variable-length build: every length is a fixed-length build of its own (gathered in
+// emission order, so read positions stay ascending), then the databases are interleaved by rank, shortest first, the
+// full-length database last.  `full` is replaced by the interleaved database.
+static int finish_variable(kmg_ctx *ctx, std::unique_ptr<kmg_db, void (*)(kmg_db *)> &full,
+                           const std::vector<SortPass> &payload) {
+    const u64 ns = ctx->sh_n;
+    const size_t vb = val_bytes(ctx->kind);
+    u32 hist[64];
+    memset(hist, 0, sizeof hist);
+    std::unique_ptr<kmg_db, void (*)(kmg_db *)> acc(nullptr, db_release);
+    if (ns) {
+        if (ns >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 records in one build");
+        PoolBuf d_hist(ctx), flag(ctx), dst(ctx), agg(ctx);
+        KMG_ALLOC(d_hist, 64 * 4);
+        KMG_HIP(hipMemsetAsync(d_hist.p, 0, 64 * 4, ctx->stream));
+        hipLaunchKernelGGL(short_hist_kernel, dim3(std::min<u32>(div_up_u64(ns, 1024), 2048)), dim3(256), 0, ctx->stream, ctx->sh_len, ns,
+                           d_hist.as<u32>());
+        KMG_HIP(read_back(ctx, hist, d_hist.p, sizeof hist));
+        KMG_ALLOC(flag, ns * 4);
+        KMG_ALLOC(dst, (ns + 1) * 4);
+        KMG_ALLOC(agg, (size_t)(div_up_u64(ns, SCAN_TILE) + 1) * 8);
+        for (int L = ctx->min_k; L < ctx->k; L++) {
+            const u32 n = hist[L];
+            if (!n) continue;
+            PoolBuf ck(ctx), cv(ctx);
+            KMG_ALLOC(ck, (size_t)n * 8);
+            KMG_ALLOC(cv, (size_t)n * vb);
+            const dim3 grid(div_up_u64(ns, 256)), blk(256);
+            hipLaunchKernelGGL(short_flag_kernel, grid, blk, 0, ctx->stream, ctx->sh_len, ns, L, flag.as<u32>());
+            KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, flag.as<u32>(), dst.as<u32>(), ns, OpSum(), 0u, agg.as<u32>(), nullptr,
+                                                        false, KP_SCAN)));
+            if (vb == 4)
+                hipLaunchKernelGGL((short_gather_kernel<u32>), grid, blk, 0, ctx->stream, ctx->sh_len, dst.as<u32>(), ns, L, ctx->sh_keys,
+                                   (const u32 *)ctx->sh_vals, ck.as<u64>(), cv.as<u32>());
+            else
+                hipLaunchKernelGGL((short_gather_kernel<u64>), grid, blk, 0, ctx->stream, ctx->sh_len, dst.as<u32>(), ns, L, ctx->sh_keys,
+                                   (const u64 *)ctx->sh_vals, ck.as<u64>(), cv.as<u64>());
+            KMG_HIP(hipGetLastError());
+            kmg_db *c = new (std::nothrow) kmg_db();
+            if (!c) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+            std::unique_ptr<kmg_db, void (*)(kmg_db *)> cls(c, db_release);
+            c->ctx = ctx; c->k = L; c->min_k = L; c->key_len = ctx->key_len; c->rc = ctx->rc; c->kind = ctx->kind;
+            void *vals = cv.detach();
+            const u64 n_dense = ctx->ranged ? (u64)n * (1u << (2 * ctx->key_len)) / std::max<u32>(ctx->range_hi - ctx->range_lo, 1u) : n;
+            int r = sort_reduce_class(ctx, ck.as<u64>(), vals, n, false, 16, payload, choose_pbits(n_dense, 2 * L), false, c, nullptr);
+            ctx->pool.release(vals);
+            KMG_TRY(r);
+            if (!acc) acc = std::move(cls);
+            else {
+                kmg_db *m = new (std::nothrow) kmg_db();
+                if (!m) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+                std::unique_ptr<kmg_db, void (*)(kmg_db *)> merged(m, db_release);
+                m->ctx = ctx; m->k = L; m->min_k = acc->min_k; m->key_len = ctx->key_len; m->rc = ctx->rc; m->kind = ctx->kind;
+                KMG_TRY(interleave_dbs(ctx, acc.get(), c, m));
+                acc = std::move(merged);
+            }
+        }
+    }
+    kmg_db *f = full.get();
+    if (acc) {
+        kmg_db *m = new (std::nothrow) kmg_db();
+        if (!m) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+        std::unique_ptr<kmg_db, void (*)(kmg_db *)> merged(m, db_release);
+        m->ctx = ctx; m->k = ctx->k; m->key_len = ctx->key_len; m->rc = ctx->rc; m->kind = ctx->kind;
+        KMG_TRY(interleave_dbs(ctx, acc.get(), f, m));
+        KMG_TRY(db_make_buckets(ctx, m));
+        full = std::move(merged);
+        f = full.get();
+    } else {
+        // no shorter k-mer came up: the full-length database with a length beside every k-mer
+        void *p;
+        if (ctx->pool.alloc(&p, f->U + 1) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+        f->lens = (uint8_t *)p;
+        KMG_HIP(hipMemsetAsync(f->lens, ctx->k, f->U + 1, ctx->stream));
+    }
+    f->min_k = ctx->min_k;
+    KMG_HIP(hipStreamSynchronize(ctx->stream));     // the class databases go back to the pool behind this
+    return KMG_OK;
+}
+
 extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows) {
     if (!ctx || !out) return KMG_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
@@ -688,7 +950,7 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     kmg_db *db = new (std::nothrow) kmg_db();
     if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
     std::unique_ptr<kmg_db, void (*)(kmg_db *)> db_guard(db, db_release);
-    db->ctx = ctx; db->k = ctx->k; db->key_len = ctx->key_len; db->rc = ctx->rc; db->kind = ctx->kind;
+    db->ctx = ctx; db->k = ctx->k; db->min_k = ctx->k; db->key_len = ctx->key_len; db->rc = ctx->rc; db->kind = ctx->kind;
 
     // payload digits (least significant): taxa order inside a k-mer / shared read indices
     std::vector<SortPass> payload;
@@ -709,63 +971,21 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     const u64 n_dense = ctx->ranged ? (u64)n * (1u << (2 * ctx->key_len)) / std::max<u32>(ctx->range_hi - ctx->range_lo, 1u) : n;
     const int pbits = prepart ? ctx->plan_pbits : choose_pbits(n_dense, 2 * ctx->k);
 
-    PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx), seg(ctx), ucount(ctx);
-    SortHeads heads;
-    memset(&heads, 0, sizeof heads);
-    const u32 ntiles = n ? div_up_u64(n, RS_TILE) : 1;
-    KMG_ALLOC(totals, 64);
-    int r = KMG_OK;
-    bool in1 = false;
-    if (n > 0) {
-        if (!ctx->rec_keys) return fail(ctx, KMG_ESTATE, "no record buffer");
-        KMG_ALLOC(k1, (size_t)n * 8);
-        KMG_ALLOC(v1, (size_t)n * vb);
-        KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
-        KMG_ALLOC(agg, (size_t)(div_up_u64((u64)RS_DIGITS * ntiles, SCAN_TILE) + 1) * 8);
-        KMG_ALLOC(seg, (((size_t)1 << pbits) + 4) * 4);
-        const int low_bit = 64 - 2 * ctx->k;
-        if (reads) {
-            KMG_ALLOC(ucount, (((size_t)1 << pbits) + 1) * 4);
-            heads.ucount = ucount.as<u32>();
-            if (compact) {
-                ctx->sort_as_reads = true;
-                r = hybrid_sort_records<u32>(ctx, ctx->rec_keys, (u32 *)ctx->rec_vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1, &heads);
-                ctx->sort_as_reads = false;
-            } else
-                r = hybrid_sort_records<u64>(ctx, ctx->rec_keys, (u64 *)ctx->rec_vals, k1.as<u64>(), v1.as<u64>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1, &heads);
-        }
-        else r = hybrid_sort_records<u32>(ctx, ctx->rec_keys, (u32 *)ctx->rec_vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1);
-    }
-    if (r == KMG_OK) {
-        const u64 *sk = in1 ? k1.as<u64>() : ctx->rec_keys;
-        const void *sv = in1 ? v1.p : ctx->rec_vals;
-        if (reads) {
-            r = heads.done ? reduce_read_heads(ctx, heads, n, db, totals.as<u64>())
-                           : reduce_read_keys(ctx, sk, n, db, totals.as<u64>());
-            // the sorted payload buffer changes owner: it is the DB's value array now
-            void *sorted_vals;
-            if (in1) sorted_vals = v1.detach();
-            else { sorted_vals = ctx->rec_vals; ctx->rec_vals = nullptr; }
-            if (compact) { db->vals_packed32 = (u32 *)sorted_vals; db->pos_bits = pos_bits; }
-            else db->vals_packed = (u64 *)sorted_vals;
-        } else r = reduce_records<u32, true>(ctx, sk, (const u32 *)sv, n, db, totals.as<u64>());
-    }
-    u64 tot[2] = {0, 0};
-    if (r == KMG_OK) {
-        hipError_t e = read_back(ctx, tot, totals.p, 16);
-        if (e != hipSuccess) { ctx->err = hipGetErrorString(e); r = KMG_EDEVICE; }
-    }
+    bool heads_done = false;
+    int r = sort_reduce_class(ctx, ctx->rec_keys, ctx->rec_vals, n, compact, pos_bits, payload, pbits, prepart, db, &heads_done);
     // the record buffers go back to the pool: the next build (or the DB arrays of this one) reuses them
     ctx->pool.release(ctx->rec_keys);
     ctx->pool.release(ctx->rec_vals);
     ctx->rec_keys = nullptr; ctx->rec_vals = nullptr; ctx->rec_cap = 0; ctx->rec_upper = 0; ctx->compact_pb = 0;
+    if (r == KMG_OK && ctx->min_k < ctx->k) r = finish_variable(ctx, db_guard, payload);
+    ctx->pool.release(ctx->sh_keys); ctx->pool.release(ctx->sh_vals); ctx->pool.release(ctx->sh_len);
+    ctx->sh_keys = nullptr; ctx->sh_vals = nullptr; ctx->sh_len = nullptr; ctx->sh_n = 0; ctx->sh_cap = 0;
     if (r != KMG_OK) return r;
-    db->U = tot[0];
-    db->V = tot[1];
+    db = db_guard.get();
     if (ctx->prof_on)
     {
-        ctx->prof[KP_REDUCE_WRITE].bytes += db->U * (heads.done ? (8 + vb) + 16 : 16) + (reads ? 0 : db->V * 8);
-        if (heads.done) ctx->prof[KP_SORT_LOCAL_V64].bytes += db->U * (8 + vb);
+        ctx->prof[KP_REDUCE_WRITE].bytes += db->U * (heads_done ? (8 + vb) + 16 : 16) + (reads ? 0 : db->V * 8);
+        if (heads_done) ctx->prof[KP_SORT_LOCAL_V64].bytes += db->U * (8 + vb);
     }
     *out = db_guard.release();
     return KMG_OK;
@@ -781,6 +1001,19 @@ extern "C" int kmg_db_info(const kmg_db *db, int *k, int *key_len, int *rc, int 
     if (payload_kind) *payload_kind = db->kind;
     if (n_unique) *n_unique = db->U;
     if (n_values) *n_values = db->V;
+    return KMG_OK;
+}
+
+extern "C" int kmg_db_min_k(const kmg_db *db) { return db ? db->min_k : 0; }
+
+extern "C" int kmg_db_fetch_lens(const kmg_db *db, uint8_t *lens) {
+    if (!db || !lens) return KMG_EINVAL;
+    kmg_ctx *ctx = db->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    if (!db->lens) { memset(lens, db->k, db->U); return KMG_OK; }
+    if (db->U) KMG_HIP(hipMemcpyAsync(lens, db->lens, db->U, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
     return KMG_OK;
 }
 
@@ -821,7 +1054,7 @@ static int db_load_common(kmg_ctx *ctx, int k, int key_len, int rc, int payload_
     KMG_HIP(hipSetDevice(ctx->device));
     kmg_db *db = new (std::nothrow) kmg_db();
     if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
-    db->ctx = ctx; db->k = k; db->key_len = key_len; db->rc = rc ? 1 : 0; db->kind = payload_kind;
+    db->ctx = ctx; db->k = k; db->min_k = k; db->key_len = key_len; db->rc = rc ? 1 : 0; db->kind = payload_kind;
     db->U = n_unique; db->V = V;
     const u32 nbuckets = 1u << (2 * key_len);
     void *p;
@@ -895,6 +1128,41 @@ extern "C" int kmg_db_load_dev(kmg_ctx *ctx, int k, int key_len, int rc, int pay
                           hipMemcpyDeviceToDevice, out);
 }
 
+extern "C" int kmg_db_load_var(kmg_ctx *ctx, int k, int min_k, int key_len, int rc, int payload_kind, const uint64_t *keys,
+                               const uint8_t *lens, uint64_t n_unique, const uint64_t *val_off, const int32_t *val_a,
+                               const int32_t *val_b, kmg_db **out) {
+    if (!ctx || !out) return KMG_EINVAL;
+    std::unique_lock<std::mutex> g(ctx->mu);
+    *out = nullptr;
+    if (k < 1 || key_len < 1 || min_k < 1 || min_k > k) return fail(ctx, KMG_EINVAL, "k, min_k and key_len must be positive, min_k <= k");
+    if (k > 32 || key_len > min_k || key_len > 12) return fail(ctx, KMG_EUNSUPPORTED, "k > 32 or key_len > min(min_k, 12)");
+    if (!val_off || (n_unique && (!keys || !lens))) return fail(ctx, KMG_EINVAL, "null keys / lens / val_off");
+    const u64 V = val_off[n_unique];
+    if (V && (!val_a || !val_b)) return fail(ctx, KMG_EINVAL, "null values");
+    for (u64 i = 0; i < n_unique; i++) {
+        const int L = lens[i];
+        if (L < min_k || L > k) return fail(ctx, KMG_EINVAL, "k-mer length outside min_k .. k");
+        if (L < 32 && (keys[i] << (2 * L)) != 0) return fail(ctx, KMG_EINVAL, "k-mer bits behind its length must be zero");
+        // Sequence.compareTo order (Sequence.java:165-187): zero-padded value, then length
+        if (i && (keys[i - 1] > keys[i] || (keys[i - 1] == keys[i] && lens[i - 1] >= lens[i])))
+            return fail(ctx, KMG_EINVAL, "k-mers must be strictly ascending");
+    }
+    // (db_load_common checks strictly ascending keys on device arrays only: host arrays were checked above)
+    KMG_TRY(db_load_common(ctx, k, key_len, rc, payload_kind, reinterpret_cast<const u64 *>(keys), n_unique,
+                           reinterpret_cast<const u64 *>(val_off), val_a, val_b, V, hipMemcpyHostToDevice, out));
+    kmg_db *db = *out;
+    db->min_k = min_k;
+    if (min_k < k) {
+        void *p;
+        if (ctx->pool.alloc(&p, n_unique + 1) != KMG_OK) { db_release(db); *out = nullptr; return fail(ctx, KMG_ENOMEM, "device allocation failed"); }
+        db->lens = (uint8_t *)p;
+        hipError_t e = n_unique ? hipMemcpyAsync(db->lens, lens, n_unique, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { ctx->err = hipGetErrorString(e); db_release(db); *out = nullptr; return KMG_EDEVICE; }
+    }
+    return KMG_OK;
+}
+
 extern "C" int kmg_db_copy_dev(const kmg_db *db, int which, void *d_dst, uint64_t first, uint64_t count) {
     if (!db || (count && !d_dst)) return KMG_EINVAL;
     kmg_ctx *ctx = db->ctx;
@@ -935,7 +1203,7 @@ extern "C" int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint6
     KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
     ProfScope ps(ctx, KP_ENCODE, 0);
     if (U) {
-        hipLaunchKernelGGL(enc_size_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys, db->val_off, U,
+        hipLaunchKernelGGL(enc_size_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys, db->lens, db->val_off, U,
                            db->k, db->key_len, db->kind, sizes.as<u32>());
     }
     KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, sizes.as<u32>(), enc_off.as<u64>(), U, OpSum(), 0ull, agg.as<u64>(),
@@ -954,7 +1222,7 @@ extern "C" int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint6
         if (cap < total) return fail(ctx, KMG_EINVAL, "encode buffer too small");
         if (total) {
             KMG_ALLOC(d_out, total);
-            hipLaunchKernelGGL(enc_write_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys,
+            hipLaunchKernelGGL(enc_write_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys, db->lens,
                                db->val_off, db->val_a, db->val_b, U, db->k, db->key_len, db->kind, enc_off.as<u64>(),
                                d_out.as<uint8_t>());
             KMG_HIP(hipMemcpyAsync(out, d_out.p, total, hipMemcpyDeviceToHost, ctx->stream));
@@ -965,49 +1233,12 @@ extern "C" int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint6
     return KMG_OK;
 }
 
-// ------------------------------------------------------------------------------------------------ merge
-extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, kmg_db **out) {
-    if (!ctx || !dbs || !out || n_dbs < 1) return KMG_EINVAL;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    *out = nullptr;
-    const kmg_db *d0 = dbs[0];
-    u64 Vt = 0;
-    int rc = 1;
-    for (int i = 0; i < n_dbs; i++) {
-        const kmg_db *d = dbs[i];
-        if (!d || d->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
-        if (d->kind != d0->kind) return fail(ctx, KMG_EINVAL, "Files contain different datatypes");          // DB.java:36-42
-        if (d->k != d0->k || d->key_len != d0->key_len)                                                    // DB.java:57-64
-            return fail(ctx, KMG_EINVAL, "Files contains different kmer parameters (min/max length, key length or reverse complement included");
-        Vt += d->V;
-        rc &= d->rc;
-    }
-    if (Vt >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 values in the merged database");
-    KMG_HIP(hipSetDevice(ctx->device));
-    const bool reads = d0->kind == KMG_PAYLOAD_READPOS;
-    const u32 n = (u32)Vt;
-
-    kmg_db *db = new (std::nothrow) kmg_db();
-    if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
-    std::unique_ptr<kmg_db, void (*)(kmg_db *)> db_guard(db, db_release);
-    db->ctx = ctx; db->k = d0->k; db->key_len = d0->key_len; db->rc = rc; db->kind = d0->kind;
+// Second half of kmg_db_merge and kmg_db_restrict: n expanded (k-mer, payload) records in (k0, v0) -> sorted, equal
+// k-mers folded with the data type's reducer (counts add per taxon, read-position sets unite) into db's CSR arrays.
+static int merge_records(kmg_ctx *ctx, kmg_db *db, PoolBuf &k0, PoolBuf &v0, PoolBuf &k1, PoolBuf &v1, u32 n, PoolBuf &totals) {
+    const bool reads = db->kind == KMG_PAYLOAD_READPOS;
     const u32 nbuckets = 1u << (2 * db->key_len);
-
-    PoolBuf k0(ctx), v0(ctx), k1(ctx), v1(ctx), table(ctx), agg(ctx), seg(ctx), totals(ctx), fk(ctx), fp(ctx), pk(ctx), pp(ctx);
-    KMG_ALLOC(totals, 64);
-    KMG_HIP(hipMemsetAsync(totals.p, 0, 64, ctx->stream));
-    KMG_ALLOC(k0, ((size_t)n + 1) * 8); KMG_ALLOC(v0, ((size_t)n + 1) * 8);
-    KMG_ALLOC(k1, ((size_t)n + 1) * 8); KMG_ALLOC(v1, ((size_t)n + 1) * 8);
-    u64 base = 0;
-    for (int i = 0; i < n_dbs; i++) {
-        const kmg_db *d = dbs[i];
-        if (d->V == 0) continue;
-        if (reads && d->vals_packed32) KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(d)));
-        if (reads && !d->vals_packed && !d->val_a) return fail(ctx, KMG_ESTATE, "database has no values");
-        hipLaunchKernelGGL(mg_expand_kernel, dim3(div_up_u64(d->V, 256)), dim3(256), 0, ctx->stream, d->keys, d->val_off, d->U, d->V,
-                           d->val_a, d->val_b, reads ? d->vals_packed : nullptr, d->kind, k0.as<u64>(), v0.as<u64>(), base);
-        base += d->V;
-    }
+    PoolBuf table(ctx), agg(ctx), seg(ctx), fk(ctx), fp(ctx), pk(ctx), pp(ctx);
     bool in1 = false;
     if (n > 0) {
         // inside a k-mer: taxa ascending (upper payload half) | (read, pos) ascending (whole payload)
@@ -1064,6 +1295,98 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
     KMG_HIP(hipGetLastError());
     db->U = tot[0];
     db->V = tot[1];
+    return KMG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ merge
+extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, kmg_db **out) {
+    if (!ctx || !dbs || !out || n_dbs < 1) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *out = nullptr;
+    const kmg_db *d0 = dbs[0];
+    u64 Vt = 0;
+    int rc = 1;
+    for (int i = 0; i < n_dbs; i++) {
+        const kmg_db *d = dbs[i];
+        if (!d || d->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
+        if (d->kind != d0->kind) return fail(ctx, KMG_EINVAL, "Files contain different datatypes");          // DB.java:36-42
+        if (d->min_k != d->k) return fail(ctx, KMG_EUNSUPPORTED, "databases of k-mers of several lengths are merged after kmg_db_restrict");
+        if (d->k != d0->k || d->key_len != d0->key_len)                                                    // DB.java:57-64
+            return fail(ctx, KMG_EINVAL, "Files contains different kmer parameters (min/max length, key length or reverse complement included");
+        Vt += d->V;
+        rc &= d->rc;
+    }
+    if (Vt >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 values in the merged database");
+    KMG_HIP(hipSetDevice(ctx->device));
+    const bool reads = d0->kind == KMG_PAYLOAD_READPOS;
+    const u32 n = (u32)Vt;
+
+    kmg_db *db = new (std::nothrow) kmg_db();
+    if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+    std::unique_ptr<kmg_db, void (*)(kmg_db *)> db_guard(db, db_release);
+    db->ctx = ctx; db->k = d0->k; db->min_k = d0->k; db->key_len = d0->key_len; db->rc = rc; db->kind = d0->kind;
+
+    PoolBuf k0(ctx), v0(ctx), k1(ctx), v1(ctx), totals(ctx);
+    KMG_ALLOC(totals, 64);
+    KMG_HIP(hipMemsetAsync(totals.p, 0, 64, ctx->stream));
+    KMG_ALLOC(k0, ((size_t)n + 1) * 8); KMG_ALLOC(v0, ((size_t)n + 1) * 8);
+    KMG_ALLOC(k1, ((size_t)n + 1) * 8); KMG_ALLOC(v1, ((size_t)n + 1) * 8);
+    u64 base = 0;
+    for (int i = 0; i < n_dbs; i++) {
+        const kmg_db *d = dbs[i];
+        if (d->V == 0) continue;
+        if (reads && d->vals_packed32) KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(d)));
+        if (reads && !d->vals_packed && !d->val_a) return fail(ctx, KMG_ESTATE, "database has no values");
+        hipLaunchKernelGGL(mg_expand_kernel, dim3(div_up_u64(d->V, 256)), dim3(256), 0, ctx->stream, d->keys, d->val_off, d->U, d->V,
+                           d->val_a, d->val_b, reads ? d->vals_packed : nullptr, d->kind, k0.as<u64>(), v0.as<u64>(), base);
+        base += d->V;
+    }
+    KMG_TRY(merge_records(ctx, db, k0, v0, k1, v1, n, totals));
+    *out = db_guard.release();
+    return KMG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ restrict
+extern "C" int kmg_db_restrict(kmg_ctx *ctx, const kmg_db *src, int length, kmg_db **out) {
+    if (!ctx || !src || !out) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *out = nullptr;
+    if (src->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
+    if (length < src->min_k || length > src->k)                                                     // DB.java:78-81
+        return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
+    if (length < src->key_len) return fail(ctx, KMG_EINVAL, "length below the key length");
+    KMG_HIP(hipSetDevice(ctx->device));
+    KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(src)));
+    const bool reads = src->kind == KMG_PAYLOAD_READPOS;
+    const u64 U = src->U;
+    kmg_db *db = new (std::nothrow) kmg_db();
+    if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+    std::unique_ptr<kmg_db, void (*)(kmg_db *)> db_guard(db, db_release);
+    db->ctx = ctx; db->k = length; db->min_k = length; db->key_len = src->key_len; db->rc = src->rc; db->kind = src->kind;
+    PoolBuf keep(ctx), dst(ctx), agg(ctx), k0(ctx), v0(ctx), k1(ctx), v1(ctx), totals(ctx);
+    KMG_ALLOC(totals, 64);
+    KMG_HIP(hipMemsetAsync(totals.p, 0, 64, ctx->stream));
+    KMG_ALLOC(keep, (U + 1) * 4);
+    KMG_ALLOC(dst, (U + 2) * 8);
+    KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
+    u64 nkept = 0;
+    if (U) {
+        hipLaunchKernelGGL(rs_keep_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, src->lens, src->k, src->val_off, U, length,
+                           keep.as<u32>());
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, keep.as<u32>(), dst.as<u64>(), U, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
+                                                    KP_SCAN)));
+        KMG_HIP(read_back(ctx, &nkept, dst.as<u64>() + U, 8));
+    }
+    if (nkept >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 values in the restricted database");
+    const u32 n = (u32)nkept;
+    KMG_ALLOC(k0, ((size_t)n + 1) * 8); KMG_ALLOC(v0, ((size_t)n + 1) * 8);
+    KMG_ALLOC(k1, ((size_t)n + 1) * 8); KMG_ALLOC(v1, ((size_t)n + 1) * 8);
+    if (n)
+        hipLaunchKernelGGL(rs_expand_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, src->keys, src->lens, src->k, src->val_off,
+                           src->val_a, src->val_b, U, length, dst.as<u64>(), src->kind, k0.as<u64>(), v0.as<u64>());
+    KMG_HIP(hipGetLastError());
+    (void)reads;
+    KMG_TRY(merge_records(ctx, db, k0, v0, k1, v1, n, totals));
     *out = db_guard.release();
     return KMG_OK;
 }
@@ -1077,6 +1400,9 @@ static int match_locked(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, l
     // DB.java:78-81: search k-mers must have the database's length; keys are compared per key bucket
     if (search->k != ref->k || search->key_len != ref->key_len)
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
+    // DB.java:83: the quick branch takes k-mers of one length -- restrict both sides first (kmg_db_restrict)
+    if (search->min_k != search->k || ref->min_k != ref->k)
+        return fail(ctx, KMG_EUNSUPPORTED, "k-mers of several lengths: restrict the databases to one length first");
     if (search->U == 0) return KMG_OK;
     ProfScope ps(ctx, KP_MATCH, 8 * (search->U + ref->U) + 8 * search->U);
     const u32 ntiles = div_up_u64(search->U, MT_TILE);
@@ -1107,6 +1433,7 @@ extern "C" int kmg_match_keys_dev(kmg_ctx *ctx, const uint64_t *d_keys, const ui
     if (ref->ctx->device != ctx->device) return fail(ctx, KMG_EINVAL, "database belongs to another device");
     if (k != ref->k)                                                                             // DB.java:78-81
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
+    if (ref->min_k != ref->k) return fail(ctx, KMG_EUNSUPPORTED, "k-mers of several lengths: restrict the database to one length first");
     if (n_runs < 1 || n_runs > MT_MAX_RUNS) return fail(ctx, KMG_EINVAL, "between 1 and 64 runs");
     MatchRuns runs;
     memset(&runs, 0, sizeof runs);
@@ -1171,6 +1498,8 @@ extern "C" int kmg_match_dev_noalloc(kmg_ctx *ctx, const kmg_db *search, const k
     if (search->ctx != ctx || ref->ctx != ctx) return fail(ctx, KMG_EINVAL, "both databases must belong to this context");
     if (search->k != ref->k || search->key_len != ref->key_len)                                  // DB.java:78-81
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
+    if (search->min_k != search->k || ref->min_k != ref->k)
+        return fail(ctx, KMG_EUNSUPPORTED, "k-mers of several lengths: restrict the databases to one length first");
     if (search->U > (u64)KMG_MATCH_NOALLOC_MAX_SEARCH)
         return fail(ctx, KMG_EINVAL, "more search k-mers than the no-allocation join holds bounds for (KMG_MATCH_NOALLOC_MAX_SEARCH)");
     if (search->U == 0) return KMG_OK;
@@ -1221,6 +1550,8 @@ extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
         return fail(ctx, KMG_EINVAL, "database belongs to another device");
     if (search->k != ref->k || search->key_len != ref->key_len)      // DB.java:78-81
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
+    if (search->min_k != search->k || ref->min_k != ref->k)     // (the trie over several lengths shares data objects)
+        return fail(ctx, KMG_EUNSUPPORTED, "inexact search over k-mers of several lengths is not supported on the GPU path");
     if ((ref_index == nullptr) != (dist == nullptr)) return fail(ctx, KMG_EINVAL, "ref_index and dist go together");
     const u64 U = search->U;
     if (U == 0) { if (pair_off) pair_off[0] = 0; return KMG_OK; }

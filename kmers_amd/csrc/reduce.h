@@ -253,46 +253,50 @@ __global__ void rd_buckets_kernel(const u64 *__restrict__ ukeys, const u64 *__re
 // Per k-mer: [s = bytes shared with the previous compressedBytes in this bucket][compressedBytes[s:]]
 // then CountDataType.compress (Counts/CountDataType.java:31-46) or SetCompressor<ReadPos> (jar, A.4).
 __device__ __forceinline__ int enc_shared(u64 prev, u64 cur, int l) {
-    // compressedBytes = [len][packed bytes]; the length byte always matches inside a bucket
+    // compressedBytes = [len][packed bytes]; called for k-mers of equal length (the length byte matches)
     u64 x = prev ^ cur;
     int same = x == 0 ? 8 : (__clzll((long long)x) >> 3);
     if (same > l) same = l;
     return 1 + same;
 }
 
-__global__ void enc_size_kernel(const u64 *__restrict__ ukeys, const u64 *__restrict__ val_off, u64 U, int k, int key_len,
-                                int kind, u32 *__restrict__ sizes) {
+// lens (may be null: every k-mer has k bases) = the length byte of every k-mer; k-mers of different lengths share
+// nothing, their first bytes differ (FileCreator.java:244-252).
+__global__ void enc_size_kernel(const u64 *__restrict__ ukeys, const uint8_t *__restrict__ lens, const u64 *__restrict__ val_off,
+                                u64 U, int k, int key_len, int kind, u32 *__restrict__ sizes) {
     u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= U) return;
-    const int l = (k - 1) / 4 + 1;
+    const int len = lens ? lens[u] : k;
+    const int l = (len - 1) / 4 + 1;
     const int sh = 64 - 2 * key_len;
     u64 cur = ukeys[u];
     int s = 0;
     if (u > 0) {
         u64 prev = ukeys[u - 1];
-        if ((prev >> sh) == (cur >> sh)) s = enc_shared(prev, cur, l);
+        if ((prev >> sh) == (cur >> sh) && (!lens || lens[u - 1] == len)) s = enc_shared(prev, cur, l);
     }
     u64 nv = val_off[u + 1] - val_off[u];
     u64 sz = 1 + (u64)(l + 1 - s) + (kind == KMG_PAYLOAD_TAXON ? 2 + 5 * nv : 4 + 6 * nv);
     sizes[u] = (u32)sz;
 }
 
-__global__ void enc_write_kernel(const u64 *__restrict__ ukeys, const u64 *__restrict__ val_off,
+__global__ void enc_write_kernel(const u64 *__restrict__ ukeys, const uint8_t *__restrict__ lens, const u64 *__restrict__ val_off,
                                  const int32_t *__restrict__ val_a, const int32_t *__restrict__ val_b, u64 U, int k,
                                  int key_len, int kind, const u64 *__restrict__ enc_off, uint8_t *__restrict__ out) {
     u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= U) return;
-    const int l = (k - 1) / 4 + 1;
+    const int len = lens ? lens[u] : k;
+    const int l = (len - 1) / 4 + 1;
     const int sh = 64 - 2 * key_len;
     u64 cur = ukeys[u];
     int s = 0;
     if (u > 0) {
         u64 prev = ukeys[u - 1];
-        if ((prev >> sh) == (cur >> sh)) s = enc_shared(prev, cur, l);
+        if ((prev >> sh) == (cur >> sh) && (!lens || lens[u - 1] == len)) s = enc_shared(prev, cur, l);
     }
     uint8_t *p = out + enc_off[u];
     *p++ = (uint8_t)s;
-    if (s == 0) *p++ = (uint8_t)k;
+    if (s == 0) *p++ = (uint8_t)len;
     for (int i = (s == 0 ? 0 : s - 1); i < l; i++) *p++ = (uint8_t)(cur >> (56 - 8 * i));
     const u64 a = val_off[u], b = val_off[u + 1];
     const u64 nv = b - a;

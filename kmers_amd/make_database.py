@@ -3,29 +3,43 @@
 import numpy as np
 
 from . import parse
+from ._lib import KMG_EUNSUPPORTED, KmersGpuError
 from .api import FileCreator
 
 
-def make_reference_db(ctx, fasta, k=32, key_length=6, dust=None, runofsame=None, key_range=None):
-    """MakeDatabase -a -K k -k k -l key_length [-D dust] [-R runofsame].  -> KmerDatabase
+def _check_eof(pf, mode, k, min_k):
+    """A file that ends inside a sequence line: the reference hands its last k-mer out twice (KmersFromFile.java:115-123,
+    193-200).  For FASTA with k-mers of one length the record splitter reproduces that; a FASTQ cut there, or any such
+    file with minK < maxK (where suffixes follow the repeated k-mer), is refused rather than built differently."""
+    if pf.eof_in_kmer and (mode == parse.FASTQ or min_k != k):
+        raise KmersGpuError(KMG_EUNSUPPORTED, "input ends inside a sequence line (no final newline): not supported "
+                            "on the GPU path for FASTQ input or with minK < maxK")
+
+
+def make_reference_db(ctx, fasta, k=32, key_length=6, dust=None, runofsame=None, key_range=None, min_k=None):
+    """MakeDatabase -a -K k -k min_k -l key_length [-D dust] [-R runofsame] (min_k: default k).  -> KmerDatabase
     fasta: the file's bytes, or what parse.parse made of them (a build in key ranges parses once)."""
+    min_k = k if min_k is None else min_k
     pf = fasta if isinstance(fasta, parse.ParsedFile) else parse.parse(fasta, parse.FASTA, k)
+    _check_eof(pf, parse.FASTA, k, min_k)
     lens = np.diff(pf.batch.seq_off.astype(np.int64))
-    bad = np.nonzero((pf.id_ok == 0) & (lens >= k))[0]
+    bad = np.nonzero((pf.id_ok == 0) & (lens >= min_k))[0]
     if bad.size:   # Integer.parseInt throws NumberFormatException at the sequence's first k-mer
         raise ValueError("NumberFormatException: FASTA header of sequence %d is not an int" % int(bad[0]))
     fc = FileCreator(ctx, key_length, k, "ref", rc=True, dust=dust, runofsame=runofsame, key_range=key_range)
-    fc.add_kmers(pf.batch)
+    fc.add_kmers(pf.batch, min_length=min_k, max_length=k)
     db = fc.create()
     db.n_windows = fc.n_windows
     return db
 
 
-def make_read_db(ctx, fastq, k=32, key_length=6, dust=None, runofsame=None, key_range=None):
+def make_read_db(ctx, fastq, k=32, key_length=6, dust=None, runofsame=None, key_range=None, min_k=None):
     """MakeDatabase -q -r map [-D dust] [-R runofsame].  -> (KmerDatabase, read-name map lines in index order)"""
+    min_k = k if min_k is None else min_k
     pf = fastq if isinstance(fastq, parse.ParsedFile) else parse.parse(fastq, parse.FASTQ, k)
+    _check_eof(pf, parse.FASTQ, k, min_k)
     fc = FileCreator(ctx, key_length, k, "read", rc=False, dust=dust, runofsame=runofsame, key_range=key_range)
-    ridx = fc.add_kmers(pf.batch)
+    ridx = fc.add_kmers(pf.batch, min_length=min_k, max_length=k)
     db = fc.create()
     db.n_windows = fc.n_windows
     # ReadIDMapping.geNext prints a header each time a new index is handed out

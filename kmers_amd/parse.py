@@ -41,7 +41,7 @@ def _load():
         for n in ("nkeys", "nvals"):
             f = getattr(lib, "kmh_decoded_" + n)
             f.restype, f.argtypes = u64, [vp]
-        for n in ("keys", "val_off", "val_a", "val_b"):
+        for n in ("keys", "val_off", "val_a", "val_b", "lens"):
             f = getattr(lib, "kmh_decoded_" + n)
             f.restype, f.argtypes = vp, [vp]
         _lib = lib
@@ -90,16 +90,17 @@ def parse(data: bytes, mode: int, k: int) -> ParsedFile:
         lib.kmh_free(h)
 
 
-def decode_blocks(data: bytes, kind: int):
+def decode_blocks(data: bytes, kind: int, with_lens=False):
     """KmerFile's prefix-delta decode (KmerFile.java:200-250) of all key blocks back to back
-    -> (keys u64, val_off u64, val_a i32, val_b i32).  kind 0 = reference (counts), 1 = reads."""
+    -> (keys u64, val_off u64, val_a i32, val_b i32[, lens u8]).  kind 0 = reference (counts), 1 = reads."""
     lib = _load()
     h = lib.kmh_decode_blocks(data, len(data), kind)
     if not h:
         raise ValueError("malformed k-mer blocks, or k-mers longer than 32 bases (not supported on the GPU path)")
     try:
         nk, nv = lib.kmh_decoded_nkeys(h), lib.kmh_decoded_nvals(h)
-        return (_arr(lib.kmh_decoded_keys(h), nk, np.uint64), _arr(lib.kmh_decoded_val_off(h), nk + 1, np.uint64),
-                _arr(lib.kmh_decoded_val_a(h), nv, np.int32), _arr(lib.kmh_decoded_val_b(h), nv, np.int32))
+        out = (_arr(lib.kmh_decoded_keys(h), nk, np.uint64), _arr(lib.kmh_decoded_val_off(h), nk + 1, np.uint64),
+               _arr(lib.kmh_decoded_val_a(h), nv, np.int32), _arr(lib.kmh_decoded_val_b(h), nv, np.int32))
+        return out + (_arr(lib.kmh_decoded_lens(h), nk, np.uint8),) if with_lens else out
     finally:
         lib.kmh_decoded_free(h)

@@ -1269,3 +1269,114 @@ def test_bench_step_shape_two_contexts(ctx):
             torch.cuda.synchronize()
     finally:
         ctx_ref.close()
+
+
+# ---------------------------------------------------------------------------- variable-length k-mers (minK < maxK)
+def _same_var_db(got, want):
+    _same_db(got, want)
+    assert got.min_length == want.min_k and got.max_length == want.k
+    assert np.array_equal(got.lens(), want.lens)
+    assert got.encode_blocks()[0] == want.encode_blocks()[0]
+    assert np.array_equal(got.encode_blocks()[1], want.encode_blocks()[1])
+
+
+@pytest.mark.parametrize("min_k,k,key_len,seed", [(3, 5, 2, 31), (4, 8, 2, 32), (24, 32, 3, 33), (20, 31, 3, 34), (6, 7, 3, 35),
+                                                  (1, 4, 1, 36), (24, 32, 6, 37), (31, 32, 5, 38), (12, 20, 4, 39)])
+def test_variable_length_builds_match_oracle(ctx, min_k, k, key_len, seed):
+    """MakeDatabase -k min_k -K k (the reference's default is -k 24 -K 32, MakeDatabase.java:106-107): the suffixes of
+    KmersFromFile.java:90-133,167-176 next to the full windows, (k-mer, length) order (Sequence.java:165-187), a length
+    byte per record in the blocks (FileCreator.java:312-347), reads numbered at their first k-mer of any length."""
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(seed)
+    small = k <= 8
+    fa = _rand_fasta(rng, 40, 160 if not small else 60, b"AACCGTN" if small else b"ACGTacgtACGTACGTN", [5, 9, 1234567, 77])
+    fq = _rand_fastq(rng, 300, 100 if not small else 30, b"AACGTN" if small else b"ACGTACGTACGTACGTN")
+    ref = km.make_reference_db(ctx, fa, k, key_len, min_k=min_k)
+    want = OracleDB(fa, 0, k, key_len, min_k=min_k)
+    _same_var_db(ref, want)
+    assert ref.n_windows == want.n_windows
+    assert len(set(want.lens.tolist())) > 1
+    rdb, names = km.make_read_db(ctx, fq, k, key_len, min_k=min_k)
+    wantr = OracleDB(fq, 1, k, key_len, min_k=min_k)
+    _same_var_db(rdb, wantr)
+    assert names == wantr.names
+    t, m, q = km.taxa_counts(ref)                       # TaxaCounts walks every stored k-mer, whatever its length
+    ot, om, oq = want.taxacounts()
+    assert np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
+    ref.close(); rdb.close()
+
+
+def test_variable_length_edge_cases(ctx):
+    """Sequences shorter than min_k, of exactly min_k .. k bases, an invalid last window (its suffixes come out twice:
+    KmersFromFile.java:128-133 after :167-176), filters, key ranges, several add calls."""
+    import kmers_amd as km
+    from kmers_amd import parse
+    from kmers_amd.api import FileCreator
+    from oracle.c_oracle import OracleDB
+    fa = (b">1\nAC\n>2\nACG\n>3\nACGT\n>4\nACGTA\n>5\nACGTAC\n>6\nACGTACG\n>7\nACGNACGTTGCA\n>8\nACGTTGCANAC\n"
+          b">9\nNNNNNNNN\n>10\nACGTACGTNACGTACGTNACGT\n>11\nTTTTTTTTTTTTTTTTT\n>12\nACGTTGCAN\n>13\nACGTTGCANA\n")
+    for min_k, k, kl in ((3, 6, 2), (2, 6, 1), (5, 6, 2), (3, 4, 2)):
+        _same_var_db(km.make_reference_db(ctx, fa, k, kl, min_k=min_k), OracleDB(fa, 0, k, kl, min_k=min_k))
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i // 2, s, b"I" * len(s)) for i, s in enumerate(
+        [b"ACGTAC", b"ACGNACGTTGCA", b"AC", b"NNNNNN", b"ACGTTGCANAC", b"ACG", b"TTTTTTTTTT", b"ACGTN"]))
+    rdb, names = km.make_read_db(ctx, fq, 6, 2, min_k=3)
+    want = OracleDB(fq, 1, 6, 2, min_k=3)
+    _same_var_db(rdb, want)
+    assert names == want.names
+    rng = np.random.default_rng(5)
+    fa2 = _rand_fasta(rng, 200, 300, b"AAAAACCGTN", [3, 4])
+    for dust, run in ((2, None), (None, 5), (3, 6)):
+        got = km.make_reference_db(ctx, fa2, 12, 3, dust=dust, runofsame=run, min_k=7)
+        _same_var_db(got, OracleDB(fa2, 0, 12, 3, dust=-1 if dust is None else dust, runofsame=-1 if run is None else run, min_k=7))
+    for rng_ in ((0, 20), (20, 64), (64, 64)):
+        got = km.make_reference_db(ctx, fa2, 12, 3, key_range=rng_, min_k=7)
+        w = OracleDB(fa2, 0, 12, 3, key_range=rng_, min_k=7) if rng_[0] < rng_[1] else None
+        if w is not None:
+            _same_var_db(got, w)
+        else:
+            assert got.n_unique == 0
+    # the same input in three add calls
+    pf = parse.parse(fa2, parse.FASTA, 12)
+    b = pf.batch
+    fc = FileCreator(ctx, 3, 12, "ref", rc=True)
+    cuts = [0, b.nseq // 3, b.nseq // 2, b.nseq]
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        lo, hi = int(b.seq_off[a]), int(b.seq_off[e])
+        fc.add_kmers(km.SequenceBatch(b.bases[lo:hi], b.seq_off[a:e + 1] - b.seq_off[a], seq_id=b.seq_id[a:e]), min_length=7, max_length=12)
+    _same_var_db(fc.create(), OracleDB(fa2, 0, 12, 3, min_k=7))
+
+
+@pytest.mark.parametrize("min_k,k,L,key_len,seed", [(3, 6, 4, 2, 41), (3, 6, 3, 2, 42), (3, 6, 6, 2, 43), (20, 31, 25, 3, 44),
+                                                    (24, 32, 24, 6, 45), (24, 32, 32, 6, 46), (24, 32, 28, 6, 47)])
+def test_restricted_match_matches_oracle(ctx, min_k, k, L, key_len, seed):
+    """Matcher -k L -K L over variable-length databases: both sides through KmerUtils.restrictedStream
+    (KmerUtils.java:59-74; kmg_db_restrict), then the quick branch's join (DB.java:129-137)."""
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(seed)
+    small = k <= 8
+    fa = _rand_fasta(rng, 30, 300 if not small else 80, b"ACGT" * 12 + b"N" if not small else b"AACCGTN", [11, 12, 13])
+    body = b"".join(l for l in fa.split(b"\n") if not l.startswith(b">"))
+    recs = []
+    for i in range(200):
+        a = int(rng.integers(0, max(len(body) - 60, 1)))
+        sq = body[a:a + int(rng.integers(min_k, 60))]
+        recs.append(b"@q%d\n%s\n+\n%s\n" % (i, sq, b"I" * len(sq)))
+    fq = b"".join(recs)
+    ref = km.make_reference_db(ctx, fa, k, key_len, min_k=min_k)
+    rdb, _ = km.make_read_db(ctx, fq, k, key_len, min_k=min_k)
+    with pytest.raises(km.KmersGpuError):                   # DB.java:83: several lengths never take the quick branch
+        km.DB([ref]).get_nearest_kmers(rdb)
+    cref = OracleDB(fa, 0, k, key_len, min_k=min_k).restrict(L)
+    creads = OracleDB(fq, 1, k, key_len, min_k=min_k).restrict(L)
+    rref, rreads = ref.restrict(L), rdb.restrict(L)
+    _same_db(rref, cref)
+    _same_db(rreads, creads)
+    assert rref.min_length == rref.max_length == L
+    hit, nh = km.DB([rref]).get_nearest_kmers(rreads)
+    ohit, onh = creads.match(cref)
+    assert nh == onh and nh > 0 and np.array_equal(hit, ohit)
+    assert "\n".join(km.match_lines(rreads, rref, hit)) + "\n" == creads.match_lines(cref, ohit).decode()
+    with pytest.raises(km.InconsistentDataException):       # DB.java:78-81
+        ref.restrict(min_k - 1)
