@@ -27,13 +27,14 @@ def main(argv=None):
                                None if a.R is None else int(a.R), hr=a.h, passes=int(a.P or 1), limit=a.L,
                                share=None if a.G is None else tuple(int(x) for x in a.G.split("/")))
     elif prog == "Matcher":
-        for f in "idozZnL":
+        for f in "idozZnLkK":
             ap.add_argument("-" + f)
         ap.add_argument("-j", action="store_true")
         a = ap.parse_args(rest)
         if int(a.n or 0) > 2:
             raise SystemExit("inexact search with more than 2 differences stays on the Java path")
-        programs.matcher(Context(0), a.i, a.d, a.o, plain=a.Z is not None, limit=a.L, max_diff=int(a.n or 0), just=a.j)
+        programs.matcher(Context(0), a.i, a.d, a.o, plain=a.Z is not None, limit=a.L, max_diff=int(a.n or 0), just=a.j,
+                         min_k=a.k, max_k=a.K)
     elif prog == "TaxaCounts":
         for f in "do":
             ap.add_argument("-" + f)

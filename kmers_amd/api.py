@@ -247,15 +247,19 @@ class FileCreator:
                                                   _ptr(batch.seq_id), _ptr(batch.seq_tok), batch.nseq, _ptr(ridx)))
         return ridx
 
-    def add_packed(self, packed, seq_off, byte_off, seq_id):
+    def add_packed(self, packed, seq_off, byte_off, seq_id, min_length=None):
         """addKmers for 2-bit packed sequences as MakeDatabase -p reads them (kmg_build_add_packed): `packed` holds
         Sequence.cBytes of every sequence back to back; the letters are restored on the device."""
         packed = np.ascontiguousarray(packed, np.uint8)
         seq_off = np.ascontiguousarray(seq_off, np.uint64)
         byte_off = np.ascontiguousarray(byte_off, np.uint64)
         seq_id = np.ascontiguousarray(seq_id, np.int32)
+        min_length = self.max_k if min_length is None else min_length
         if self.min_k == -1:
-            self.min_k = self.max_k
+            self.min_k = min_length
+        if min_length != self.max_k and not self._min_set:
+            self.ctx.check(self.ctx.lib.kmg_build_set_min_k(self.ctx.h, int(min_length)))
+            self._min_set = True
         self.ctx.check(self.ctx.lib.kmg_build_add_packed(self.ctx.h, _ptr(packed), len(packed), _ptr(seq_off), _ptr(byte_off),
                                                          _ptr(seq_id), len(seq_id)))
 
@@ -293,10 +297,17 @@ class DB:
                     _lib.KMG_EINVAL, "Files contains different kmer parameters (min/max length, key length or "
                     "reverse complement included")
         self.files = list(files)
-        self.merged = files[0] if len(files) == 1 else merge_databases(self.files)
+        self._merged = files[0] if len(files) == 1 else None
         self.ctx = f0.ctx
         self.min_length, self.max_length, self.key_length = f0.min_length, f0.max_length, f0.key_length
         self.max_key = 4 ** self.key_length
+
+    @property
+    def merged(self):
+        """The files' k-mers as one database (merged on first use)."""
+        if self._merged is None:
+            self._merged = merge_databases(self.files)
+        return self._merged
 
     def get_max_key(self):
         return self.max_key

@@ -1,17 +1,19 @@
 // kmg_cli.cpp -- native (C++) host side of the hot path: the three reference programs that sit on it, driven
 // through the C ABI of libkmers_gpu.so, plus the on-disk container they read and write.
 //
-//   kmg Database.MakeDatabase -a|-q -i in -o out [-K k -k k] [-l keylen] [-z level | -Z] [-h] [-S maxsize] [-r readmap] [-D n] [-R n] [-t threads]
-//   kmg Database.Matcher      -i search.db -d ref.db -o out [-Z x] [-t threads]
+//   kmg Database.MakeDatabase -a|-q|-p -i in -o out [-K maxK -k minK] [-l keylen] [-z level | -Z] [-h] [-S maxsize] [-r readmap] [-D n] [-R n] [-L a-b] [-t threads] [-P passes] [-G r/n]
+//   kmg Database.Matcher      -i search.db -d ref.db -o out [-Z x] [-n 0|1|2 [-j]] [-k L -K L] [-L a-b] [-t threads]
 //   kmg Utils.TaxaCounts      -d ref.db -o out
+//   kmg Utils.CollectByRead / Utils.ReadClassifier -i in -o out;  kmg Pipeline.ReadCalls -q reads.fq -d ref.db -o calls
 //
-// Mirrors Database/MakeDatabase.java:100-185 (option letters and defaults), Database/Matcher.java:60-250
-// (-n 0 only), Utils/TaxaCounts.java:100-150 (default mode).  The container is jar IndexedFiles.* (SURVEY.md
+// Mirrors Database/MakeDatabase.java:100-185 (option letters and defaults: -K 32 -k 24 -l 6 -z 5),
+// Database/Matcher.java:60-250 (exact join; -n 1 | 2 for k-mers of one length), Utils/TaxaCounts.java:100-150
+// (default mode).  The container is jar IndexedFiles.* (SURVEY.md
 // Appendix A.1-A.3): header | gzip-member blocks | index block | footer; every key's block is its own gzip
 // member, so blocks are deflated / inflated on a thread pool and written in key order
 // (FileCreator.java:385-391 enforces that order with OrderedLatches).  Options outside the GPU path
-// (minK != maxK, k > 32, -n > 0, -p, -x) exit with status 3 so that a wrapper can fall
-// back to the Java program.  Plain C++17 + zlib; no HIP in this file.
+// (k > 32, -n > 2, a search over several k-mer lengths, -h with minK < maxK, -m, -N, -x ...) exit with status 3 so that a
+// wrapper can fall back to the Java program.  Plain C++17 + zlib; no HIP in this file.
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -54,6 +56,8 @@ const uint64_t *kmh_decoded_keys(const kmh_batch *);
 const uint64_t *kmh_decoded_val_off(const kmh_batch *);
 const int32_t *kmh_decoded_val_a(const kmh_batch *);
 const int32_t *kmh_decoded_val_b(const kmh_batch *);
+const uint8_t *kmh_decoded_lens(const kmh_batch *);
+int kmh_eof_in_kmer(const kmh_batch *);
 }
 
 namespace {
@@ -370,6 +374,10 @@ struct DatabaseWriter {
 
 void DatabaseWriter::add(const kmg_db *db, size_t key_lo, size_t key_hi) {
     const DbInfo d = db_info(db);
+    const int min_k = kmg_db_min_k(db);
+    // (FileCreator.diff, FileCreator.java:234-242, runs off the end of the shorter of two k-mers where one is a prefix
+    // of the other: the reference itself throws on such a database)
+    if (hr && min_k != d.k) throw Unsupported("human-readable databases (-h) hold k-mers of one length on the GPU path");
     const size_t nkeys = (size_t)1 << (2 * d.key_len);
     std::vector<uint8_t> bytes;
     std::vector<uint64_t> off(nkeys + 1);
@@ -379,7 +387,7 @@ void DatabaseWriter::add(const kmg_db *db, size_t key_lo, size_t key_hi) {
         g.check(kmg_db_encode(g.ctx, db, nullptr, 0, &nbytes, nullptr));
         bytes.resize(std::max<uint64_t>(nbytes, 1));
         g.check(kmg_db_encode(g.ctx, db, bytes.data(), nbytes, &nbytes, off.data()));
-        meta.push_back((char)d.k); meta.push_back((char)d.k); meta.push_back((char)d.key_len);   // FileCreator.java:153-164
+        meta.push_back((char)min_k); meta.push_back((char)d.k); meta.push_back((char)d.key_len); // FileCreator.java:153-164
         if (d.kind == KMG_PAYLOAD_TAXON) { put_be32(meta, 1); put_be32(meta, 2048); }             // CountDataType.java:115-121
         else { put_be32(meta, 2); put_be32(meta, 257); put_be32(meta, 2052); }                    // SetCompressor ++ ReadPosDataType
         meta.push_back((char)(d.rc ? 1 : 0));
@@ -541,7 +549,7 @@ kmg_db *load_database(const Gpu &g, const IndexedInputFile &f, const std::string
     std::vector<uint32_t> ids(nid);
     for (uint32_t i = 0; i < nid; i++) ids[i] = get_be32((const uint8_t *)m.data() + 7 + 4 * i);
     const int rc = m[7 + 4 * nid] == 1;
-    if (min_k != max_k || max_k > 32) throw Unsupported("minK != maxK or k > 32: use the Java path");
+    if (max_k > 32) throw Unsupported("k > 32: use the Java path");
     int kind;
     if (ids == std::vector<uint32_t>{2048}) kind = KMG_PAYLOAD_TAXON;
     else if (ids == std::vector<uint32_t>{257, 2052}) kind = KMG_PAYLOAD_READPOS;
@@ -566,11 +574,15 @@ kmg_db *load_database(const Gpu &g, const IndexedInputFile &f, const std::string
     }
     std::vector<uint64_t> keys, val_off;
     std::vector<int32_t> va, vb;
+    std::vector<uint8_t> lens;
+    const bool var = min_k != max_k;
     if (!bad) {
         keys.resize(kbase[nk] + 1); val_off.resize(kbase[nk] + 1); va.resize(vbase[nk] + 1); vb.resize(vbase[nk] + 1);
+        if (var) lens.resize(kbase[nk] + 1);
         parallel_for(nk, [&](size_t i) {
             const uint64_t n = kmh_decoded_nkeys(dec[i]), v = kmh_decoded_nvals(dec[i]);
             if (n) memcpy(&keys[kbase[i]], kmh_decoded_keys(dec[i]), n * 8);
+            if (n && var) memcpy(&lens[kbase[i]], kmh_decoded_lens(dec[i]), n);
             const uint64_t *o = kmh_decoded_val_off(dec[i]);
             for (uint64_t j = 0; j < n; j++) val_off[kbase[i] + j] = vbase[i] + o[j];
             if (v) {
@@ -583,7 +595,11 @@ kmg_db *load_database(const Gpu &g, const IndexedInputFile &f, const std::string
     for (auto d : dec) if (d) kmh_decoded_free(d);
     if (bad) throw std::runtime_error("corrupt k-mer blocks (or k > 32): " + path);
     kmg_db *db = nullptr;
-    g.check(kmg_db_load(g.ctx, max_k, key_len, rc, kind, keys.data(), kbase[nk], val_off.data(), va.data(), vb.data(), &db));
+    if (var)
+        g.check(kmg_db_load_var(g.ctx, max_k, min_k, key_len, rc, kind, keys.data(), lens.data(), kbase[nk], val_off.data(), va.data(),
+                                vb.data(), &db));
+    else
+        g.check(kmg_db_load(g.ctx, max_k, key_len, rc, kind, keys.data(), kbase[nk], val_off.data(), va.data(), vb.data(), &db));
     return db;
 }
 
@@ -657,7 +673,7 @@ struct StageClock {
 // MakeDatabase -p (MakeDatabase.java:186-237,320-420): the input is the IndexedFile OtherFiles.SeqToTaxID writes --
 // String keys, blocks of (taxid, Sequence) records, binary [int taxid][int length][2 bits per base] or
 // human-readable lines `taxid ~ SEQUENCE` -- and every window of every sequence goes into one reference database.
-int make_database_preprocessed(const Args &a, int k, int key_len, int level) {
+int make_database_preprocessed(const Args &a, int k, int min_k, int key_len, int level) {
     StageClock clk(a.has('v'));
     IndexedInputFile in(a.get('i'));
     if (!in.string_keys) throw std::runtime_error("not a preprocessed file (its keys are not strings): " + a.get('i'));
@@ -710,6 +726,10 @@ int make_database_preprocessed(const Args &a, int k, int key_len, int level) {
     Gpu g;
     g.check(kmg_build_begin(g.ctx, k, key_len, 1, KMG_PAYLOAD_TAXON));
     if (a.has('D') || a.has('R')) g.check(kmg_build_set_filters(g.ctx, a.geti('D', -1), a.geti('R', -1)));
+    // PreProcessedSpliterator with minK < maxK (MakeDatabase.java:393-404) hands out from every start the k-mer of
+    // min(maxK, bases left) bases: every window plus the suffixes of length maxK-1 .. minK at the sequence's end --
+    // what the text path yields for the same, all-valid, sequence
+    if (min_k != k) g.check(kmg_build_set_min_k(g.ctx, min_k));
     if (!ids.empty()) {
         if (in.hr)
             g.check(kmg_build_add(g.ctx, (const uint8_t *)bases.data(), bases.size(), off.data(), ids.data(), nullptr, ids.size(), nullptr));
@@ -733,17 +753,24 @@ int make_database_preprocessed(const Args &a, int k, int key_len, int level) {
 // (kmg_build_set_key_range), each handed to per_pass(db, first key, end key) and freed; returns NULL then.
 kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int key_len, bool filters, int dust, int runofsame,
                         const std::string &read_map, uint64_t *n_reads, uint64_t *nwin, StageClock &clk, int passes = 1,
-                        const std::function<void(kmg_db *, size_t, size_t)> &per_pass = nullptr, int share = 0, int shares = 1) {
+                        const std::function<void(kmg_db *, size_t, size_t)> &per_pass = nullptr, int share = 0, int shares = 1,
+                        int min_k = 0) {
+    if (min_k <= 0) min_k = k;
     const std::string data = read_input(path);
     clk.lap("read input");
     const std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch(kmh_parse((const uint8_t *)data.data(), data.size(), reads ? 1 : 0, k), kmh_free);
     const kmh_batch *b = batch.get();
     const uint64_t nseq = kmh_nseq(b);
     const uint64_t *off = kmh_seq_off(b);
+    // A file that ends inside a sequence line: the reference hands its last k-mer out twice (KmersFromFile.java:115-123,
+    // 193-200).  For FASTA with k-mers of one length the record splitter reproduces that; a FASTQ cut there, or any such
+    // file with minK < maxK (where suffixes follow the repeated k-mer), is refused rather than built differently.
+    if (kmh_eof_in_kmer(b) && (reads || min_k != k))
+        throw Unsupported("input ends inside a sequence line (no final newline): not supported on the GPU path for FASTQ input or with minK < maxK");
     if (!reads) {
         const uint8_t *ok = kmh_id_ok(b);
         for (uint64_t s = 0; s < nseq; s++)   // Integer.parseInt throws at the sequence's first k-mer
-            if (!ok[s] && off[s + 1] - off[s] >= (uint64_t)k)
+            if (!ok[s] && off[s + 1] - off[s] >= (uint64_t)min_k)
                 throw std::runtime_error("NumberFormatException: FASTA header of sequence " + std::to_string(s) + " is not an int");
     }
     clk.lap("split records (host)");
@@ -760,6 +787,7 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
         if (hi <= lo) continue;
         g.check(kmg_build_begin(g.ctx, k, key_len, reads ? 0 : 1, reads ? KMG_PAYLOAD_READPOS : KMG_PAYLOAD_TAXON));
         if (filters) g.check(kmg_build_set_filters(g.ctx, dust, runofsame));
+        if (min_k != k) g.check(kmg_build_set_min_k(g.ctx, min_k));
         if (ranged) g.check(kmg_build_set_key_range(g.ctx, (uint32_t)lo, (uint32_t)hi));
         g.check(kmg_build_add(g.ctx, kmh_bases(b), kmh_nbases(b), off, reads ? nullptr : kmh_seq_id(b),
                               reads ? kmh_seq_tok(b) : nullptr, nseq, reads ? ridx.data() : nullptr));
@@ -805,12 +833,13 @@ int make_database(int argc, char **argv) {
     const int k = a.geti('K', 32), min_k = a.geti('k', 24), key_len = a.geti('l', 6);     // MakeDatabase.java:106-109
     const int level = a.has('Z') ? -1 : a.geti('z', 5);
     g_threads = std::max(1, a.geti('t', g_threads));
-    if (min_k != k) throw Unsupported("minK != maxK is not supported on the GPU path");
+    if (min_k > k) throw std::runtime_error("-k (shortest k-mer) above -K (longest)");
+    if (min_k != k && a.has('h')) throw Unsupported("human-readable databases (-h) hold k-mers of one length on the GPU path");
     if ((int)a.has('a') + (int)a.has('q') + (int)a.has('p') != 1)
         throw std::runtime_error("exactly one of -a (FASTA reference) / -q (FASTQ reads) / -p (preprocessed) is required");
     if (!a.has('i') || !a.has('o')) throw std::runtime_error("-i and -o are required");
     if (a.has('p') && (a.has('P') || a.has('G'))) throw std::runtime_error("-P and -G go with -a / -q");
-    if (a.has('p')) return make_database_preprocessed(a, k, key_len, level);
+    if (a.has('p')) return make_database_preprocessed(a, k, min_k, key_len, level);
     const bool reads = a.has('q');
     if (reads && !a.has('r')) throw std::runtime_error("-r <read map file> is required with -q");   // MakeDatabase.java:172-173
     StageClock clk(a.has('v'));
@@ -838,7 +867,7 @@ int make_database(int argc, char **argv) {
         w.add(part, lo, hi);
     };
     kmg_db *db = build_from_text(g, a.get('i'), reads, k, key_len, a.has('D') || a.has('R'), a.geti('D', -1), a.geti('R', -1),
-                                 reads && share == 0 ? a.get('r') : "", nullptr, &nwin, clk, passes, emit, share, shares);
+                                 reads && share == 0 ? a.get('r') : "", nullptr, &nwin, clk, passes, emit, share, shares, min_k);
     if (db) {
         emit(db, 0, (size_t)1 << (2 * key_len));
         kmg_db_free(db);
@@ -979,10 +1008,31 @@ int matcher(int argc, char **argv) {
         // reference stays loaded then and only the search side is walked in slices)
         if (max_diff > 0 && !ref_whole) ref_whole = ref_set.load(g);
         kmg_db *ref = max_diff > 0 ? ref_whole : ref_set.load(g, lo, hi), *search = search_set.load(g, lo, hi);
+        // -k / -K default to the search file's lengths (Matcher.java:147-148).  One length L: both sides go through
+        // KmerUtils.restrictedStream (KmerFile.allRestrictedKmers, Matcher.java:241; DB.java:134) -- kmg_db_restrict --
+        // and take the exact join.  A search over several lengths is the trie (DB.java:83): Java path.
+        {
+            const DbInfo s0 = db_info(search), r0 = db_info(ref);
+            const int s_min = kmg_db_min_k(search), r_min = kmg_db_min_k(ref);
+            const int want_min = a.geti('k', s_min), want_max = a.geti('K', s0.k);
+            if (want_min != want_max) throw Unsupported("a search over k-mers of several lengths (-k < -K) stays on the Java path");
+            if (want_min < r_min || want_max > r0.k)                                                  // DB.java:78-81
+                throw std::runtime_error("InconsistentDataException: Search kmers contain kmers of a length inconsistent with the database");
+            if (s_min != s0.k || s0.k != want_min) {
+                kmg_db *cut = nullptr;
+                g.check(kmg_db_restrict(g.ctx, search, want_min, &cut));
+                kmg_db_free(search);
+                search = cut;
+            }
+            if (r_min != r0.k || r0.k != want_min) {
+                if (max_diff > 0) throw Unsupported("inexact search over a database of several k-mer lengths stays on the Java path");
+                kmg_db *cut = nullptr;
+                g.check(kmg_db_restrict(g.ctx, ref, want_min, &cut));
+                kmg_db_free(ref);
+                ref = cut;
+            }
+        }
         const DbInfo rd = db_info(ref), sd = db_info(search);
-        // -k / -K default to the search file's lengths (Matcher.java:147-148); anything else restricts the k-mers to
-        // other lengths (KmerUtils.restrictedStream), which is the variable-length path
-        if (a.geti('k', sd.k) != sd.k || a.geti('K', sd.k) != sd.k) throw Unsupported("-k / -K other than the files' k-mer length");
         if (!rd.rc)   // DB.java:57-64
             throw std::runtime_error("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included");
         std::vector<int64_t> hit(sd.U + 1);

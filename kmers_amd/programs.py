@@ -15,7 +15,7 @@ import numpy as np
 from . import container, parse
 from .api import (DB, KmerDatabase, KmersGpuError, READ_ID, REF_ID, classify_reads, collect_by_read_blocks, kmer_strings,
                   match_lines, merge_databases, read_call_blocks, taxa_count_lines)
-from ._lib import KMG_EUNSUPPORTED, PAYLOAD_READPOS, PAYLOAD_TAXON
+from ._lib import KMG_EINVAL, KMG_EUNSUPPORTED, InconsistentDataException, PAYLOAD_READPOS, PAYLOAD_TAXON
 from .make_database import make_read_db, make_reference_db
 
 
@@ -34,6 +34,10 @@ def write_database(db: KmerDatabase, path, zip_level=5, hr=False, out=None, key_
     (FileCreator.java:166-179, 234-242, 349-370), text index.
     out / key_range: append the blocks of keys [first, end) to an open file instead (a database built in key
     ranges, one call per range in ascending order; the first call writes the meta block, the caller closes)."""
+    if hr and db.min_length != db.max_length:
+        # (FileCreator.diff, FileCreator.java:234-242, runs off the end of the shorter of two k-mers where one is a
+        # prefix of the other: the reference itself throws on such a database)
+        raise KmersGpuError(KMG_EUNSUPPORTED, "human-readable databases (-h) hold k-mers of one length on the GPU path")
     part = out is not None
     first, end = key_range if key_range is not None else (0, 4 ** db.key_length)
     if with_meta is None:
@@ -130,16 +134,16 @@ def open_database(ctx, path, key_range=None) -> KmerDatabase:
     if f.hr:
         return _read_hr_database(ctx, f, first, last)
     min_k, max_k, key_len, ids, rc = read_meta(f)
-    if min_k != max_k or max_k > 32:
-        raise KmersGpuError(KMG_EUNSUPPORTED, "minK != maxK or k > 32: use the Java path")
+    if max_k > 32:
+        raise KmersGpuError(KMG_EUNSUPPORTED, "k > 32: use the Java path")
     if ids == REF_ID:
         kind = PAYLOAD_TAXON
     elif ids == READ_ID:
         kind = PAYLOAD_READPOS
     else:
         raise ValueError("UnexpectedDataTypeException: %s" % path)       # KmerFile.java:30-33
-    keys, val_off, val_a, val_b = parse.decode_blocks(f.read_keys(first, last), kind)
-    return KmerDatabase.load(ctx, max_k, key_len, rc, kind, keys, val_off, val_a, val_b)
+    keys, val_off, val_a, val_b, lens = parse.decode_blocks(f.read_keys(first, last), kind, with_lens=True)
+    return KmerDatabase.load(ctx, max_k, key_len, rc, kind, keys, val_off, val_a, val_b, lens=lens, min_length=min_k)
 
 
 _UNPACK = np.array([[65, 67, 84, 71][(b >> s) & 3] for b in range(256) for s in (6, 4, 2, 0)], np.uint8).reshape(256, 4)
@@ -200,14 +204,16 @@ def read_preprocessed(path, packed=False, limit=None):
 def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length=6, zip_level=5, read_map_path=None,
                   dust=None, runofsame=None, hr=False, passes=1, limit=None, share=None):
     """MakeDatabase -a (mode 'a') / -q (mode 'q') / -p (mode 'p', preprocessed input).  Defaults as the reference's
-    (-K 32 -k 24 -l 6 -z 5, MakeDatabase.java:106-109); minK != maxK is refused (GPU path limit).
+    (-K 32 -k 24 -l 6 -z 5, MakeDatabase.java:106-109); min_k < k builds k-mers of every length min_k .. k.
     passes > 1 (-P, no counterpart in the reference; modes 'a' and 'q'): the database is built and written in that many
     key ranges, one after the other -- the same file, for inputs that do not fit one build; returns None then.
     share = (r, n) (-G r/n, no counterpart either): this process builds the r-th of n equal key ranges and writes it as
     <output>.<r+1>: n processes, one per GPU, no communication, and the files are a database set as the reference reads
     it (name.1 .. name.N, Matcher.java:80-89); the read map is written by share 0."""
-    if min_k != k:
-        raise KmersGpuError(KMG_EUNSUPPORTED, "minK != maxK is not supported on the GPU path")
+    if min_k > k:
+        raise ValueError("-k (shortest k-mer) above -K (longest)")
+    if hr and min_k != k:
+        raise KmersGpuError(KMG_EUNSUPPORTED, "human-readable databases (-h) hold k-mers of one length on the GPU path")
     if (passes > 1 or share is not None) and mode in ("a", "q"):
         from . import parse
         if mode == "q" and read_map_path is None:
@@ -223,9 +229,9 @@ def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length
         for ps in range(passes):
             rng = (r_lo + (r_hi - r_lo) * ps // passes, r_lo + (r_hi - r_lo) * (ps + 1) // passes)
             if mode == "a":
-                db = make_reference_db(ctx, pf, k, key_length, dust, runofsame, key_range=rng)
+                db = make_reference_db(ctx, pf, k, key_length, dust, runofsame, key_range=rng, min_k=min_k)
             else:
-                db, names = make_read_db(ctx, pf, k, key_length, dust, runofsame, key_range=rng)
+                db, names = make_read_db(ctx, pf, k, key_length, dust, runofsame, key_range=rng, min_k=min_k)
             write_database(db, output_path, zip_level, hr, out=out, key_range=rng, with_meta=ps == 0)
             db.close()
         out.close()
@@ -238,22 +244,25 @@ def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length
         # MakeDatabase.java:186-237: reference payload, reverse complements included, every index of the input
         from .api import FileCreator
         fc = FileCreator(ctx, key_length, k, "ref", rc=True, dust=dust, runofsame=runofsame)
+        # (PreProcessedSpliterator with minK < maxK, MakeDatabase.java:393-404, hands out from every start the k-mer of
+        # min(maxK, bases left) bases: every window plus the suffixes of length maxK-1 .. minK at the sequence's end --
+        # what the text path yields for the same, all-valid, sequence)
         got = read_preprocessed(input_path, packed=True, limit=limit)
         if isinstance(got, tuple):                       # binary file: the packed bases go to the device as they are
             if len(got[3]):
-                fc.add_packed(*got)
+                fc.add_packed(*got, min_length=min_k)
         else:
-            fc.add_kmers(got)
+            fc.add_kmers(got, min_length=min_k, max_length=k)
         db = fc.create()
         write_database(db, output_path, zip_level, hr)
         return db
     data = open(input_path, "rb").read()
     if mode == "a":
-        db = make_reference_db(ctx, data, k, key_length, dust, runofsame)
+        db = make_reference_db(ctx, data, k, key_length, dust, runofsame, min_k=min_k)
     elif mode == "q":
         if read_map_path is None:      # new File(null) -> NullPointerException in the reference (:172-173)
             raise ValueError("-r <read map file> is required with -q")
-        db, names = make_read_db(ctx, data, k, key_length, dust, runofsame)
+        db, names = make_read_db(ctx, data, k, key_length, dust, runofsame, min_k=min_k)
         with gzip.open(read_map_path, "wt") as g:
             for nm in names:
                 g.write(nm + "\n")
@@ -263,9 +272,12 @@ def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length
     return db
 
 
-def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max_diff=0, just=False):
+def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max_diff=0, just=False, min_k=None, max_k=None):
     """Matcher with -n 0: one line per matched search k-mer, ascending (Matcher.java:235-250); output is
-    gzip at the default level unless plain (-Z x).  limit = "start" or "start-end" (-L, Matcher.java:159-171): only
+    gzip at the default level unless plain (-Z x).  min_k / max_k = -k / -K, by default the search file's lengths
+    (Matcher.java:147-148): with one length L both sides go through KmerUtils.restrictedStream (KmerFile.java:80-83,
+    DB.java:134; kmg_db_restrict) and take the exact join; a search over several lengths is the trie (DB.java:83),
+    which stays on the Java path.  limit = "start" or "start-end" (-L, Matcher.java:159-171): only
     the search k-mers of keys start .. end; a k-mer and its match share their key, so the same slice of the
     reference is all that is loaded."""
     key_range = None
@@ -280,6 +292,16 @@ def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max
     # k-mer's (KmerUtils.getCloseKeys), so -L then limits the search side only
     db = DB([open_database(ctx, f, key_range if max_diff == 0 else None) for f in dbfiles])
     searches = [open_database(ctx, f, key_range) for f in sfiles]
+    min_k = searches[0].min_length if min_k is None else int(min_k)
+    max_k = searches[0].max_length if max_k is None else int(max_k)
+    if min_k != max_k:
+        raise KmersGpuError(KMG_EUNSUPPORTED, "a search over k-mers of several lengths (-k < -K) stays on the Java path")
+    if min_k < db.min_length or max_k > db.max_length:          # DB.java:78-81
+        raise InconsistentDataException(KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database")
+    if any(s.min_length != s.max_length or s.k != min_k for s in searches):
+        searches = [s.restrict(min_k) for s in searches]        # KmerFile.allRestrictedKmers (Matcher.java:241)
+    if db.min_length != db.max_length or db.max_length != min_k:
+        db = DB([f.restrict(min_k) for f in db.files])          # DB.java:134, per key; the files' k-mers merged after
     search = searches[0] if len(searches) == 1 else merge_databases(searches)   # Matcher.java:111-128 via KmerUtils
     if max_diff > 0:        # -n [-j]: DB.getNearestKmers' other branch, k-mers of one length (kmg_match_near)
         from .api import near_match_lines

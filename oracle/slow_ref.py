@@ -1019,6 +1019,34 @@ def preprocessed_kmers_as_fasta(groups):
     return b"".join(b">%d\n%s\n" % (t, s.encode()) for key in sorted(groups) for t, s in groups[key])
 
 
+def preprocessed_kmers(groups, min_k, max_k):
+    """PreProcessedSpliterator.tryAdvance (MakeDatabase.java:358-407), literally, over every index of the input in
+    turn (MakeDatabase.java:192-237): sequences shorter than minK are skipped; from every start the k-mer of
+    min(maxK, bases left) bases, until fewer than minK bases are left.  -> [(Kmer, taxid)] in stream order."""
+    code = {"A": 0, "C": 1, "T": 2, "G": 3}
+    out = []
+    for key in sorted(groups):
+        records = iter(groups[key])
+        curseq, curid, curstart = None, None, 0
+        while True:
+            done = False
+            while curseq is None or len(curseq) < min_k:          # :361-391
+                nxt = next(records, None)
+                if nxt is None:
+                    done = True
+                    break
+                curid, curseq, curstart = nxt[0], nxt[1], 0
+            if done:
+                break
+            end = min(curstart + max_k, len(curseq))              # :393-396
+            piece = curseq[curstart:end]
+            curstart += 1
+            if len(curseq) - curstart < min_k:                    # :399-402
+                curseq = None
+            out.append((Kmer([code[c] for c in piece.upper()]), curid))   # Kmer.createUnchecked(raw codes)
+    return out
+
+
 def hr_database_blocks(k, key_len, rc, kind, keys, val_off, val_a, val_b, bucket_off):
     """The blocks FileCreator.create writes with hr = true (MakeDatabase -h), from a database's CSR arrays:
     meta = minK, maxK, keyLength, Compressor.getStringID(id), rc as text lines (FileCreator.java:166-179); per

@@ -48,6 +48,46 @@ def make_inputs(seed, ng, glen, nr, rlen, alphabet, paired):
     return fa, b"".join(recs)
 
 
+# variable-length k-mers (MakeDatabase -k minK -K maxK; the reference's defaults are -k 24 -K 32, MakeDatabase.java:106-107)
+VAR_CASES = [
+    # name, minK, maxK, key_len, restricted length of the match (Matcher -k L -K L), seed, fasta alphabet
+    ("default_k24_32", 24, 32, 3, 27, 201, b"ACGTACGTACGTACGTN"),
+    ("short_k3_6", 3, 6, 2, 4, 202, b"AACCGTN"),
+]
+
+
+def main_var():
+    for name, mn, mx, l, L, seed, alphabet in VAR_CASES:
+        fa, fq = make_inputs(seed, 3, 260, 30, 70, alphabet, True)
+        first = fa.split(b"\n")[1]
+        fa += b">9\n%s\n>9\n%s\n" % (first[:mx - 2], first[5:5 + mn])      # sequences of maxK-2 and of minK bases
+        ref = R.build_ref_db(fa, mx, l, min_k=mn)
+        reads, names = R.build_read_db(fq, mx, l, min_k=mn)
+        db = R.DB([ref])
+        lines = R.match_lines(reads, db, min_k=L, max_k=L)
+        counts = R.taxa_counts(db)
+        c_ref, c_reads = OracleDB(fa, 0, mx, l, min_k=mn), OracleDB(fq, 1, mx, l, min_k=mn)
+        assert c_ref.encode_blocks()[0] == b"".join(ref[key] for key in range(4 ** l)), name
+        assert c_reads.encode_blocks()[0] == b"".join(reads[key] for key in range(4 ** l)) and c_reads.names == names, name
+        cr, cs = c_ref.restrict(L), c_reads.restrict(L)
+        hit, _ = cs.match(cr)
+        assert cs.match_lines(cr, hit).decode().splitlines() == lines and len(lines) > 20, name
+        t, m, q = c_ref.taxacounts()
+        assert ["%d\t%d\t%d" % x for x in zip(t, m, q)] == counts, name
+        out = {
+            "comment": "outputs of oracle/slow_ref.py (restatement of the reference), not of Kmers.jar; see make_golden.py",
+            "min_k": mn, "k": mx, "key_len": l, "restrict": L, "fasta": fa.decode(), "fastq": fq.decode(),
+            "ref_blocks": {str(key): ref[key].hex() for key in sorted(ref)},
+            "read_blocks": {str(key): reads[key].hex() for key in sorted(reads)},
+            "read_names": names, "match_lines_restricted": lines, "taxa_counts": counts,
+        }
+        path = os.path.join(ROOT, "tests", "golden", "var_%s.json" % name)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=0, sort_keys=True)
+            f.write("\n")
+        print(name, len(lines), "match lines,", os.path.getsize(path), "bytes")
+
+
 def main():
     for name, k, l, seed, ng, glen, nr, rlen, alphabet, dust, run, paired in CASES:
         fa, fq = make_inputs(seed, ng, glen, nr, rlen, alphabet, paired)
@@ -88,3 +128,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main_var()

@@ -52,7 +52,12 @@ def test_native_cli_builds_and_refuses_what_is_off_the_gpu_path():
     assert os.path.exists(kmg)
     run = lambda *a: subprocess.run([kmg] + list(a), capture_output=True, text=True, timeout=60)
     assert run().returncode == 1
-    assert run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y").returncode == 3          # default -k 24 != -K 32
+    # the reference's defaults, -K 32 -k 24, are on the GPU path (tests/test_gpu_programs.py builds with them): here the
+    # run gets as far as the missing input / the missing GPU, not status 3
+    assert run("Database.MakeDatabase", "-a", "-i", "/nonexistent/x", "-o", "y").returncode == 1
+    assert run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y", "-h").returncode == 3    # -h with minK < maxK
+    r = run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y", "-K", "20", "-k", "24")
+    assert r.returncode == 1 and "above" in r.stderr
     assert run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y", "-K", "31", "-k", "31", "-m", "5").returncode == 3
     assert run("Database.Matcher", "-i", "a", "-d", "b", "-o", "c", "-n", "3").returncode == 3          # -n 1, 2 run on the GPU
     r = run("Database.MakeDatabase", "-a", "-q", "-i", "x", "-o", "y", "-K", "31", "-k", "31")

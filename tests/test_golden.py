@@ -107,3 +107,68 @@ def test_gpu_reproduces_golden(path):
                 assert blob[int(off[key]):int(off[key + 1])] == (want[key] if lo <= key < hi else b""), key
             db.close()
     ctx.close()
+
+
+# ---- variable-length k-mers (MakeDatabase -k minK -K maxK; Matcher -k L -K L) ----------------------------------------
+VAR_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "var_*.json")))
+
+
+def _load_var(path):
+    g = json.load(open(path))
+    g["ref_blocks"] = {int(k): bytes.fromhex(v) for k, v in g["ref_blocks"].items()}
+    g["read_blocks"] = {int(k): bytes.fromhex(v) for k, v in g["read_blocks"].items()}
+    return g
+
+
+@pytest.mark.parametrize("path", VAR_CASES, ids=[os.path.basename(p)[4:-5] for p in VAR_CASES])
+def test_restatements_reproduce_variable_length_golden(path):
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    g = _load_var(path)
+    mn, k, l, L = g["min_k"], g["k"], g["key_len"], g["restrict"]
+    fa, fq = g["fasta"].encode(), g["fastq"].encode()
+    ref = R.build_ref_db(fa, k, l, min_k=mn)
+    reads, names = R.build_read_db(fq, k, l, min_k=mn)
+    assert ref == g["ref_blocks"] and reads == g["read_blocks"] and names == g["read_names"]
+    assert ref[-1][0] == mn and ref[-1][1] == k
+    db = R.DB([ref])
+    assert R.match_lines(reads, db, min_k=L, max_k=L) == g["match_lines_restricted"] and R.taxa_counts(db) == g["taxa_counts"]
+    c_ref, c_reads = OracleDB(fa, 0, k, l, min_k=mn), OracleDB(fq, 1, k, l, min_k=mn)
+    for c, want in ((c_ref, g["ref_blocks"]), (c_reads, g["read_blocks"])):
+        blob, off = c.encode_blocks()
+        for key in range(4 ** l):
+            assert blob[int(off[key]):int(off[key + 1])] == want[key]
+    assert c_reads.names == g["read_names"]
+    cr, cs = c_ref.restrict(L), c_reads.restrict(L)
+    hit, _ = cs.match(cr)
+    assert cs.match_lines(cr, hit).decode().splitlines() == g["match_lines_restricted"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", VAR_CASES, ids=[os.path.basename(p)[4:-5] for p in VAR_CASES])
+def test_gpu_reproduces_variable_length_golden(path):
+    import kmers_amd as km
+    g = _load_var(path)
+    mn, k, l, L = g["min_k"], g["k"], g["key_len"], g["restrict"]
+    ctx = km.Context(0)
+    ref = km.make_reference_db(ctx, g["fasta"].encode(), k, l, min_k=mn)
+    reads, names = km.make_read_db(ctx, g["fastq"].encode(), k, l, min_k=mn)
+    for db, want in ((ref, g["ref_blocks"]), (reads, g["read_blocks"])):
+        blob, off = db.encode_blocks()
+        assert db.meta() == want[-1]
+        for key in range(4 ** l):
+            assert blob[int(off[key]):int(off[key + 1])] == want[key], key
+    assert names == g["read_names"]
+    assert km.taxa_count_lines(ref) == g["taxa_counts"]
+    rr, rs = ref.restrict(L), reads.restrict(L)
+    hit, nh = km.DB([rr]).get_nearest_kmers(rs)
+    assert km.match_lines(rs, rr, hit) == g["match_lines_restricted"] and nh == len(g["match_lines_restricted"])
+    # the same in two key ranges
+    nkeys = 4 ** l
+    for lo, hi in ((0, nkeys // 2), (nkeys // 2, nkeys)):
+        part = km.make_reference_db(ctx, g["fasta"].encode(), k, l, key_range=(lo, hi), min_k=mn)
+        blob, off = part.encode_blocks()
+        for key in range(nkeys):
+            assert blob[int(off[key]):int(off[key + 1])] == (g["ref_blocks"][key] if lo <= key < hi else b""), key
+        part.close()
+    ctx.close()

@@ -1380,3 +1380,64 @@ def test_restricted_match_matches_oracle(ctx, min_k, k, L, key_len, seed):
     assert "\n".join(km.match_lines(rreads, rref, hit)) + "\n" == creads.match_lines(cref, ohit).decode()
     with pytest.raises(km.InconsistentDataException):       # DB.java:78-81
         ref.restrict(min_k - 1)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KMERS_FUZZ_VAR_SEEDS", "12"))))
+def test_fuzz_variable_length_against_oracle(ctx, seed):
+    """Random minK < maxK, key length, input shape, batch cuts, filters and key ranges; then Matcher -k L -K L at a
+    random length."""
+    import kmers_amd as km
+    from kmers_amd import parse, synth
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(7000 + seed)
+    k = int(rng.integers(6, 33))
+    mn = int(rng.integers(max(1, k - 10), k))
+    l = int(rng.integers(1, min(mn, 6) + 1))
+    n_gen, glen = int(rng.integers(1, 5)), int(rng.integers(300, 20000))
+    taxa, genomes = synth.random_genomes(500 + seed, n_gen, glen, first_taxon=int(rng.integers(-5, 1000)),
+                                         shared_frac=float(rng.choice([0.0, 0.3])))
+    if rng.random() < 0.3:
+        genomes[0][: glen // 2] = ord("A")
+    n_reads, rlen = int(rng.integers(50, 4000)), int(rng.integers(mn, 200))
+    reads = synth.random_reads(600 + seed, genomes, n_reads, rlen, 0.02, n_rate=float(rng.choice([0.0, 0.01, 0.05])))
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    # ragged read lengths around minK .. maxK: cut some reads short
+    recs = fq.split(b"\n")
+    for i in range(0, len(recs) - 3, 4):
+        if rng.random() < 0.3:
+            n = int(rng.integers(0, min(len(recs[i + 1]), k + 3) + 1))
+            recs[i + 1], recs[i + 3] = recs[i + 1][:n], recs[i + 3][:n]
+    fq = b"\n".join(recs)
+    dust = int(rng.integers(1, 4)) if rng.random() < 0.25 else None
+    run = int(rng.integers(3, 9)) if rng.random() < 0.25 else None
+    key_range = None
+    if rng.random() < 0.3:
+        a = int(rng.integers(0, 4 ** l))
+        key_range = (a, int(rng.integers(a + 1, 4 ** l + 1)))
+    built = {}
+    for data, mode, kind, rc in ((fa, parse.FASTA, "ref", True), (fq, parse.FASTQ, "read", False)):
+        b = parse.parse(data, mode, k).batch
+        ncut = int(rng.integers(0, 3))
+        cuts = [0] + sorted(int(x) for x in rng.integers(0, b.nseq + 1, size=ncut)) + [b.nseq]
+        fc = km.FileCreator(ctx, l, k, kind, rc=rc, dust=dust, runofsame=run, key_range=key_range)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            a0, a1 = int(b.seq_off[lo]), int(b.seq_off[hi])
+            fc.add_kmers(km.SequenceBatch(b.bases[a0:a1], b.seq_off[lo:hi + 1] - b.seq_off[lo],
+                                          seq_id=None if b.seq_id is None else b.seq_id[lo:hi],
+                                          seq_tok=None if b.seq_tok is None else b.seq_tok[lo:hi]), min_length=mn, max_length=k)
+        got = fc.create()
+        want = OracleDB(data, 0 if kind == "ref" else 1, k, l, threads=4, dust=-1 if dust is None else dust,
+                        runofsame=-1 if run is None else run, key_range=key_range, min_k=mn)
+        _same_var_db(got, want)
+        assert fc.n_windows == want.n_windows
+        built[kind] = (got, want)
+    L = int(rng.integers(max(mn, l), k + 1))
+    (ref, o_ref), (rdb, o_reads) = built["ref"], built["read"]
+    rr, rs, orr, ors = ref.restrict(L), rdb.restrict(L), o_ref.restrict(L), o_reads.restrict(L)
+    _same_db(rr, orr)
+    _same_db(rs, ors)
+    hit, nh = km.DB([rr]).get_nearest_kmers(rs)
+    o_hit, o_nh = ors.match(orr)
+    assert nh == o_nh and np.array_equal(hit, o_hit)
+    for d in (ref, rdb, rr, rs):
+        d.close()

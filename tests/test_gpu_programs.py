@@ -258,9 +258,11 @@ def test_native_cli_matches_python_drivers(tmp_path):
     R.write_indexed_file(p("f.want"), _oracle_blocks(o_f), None)
     assert open(p("f.db"), "rb").read() == open(p("f.want"), "rb").read()
     # what is not on the GPU path exits with status 3 (wrapper falls back to Java)
-    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("x.db"), "-K", "32", "-k", "24", rc=3)
+    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("x.db"), "-K", "32", "-k", "24", "-h", rc=3)
     run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-n", "3", rc=3)
-    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-k", str(k - 2), "-K", str(k - 2), rc=3)
+    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-k", str(k - 2), "-K", str(k), rc=3)      # the trie
+    # DB.java:78-81: search k-mers shorter than the database's -> InconsistentDataException
+    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-k", str(k - 2), "-K", str(k - 2), rc=1)
     run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("mk.txt"), "-Z", "x", "-k", str(k), "-K", str(k))
     assert open(p("mk.txt"), "rb").read() == want
     # a reference given as name.1 .. name.N is merged (DB.java:99-109): same results as the single file
@@ -429,3 +431,103 @@ def test_preprocessed_input(tmp_path):
         assert cli(["Database.MakeDatabase", "-p", "-i", path, "-o", path + ".L.py.db", "-K", str(k), "-k", str(k), "-l", str(l),
                     "-Z", "-L", "NC01-NC02"]) == 0
         assert open(path + ".L.py.db", "rb").read() == open(str(tmp_path / "want.L.db"), "rb").read()
+
+
+def _oracle_var_blocks(odb):
+    blocks = _oracle_blocks(odb)
+    blocks[-1] = bytes([odb.min_k]) + blocks[-1][1:]          # meta: [minK][maxK][keyLength]... (FileCreator.java:153-164)
+    return blocks
+
+
+def test_default_options_build_variable_length_databases(tmp_path):
+    """`MakeDatabase -a -i x -o y` with no -K / -k is -K 32 -k 24 (MakeDatabase.java:106-107): k-mers of 24 .. 32 bases.
+    Both drivers' unzipped files equal the oracle's byte for byte; `Matcher -k L -K L` restricts both files to one
+    length (KmerUtils.restrictedStream) and joins; TaxaCounts walks every stored k-mer."""
+    import subprocess
+    import kmers_amd as km
+    from kmers_amd import synth
+    from kmers_amd.__main__ import main as cli
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    kmg = os.path.join(os.path.dirname(km.__file__), "kmg")
+    taxa, genomes = synth.random_genomes(91, 6, 3000, first_taxon=700, shared_frac=0.3)
+    reads = synth.random_reads(92, genomes, 800, 90, 0.01, n_rate=0.01)
+    fa_b, fq_b = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    # some sequences between 24 and 32 bases, and shorter than 24
+    fa_b += b">700\nACGTACGTTGCAACGTTGCATGCATGCAAC\n>701\nACGTACGTTGCAACGTTGCATGCATG\n>702\nACGTACGTTGCAACGTTGCAT\n"
+    fa, fq = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fq")
+    open(fa, "wb").write(fa_b)
+    open(fq, "wb").write(fq_b)
+    o_ref, o_reads = OracleDB(fa_b, 0, 32, 6, min_k=24), OracleDB(fq_b, 1, 32, 6, min_k=24)
+    assert len(set(o_ref.lens.tolist())) == 9 and len(set(o_reads.lens.tolist())) == 9
+    want_ref, want_reads = str(tmp_path / "ref.want"), str(tmp_path / "reads.want")
+    R.write_indexed_file(want_ref, _oracle_var_blocks(o_ref), None)
+    R.write_indexed_file(want_reads, _oracle_var_blocks(o_reads), None)
+    run = lambda *a: subprocess.run([kmg] + list(a), capture_output=True, text=True, timeout=300)
+    for tag, drv in (("kmg", lambda *a: run(*a).returncode), ("py", lambda *a: cli(list(a)))):
+        ref_db, reads_db = str(tmp_path / ("ref.%s.db" % tag)), str(tmp_path / ("reads.%s.db" % tag))
+        assert drv("Database.MakeDatabase", "-a", "-i", fa, "-o", ref_db, "-Z") == 0
+        assert drv("Database.MakeDatabase", "-q", "-i", fq, "-o", reads_db, "-r", str(tmp_path / ("map.%s.gz" % tag)), "-Z") == 0
+        assert open(ref_db, "rb").read() == open(want_ref, "rb").read()
+        assert open(reads_db, "rb").read() == open(want_reads, "rb").read()
+        assert gzip.open(str(tmp_path / ("map.%s.gz" % tag)), "rt").read().splitlines() == o_reads.names
+        # zipped flavour: payload-equal
+        assert drv("Database.MakeDatabase", "-a", "-i", fa, "-o", ref_db + ".z") == 0
+        assert R.read_indexed_file(ref_db + ".z") == R.read_indexed_file(want_ref)
+        for L in (24, 27, 32):
+            out = str(tmp_path / ("m%d.%s.txt" % (L, tag)))
+            assert drv("Database.Matcher", "-i", reads_db, "-d", ref_db, "-o", out, "-Z", "x", "-k", str(L), "-K", str(L)) == 0
+            cr, cs = o_ref.restrict(L), o_reads.restrict(L)
+            hit, nh = cs.match(cr)
+            assert open(out, "rb").read() == cs.match_lines(cr, hit) and nh > 100
+        # a search over several lengths is the trie: off the GPU path
+        if tag == "kmg":
+            assert run("Database.Matcher", "-i", reads_db, "-d", ref_db, "-o", str(tmp_path / "x.txt"), "-Z", "x").returncode == 3
+            assert run("Database.MakeDatabase", "-a", "-i", fa, "-o", str(tmp_path / "h.db"), "-h").returncode == 3
+        counts = str(tmp_path / ("counts.%s.tsv" % tag))
+        assert drv("Utils.TaxaCounts", "-d", ref_db, "-o", counts) == 0
+        t, m, q = o_ref.taxacounts()
+        assert open(counts).read().splitlines() == ["%d\t%d\t%d" % x for x in zip(t, m, q)]
+    # a FASTQ cut inside a sequence line, and any such file with minK < maxK, is refused (status 3), not built differently
+    cut = str(tmp_path / "cut.fq")
+    open(cut, "wb").write(fq_b[:fq_b.rindex(b"\n+\n") - 3])
+    assert run("Database.MakeDatabase", "-q", "-i", cut, "-o", str(tmp_path / "cut.db"), "-r", str(tmp_path / "cut.map"), "-K", "31", "-k", "31").returncode == 3
+    cutfa = str(tmp_path / "cut.fa")
+    open(cutfa, "wb").write(fa_b[:-1])
+    assert run("Database.MakeDatabase", "-a", "-i", cutfa, "-o", str(tmp_path / "cutfa.db")).returncode == 3
+    assert run("Database.MakeDatabase", "-a", "-i", cutfa, "-o", str(tmp_path / "cutfa.db"), "-K", "31", "-k", "31").returncode == 0
+
+
+def test_preprocessed_input_variable_length(tmp_path):
+    """MakeDatabase -p with the default -K 32 -k 24: PreProcessedSpliterator (MakeDatabase.java:358-407), restated
+    literally, yields what the text path yields for the same sequences -- checked here in the oracle -- and the
+    GPU build of the preprocessed file equals the oracle's build of that FASTA."""
+    import subprocess
+    import kmers_amd as km
+    from kmers_amd.__main__ import main as cli
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    kmg = os.path.join(os.path.dirname(km.__file__), "kmg")
+    rng = np.random.default_rng(17)
+    groups = {}
+    for g in range(3):
+        recs = []
+        for _ in range(12):
+            n = int(rng.integers(1, 120))
+            recs.append((int(rng.integers(1, 50)), "".join("ACGT"[i] for i in rng.integers(0, 4, n))))
+        groups["grp%d" % g] = recs
+    fa = R.preprocessed_kmers_as_fasta(groups)
+    for mn, mx in ((24, 32), (3, 6)):
+        lit = sorted((str(k), t) for k, t in R.preprocessed_kmers(groups, mn, mx))
+        txt = sorted((str(k), t) for k, t in R.kmers_from_file(fa, R.fa_state_changer(), mn, mx, R.fa_to_refdb_mapper))
+        assert lit == txt and len(lit) > 100
+    want = str(tmp_path / "want.db")
+    R.write_indexed_file(want, _oracle_var_blocks(OracleDB(fa, 0, 32, 6, min_k=24)), None)
+    for z, hr in ((5, False), (None, True)):
+        path = str(tmp_path / ("pre.%s.%d" % (z, hr)))
+        R.write_preprocessed_file(path, groups, z, hr)
+        r = subprocess.run([kmg, "Database.MakeDatabase", "-p", "-i", path, "-o", path + ".db", "-Z"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert open(path + ".db", "rb").read() == open(want, "rb").read()
+        assert cli(["Database.MakeDatabase", "-p", "-i", path, "-o", path + ".py.db", "-Z"]) == 0
+        assert open(path + ".py.db", "rb").read() == open(want, "rb").read()
