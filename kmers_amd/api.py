@@ -451,11 +451,14 @@ def kmer_strings(keys, k):
     return [row.tobytes().decode() for row in _BASES[codes]]
 
 
-def match_lines(search, ref, hit):
+def match_lines(search, ref, hit, stored=False):
     """One line per matched search k-mer, ascending (Matcher.java:247-249): KMER \\t r:p|r:p \\t -|TxC|TxC
-    (ResultsDataType.java:15-35).  Reference counts are the stored bytes, i.e. saturated at 255
-    (CountDataType.java:40)."""
+    (ResultsDataType.java:15-35).  Matcher reads its databases from files, whose counts are bytes saturated at 255
+    (CountDataType.java:40): for handles straight from a build the counts are capped here to what the file would
+    hold; stored=True says the handles were loaded from files (a set of several files adds the stored bytes as
+    longs, DB.java:99-109, and a line can show more than 255)."""
     s, r = search.fetch(), ref.fetch()
+    cap = (1 << 31) if stored else 255
     idx = np.nonzero(hit >= 0)[0]
     names = kmer_strings(s["keys"][idx], search.k)
     lines = []
@@ -464,10 +467,10 @@ def match_lines(search, ref, hit):
         if search.kind == PAYLOAD_READPOS:
             left = "|".join("%d:%d" % (x, y) for x, y in zip(s["val_a"][a:b].tolist(), s["val_b"][a:b].tolist()))
         else:
-            left = "|".join("%dx%d" % (x, min(y, 255)) for x, y in zip(s["val_a"][a:b].tolist(), s["val_b"][a:b].tolist()))
+            left = "|".join("%dx%d" % (x, min(y, cap)) for x, y in zip(s["val_a"][a:b].tolist(), s["val_b"][a:b].tolist()))
         h = int(hit[i])
         c, d = int(r["val_off"][h]), int(r["val_off"][h + 1])
-        right = "|".join("%dx%d" % (x, min(y, 255)) for x, y in zip(r["val_a"][c:d].tolist(), r["val_b"][c:d].tolist()))
+        right = "|".join("%dx%d" % (x, min(y, cap)) for x, y in zip(r["val_a"][c:d].tolist(), r["val_b"][c:d].tolist()))
         lines.append("%s\t%s\t-|%s" % (name, left, right))
     return lines
 
@@ -481,7 +484,7 @@ def _revcomp_key(key, k):
     return out << (64 - 2 * k)
 
 
-def near_match_lines(search, ref, max_diff, just=False):
+def near_match_lines(search, ref, max_diff, just=False, stored=False):
     """Matcher -n max_diff [-j] for k-mers of one length: one line per search k-mer that has a match within max_diff
     differences, `KMER \\t values \\t DIFF|TxC|TxC DIFF|TxC ...` (ResultsDataType.java:15-35).  The GPU hands over
     every reference k-mer within reach in ascending order (kmg_match_near); here, per search k-mer and on a handful
@@ -490,6 +493,7 @@ def near_match_lines(search, ref, max_diff, just=False):
     are ordered by number of differences, then (position, base) (KmerDiffComparaotr, :119-147), and a difference
     prints as position + new base, no difference as "-" (KmerDiff.java:54-67)."""
     ref = ref.merged if isinstance(ref, DB) else ref
+    cap = (1 << 31) if stored else 255            # see match_lines
     off, idx, dist = match_near(search, ref, max_diff)
     s, r = search.fetch(), ref.fetch()
     k = search.k
@@ -524,12 +528,12 @@ def near_match_lines(search, ref, max_diff, just=False):
         if search.kind == PAYLOAD_READPOS:
             left = "|".join("%d:%d" % (x, y) for x, y in zip(s["val_a"][a0:a1].tolist(), s["val_b"][a0:a1].tolist()))
         else:
-            left = "|".join("%dx%d" % (x, min(y, 255)) for x, y in zip(s["val_a"][a0:a1].tolist(), s["val_b"][a0:a1].tolist()))
+            left = "|".join("%dx%d" % (x, min(y, cap)) for x, y in zip(s["val_a"][a0:a1].tolist(), s["val_b"][a0:a1].tolist()))
         parts = []
         for (_, diffs), h in entries:
             c0, c1 = int(r["val_off"][h]), int(r["val_off"][h + 1])
             text = "".join("%d%s" % (p, letters[b]) for p, b in diffs) if diffs else "-"
-            parts.append("%s|%s" % (text, "|".join("%dx%d" % (x, min(y, 255)) for x, y in
+            parts.append("%s|%s" % (text, "|".join("%dx%d" % (x, min(y, cap)) for x, y in
                                                       zip(r["val_a"][c0:c1].tolist(), r["val_b"][c0:c1].tolist()))))
         lines.append("%s\t%s\t%s" % (name, left, " ".join(parts)))
     return lines

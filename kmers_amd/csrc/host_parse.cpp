@@ -27,6 +27,8 @@ struct Batch {
     std::vector<uint64_t> name_off;  // token t's header = names[name_off[t] .. name_off[t+1])
     std::string names;
     int eof_in_kmer = 0;             // file ended inside a sequence line whose last char was a base
+    int high_bytes = 0;              // a sequence character >= 128 was seen (see kmh_high_bytes)
+    int empty_header = 0;            // FASTQ: a record with an empty header line was seen (see kmh_empty_header)
     std::string err;
 };
 
@@ -136,6 +138,7 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
             if (!cur_ok) cur_id = 0;
         } else {
             cur_tok = intern.intern(data + id_start, id_len, b->names, b->name_off);
+            if (id_len == 0) b->empty_header = 1;
         }
     };
     b->seq_off.push_back(0);   // seq_off = [0, end_0, end_1, ...]: a sequence is opened/closed in turn
@@ -184,9 +187,13 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
             const uint8_t *nl = (const uint8_t *)memchr(data + i, '\n', n - i);
             const uint64_t end = nl ? (uint64_t)(nl - data) : n;
             const uint8_t s1 = spc[S_KMER][0], s2 = nsp[S_KMER] == 2 ? spc[S_KMER][1] : spc[S_KMER][0];
-            unsigned odd = 0;
-            for (uint64_t q = i; q < end; q++) odd |= (unsigned)(data[q] <= 32) | (unsigned)(data[q] == s1) | (unsigned)(data[q] == s2);
+            unsigned odd = 0, high = 0;
+            for (uint64_t q = i; q < end; q++) {
+                odd |= (unsigned)(data[q] <= 32) | (unsigned)(data[q] == s1) | (unsigned)(data[q] == s2);
+                high |= data[q];
+            }
             if (!odd) {
+                b->high_bytes |= (int)(high >> 7);
                 memcpy(out + nout, data + i, end - i);
                 nout += end - i;
                 last_was_base = true;
@@ -203,10 +210,10 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
         }
         if (state == S_KMER) {
             // sequence characters: everything > 32 is a base position (KmersFromFile.java:154-158)
-            if (c > 32) { out[nout++] = c; last_was_base = true; } else last_was_base = false;
+            if (c > 32) { out[nout++] = c; last_was_base = true; b->high_bytes |= c >> 7; } else last_was_base = false;
             while (j < n && !sp[data[j]]) {
                 const uint8_t d = data[j++];
-                if (d > 32) { out[nout++] = d; last_was_base = true; } else last_was_base = false;
+                if (d > 32) { out[nout++] = d; last_was_base = true; b->high_bytes |= d >> 7; } else last_was_base = false;
             }
         } else {
             while (j < n && !sp[data[j]]) j++;
@@ -248,6 +255,15 @@ uint64_t kmh_ntok(const kmh_batch *h) { return ((const Batch *)h)->name_off.size
 const uint64_t *kmh_name_off(const kmh_batch *h) { return ((const Batch *)h)->name_off.data(); }
 const char *kmh_names(const kmh_batch *h) { return ((const Batch *)h)->names.data(); }
 int kmh_eof_in_kmer(const kmh_batch *h) { return ((const Batch *)h)->eof_in_kmer; }
+// 1 if a sequence line held a byte >= 128.  The reference reads such a window by the sign of its FIRST byte
+// (Sequence.java:15-33: `chars[0] > 4` on signed bytes -- a window that starts with a negative byte takes the "already
+// codes" branch and is a k-mer of garbage codes iff all of its bytes are negative); the GPU path treats every such byte
+// as an invalid base, so the drivers refuse input that holds one instead of building something different.
+int kmh_high_bytes(const kmh_batch *h) { return ((const Batch *)h)->high_bytes; }
+// 1 if a FASTQ record had an empty header.  ReadIDMapping starts with curReadS = "" (ReadIDMapping.java:10-16), so a
+// first emitting read whose header is empty gets index -1 and no name line there; the GPU numbering starts at 0.  The
+// drivers refuse such input instead of numbering it differently.
+int kmh_empty_header(const kmh_batch *h) { return ((const Batch *)h)->empty_header; }
 
 
 // ---- KmerFile decode (KmerFiles/KmerFile.java:200-250, CompressedKmerSpliterator.tryAdvance) ----------

@@ -58,6 +58,8 @@ const int32_t *kmh_decoded_val_a(const kmh_batch *);
 const int32_t *kmh_decoded_val_b(const kmh_batch *);
 const uint8_t *kmh_decoded_lens(const kmh_batch *);
 int kmh_eof_in_kmer(const kmh_batch *);
+int kmh_high_bytes(const kmh_batch *);
+int kmh_empty_header(const kmh_batch *);
 }
 
 namespace {
@@ -765,6 +767,12 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
     // A file that ends inside a sequence line: the reference hands its last k-mer out twice (KmersFromFile.java:115-123,
     // 193-200).  For FASTA with k-mers of one length the record splitter reproduces that; a FASTQ cut there, or any such
     // file with minK < maxK (where suffixes follow the repeated k-mer), is refused rather than built differently.
+    // Sequence.java:15-33 decides by the sign of a window's first byte: windows made of bytes >= 128 only are k-mers of
+    // garbage codes there, invalid here -- refused rather than built differently
+    if (kmh_high_bytes(b)) throw Unsupported("sequence lines hold bytes >= 128: not supported on the GPU path");
+    // ReadIDMapping starts with curReadS = "" (ReadIDMapping.java:10-16): a first emitting read with an empty header gets
+    // index -1 and no name line there
+    if (reads && kmh_empty_header(b)) throw Unsupported("a FASTQ record with an empty header: not supported on the GPU path");
     if (kmh_eof_in_kmer(b) && (reads || min_k != k))
         throw Unsupported("input ends inside a sequence line (no final newline): not supported on the GPU path for FASTQ input or with minK < maxK");
     if (!reads) {
@@ -894,7 +902,9 @@ HostDb fetch(const Gpu &g, const kmg_db *db) {
 }
 
 // "r:p|r:p" (SetCompressor.toString over ReadPosDataType.java:46-49) or "TxC|TxC" (CountDataType.java:109-113;
-// counts print as the stored byte, i.e. saturated at 255, CountDataType.java:40)
+// counts are what the files hold -- bytes saturated at 255 when written, CountDataType.java:40 -- and, for a database
+// given as several files, their sums: DB.kmers adds them as longs without saturating again, DB.java:99-109, so a line
+// can show more than 255)
 // decimal text of a Java int, appended (the match text holds hundreds of millions of them)
 inline void append_int(std::string &s, int32_t v) {
     char buf[12];
@@ -910,7 +920,7 @@ void append_values(std::string &s, const HostDb &h, uint64_t i) {
         if (v != h.val_off[i]) s.push_back('|');
         append_int(s, h.a[v]);
         s.push_back(reads ? ':' : 'x');
-        append_int(s, reads ? h.b[v] : std::min(h.b[v], 255));
+        append_int(s, h.b[v]);
     }
 }
 
@@ -1500,6 +1510,9 @@ int read_calls(int argc, char **argv) {
     clk.lap("read input");
     const std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch(kmh_parse((const uint8_t *)data.data(), data.size(), 1, k), kmh_free);
     const kmh_batch *b = batch.get();
+    if (kmh_high_bytes(b)) throw Unsupported("sequence lines hold bytes >= 128: not supported on the GPU path");
+    if (kmh_empty_header(b)) throw Unsupported("a FASTQ record with an empty header: not supported on the GPU path");
+    if (kmh_eof_in_kmer(b)) throw Unsupported("input ends inside a sequence line (no final newline): not supported on the GPU path for FASTQ input");
     const uint64_t nseq = kmh_nseq(b);
     const uint64_t *off = kmh_seq_off(b);
     const int64_t *tok = kmh_seq_tok(b);

@@ -11,6 +11,14 @@ def _check_eof(pf, mode, k, min_k):
     """A file that ends inside a sequence line: the reference hands its last k-mer out twice (KmersFromFile.java:115-123,
     193-200).  For FASTA with k-mers of one length the record splitter reproduces that; a FASTQ cut there, or any such
     file with minK < maxK (where suffixes follow the repeated k-mer), is refused rather than built differently."""
+    if pf.high_bytes:
+        # Sequence.java:15-33 decides by the sign of a window's first byte: windows of bytes >= 128 only are k-mers of
+        # garbage codes there, invalid here -- refused rather than built differently
+        raise KmersGpuError(KMG_EUNSUPPORTED, "sequence lines hold bytes >= 128: not supported on the GPU path")
+    if mode == parse.FASTQ and pf.empty_header:
+        # ReadIDMapping starts with curReadS = "" (ReadIDMapping.java:10-16): a first emitting read with an empty header
+        # gets index -1 and no name line there
+        raise KmersGpuError(KMG_EUNSUPPORTED, "a FASTQ record with an empty header: not supported on the GPU path")
     if pf.eof_in_kmer and (mode == parse.FASTQ or min_k != k):
         raise KmersGpuError(KMG_EUNSUPPORTED, "input ends inside a sequence line (no final newline): not supported "
                             "on the GPU path for FASTQ input or with minK < maxK")

@@ -34,6 +34,10 @@ def _load():
             f.restype, f.argtypes = vp, [vp]
         lib.kmh_eof_in_kmer.restype = C.c_int
         lib.kmh_eof_in_kmer.argtypes = [vp]
+        lib.kmh_high_bytes.restype = C.c_int
+        lib.kmh_high_bytes.argtypes = [vp]
+        lib.kmh_empty_header.restype = C.c_int
+        lib.kmh_empty_header.argtypes = [vp]
         lib.kmh_decode_blocks.restype = vp
         lib.kmh_decode_blocks.argtypes = [C.c_char_p, u64, C.c_int]
         lib.kmh_decoded_free.argtypes = [vp]
@@ -61,11 +65,13 @@ def maybe_gunzip(data: bytes) -> bytes:
 
 
 class ParsedFile:
-    def __init__(self, batch, names, id_ok, eof_in_kmer):
+    def __init__(self, batch, names, id_ok, eof_in_kmer, high_bytes=0, empty_header=0):
         self.batch = batch
         self.names = names            # FASTQ: header string of every token
         self.id_ok = id_ok            # FASTA: header parsed as a Java int
         self.eof_in_kmer = eof_in_kmer
+        self.empty_header = empty_header   # FASTQ: an empty header line (ReadIDMapping.java:10-16 starts with "")
+        self.high_bytes = high_bytes  # a sequence line held a byte >= 128 (Sequence.java:15-33 reads those differently)
 
 
 def parse(data: bytes, mode: int, k: int) -> ParsedFile:
@@ -79,13 +85,14 @@ def parse(data: bytes, mode: int, k: int) -> ParsedFile:
         if mode == FASTA:
             ids = _arr(lib.kmh_seq_id(h), nseq, np.int32)
             ok = _arr(lib.kmh_id_ok(h), nseq, np.uint8)
-            return ParsedFile(SequenceBatch(bases, off, seq_id=ids), None, ok, lib.kmh_eof_in_kmer(h))
+            return ParsedFile(SequenceBatch(bases, off, seq_id=ids), None, ok, lib.kmh_eof_in_kmer(h), lib.kmh_high_bytes(h))
         tok = _arr(lib.kmh_seq_tok(h), nseq, np.int64)
         nt = lib.kmh_ntok(h)
         noff = _arr(lib.kmh_name_off(h), nt + 1, np.uint64)
         raw = _arr(lib.kmh_names(h), int(noff[-1]) if nt else 0, np.uint8).tobytes()
         names = [raw[int(noff[i]):int(noff[i + 1])].decode("latin-1") for i in range(nt)]
-        return ParsedFile(SequenceBatch(bases, off, seq_tok=tok), names, None, lib.kmh_eof_in_kmer(h))
+        return ParsedFile(SequenceBatch(bases, off, seq_tok=tok), names, None, lib.kmh_eof_in_kmer(h), lib.kmh_high_bytes(h),
+                          lib.kmh_empty_header(h))
     finally:
         lib.kmh_free(h)
 

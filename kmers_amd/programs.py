@@ -307,10 +307,10 @@ def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max
         from .api import near_match_lines
         if not db.merged.rc:
             raise ValueError("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included")
-        lines = near_match_lines(search, db.merged, max_diff, just)
+        lines = near_match_lines(search, db.merged, max_diff, just, stored=True)
     else:
         hit, _ = db.get_nearest_kmers(search)
-        lines = match_lines(search, db.merged, hit)
+        lines = match_lines(search, db.merged, hit, stored=True)
     text = "".join(l + "\n" for l in lines).encode()
     with (open(output_path, "wb") if plain else gzip.open(output_path, "wb")) as f:
         f.write(text)

@@ -531,3 +531,59 @@ def test_preprocessed_input_variable_length(tmp_path):
         assert open(path + ".db", "rb").read() == open(want, "rb").read()
         assert cli(["Database.MakeDatabase", "-p", "-i", path, "-o", path + ".py.db", "-Z"]) == 0
         assert open(path + ".py.db", "rb").read() == open(want, "rb").read()
+
+
+def test_counts_saturate_at_255_when_written_and_add_when_merged(tmp_path):
+    """CountDataType.compress stores min(count, 255) (CountDataType.java:40); DB.kmers over two files adds the stored
+    bytes as longs (DB.java:99-109), so a match line can show 510.  And the fences: bytes >= 128 in a
+    sequence line, an empty FASTQ header, a FASTQ cut inside its sequence line leave with status 3."""
+    import subprocess
+    import kmers_amd as km
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    kmg = os.path.join(os.path.dirname(km.__file__), "kmg")
+    run = lambda *a: subprocess.run([kmg] + list(a), capture_output=True, text=True, timeout=300)
+    k, l = 9, 2
+    unit = b"ACGGTCATTGCAGTCCA"                                   # 17 bases: 17 distinct 9-mers in the periodic sequence
+    fa = b">5\n" + unit * 300 + b"\n>6\n" + unit * 2 + b"ACGT\n>5\n" + unit * 40 + b"\n"
+    fq = b"@r0\n" + unit * 2 + b"\n+\n" + b"I" * 34 + b"\n"
+    p = lambda n: str(tmp_path / n)
+    open(p("ref.fa"), "wb").write(fa)
+    open(p("reads.fq"), "wb").write(fq)
+    ctx = km.Context(0)
+    ref = km.make_reference_db(ctx, fa, k, l)
+    o_ref = OracleDB(fa, 0, k, l)
+    h = ref.fetch()
+    assert np.array_equal(h["val_b"], o_ref.val_b) and int(o_ref.val_b.max()) > 255        # unsaturated in memory (TreeCountMap)
+    blob, off = ref.encode_blocks()
+    oblob, ooff = o_ref.encode_blocks()
+    assert blob == oblob and np.array_equal(off, ooff)
+    py = R.build_ref_db(fa, k, l)
+    assert blob == b"".join(py[key] for key in range(4 ** l))
+    assert b"\x00\x00\x00\x05\xff" in blob                        # taxon 5, count byte FF
+    ref.close(); ctx.close()
+    # the same database as two files of a set: counts add on the way in, 255 + 255 = 510 in the match text
+    for i in (1, 2):
+        assert run("Database.MakeDatabase", "-a", "-i", p("ref.fa"), "-o", p("set.db.%d" % i), "-K", str(k), "-k", str(k), "-l", str(l), "-Z").returncode == 0
+    assert run("Database.MakeDatabase", "-q", "-i", p("reads.fq"), "-o", p("reads.db"), "-r", p("map.gz"), "-K", str(k), "-k", str(k), "-l", str(l)).returncode == 0
+    assert run("Database.Matcher", "-i", p("reads.db"), "-d", p("set.db"), "-o", p("m.txt"), "-Z", "x").returncode == 0
+    o_reads, _ = R.build_read_db(fq, k, l)
+    want = R.match_lines(o_reads, R.DB([py, py]))
+    got = open(p("m.txt")).read().splitlines()
+    assert got == want and any("5x510" in ln for ln in got)
+    from kmers_amd.__main__ import main as cli
+    assert cli(["Database.Matcher", "-i", p("reads.db"), "-d", p("set.db"), "-o", p("m.py.txt"), "-Z", "x"]) == 0
+    assert open(p("m.py.txt")).read().splitlines() == want
+    # fences (status 3: the wrapper falls back to the Java program)
+    open(p("high.fa"), "wb").write(b">1\nACGT\xc3\xa9ACGTACGTACGT\n")
+    assert run("Database.MakeDatabase", "-a", "-i", p("high.fa"), "-o", p("x.db"), "-K", "4", "-k", "4", "-l", "2").returncode == 3
+    open(p("empty.fq"), "wb").write(b"@\nACGTACGT\n+\nIIIIIIII\n@r1\nACGTACGT\n+\nIIIIIIII\n")
+    assert run("Database.MakeDatabase", "-q", "-i", p("empty.fq"), "-o", p("x.db"), "-r", p("x.map"), "-K", "4", "-k", "4", "-l", "2").returncode == 3
+    open(p("cut.fq"), "wb").write(b"@r1\nACGTACGT\n+\nIIIIIIII\n@r2\nACGTAC")
+    assert run("Database.MakeDatabase", "-q", "-i", p("cut.fq"), "-o", p("x.db"), "-r", p("x.map"), "-K", "4", "-k", "4", "-l", "2").returncode == 3
+    with pytest.raises(km.KmersGpuError):
+        c2 = km.Context(0)
+        try:
+            km.make_read_db(c2, b"@r1\nACGTACGT\n+\nIIIIIIII\n@r2\nACGTAC", 4, 2)
+        finally:
+            c2.close()
