@@ -22,8 +22,20 @@
 #define EP_SQCAP 96                      // sequences of a tile whose payload data is cached in LDS
 #endif
 
+// The count pass leaves every tile's prepared image behind -- packed bases, sequence-start bitmap, and per thread
+// the "this window is a record" bits after validity, filters and key range -- so that the write pass neither
+// loads nor packs the bases again, nor repeats the sequence-start scan, the validity bitmap, or the -D / -R
+// predicates: it starts at the ranking step.  2.6 KB per 4 KB of bases, written once and read once.
+#define EP_IMG_PK 0                                   // EX_TILE / 16 + 4 packed words
+#define EP_IMG_STB (EX_TILE / 16 + 4)                 // EX_TILE / 32 + 2 start-bitmap words (MSB first), padded to + 4
+#define EP_IMG_VM (EP_IMG_STB + EX_TILE / 32 + 4)     // EP_BLOCK bytes: forward-record bits of thread tid (bit j = round j)
+#define EP_IMG_RM (EP_IMG_VM + EP_BLOCK / 4)          // EP_BLOCK bytes: reverse-complement-record bits
+#define EP_IMG_FLAG (EP_IMG_RM + EP_BLOCK / 4)        // 1 = some position starts several sequences: look sequences up
+#define EP_IMG_WORDS (EP_IMG_FLAG + 4)
+
 struct PartArgs {
     ExtractArgs e;
+    u32 *img;          // [tile][EP_IMG_WORDS]
     int dshift;        // the partition digit: (key >> dshift) & dmask
     u32 dmask;
     u32 *table;        // [digit][column] counts (count pass) / exclusive offsets (write pass)
@@ -33,10 +45,23 @@ struct PartArgs {
 };
 
 // the k-mer starting at tile position p, from the packed LDS image (3 words that the whole wave shares)
-__device__ __forceinline__ u64 ep_window(const u32 *pk, u32 p, u64 kmask) {
+// (the write pass keeps the 64-bit form: the funnel-shift form costs it registers it does not have -- 6 spills, +13 %)
+__device__ __forceinline__ u64 ep_window64(const u32 *pk, u32 p, u64 kmask) {
     const u32 w = p >> 4, r = p & 15;
     const u64 hi = ((u64)pk[w] << 32) | pk[w + 1];
     return ((hi << (2 * r)) | ((u64)pk[w + 2] >> (32 - 2 * r))) & kmask;
+}
+// upper word of the k-mer starting at p (its first 16 bases): all the partition digit of a forward record needs
+__device__ __forceinline__ u32 ep_window_hi(const u32 *pk, u32 p, u64 kmask) {
+    const u32 w = p >> 4;
+    return __funnelshift_l(pk[w + 1], pk[w], 2 * (p & 15)) & (u32)(kmask >> 32);
+}
+// (two 32-bit funnel shifts: 64-bit shifts by a lane-varying amount run at a quarter of the rate)
+__device__ __forceinline__ u64 ep_window(const u32 *pk, u32 p, u64 kmask) {
+    const u32 w = p >> 4, r2 = 2 * (p & 15);
+    const u32 a = pk[w], b = pk[w + 1], c = pk[w + 2];
+    const u32 hi = __funnelshift_l(b, a, r2), lo = __funnelshift_l(c, b, r2);
+    return (((u64)hi << 32) | lo) & kmask;
 }
 
 // OR of x << j for j = 0 .. n-1 (1 <= n <= 32), by doubling: bit p of the result (MSB first) says whether any of the
@@ -48,10 +73,9 @@ __device__ __forceinline__ u64 ep_or_span(u64 x, int n) {
     return x;
 }
 
-// seqrel is kept in 16 bits; a tile that sees 65535 or more sequence starts (tens of thousands of EMPTY
-// sequences inside 4 K bases) stores the clamp value and those positions look their sequence up instead:
-// the sequence of the base at absolute position g is the largest s with seq_off[s] <= g.
-#define EP_REL_CLAMP 0xFFFFu
+// The sequence of the base at absolute position g is the largest s with seq_off[s] <= g.  Tiles count the start
+// bits at or before a position instead (wpre + popcount); this search is for tiles in which several sequences start
+// at one position (empty sequences), where bits cannot count them.
 __device__ __forceinline__ u32 ep_seq_rel(const ExtractArgs &a, u32 s_lo, u32 s_end, u64 g) {
     u64 lo = s_lo, hi = (u64)s_end + 1;   // first index in (s_lo, s_end] with seq_off > g
     while (hi - lo > 1) {
@@ -61,31 +85,19 @@ __device__ __forceinline__ u32 ep_seq_rel(const ExtractArgs &a, u32 s_lo, u32 s_
     return (u32)(lo - s_lo);
 }
 
-// Register budget: the write pass keeps only validity masks and ranks per window and re-reads the k-mer
-// from the LDS image where it needs it (broadcast reads), which fits 3 workgroups per CU (<= 80 VGPRs,
-// ~52 KB of LDS: LDS is handed out in 1280-byte granules on gfx950, 42 granules = 53,760 B is the most a
-// workgroup may take for three to fit -- 54,160 B measured as two per CU and 10 % slower).
-template <bool WRITE, typename V>
-__global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(PartArgs pa) {
+// ---- count pass: everything up to "which windows are records", the digit histograms, and the tile image -------
+// RC: reverse-complement records asked for.  FILT: -D / -R filters or a key range are on (else none of that code is
+// even compiled in: the common path is branch-free per window).
+template <bool RC, bool FILT>
+__global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArgs pa) {
     const ExtractArgs &a = pa.e;
     __shared__ u32 pk[EX_TILE / 16 + 4];
     __shared__ u32 inv[EX_TILE / 32 + 2];
-    __shared__ u32 stb[EX_TILE / 32 + 2];
-    __shared__ uint16_t seqrel[EX_TILE + EX_EXT];      // #sequences (beyond the tile's first) starting at or before p
-    __shared__ u32 cnt32[WRITE ? 1 : EX_TILE + EX_EXT]; // sequence starts per position (write pass: inside `stage`)
-    __shared__ u32 hist[2][WRITE ? 1 : RS_DIGITS];     // count pass: forward / RC digit histograms
-    __shared__ uint16_t wcnt[WRITE ? EP_WAVES : 1][RS_DIGITS];
-    __shared__ uint16_t dstart[RS_DIGITS];             // <= EX_TILE
-    __shared__ u32 gdelta[RS_DIGITS];
-    __shared__ u64 stage[WRITE ? EX_TILE : 1];
-    __shared__ uint8_t sdig[WRITE ? EX_TILE : 1];
-    __shared__ u32 scan_smem[EP_WAVES];
-    __shared__ u32 s_tot[2];                           // count pass: forward / RC records of the tile
-    // write pass: payload source of the tile's first EP_SQCAP sequences (taxon | read index) and the low 32 bits
-    // of t0 - seq_off[s], so that building the payloads needs no global load (later sequences: global path)
-    __shared__ u32 sq_val[WRITE ? EP_SQCAP : 1];
-    __shared__ u32 sq_neg[WRITE ? EP_SQCAP : 1];
-    u32 *starts = WRITE ? reinterpret_cast<u32 *>(stage) : cnt32;
+    __shared__ u32 stb[EX_TILE / 32 + 2];              // "a sequence starts here" bitmap, MSB first
+    __shared__ u32 wpre[EX_TILE / 32];                 // sequence starts before bitmap word w
+    __shared__ u32 hist[2][RS_DIGITS];                 // forward / RC digit histograms
+    __shared__ u32 s_tot[2];                           // forward / RC records of the tile
+    __shared__ u32 s_dup;                              // some position starts more than one sequence (empty sequences)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order (see rs_scatter_kernel): neighbouring tiles' runs are adjacent in the output
@@ -95,25 +107,11 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
     const u64 t0 = (u64)tile * EX_TILE;
     const int k = a.k;
     const u32 col0 = tile * (a.rc ? 2u : 1u);
-    // Global loads that later phases depend on are issued up front, so that their latency overlaps the packing:
-    // the tile's sequence range, this thread's sequence start, the scanned table entries of digit `tid`.
+    // Global loads that later phases depend on are issued up front, so that their latency overlaps the packing
     const u32 s_lo = a.tile_seq[tile];
     const u32 s_end = a.tile_end[tile];
     const u64 my_s = (u64)s_lo + 1 + tid;
     const u64 my_start = my_s <= s_end ? a.seq_off[my_s] : 0;
-    u32 tbl0 = 0, tbl1 = 0, out_base = 0;
-    if (WRITE) {
-        out_base = pa.out_base;
-        if (tid < RS_DIGITS) {
-            tbl0 = pa.table[(u64)tid * pa.ncols + col0];
-            if (a.rc) tbl1 = pa.table[(u64)tid * pa.ncols + col0 + 1];
-        }
-        if (tid < EP_SQCAP && (u64)s_lo + tid <= s_end) {
-            const u64 sq = (u64)s_lo + tid;
-            sq_val[tid] = a.kind == KMG_PAYLOAD_TAXON ? (u32)a.seq_id[sq] : (u32)a.read_index[sq];
-            sq_neg[tid] = (u32)(t0 - a.seq_off[sq]);
-        }
-    }
 
     // ---- 1. load + pack (as extract_kernel) --------------------------------------------------------
     const bool aligned = (((uintptr_t)a.bases) & 15) == 0;
@@ -148,53 +146,38 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
         pk[chunk] = word;
         reinterpret_cast<uint16_t *>(inv)[chunk ^ 1] = (uint16_t)bad;
     }
-    for (int i = tid; i < EX_TILE + EX_EXT; i += EP_BLOCK) starts[i] = 0;
     if (tid < RS_DIGITS) {
-        if (WRITE) {
-#pragma unroll
-            for (int w = 0; w < EP_WAVES; w++) wcnt[w][tid] = 0;
-        } else {
-            hist[0][tid] = 0;
-            hist[1][tid] = 0;
-            if (tid < 2) s_tot[tid] = 0;
-        }
+        hist[0][tid] = 0;
+        hist[1][tid] = 0;
+        if (tid < EX_TILE / 32 + 2) stb[tid] = 0;
+        if (tid < 2) s_tot[tid] = 0;
+        if (tid == 2) s_dup = 0;
     }
     __syncthreads();
 
-    // ---- 2. sequence starts -> per-position sequence index ------------------------------------------
-    if (my_s <= s_end) atomicAdd(&starts[(u32)(my_start - t0)], 1u);
-    for (u64 s = my_s + EP_BLOCK; s <= s_end; s += EP_BLOCK) atomicAdd(&starts[(u32)(a.seq_off[s] - t0)], 1u);
+    // ---- 2. sequence starts -> bitmap; the sequence of position p = the tile's first + the starts at or before p ---
+    // (a start that finds its bit set already shares its position with another one -- an empty sequence: such
+    // tiles look every sequence up by binary search instead of counting bits)
+    for (u64 sq = my_s; sq <= s_end; sq += EP_BLOCK) {
+        const u32 pos = (u32)((sq == my_s ? my_start : a.seq_off[sq]) - t0);
+        const u32 bit = 0x80000000u >> (pos & 31);
+        if (atomicOr(&stb[pos >> 5], bit) & bit) s_dup = 1;
+    }
     __syncthreads();
-    {
-        // blocked: thread owns positions 8*tid .. 8*tid+7 = byte `tid` of the MSB-first start bitmap
-        u32 c[8];
-        u32 sum = 0, bits = 0;
+    if (wave == EP_WAVES - 1) {
+        const u32 c0 = __popc(stb[2 * lane]), c1 = __popc(stb[2 * lane + 1]);
+        u32 inc = c0 + c1;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            c[i] = starts[tid * 8 + i];
-            bits = (bits << 1) | (c[i] != 0);
-            sum += c[i];
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const u32 o = __shfl_up(inc, dd, 64);
+            if (lane >= dd) inc += o;
         }
-        reinterpret_cast<uint8_t *>(stb)[(tid & ~3) + (3 - (tid & 3))] = (uint8_t)bits;
-        if (tid < EX_EXT / 8) {
-            u32 eb = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) eb = (eb << 1) | (starts[EX_TILE + tid * 8 + i] != 0);
-            const int bn = EX_TILE / 8 + tid;
-            reinterpret_cast<uint8_t *>(stb)[(bn & ~3) + (3 - (bn & 3))] = (uint8_t)eb;
-        }
-        u32 total;
-        u32 incl = block_scan_inclusive<u32, OpSum, EP_WAVES>(sum, OpSum(), scan_smem, &total);
-        u32 run = incl - sum;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            run += c[i];
-            seqrel[tid * 8 + i] = (uint16_t)(run < EP_REL_CLAMP ? run : EP_REL_CLAMP);
-        }
+        wpre[2 * lane] = inc - c0 - c1;
+        wpre[2 * lane + 1] = inc - c1;
     }
     // Window validity for the whole tile, 32 positions per thread and bit-parallel: a window [p, p+k) is good when
-    // it holds no invalid base, no sequence starts at p+1 .. p+k-1, and it ends inside the input.  (stb is complete:
-    // the scan above had barriers after its last store.)  The bitmap replaces `inv`, which nothing reads afterwards.
+    // it holds no invalid base, no sequence starts at p+1 .. p+k-1, and it ends inside the input.  The bitmap replaces
+    // `inv`, which nothing reads afterwards.
     u32 vw = 0;
     if (tid < EX_TILE / 32) {
         const u64 B = ((u64)inv[tid] << 32) | inv[tid + 1];
@@ -213,64 +196,141 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
     const u64 kmask = k == 32 ? ~0ull : ~(~0ull >> (2 * k));
     const u64 rcx = 0xAAAAAAAAAAAAAAAAull & kmask;
     const u32 pbase = wave * (64 * EP_ROUNDS) + lane;
+    const bool dup = s_dup != 0;
     u32 vmask = 0, rmask = 0, nfwd = 0, nrc = 0;
-    // (not unrolled in the write pass: the eight copies of the window logic with both filters inlined cost
-    // registers the rank and staging steps need -- spills there are real memory traffic)
-#pragma unroll WRITE ? 1 : EP_ROUNDS
+#pragma unroll
     for (int j = 0; j < EP_ROUNDS; j++) {
         const u32 p = pbase + j * 64;
-        const u64 key = ep_window(pk, p, kmask);
+        // (without reverse complements or filters only the digit is needed here: the upper word)
+        const u64 key = (RC || FILT) ? ep_window(pk, p, kmask) : ((u64)ep_window_hi(pk, p, kmask) << 32);
         bool ok = (inv[p >> 5] >> (31 - (p & 31))) & 1u;
-        if (!WRITE && ok && a.has_kmer) {
-            u32 rel = seqrel[p];
-            if (rel == EP_REL_CLAMP) rel = ep_seq_rel(a, s_lo, s_end, t0 + p);
+        // a sequence's first k-mer (of this tile) sits behind a window that is none: a window across its start (k > 1),
+        // one with an invalid base, or the tile's edge -- marking there marks every sequence that has a k-mer
+        if (ok && a.has_kmer && (k == 1 || p == 0 || !((inv[(p - 1) >> 5] >> (31 - ((p - 1) & 31))) & 1u))) {
+            u32 rel;
+            if (dup) rel = ep_seq_rel(a, s_lo, s_end, t0 + p);
+            else rel = wpre[p >> 5] + __popc(stb[p >> 5] >> (31 - (p & 31)));
             a.has_kmer[s_lo + rel] = 1;
         }
-        if (ok && a.runofsame >= 0) ok = runofsame_keep(key, k, a.runofsame);
-        if (ok && a.dust >= 0) ok = dust_keep(key, k, a.dust);
+        if (FILT) {
+            if (ok && a.runofsame >= 0) ok = runofsame_keep(key, k, a.runofsame);
+            if (ok && a.dust >= 0) ok = dust_keep(key, k, a.dust);
+        }
         bool emit_rc = false;
         u64 rk = 0;
-        if (a.rc && ok) {
+        if (RC) {
             const u64 rev = revpairs64(key >> (64 - 2 * k));
-            emit_rc = !(((k & 1) == 0) && rev == key);
+            emit_rc = ok && !(((k & 1) == 0) && rev == key);
             rk = rev ^ rcx;
         }
-        if (a.ranged) {
+        if (FILT && a.ranged) {
             const u32 fb = (u32)(key >> a.range_shift), rb = (u32)(rk >> a.range_shift);
             emit_rc = emit_rc && rb >= a.range_lo && rb < a.range_hi;
             ok = ok && fb >= a.range_lo && fb < a.range_hi;
         }
         vmask |= (u32)ok << j;
-        rmask |= (u32)emit_rc << j;
-        if (!WRITE) {
-            if (ok) atomicAdd(&hist[0][(u32)(key >> pa.dshift) & pa.dmask], 1u);
-            if (emit_rc) atomicAdd(&hist[1][(u32)(rk >> pa.dshift) & pa.dmask], 1u);
-            nfwd += __popcll(__ballot(ok));          // wave-uniform running totals
+        if (RC) rmask |= (u32)emit_rc << j;
+        // (the partition digit lies in the key's upper word: dshift >= 32 for every plan, see choose_pbits)
+        if (ok) atomicAdd(&hist[0][((u32)(key >> 32) >> (pa.dshift - 32)) & pa.dmask], 1u);
+        nfwd += __popcll(__ballot(ok));          // wave-uniform running totals
+        if (RC) {
+            if (emit_rc) atomicAdd(&hist[1][((u32)(rk >> 32) >> (pa.dshift - 32)) & pa.dmask], 1u);
             nrc += __popcll(__ballot(emit_rc));
         }
     }
-    if (!WRITE && lane == 0) {
+    if (lane == 0) {
         atomicAdd(&s_tot[0], nfwd);
         atomicAdd(&s_tot[1], nrc);
     }
+    // the tile image for the write pass
+    u32 *img = pa.img + (u64)tile * EP_IMG_WORDS;
+    if (tid < (EX_TILE + EX_EXT) / 16) img[EP_IMG_PK + tid] = pk[tid];
+    if (tid < EX_TILE / 32 + 2) img[EP_IMG_STB + tid] = stb[tid];
+    reinterpret_cast<uint8_t *>(img + EP_IMG_VM)[tid] = (uint8_t)vmask;
+    if (RC) reinterpret_cast<uint8_t *>(img + EP_IMG_RM)[tid] = (uint8_t)rmask;
     __syncthreads();
 
-    if (!WRITE) {
-        // histogram columns + the tile's record / forward-window totals
-        u32 hf = 0, hr = 0;
-        if (tid < RS_DIGITS) {
-            hf = hist[0][tid];
-            hr = hist[1][tid];
-            pa.table[(u64)tid * pa.ncols + col0] = hf;
-            if (a.rc) pa.table[(u64)tid * pa.ncols + col0 + 1] = hr;
-        }
-        if (tid == 0) {
-            a.tile_count[tile] = s_tot[0] + s_tot[1];
-            a.tile_fwd[tile] = s_tot[0];
-        }
-        return;
+    // histogram columns + the tile's record / forward-window totals
+    if (tid < RS_DIGITS) {
+        pa.table[(u64)tid * pa.ncols + col0] = hist[0][tid];
+        if (RC) pa.table[(u64)tid * pa.ncols + col0 + 1] = hist[1][tid];
     }
+    if (tid == 0) {
+        a.tile_count[tile] = s_tot[0] + s_tot[1];
+        a.tile_fwd[tile] = s_tot[0];
+        img[EP_IMG_FLAG] = dup ? 1u : 0u;
+    }
+}
 
+// ---- write pass: from the tile image straight to ranking, staging and the partitioned stores ---------------------
+// Register budget: only the record bits and ranks live per window; the k-mer is re-read from the LDS image where it
+// is needed (broadcast reads), which fits 3 workgroups per CU (<= 80 VGPRs, < 53,760 B of LDS: LDS is handed out in
+// 1280-byte granules on gfx950).
+template <typename V>
+__global__ __launch_bounds__(EP_BLOCK, 6) void extract_part_write_kernel(PartArgs pa) {
+    const ExtractArgs &a = pa.e;
+    __shared__ u32 pk[EX_TILE / 16 + 4];
+    __shared__ u32 stb[EX_TILE / 32 + 4];
+    __shared__ u32 wpre[EX_TILE / 32];                 // sequence starts before bitmap word w
+    __shared__ uint16_t wcnt[EP_WAVES][RS_DIGITS];
+    __shared__ uint16_t dstart[RS_DIGITS];             // <= EX_TILE
+    __shared__ u32 gdelta[RS_DIGITS];
+    __shared__ u64 stage[EX_TILE];
+    __shared__ uint8_t sdig[EX_TILE];
+    __shared__ u32 scan_smem[EP_WAVES];
+    // payload source of the tile's first EP_SQCAP sequences (taxon | read index) and the low 32 bits of
+    // t0 - seq_off[s], so that building the payloads needs no global load (later sequences: global path)
+    __shared__ u32 sq_val[EP_SQCAP];
+    __shared__ u32 sq_neg[EP_SQCAP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 per_xcd = (pa.ntiles + 7) / 8;
+    const u32 tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= pa.ntiles) return;
+    const u64 t0 = (u64)tile * EX_TILE;
+    const int k = a.k;
+    const u32 col0 = tile * (a.rc ? 2u : 1u);
+    const u32 *img = pa.img + (u64)tile * EP_IMG_WORDS;
+    // everything the tile needs from global memory is asked for up front
+    const u32 img_w = tid < EP_IMG_VM ? img[tid] : 0u;               // packed bases, then the start bitmap
+    const u32 vmask = reinterpret_cast<const uint8_t *>(img + EP_IMG_VM)[tid];
+    const u32 rmask = a.rc ? reinterpret_cast<const uint8_t *>(img + EP_IMG_RM)[tid] : 0u;
+    const bool dup = img[EP_IMG_FLAG] != 0;
+    const u32 s_lo = a.tile_seq[tile];
+    const u32 s_end = a.tile_end[tile];
+    u32 tbl0 = 0, tbl1 = 0;
+    const u32 out_base = pa.out_base;
+    if (tid < RS_DIGITS) {
+        tbl0 = pa.table[(u64)tid * pa.ncols + col0];
+        if (a.rc) tbl1 = pa.table[(u64)tid * pa.ncols + col0 + 1];
+#pragma unroll
+        for (int w = 0; w < EP_WAVES; w++) wcnt[w][tid] = 0;
+    }
+    if (tid < EP_SQCAP && (u64)s_lo + tid <= s_end) {
+        const u64 sq = (u64)s_lo + tid;
+        sq_val[tid] = a.kind == KMG_PAYLOAD_TAXON ? (u32)a.seq_id[sq] : (u32)a.read_index[sq];
+        sq_neg[tid] = (u32)(t0 - a.seq_off[sq]);
+    }
+    if (tid < EP_IMG_STB) pk[tid] = img_w;
+    else if (tid < EP_IMG_VM) stb[tid - EP_IMG_STB] = img_w;
+    __syncthreads();
+    if (wave == 0) {
+        // starts before each bitmap word: lane owns words 2*lane, 2*lane + 1
+        const u32 c0 = __popc(stb[2 * lane]), c1 = __popc(stb[2 * lane + 1]);
+        u32 inc = c0 + c1;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const u32 o = __shfl_up(inc, dd, 64);
+            if (lane >= dd) inc += o;
+        }
+        wpre[2 * lane] = inc - c0 - c1;
+        wpre[2 * lane + 1] = inc - c1;
+    }
+    // (wpre is read in the payload step, behind the ranking step's barriers)
+
+    const u64 kmask = k == 32 ? ~0ull : ~(~0ull >> (2 * k));
+    const u64 rcx = 0xAAAAAAAAAAAAAAAAull & kmask;
+    const u32 pbase = wave * (64 * EP_ROUNDS) + lane;
     V *out_vals = reinterpret_cast<V *>(a.out_vals);
     for (int sp = 0; sp < (a.rc ? 2 : 1); sp++) {
         const u32 imask = sp == 0 ? vmask : rmask;
@@ -283,9 +343,10 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
 #pragma unroll
         for (int j = 0; j < EP_ROUNDS; j++) {
             const bool valid = (imask >> j) & 1;
-            u64 key = ep_window(pk, pb + j * 64, kmask);
-            if (sp) key = revpairs64(key >> (64 - 2 * k)) ^ rcx;
-            const u32 d = (u32)(key >> pa.dshift) & pa.dmask;
+            u32 khi;                                     // upper word of the record's key: the digit lies there
+            if (sp) khi = (u32)((revpairs64(ep_window64(pk, pb + j * 64, kmask) >> (64 - 2 * k)) ^ rcx) >> 32);
+            else khi = ep_window_hi(pk, pb + j * 64, kmask);
+            const u32 d = (khi >> (pa.dshift - 32)) & pa.dmask;                  // dshift >= 32 (choose_pbits <= 24)
             u32 below, total;
             wave_match(d, valid, below, total);
             const u32 before = wcnt[wave][d];
@@ -318,7 +379,7 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
 #pragma unroll
         for (int j = 0; j < EP_ROUNDS; j++) {
             if ((imask >> j) & 1) {
-                u64 key = ep_window(pk, pb + j * 64, kmask);
+                u64 key = ep_window64(pk, pb + j * 64, kmask);
                 if (sp) key = revpairs64(key >> (64 - 2 * k)) ^ rcx;
                 const u32 d = lpos[j] >> 16;
                 const u32 slot = (lpos[j] & 0xFFFFu) + dstart[d] + wcnt[wave][d];
@@ -339,8 +400,10 @@ __global__ __launch_bounds__(EP_BLOCK, WRITE ? 6 : 8) void extract_part_kernel(P
             if ((imask >> j) & 1) {
                 // payload of the window (the sequence tables are tiny and cached: a tile spans few sequences)
                 const u32 p = pb + j * 64;
-                u32 rel = seqrel[p];
-                if (rel == EP_REL_CLAMP) rel = ep_seq_rel(a, s_lo, s_end, t0 + p);
+                // the window's sequence = the tile's first + the sequence starts at or before p
+                u32 rel;
+                if (dup) rel = ep_seq_rel(a, s_lo, s_end, t0 + p);
+                else rel = wpre[p >> 5] + __popc(stb[p >> 5] >> (31 - (p & 31)));
                 u32 sv, neg;
                 if (rel < EP_SQCAP) { sv = sq_val[rel]; neg = sq_neg[rel]; }
                 else {

@@ -260,14 +260,14 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     // full windows, so the state snapshot of the fused path would be stale)
     const bool var = ctx->min_k < ctx->k;
     const int plan = (ctx->n_adds == 0 && !var) ? choose_pbits(expect, 2 * ctx->k) : 0;
-    const bool part = plan > 0 && nbases < 0xFFFFFFF0ull / 2;
+    const bool part = plan > 0 && plan <= 32 && nbases < 0xFFFFFFF0ull / 2;   // (<= 32: the partition digit lies in the key's upper word)
     ctx->prepart = part;
     ctx->plan_pbits = plan;
     ctx->n_adds++;
     ctx->snap_valid = false;
     PartArgs pa;
     memset(&pa, 0, sizeof pa);
-    PoolBuf table(ctx), tagg(ctx), mx(ctx);
+    PoolBuf table(ctx), tagg(ctx), mx(ctx), img(ctx);
     bool len_pending = false;
     if (part && reads) {
         // Compact payloads: when every (read, pos) of the batch fits 32 bits -- pos < 2^pb from the longest
@@ -290,6 +290,8 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         pa.dshift = d0.shift; pa.dmask = (1u << d0.bits) - 1u;
         pa.ntiles = ntiles; pa.ncols = ntiles * (ctx->rc ? 2 : 1);
         KMG_ALLOC(table, (size_t)RS_DIGITS * pa.ncols * 4);
+        KMG_ALLOC(img, (size_t)ntiles * EP_IMG_WORDS * 4);      // the count pass's tile images, read back by the write pass
+        pa.img = img.as<u32>();
         KMG_ALLOC(tagg, (size_t)(div_up_u64((u64)RS_DIGITS * pa.ncols, SCAN_TILE) + 1) * 8);
         pa.table = table.as<u32>();
         // forward and RC records of a tile are written as two runs: (read, pos) order inside a k-mer is
@@ -302,7 +304,14 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         if (part) {
             pa.e = a;
             // (the payload type only matters to the write pass)
-            hipLaunchKernelGGL((extract_part_kernel<false, u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+            const bool filt = ctx->dust >= 0 || ctx->runofsame >= 0 || ctx->ranged;
+            if (ctx->rc) {
+                if (filt) hipLaunchKernelGGL((extract_part_count_kernel<true, true>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+                else hipLaunchKernelGGL((extract_part_count_kernel<true, false>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+            } else {
+                if (filt) hipLaunchKernelGGL((extract_part_count_kernel<false, true>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+                else hipLaunchKernelGGL((extract_part_count_kernel<false, false>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+            }
         } else hipLaunchKernelGGL((extract_kernel<false>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
         hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_fwd.as<u32>(),
                            ntiles, ctx->d_state + ST_NWIN);
@@ -382,8 +391,8 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases /* + records * rec_b, added at finish when N is known */);
         pa.e = a;
         pa.out_base = 0;
-        if (reads && !compact) hipLaunchKernelGGL((extract_part_kernel<true, u64>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
-        else hipLaunchKernelGGL((extract_part_kernel<true, u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+        if (reads && !compact) hipLaunchKernelGGL((extract_part_write_kernel<u64>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+        else hipLaunchKernelGGL((extract_part_write_kernel<u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
     } else {
         KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, tile_count.as<u32>(), tile_off.as<u64>(), ntiles, OpSum(), 0ull,
                                                     agg.as<u64>(), nullptr, true, KP_SCAN)));
