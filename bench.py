@@ -200,8 +200,9 @@ def main():
 
     stage_s = {"ref_build": 0.0, "read_build": 0.0, "match": 0.0}
 
-    ranges = None
+    ranges, comm = None, None
     if use_dist:
+        comm = kd.Comm(ctx)        # the library's own RCCL communicator (csrc/comm.h): the exchange runs under the C ABI
         # The partition of the key space is a property of the reference, planned once: balanced ranges from the bucket
         # histogram of one complete build (every rank holds the whole input, so all ranks find the same ranges).
         submit(ctx_ref, d_ref_bases, d_ref_off, d_ref_id, None, len(genomes), 0, 1)
@@ -219,7 +220,7 @@ def main():
         shard = km.KmerDatabase(ctx_ref, ref_h)
         rdb_h, nw_reads = finish(ctx)
         rdb = km.KmerDatabase(ctx, rdb_h)
-        _, hit = kd.match_key_range_shard(ctx, rdb, shard, ranges, want_owner=False)
+        _, hit = kd.match_key_range_shard(ctx, rdb, shard, ranges, want_owner=False, comm=comm)
         u = rdb.n_unique
         rdb.close()
         shard.close()

@@ -236,6 +236,33 @@ int kmg_match_dev_noalloc(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref,
 int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int max_diff, uint64_t *pair_off,
                    int64_t *ref_index, uint8_t *dist, uint64_t capacity, uint64_t *n_pairs);
 
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI (no counterpart in the reference, which is one process) ------
+ * The reference's form of a database in pieces is the file set name.1 .. name.N (Matcher.java:80-89), walked in ascending
+ * k-mer order (DB.kmers, DB.java:99-109).  Here piece g is the contiguous range of key buckets [bounds[g], bounds[g+1])
+ * (Kmer.key(key_len), Kmer.java:47-55) that GPU g owns; bounds has nranks + 1 ascending entries in 0 .. 4^key_len.
+ * kmg_comm_unique_id : rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means.
+ * kmg_comm_create    : every rank, with the context whose GPU and stream the exchange uses (ncclCommInitRank).  RCCL is
+ *                      looked up at run time; KMG_EUNSUPPORTED where librccl.so is absent.
+ * kmg_match_sharded  : the sharded Matcher join.  Collective: every rank calls it with its own search database and its
+ *                      own shard of the reference.  The search k-mers are cut at the bounds (a database is sorted: each
+ *                      owner's part is a slice), exchanged by grouped ncclSend / ncclRecv, joined at the owners in one
+ *                      launch (kmg_match_keys_dev's kernels) and the hit indices exchanged back:
+ *                      d_hit_index[i] (DEVICE, n_unique of `search`) = index INTO THE OWNER'S SHARD of the k-mer equal to
+ *                      search k-mer i, -1 = none; the owner of k-mer i is the range its bucket falls in.  Asynchronous on
+ *                      kmg_stream() after two small host round trips (cut points, counts).
+ * kmg_db_exchange_by_key_range: for inputs that are sharded too -- every rank holds the database of ITS part of the
+ *                      input; each range's slice travels to its owner (four all-to-all-v: k-mers, values per k-mer, two
+ *                      value arrays) and the owner merges what arrived as kmg_db_merge does.  *out = this rank's shard. */
+typedef struct kmg_comm kmg_comm;
+#define KMG_COMM_ID_BYTES 128
+int  kmg_comm_unique_id(uint8_t *id /* KMG_COMM_ID_BYTES */);
+int  kmg_comm_create(kmg_ctx *ctx, int nranks, int rank, const uint8_t *id, kmg_comm **out);
+void kmg_comm_destroy(kmg_comm *comm);
+int  kmg_comm_info(const kmg_comm *comm, int *nranks, int *rank);
+int  kmg_match_sharded(kmg_comm *comm, const kmg_db *search, const kmg_db *ref_shard, const uint32_t *bounds,
+                       int64_t *d_hit_index);
+int  kmg_db_exchange_by_key_range(kmg_comm *comm, const kmg_db *local, const uint32_t *bounds, kmg_db **out);
+
 /* ---- TaxaCounts default mode (replaces TaxaCounts.java:119-130,355-360,386-395) --------------
  * Over every stored k-mer: match[t]++ for each taxon of its list, unique[t]++ if the list has
  * exactly one taxon.  Output ascending by taxon.  In: *n_taxa = capacity; out: taxa found

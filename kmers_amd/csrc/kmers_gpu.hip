@@ -1434,11 +1434,19 @@ extern "C" int kmg_match_dev(kmg_ctx *ctx, const kmg_db *search, const kmg_db *r
     return match_locked(ctx, search, ref, (long long *)d_hit_index, nullptr);
 }
 
+static int match_keys_locked(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run_off, int n_runs, int k,
+                             const kmg_db *ref, int64_t *d_hit_index);
+
 extern "C" int kmg_match_keys_dev(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run_off, int n_runs, int k,
                                   const kmg_db *ref, int64_t *d_hit_index) {
     if (!ctx || !ref || !run_off) return KMG_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
     KMG_HIP(hipSetDevice(ctx->device));
+    return match_keys_locked(ctx, d_keys, run_off, n_runs, k, ref, d_hit_index);
+}
+
+static int match_keys_locked(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run_off, int n_runs, int k,
+                             const kmg_db *ref, int64_t *d_hit_index) {
     if (ref->ctx->device != ctx->device) return fail(ctx, KMG_EINVAL, "database belongs to another device");
     if (k != ref->k)                                                                             // DB.java:78-81
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
@@ -1893,3 +1901,6 @@ extern "C" int kmg_calib_copy(kmg_ctx *ctx, uint64_t n_words) {
 
 extern "C" const char *kmg_prof_name(int id) { return (id >= 0 && id < KP_COUNT_) ? kp_names[id] : ""; }
 extern "C" int kmg_prof_count(void) { return KP_COUNT_; }
+
+// ------------------------------------------------------------------------------------------------ multi-GPU
+#include "comm.h"

@@ -11,12 +11,79 @@ of its own input shard, cuts it at the range bounds -- the k-mers are sorted, so
 contiguous CSR slice, no scatter kernel is needed -- and one all-to-all-v per array (`exchange_csr`) sends the
 parts to their owners, which merge them on the GPU (`kmg_db_merge`: counts add, read lists unite).  Matching
 against a range-sharded reference is the same cut on the search k-mers, one all-to-all of keys, a local join,
-and the reverse all-to-all of the hit indices (`match_by_key_range`).  The collectives are
-`torch.distributed.all_to_all_single` (RCCL grouped send/recv under "nccl"; the CPU tests run them on gloo).
+and the reverse all-to-all of the hit indices (`match_by_key_range`).
+
+On GPUs both exchange steps live under the C ABI (csrc/comm.h: kmg_match_sharded, kmg_db_exchange_by_key_range --
+grouped ncclSend / ncclRecv on the library's stream), so that a JNI / FFM caller reaches them too; `Comm` below is
+their Python face and needs torch.distributed only to hand rank 0's RCCL id to the other ranks.  The tensor versions
+(`exchange_csr_tensors`, `match_by_key_range_tensors`; `torch.distributed.all_to_all_single`) are the same
+arithmetic on torch tensors: the CPU tests run them on gloo against the single-process oracle.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+class Comm:
+    """kmg_comm: this rank's end of the RCCL communicator the library's exchange steps run on (one per context)."""
+
+    def __init__(self, ctx, rank=None, world=None, group=None):
+        import ctypes as C
+        self.ctx = ctx
+        self.rank = (dist.get_rank(group) if dist.is_initialized() else 0) if rank is None else rank
+        self.world = (dist.get_world_size(group) if dist.is_initialized() else 1) if world is None else world
+        ident = np.zeros(128, np.uint8)
+        if self.rank == 0:
+            rc = ctx.lib.kmg_comm_unique_id(ident.ctypes.data_as(C.c_void_p))
+            if rc != 0:
+                raise RuntimeError("kmg_comm_unique_id failed (%d): is RCCL installed?" % rc)
+        if self.world > 1:
+            # rank 0's id travels over the process group the caller already has (any backend)
+            t = torch.from_numpy(ident.astype(np.int32))
+            backend = dist.get_backend(group)
+            t = t.to(torch.device("cuda", ctx.device)) if backend == "nccl" else t
+            dist.broadcast(t, src=0, group=group)
+            ident = t.cpu().numpy().astype(np.uint8)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.kmg_comm_create(ctx.h, self.world, self.rank, ident.ctypes.data_as(C.c_void_p), C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def bounds(ranges):
+        """(first, end) bucket ranges of the ranks, contiguous and ascending -> the nranks + 1 bounds the C ABI takes."""
+        b = [int(r[0]) for r in ranges] + [int(ranges[-1][1])]
+        for (a0, a1), nxt in zip(ranges, b[1:]):
+            if int(a1) != nxt:
+                raise ValueError("key ranges must be contiguous")
+        return np.array(b, np.uint32)
+
+    def match_sharded(self, search_db, ref_shard, ranges, out=None):
+        """kmg_match_sharded -> int64 tensor on the context's GPU: for every k-mer of search_db its hit index inside
+        the OWNER's shard, -1 = none."""
+        import ctypes as C
+        dev = torch.device("cuda", self.ctx.device)
+        if out is None:
+            out = torch.empty(search_db.n_unique, dtype=torch.int64, device=dev)
+        b = self.bounds(ranges)
+        torch.cuda.current_stream(dev).synchronize()          # `out` may still be in use on torch's stream
+        self.ctx.check(self.ctx.lib.kmg_match_sharded(self.h, search_db.h, ref_shard.h, b.ctypes.data_as(C.c_void_p),
+                                                      out.data_ptr() if out.numel() else None))
+        torch.cuda.ExternalStream(self.ctx.stream, device=dev).synchronize()
+        return out
+
+    def exchange_by_key_range(self, local_db, ranges):
+        """kmg_db_exchange_by_key_range -> KmerDatabase: every rank's k-mers of THIS rank's key range, merged."""
+        import ctypes as C
+        from .api import KmerDatabase
+        b = self.bounds(ranges)
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.kmg_db_exchange_by_key_range(self.h, local_db.h, b.ctypes.data_as(C.c_void_p), C.byref(h)))
+        return KmerDatabase(self.ctx, h)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.kmg_comm_destroy(self.h)
+            self.h = None
 
 
 def shard_range(n, rank, world):
@@ -190,12 +257,15 @@ def exchange_csr(csr, ranges, key_len, device="cpu", group=None):
                  val_a=a.cpu().numpy().copy(), val_b=b.cpu().numpy().copy()) for k, o, a, b in parts]
 
 
-def build_key_range_shard(ctx, local_db, ranges, device=None, group=None):
-    """The exchange step of a sharded build: local_db (KmerDatabase of this rank's input shard) -> KmerDatabase
+def build_key_range_shard(ctx, local_db, ranges, device=None, group=None, comm=None):
+    """(comm given: kmg_db_exchange_by_key_range does all of it under the C ABI.)
+    The exchange step of a sharded build: local_db (KmerDatabase of this rank's input shard) -> KmerDatabase
     holding every rank's k-mers of THIS rank's key range, merged on the GPU.  Device-resident end to end: the
     CSR arrays are copied out of the library into torch tensors on the context's GPU (kmg_db_copy_dev), cut at
     the bucket offsets the database already holds, exchanged GPU to GPU and handed back with kmg_db_load_dev."""
     from .api import KmerDatabase, merge_databases
+    if comm is not None:
+        return comm.exchange_by_key_range(local_db, ranges)
     dev = torch.device("cuda", ctx.device) if device is None else torch.device(device)
     keys, val_off, val_a, val_b = local_db.to_tensors(dev)
     boff = local_db.bucket_offsets()
@@ -275,12 +345,22 @@ def shard_matcher(ctx, like_db, ref_shard):
     return local_match
 
 
-def match_key_range_shard(ctx, search_db, ref_shard, ranges, group=None, want_owner=True):
+def match_key_range_shard(ctx, search_db, ref_shard, ranges, group=None, want_owner=True, comm=None):
     """The sharded Matcher join, device-resident: search_db's k-mers (this rank's read database) are cut at the
     key-range bounds, exchanged GPU to GPU, joined by every owner against its reference shard and the hit indices
     come back the same way.  -> (owner int32 tensor, hit int64 tensor) on the context's GPU, one entry per k-mer
-    of search_db."""
+    of search_db.  comm (a Comm): the whole step runs under the C ABI (kmg_match_sharded); without one, the torch
+    version of the same arithmetic."""
     dev = torch.device("cuda", ctx.device)
+    if comm is not None:
+        hit = comm.match_sharded(search_db, ref_shard, ranges)
+        if not want_owner:
+            return None, hit
+        boff = search_db.bucket_offsets()
+        owner = torch.full((search_db.n_unique,), -1, dtype=torch.int32, device=dev)
+        for g_, r in enumerate(ranges):
+            owner[int(boff[r[0]]):int(boff[r[1]])] = g_
+        return owner, hit
     keys = torch.empty(search_db.n_unique, dtype=torch.int64, device=dev)
     torch.cuda.current_stream(dev).synchronize()
     ctx.check(ctx.lib.kmg_db_copy_dev(search_db.h, 0, keys.data_ptr() if keys.numel() else None, 0, keys.numel()))

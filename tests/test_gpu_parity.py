@@ -1441,3 +1441,52 @@ def test_fuzz_variable_length_against_oracle(ctx, seed):
     assert nh == o_nh and np.array_equal(hit, o_hit)
     for d in (ref, rdb, rr, rs):
         d.close()
+
+
+def test_exchange_under_the_c_abi_world_of_one(ctx):
+    """kmg_comm_create / kmg_match_sharded / kmg_db_exchange_by_key_range with one rank: the grouped ncclSend / ncclRecv
+    are sends to self, everything else (cuts, count exchange, one-launch join of the received runs, reverse exchange,
+    rebuilding and merging the received parts) is the code the N-GPU run takes.  Against the oracle's whole-database
+    join, with ranges that leave some buckets without an owner."""
+    import kmers_amd as km
+    from kmers_amd import dist as kd, synth
+    from oracle.c_oracle import OracleDB
+    k, l = 21, 4
+    taxa, genomes = synth.random_genomes(301, 4, 30000, shared_frac=0.3)
+    reads = synth.random_reads(302, genomes, 4000, 100, 0.01, n_rate=0.002)
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    ref = km.make_reference_db(ctx, fa, k, l)
+    rdb, _ = km.make_read_db(ctx, fq, k, l)
+    o_ref, o_reads = OracleDB(fa, 0, k, l), OracleDB(fq, 1, k, l)
+    o_hit, _ = o_reads.match(o_ref)
+    try:
+        comm = kd.Comm(ctx, rank=0, world=1)
+    except km.KmersGpuError as e:
+        pytest.skip("no RCCL on this machine: %s" % e)
+    # the whole key space owned by the one rank: the plain join
+    hit = comm.match_sharded(rdb, ref, [(0, 4 ** l)])
+    assert np.array_equal(hit.cpu().numpy(), o_hit)
+    owner, hit2 = kd.match_key_range_shard(ctx, rdb, ref, [(0, 4 ** l)], comm=comm)
+    assert np.array_equal(hit2.cpu().numpy(), o_hit) and int(owner.min()) == 0 == int(owner.max())
+    # a range that leaves the first and the last buckets without an owner: those k-mers find nothing
+    lo, hi = 37, 4 ** l - 11
+    sub = comm.match_sharded(rdb, ref, [(lo, hi)])
+    boff = o_reads.bucket_off
+    want = o_hit.copy()
+    want[:int(boff[lo])] = -1
+    want[int(boff[hi]):] = -1
+    assert np.array_equal(sub.cpu().numpy(), want) and (want >= 0).sum() > 1000
+    # the database exchange: the rank's own slice comes back, merged into one database
+    shard = comm.exchange_by_key_range(ref, [(lo, hi)])
+    h = shard.fetch()
+    a, b = int(o_ref.bucket_off[lo]), int(o_ref.bucket_off[hi])
+    va, vb = int(o_ref.val_off[a]), int(o_ref.val_off[b])
+    assert np.array_equal(h["keys"], o_ref.keys[a:b]) and np.array_equal(h["val_off"], o_ref.val_off[a:b + 1] - o_ref.val_off[a])
+    assert np.array_equal(h["val_a"], o_ref.val_a[va:vb]) and np.array_equal(h["val_b"], o_ref.val_b[va:vb])
+    whole = kd.build_key_range_shard(ctx, rdb, [(0, 4 ** l)], comm=comm)          # a read database, all of it
+    _same_db(whole, o_reads)
+    empty = comm.exchange_by_key_range(ref, [(5, 5)])
+    assert empty.n_unique == 0 and empty.n_values == 0
+    for d in (shard, whole, empty, ref, rdb):
+        d.close()
+    comm.close()
