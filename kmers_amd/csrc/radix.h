@@ -515,31 +515,23 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
 // buffers (whose records it holds in LDS by then), the segment's distinct k-mers (keys_in[s0 ..]) and the
 // index of each one's first record (vals_in[s0 ..], in the payload's own width), their number to ucount[segment], and
 // only the payloads to vals_out: the per-record sorted keys are never needed again.
-template <typename V, bool HEADS>
-__global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *keys_in, V *vals_in, u64 *__restrict__ keys_out,
-                                                               V *__restrict__ vals_out, const u32 *__restrict__ seg_off,
-                                                               LocalPasses lp, int pbits, u32 *__restrict__ ucount) {
-    __shared__ uint16_t wcnt[LS_WAVES][RS_DIGITS];
-    __shared__ uint16_t wbase[LS_WAVES][RS_DIGITS];
-    __shared__ u64 swords[LS_MAX];
-    __shared__ V svals[LS_MAX];
-
-    const u32 s0 = seg_off[blockIdx.x];
-    const u32 m = seg_off[blockIdx.x + 1] - s0;
-    if (m == 0 || m > LS_MAX) {
-        if (HEADS && threadIdx.x == 0) ucount[blockIdx.x] = 0;   // (the host never asks for HEADS with oversize segments)
-        return;
-    }
+// (the body is compiled once per number of rounds -- ROUNDS x 512 slots cover the segment -- so that every loop over a
+// thread's records is straight-line code: the rounds' ballot chains and counter look-ups overlap instead of queueing
+// behind one scalar branch per round)
+template <typename V, bool HEADS, int ROUNDS>
+__device__ __forceinline__ void ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *__restrict__ keys_out, V *__restrict__ vals_out,
+                                                const LocalPasses &lp, int pbits, u32 *__restrict__ ucount, u32 s0, u32 m,
+                                                uint16_t (*wcnt)[RS_DIGITS], uint16_t (*wbase)[RS_DIGITS], u64 *swords, V *svals) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rounds = (int)((m + LS_BLOCK - 1) / LS_BLOCK);
+    constexpr int rounds = ROUNDS;
     const u32 wave_base = wave * 64 * rounds;
 
     // Slots [m, rounds * 512) hold all-ones sentinels: they sort behind every record (stably, they are
     // loaded last), so no step below needs a per-lane validity branch.
-    u64 sw[LS_ITEMS];
-    u32 rank[LS_ITEMS];
+    u64 sw[ROUNDS];
+    u32 rank[ROUNDS];
 #pragma unroll
-    for (int j = 0; j < LS_ITEMS; j++) {
+    for (int j = 0; j < ROUNDS; j++) {
         const u32 li = wave_base + j * 64 + lane;
         const bool valid = j < rounds && li < m;
         sw[j] = valid ? ((keys_in[s0 + li] << pbits) | li) : ~0ull;
@@ -550,15 +542,13 @@ __global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *
         const int shift = lp.shift[p] + pbits;
         const u32 mask = (1u << lp.bits[p]) - 1u;
 #pragma unroll
-        for (int j = 0; j < LS_ITEMS; j++) {
-            if (j < rounds) {
-                const u32 d = (u32)(sw[j] >> shift) & mask;
-                u32 below, total;
-                wave_match(d, true, below, total);
-                const u32 before = wcnt[wave][d];
-                rank[j] = before + below;
-                if (below == 0) wcnt[wave][d] = before + total;
-            }
+        for (int j = 0; j < ROUNDS; j++) {
+            const u32 d = (u32)(sw[j] >> shift) & mask;
+            u32 below, total;
+            wave_match(d, true, below, total);
+            const u32 before = wcnt[wave][d];
+            rank[j] = before + below;
+            if (below == 0) wcnt[wave][d] = before + total;
         }
         __syncthreads();
         if (wave == 0) {
@@ -587,18 +577,18 @@ __global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *
                 *reinterpret_cast<uint2 *>(&wbase[w][4 * lane]) = make_uint2(start.x + pre[w].x, start.y + pre[w].y);
         }
         __syncthreads();
-        u32 pos[LS_ITEMS];
+        u32 pos[ROUNDS];
 #pragma unroll
-        for (int j = 0; j < LS_ITEMS; j++)
+        for (int j = 0; j < ROUNDS; j++)
             if (j < rounds) pos[j] = wbase[wave][(u32)(sw[j] >> shift) & mask] + rank[j];
 #pragma unroll
-        for (int j = 0; j < LS_ITEMS; j++)
+        for (int j = 0; j < ROUNDS; j++)
             if (j < rounds) swords[pos[j]] = sw[j];
         __syncthreads();
         *reinterpret_cast<uint2 *>(&wcnt[wave][4 * lane]) = make_uint2(0, 0);
         if (p + 1 < lp.n) {
 #pragma unroll
-            for (int j = 0; j < LS_ITEMS; j++)
+            for (int j = 0; j < ROUNDS; j++)
                 if (j < rounds) sw[j] = swords[wave_base + j * 64 + lane];
         }
     }
@@ -614,11 +604,11 @@ __global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *
     // the last pass's closing barrier ordered every load of this block's input slice before these stores
     u32 *wtot = reinterpret_cast<u32 *>(&wbase[0][0]);   // head counts per (round, wave), in record order
     const u64 below_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    u64 hw[LS_ITEMS];
-    u32 hbelow[LS_ITEMS];
+    u64 hw[ROUNDS];
+    u32 hbelow[ROUNDS];
     u32 hmask = 0;
 #pragma unroll
-    for (int r = 0; r < LS_ITEMS; r++) {
+    for (int r = 0; r < ROUNDS; r++) {
         if (r < rounds) {
             const u32 i = r * LS_BLOCK + tid;
             const bool inb = i < m;
@@ -643,7 +633,7 @@ __global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *
     }
     const u32 exc = inc - c;
 #pragma unroll
-    for (int r = 0; r < LS_ITEMS; r++) {
+    for (int r = 0; r < ROUNDS; r++) {
         if (r < rounds) {
             const u32 base = __shfl(exc, r * LS_WAVES + wave, 64);
             if ((hmask >> r) & 1) {
@@ -655,6 +645,30 @@ __global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *
     }
     const u32 nheads = __shfl(inc, 63, 64);
     if (tid == 0) ucount[blockIdx.x] = nheads;
+}
+
+template <typename V, bool HEADS>
+__global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *keys_in, V *vals_in, u64 *__restrict__ keys_out,
+                                                               V *__restrict__ vals_out, const u32 *__restrict__ seg_off,
+                                                               LocalPasses lp, int pbits, u32 *__restrict__ ucount) {
+    __shared__ uint16_t wcnt[LS_WAVES][RS_DIGITS];
+    __shared__ uint16_t wbase[LS_WAVES][RS_DIGITS];
+    __shared__ u64 swords[LS_MAX];
+    __shared__ V svals[LS_MAX];
+
+    const u32 s0 = seg_off[blockIdx.x];
+    const u32 m = seg_off[blockIdx.x + 1] - s0;
+    if (m == 0 || m > LS_MAX) {
+        if (HEADS && threadIdx.x == 0) ucount[blockIdx.x] = 0;   // (the host never asks for HEADS with oversize segments)
+        return;
+    }
+    switch ((m + LS_BLOCK - 1) / LS_BLOCK) {
+        case 1: ls_sortidx_body<V, HEADS, 1>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        case 2: ls_sortidx_body<V, HEADS, 2>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        case 3: ls_sortidx_body<V, HEADS, 3>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        case 4: ls_sortidx_body<V, HEADS, 4>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        default: ls_sortidx_body<V, HEADS, 5>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+    }
 }
 
 // Gathers what ls_sortidx_kernel<.., true> left per segment into the DB arrays: one block per segment.
