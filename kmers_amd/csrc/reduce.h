@@ -13,33 +13,31 @@
 
 // A record starts a new k-mer run if its key differs from its predecessor's; a new (k-mer, taxon) run if
 // additionally / alternatively the payload differs.  For read DBs every record is its own value.
+// Coalesced: lane i of a round reads record base + i (and its predecessor, which the neighbouring lane just
+// loaded: a cache hit); heads are ranked with ballots, so the lanes of a wave store to consecutive slots.
+#define RD_WAVES (RD_BLOCK / 64)
 template <typename V, bool IS_REF>
 __global__ __launch_bounds__(RD_BLOCK) void rd_count_kernel(const u64 *__restrict__ keys, const V *__restrict__ vals,
                                                              u32 n, u32 *__restrict__ cnt_k, u32 *__restrict__ cnt_v) {
     __shared__ u32 smem[4];
-    const u32 base = blockIdx.x * RD_TILE + threadIdx.x * RD_ITEMS;
+    const u32 base = blockIdx.x * RD_TILE;
     u32 ck = 0, cv = 0;
-    u64 pk = 0;
-    V pv = 0;
-    if (base > 0 && base < n) { pk = keys[base - 1]; if (IS_REF) pv = vals[base - 1]; }
 #pragma unroll
-    for (int i = 0; i < RD_ITEMS; i++) {
-        u32 idx = base + i;
+    for (int r = 0; r < RD_ITEMS; r++) {
+        const u32 idx = base + r * RD_BLOCK + threadIdx.x;
+        bool hk = false, hv = false;
         if (idx < n) {
-            u64 kk = keys[idx];
-            bool hk = idx == 0 || kk != pk;
-            ck += hk;
-            if (IS_REF) {
-                V vv = vals[idx];
-                cv += hk || vv != pv;
-                pv = vv;
-            }
-            pk = kk;
+            const u64 kk = keys[idx];
+            hk = idx == 0 || kk != keys[idx - 1];
+            if (IS_REF) hv = hk || vals[idx] != vals[idx - 1];
         }
+        ck += __popcll(__ballot(hk));       // wave-uniform counts
+        if (IS_REF) cv += __popcll(__ballot(hv));
     }
+    const bool first = (threadIdx.x & 63) == 0;
     u32 tk, tv = 0;
-    block_scan_inclusive(ck, OpSum(), smem, &tk);
-    if (IS_REF) block_scan_inclusive(cv, OpSum(), smem, &tv);
+    block_scan_inclusive(first ? ck : 0u, OpSum(), smem, &tk);
+    if (IS_REF) block_scan_inclusive(first ? cv : 0u, OpSum(), smem, &tv);
     if (threadIdx.x == 0) {
         cnt_k[blockIdx.x] = tk;
         if (IS_REF) cnt_v[blockIdx.x] = tv;
@@ -52,56 +50,81 @@ __global__ __launch_bounds__(RD_BLOCK) void rd_write_kernel(const u64 *__restric
                                                              const u64 *__restrict__ off_v, u64 *__restrict__ ukeys,
                                                              u64 *__restrict__ val_off, int32_t *__restrict__ val_a,
                                                              int32_t *__restrict__ val_b, u32 *__restrict__ vstart) {
-    __shared__ u32 smem[4];
-    const u32 base = blockIdx.x * RD_TILE + threadIdx.x * RD_ITEMS;
+    __shared__ u32 wck[RD_ITEMS][RD_WAVES], wcv[RD_ITEMS][RD_WAVES];     // heads per (round, wave), in record order
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 base = blockIdx.x * RD_TILE;
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     u64 kk[RD_ITEMS];
     V vv[RD_ITEMS];
-    u32 hk = 0, hv = 0, ck = 0, cv = 0;
-    u64 pk = 0;
-    V pv = 0;
-    if (base > 0 && base < n) { pk = keys[base - 1]; if (IS_REF) pv = vals[base - 1]; }
+    u32 hk = 0, hv = 0;
+    uint8_t prek[RD_ITEMS], prev[RD_ITEMS];
 #pragma unroll
-    for (int i = 0; i < RD_ITEMS; i++) {
-        u32 idx = base + i;
-        kk[i] = 0; vv[i] = 0;
+    for (int r = 0; r < RD_ITEMS; r++) {
+        const u32 idx = base + r * RD_BLOCK + tid;
+        bool h = false, h2 = false;
+        kk[r] = 0; vv[r] = 0;
         if (idx < n) {
-            kk[i] = keys[idx];
-            vv[i] = vals[idx];
-            bool h = idx == 0 || kk[i] != pk;
-            hk |= (u32)h << i;
-            ck += h;
-            if (IS_REF) {
-                bool h2 = h || vv[i] != pv;
-                hv |= (u32)h2 << i;
-                cv += h2;
-                pv = vv[i];
-            }
-            pk = kk[i];
+            kk[r] = keys[idx];
+            vv[r] = vals[idx];
+            h = idx == 0 || kk[r] != keys[idx - 1];
+            if (IS_REF) h2 = h || vv[r] != vals[idx - 1];
+        }
+        const u64 bk = __ballot(h);
+        prek[r] = (uint8_t)__popcll(bk & lt);
+        hk |= (u32)h << r;
+        if (lane == 0) wck[r][wave] = __popcll(bk);
+        if (IS_REF) {
+            const u64 bv = __ballot(h2);
+            prev[r] = (uint8_t)__popcll(bv & lt);
+            hv |= (u32)h2 << r;
+            if (lane == 0) wcv[r][wave] = __popcll(bv);
         }
     }
-    u32 tk, tv;
-    u32 ik = block_scan_inclusive(ck, OpSum(), smem, &tk);
-    u64 u = off_k[blockIdx.x] + (ik - ck);
-    u64 v = 0;
-    if (IS_REF) {
-        u32 iv = block_scan_inclusive(cv, OpSum(), smem, &tv);
-        v = off_v[blockIdx.x] + (iv - cv);
-    }
+    __syncthreads();
+    if (tid < RD_ITEMS * RD_WAVES) {                    // 32 (round, wave) counts: exclusive scan by one half-wave
+        u32 v = wck[tid >> 2][tid & 3], inc = v;
 #pragma unroll
-    for (int i = 0; i < RD_ITEMS; i++) {
-        u32 idx = base + i;
+        for (int d = 1; d < 32; d <<= 1) {
+            u32 o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        wck[tid >> 2][tid & 3] = inc - v;
+    } else if (IS_REF && tid >= 64 && tid < 64 + RD_ITEMS * RD_WAVES) {
+        const int t = tid - 64;
+        u32 v = wcv[t >> 2][t & 3], inc = v;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            u32 o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        wcv[t >> 2][t & 3] = inc - v;
+    }
+    __syncthreads();
+    const u64 ubase = off_k[blockIdx.x];
+    const u64 vbase = IS_REF ? off_v[blockIdx.x] : 0;
+#pragma unroll
+    for (int r = 0; r < RD_ITEMS; r++) {
+        const u32 idx = base + r * RD_BLOCK + tid;
         if (idx >= n) break;
         if (IS_REF) {
-            if ((hv >> i) & 1) {
-                if ((hk >> i) & 1) { ukeys[u] = kk[i]; val_off[u] = v; u++; }
-                val_a[v] = (int32_t)vv[i];
+            if ((hv >> r) & 1) {
+                const u64 v = vbase + wcv[r][wave] + prev[r];
+                if ((hk >> r) & 1) {
+                    const u64 u = ubase + wck[r][wave] + prek[r];
+                    ukeys[u] = kk[r];
+                    val_off[u] = v;
+                }
+                val_a[v] = (int32_t)vv[r];
                 vstart[v] = idx;
-                v++;
             }
         } else {
-            if ((hk >> i) & 1) { ukeys[u] = kk[i]; val_off[u] = idx; u++; }
+            if ((hk >> r) & 1) {
+                const u64 u = ubase + wck[r][wave] + prek[r];
+                ukeys[u] = kk[r];
+                val_off[u] = idx;
+            }
             // payload = read << 16 | pos16  ->  ReadPos(int read, short pos)
-            u64 p = (u64)vv[i];
+            u64 p = (u64)vv[r];
             val_a[idx] = (int32_t)(p >> 16);
             val_b[idx] = (int32_t)(int16_t)(p & 0xFFFFu);
         }
