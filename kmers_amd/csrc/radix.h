@@ -340,27 +340,20 @@ __device__ __forceinline__ bool ls_greater(u64 ka, V va, u64 kb, V vb, int mode)
 // on the top LS_TOP digits of the remaining key bits, then a comparison finish inside the short runs that
 // still agree on those digits.  A segment with an over-long run is sorted with the complete digit list
 // (payload digits, then every key digit), which is correct from any arrangement the stable steps produce.
-template <typename V>
-__global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
-                                                            u64 *__restrict__ keys_out, V *__restrict__ vals_out,
-                                                            const u32 *__restrict__ seg_off, LocalPasses lp) {
-    __shared__ uint16_t wcnt[LS_WAVES][RS_DIGITS];    // per-wave digit counts of the current pass (<= LS_MAX)
-    __shared__ uint16_t wbase[LS_WAVES][RS_DIGITS];   // per-wave first LDS slot of each digit
-    __shared__ u64 skeys[LS_MAX];
-    __shared__ V svals[LS_MAX];
-
-    const u32 s0 = seg_off[blockIdx.x];
-    const u32 m = seg_off[blockIdx.x + 1] - s0;
-    if (m == 0 || m > LS_MAX) return;   // oversize segments: the host falls back to full LSD passes
+// (compiled once per number of rounds, as ls_sortidx_body: straight-line loops over a thread's records)
+template <typename V, int ROUNDS>
+__device__ __forceinline__ void ls_sort_body(const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
+                                             u64 *__restrict__ keys_out, V *__restrict__ vals_out, const LocalPasses &lp, u32 s0, u32 m,
+                                             uint16_t (*wcnt)[RS_DIGITS], uint16_t (*wbase)[RS_DIGITS], u64 *skeys, V *svals) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rounds = (int)((m + LS_BLOCK - 1) / LS_BLOCK);          // block-uniform
+    constexpr int rounds = ROUNDS;
     const u32 wave_base = wave * 64 * rounds;
 
-    u64 key[LS_ITEMS];
-    V val[LS_ITEMS];
-    u32 rank[LS_ITEMS];
+    u64 key[ROUNDS];
+    V val[ROUNDS];
+    u32 rank[ROUNDS];
 #pragma unroll
-    for (int j = 0; j < LS_ITEMS; j++) {
+    for (int j = 0; j < ROUNDS; j++) {
         const u32 li = wave_base + j * 64 + lane;
         const bool valid = j < rounds && li < m;
         key[j] = valid ? keys_in[s0 + li] : 0;
@@ -368,7 +361,7 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
     }
     if (lp.n == 0) {
 #pragma unroll
-        for (int j = 0; j < LS_ITEMS; j++) {
+        for (int j = 0; j < ROUNDS; j++) {
             const u32 li = wave_base + j * 64 + lane;
             if (j < rounds && li < m) { keys_out[s0 + li] = key[j]; vals_out[s0 + li] = val[j]; }
         }
@@ -384,7 +377,7 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
         const int shift = lp.shift[p], src = lp.src[p], nbits = lp.bits[p];
         const u32 mask = (1u << nbits) - 1u;
 #pragma unroll
-        for (int j = 0; j < LS_ITEMS; j++) {
+        for (int j = 0; j < ROUNDS; j++) {
             if (j < rounds) {
                 const u32 li = wave_base + j * 64 + lane;
                 const bool valid = li < m;
@@ -422,7 +415,7 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
         }
         // same-wave LDS accesses execute in order: wbase is complete for this wave's reads below
 #pragma unroll
-        for (int j = 0; j < LS_ITEMS; j++) {
+        for (int j = 0; j < ROUNDS; j++) {
             const u32 li = wave_base + j * 64 + lane;
             if (j < rounds && li < m) {
                 const u32 d = rs_digit<V>(key[j], val[j], shift, mask, src);
@@ -446,9 +439,9 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
             // LS_RUNCAP would make this quadratic: such segments take the complete digit list instead.
             fast = false;
             bool toolong = false;
-            u32 npos[LS_ITEMS];
+            u32 npos[ROUNDS];
 #pragma unroll
-            for (int j = 0; j < LS_ITEMS; j++) {
+            for (int j = 0; j < ROUNDS; j++) {
                 const u32 li = wave_base + j * 64 + lane;
                 npos[j] = li;
                 if (j < rounds && li < m) {
@@ -482,7 +475,7 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
             const bool fallback = __syncthreads_or(toolong);   // also: every LDS read above is done
             if (!fallback) {
 #pragma unroll
-                for (int j = 0; j < LS_ITEMS; j++) {
+                for (int j = 0; j < ROUNDS; j++) {
                     const u32 li = wave_base + j * 64 + lane;
                     if (j < rounds && li < m) { skeys[npos[j]] = key[j]; svals[npos[j]] = val[j]; }
                 }
@@ -492,7 +485,7 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
             p = 0;   // complete digit list, starting from the (stably permuted) current arrangement
         }
 #pragma unroll
-        for (int j = 0; j < LS_ITEMS; j++) {
+        for (int j = 0; j < ROUNDS; j++) {
             const u32 li = wave_base + j * 64 + lane;
             if (j < rounds && li < m) { key[j] = skeys[li]; val[j] = svals[li]; }
         }
@@ -501,6 +494,27 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
     for (u32 i = tid; i < m; i += LS_BLOCK) {
         keys_out[s0 + i] = skeys[i];
         vals_out[s0 + i] = svals[i];
+    }
+}
+
+template <typename V>
+__global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
+                                                            u64 *__restrict__ keys_out, V *__restrict__ vals_out,
+                                                            const u32 *__restrict__ seg_off, LocalPasses lp) {
+    __shared__ uint16_t wcnt[LS_WAVES][RS_DIGITS];    // per-wave digit counts of the current pass (<= LS_MAX)
+    __shared__ uint16_t wbase[LS_WAVES][RS_DIGITS];   // per-wave first LDS slot of each digit
+    __shared__ u64 skeys[LS_MAX];
+    __shared__ V svals[LS_MAX];
+
+    const u32 s0 = seg_off[blockIdx.x];
+    const u32 m = seg_off[blockIdx.x + 1] - s0;
+    if (m == 0 || m > LS_MAX) return;   // oversize segments: the host falls back to full LSD passes
+    switch ((m + LS_BLOCK - 1) / LS_BLOCK) {
+        case 1: ls_sort_body<V, 1>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
+        case 2: ls_sort_body<V, 2>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
+        case 3: ls_sort_body<V, 3>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
+        case 4: ls_sort_body<V, 4>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
+        default: ls_sort_body<V, 5>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
     }
 }
 
