@@ -34,41 +34,69 @@ __global__ void match_bounds_kernel(const u64 *__restrict__ skeys, u64 ns, const
 // One workgroup joins MT_TILE consecutive search k-mers.  Both sides are ascending, so the reference k-mers
 // that can match them form one contiguous range (match_bounds_kernel); the block stages it in LDS (it is a
 // few hundred k-mers when the two sets are of similar density) and every search k-mer is then binary-searched
-// in LDS instead of through L2.  Ranges that do not fit are searched in place.  hit[i] = index of the k-mer
-// in the reference, or -1.
+// in LDS instead of through L2.  A range that does not fit goes through LDS in pieces (a reference denser than the
+// search set: BASELINE config 3 has 1.7 reference k-mers per search k-mer); only ranges beyond MT_CHUNKS pieces are
+// searched in place.  hit[i] = index of the k-mer in the reference, or -1.
+#define MT_CHUNKS 8                     // a tile's reference range is staged in up to this many LDS-sized pieces
 __device__ __forceinline__ void match_tile(const u64 *__restrict__ skeys, u64 q0, u64 q1, const u64 *__restrict__ rkeys,
                                            u64 r_lo, u64 r_hi, long long *__restrict__ hit, u64 *__restrict__ nhits) {
     __shared__ u64 sref[MT_RMAX];
     __shared__ u32 smem[4];
-    const u32 cnt = (u32)(r_hi - r_lo < MT_RMAX ? r_hi - r_lo : MT_RMAX);
-    const bool staged = r_hi - r_lo <= MT_RMAX;
-    if (staged)
-        for (u32 i = threadIdx.x; i < cnt; i += MT_BLOCK) sref[i] = rkeys[r_lo + i];
-    __syncthreads();
+    const u64 span = r_hi - r_lo;
     u32 nfound = 0;
+    if (span <= (u64)MT_RMAX * MT_CHUNKS) {
+        // Both sides ascend: the range goes through LDS piece by piece, and a search k-mer is looked up in the first
+        // piece whose last k-mer is not below it (every earlier piece ends below it, every later one starts above).
+        u64 key[MT_ITEMS];
+        long long res[MT_ITEMS];
+        u32 open = 0;
 #pragma unroll
-    for (int j = 0; j < MT_ITEMS; j++) {
-        const u64 i = q0 + (u64)j * MT_BLOCK + threadIdx.x;
-        if (i < q1) {
-            const u64 key = skeys[i];
-            long long res = -1;
-            if (staged) {
-                u32 lo = 0, hi = cnt;
-                while (lo < hi) {
-                    const u32 mid = (lo + hi) >> 1;
-                    if (sref[mid] < key) lo = mid + 1; else hi = mid;
+        for (int j = 0; j < MT_ITEMS; j++) {
+            const u64 i = q0 + (u64)j * MT_BLOCK + threadIdx.x;
+            key[j] = 0; res[j] = -1;
+            if (i < q1) { key[j] = skeys[i]; open |= 1u << j; }
+        }
+        for (u64 c0 = 0; c0 < span; c0 += MT_RMAX) {
+            const u32 cnt = (u32)(span - c0 < MT_RMAX ? span - c0 : MT_RMAX);
+            if (c0) __syncthreads();                        // the previous piece's readers are done
+            for (u32 i = threadIdx.x; i < cnt; i += MT_BLOCK) sref[i] = rkeys[r_lo + c0 + i];
+            __syncthreads();
+            const u64 last = sref[cnt - 1];
+#pragma unroll
+            for (int j = 0; j < MT_ITEMS; j++) {
+                if (((open >> j) & 1) && key[j] <= last) {
+                    u32 lo = 0, hi = cnt;
+                    while (lo < hi) {
+                        const u32 mid = (lo + hi) >> 1;
+                        if (sref[mid] < key[j]) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo < cnt && sref[lo] == key[j]) res[j] = (long long)(r_lo + c0 + lo);
+                    open &= ~(1u << j);
                 }
-                if (lo < cnt && sref[lo] == key) res = (long long)(r_lo + lo);
-            } else {
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MT_ITEMS; j++) {
+            const u64 i = q0 + (u64)j * MT_BLOCK + threadIdx.x;
+            if (i < q1) { hit[i] = res[j]; nfound += res[j] >= 0; }
+        }
+    } else {
+        // a sparse search set over a dense reference: staging would read far more than the probes do
+#pragma unroll
+        for (int j = 0; j < MT_ITEMS; j++) {
+            const u64 i = q0 + (u64)j * MT_BLOCK + threadIdx.x;
+            if (i < q1) {
+                const u64 key = skeys[i];
+                long long res = -1;
                 u64 lo = r_lo, hi = r_hi;
                 while (lo < hi) {
                     const u64 mid = (lo + hi) >> 1;
                     if (rkeys[mid] < key) lo = mid + 1; else hi = mid;
                 }
                 if (lo < r_hi && rkeys[lo] == key) res = (long long)lo;
+                hit[i] = res;
+                nfound += res >= 0;
             }
-            hit[i] = res;
-            nfound += res >= 0;
         }
     }
     if (nhits) {   // uniform
