@@ -1813,12 +1813,28 @@ extern "C" int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, in
     const int32_t tmin = h_mm[0];
     const u64 range = (u64)((long long)h_mm[1] - (long long)tmin) + 1;      // <= 2^32
     const u64 nwords = (range + 31) / 32;
+    const bool dense = range <= TX_LDS_BIG;     // rows addressed by taxon - min; presence read off the counts afterwards
+    PoolBuf dm(ctx), du(ctx);
     KMG_ALLOC(bits, nwords * 4);
     KMG_ALLOC(cnt, nwords * 4);
     KMG_ALLOC(prefix, (nwords + 1) * 4);
     KMG_ALLOC(agg, (size_t)(div_up_u64(nwords, SCAN_TILE) + 1) * 8);
-    KMG_HIP(hipMemsetAsync(bits.p, 0, nwords * 4, ctx->stream));
-    hipLaunchKernelGGL(taxa_present_kernel, dim3(vgrid), dim3(256), 0, ctx->stream, db->val_a, V, tmin, bits.as<u32>());
+#define TAXA_COUNT(MODE, DIRECT, GRID, BLOCK, ROWS_, M, Q)                                                                  \
+    hipLaunchKernelGGL((taxa_count_kernel<MODE, DIRECT>), dim3(GRID), dim3(BLOCK), 0, ctx->stream, db->val_off, db->val_a, db->U, \
+                       V, bits.as<u32>(), prefix.as<u32>(), tmin, (u32)(ROWS_), M.as<u64>(), Q.as<u64>())
+    if (dense) {
+        KMG_ALLOC(dm, range * 8);
+        KMG_ALLOC(du, range * 8);
+        KMG_HIP(hipMemsetAsync(dm.p, 0, range * 8, ctx->stream));
+        KMG_HIP(hipMemsetAsync(du.p, 0, range * 8, ctx->stream));
+        if (range <= TX_LDS_SMALL) TAXA_COUNT(0, true, std::min<u32>(div_up_u64(db->U, 256 * TX_UNROLL), 2048), 256, range, dm, du);
+        else TAXA_COUNT(1, true, std::min<u32>(div_up_u64(db->U, 1024 * TX_UNROLL), 256), 1024, range, dm, du);
+        hipLaunchKernelGGL(taxa_rows_present_kernel, dim3(div_up_u64(nwords, 256)), dim3(256), 0, ctx->stream, dm.as<u64>(), (u32)range,
+                           bits.as<u32>());
+    } else {
+        KMG_HIP(hipMemsetAsync(bits.p, 0, nwords * 4, ctx->stream));
+        hipLaunchKernelGGL(taxa_present_kernel, dim3(vgrid), dim3(256), 0, ctx->stream, db->val_a, V, tmin, bits.as<u32>());
+    }
     hipLaunchKernelGGL(taxa_popc_kernel, dim3(div_up_u64(nwords, 256)), dim3(256), 0, ctx->stream, bits.as<u32>(), nwords, cnt.as<u32>());
     KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, cnt.as<u32>(), prefix.as<u32>(), nwords, OpSum(), 0u, agg.as<u32>(),
                                                 total.as<u32>(), false, KP_SCAN)));
@@ -1827,19 +1843,19 @@ extern "C" int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, in
     KMG_ALLOC(taxa, (size_t)nt * 4);
     KMG_ALLOC(cm, (size_t)nt * 8);
     KMG_ALLOC(cu, (size_t)nt * 8);
-    KMG_HIP(hipMemsetAsync(cm.p, 0, (size_t)nt * 8, ctx->stream));
-    KMG_HIP(hipMemsetAsync(cu.p, 0, (size_t)nt * 8, ctx->stream));
     hipLaunchKernelGGL(taxa_list_kernel, dim3(div_up_u64(nwords, 256)), dim3(256), 0, ctx->stream, bits.as<u32>(), prefix.as<u32>(),
                        nwords, tmin, taxa.as<int32_t>());
-    if (nt <= TX_LDS_SMALL)
-        hipLaunchKernelGGL((taxa_count_kernel<0>), dim3(std::min<u32>(div_up_u64(db->U, 256), 2048)), dim3(256), 0, ctx->stream,
-                           db->val_off, db->val_a, db->U, bits.as<u32>(), prefix.as<u32>(), tmin, nt, cm.as<u64>(), cu.as<u64>());
-    else if (nt <= TX_LDS_BIG)
-        hipLaunchKernelGGL((taxa_count_kernel<1>), dim3(std::min<u32>(div_up_u64(db->U, 1024), 256)), dim3(1024), 0, ctx->stream,
-                           db->val_off, db->val_a, db->U, bits.as<u32>(), prefix.as<u32>(), tmin, nt, cm.as<u64>(), cu.as<u64>());
-    else
-        hipLaunchKernelGGL((taxa_count_kernel<2>), dim3(std::min<u32>(div_up_u64(db->U, 256), 4096)), dim3(256), 0, ctx->stream,
-                           db->val_off, db->val_a, db->U, bits.as<u32>(), prefix.as<u32>(), tmin, nt, cm.as<u64>(), cu.as<u64>());
+    if (dense) {
+        hipLaunchKernelGGL(taxa_rows_gather_kernel, dim3(div_up_u64(range, 256)), dim3(256), 0, ctx->stream, dm.as<u64>(), du.as<u64>(),
+                           (u32)range, bits.as<u32>(), prefix.as<u32>(), cm.as<u64>(), cu.as<u64>());
+    } else {
+        KMG_HIP(hipMemsetAsync(cm.p, 0, (size_t)nt * 8, ctx->stream));
+        KMG_HIP(hipMemsetAsync(cu.p, 0, (size_t)nt * 8, ctx->stream));
+        if (nt <= TX_LDS_SMALL) TAXA_COUNT(0, false, std::min<u32>(div_up_u64(db->U, 256 * TX_UNROLL), 2048), 256, nt, cm, cu);
+        else if (nt <= TX_LDS_BIG) TAXA_COUNT(1, false, std::min<u32>(div_up_u64(db->U, 1024 * TX_UNROLL), 256), 1024, nt, cm, cu);
+        else TAXA_COUNT(2, false, std::min<u32>(div_up_u64(db->U, 256 * TX_UNROLL), 4096), 256, nt, cm, cu);
+    }
+#undef TAXA_COUNT
     KMG_HIP(hipGetLastError());
     const u64 w = std::min<u64>(nt, cap);
     if (w) {

@@ -183,10 +183,21 @@ __global__ void taxa_minmax_init_kernel(int32_t *mm) {
 }
 __global__ __launch_bounds__(256) void taxa_minmax_kernel(const int32_t *__restrict__ val_a, u64 V, int32_t *__restrict__ mm) {
     int32_t lo = 0x7FFFFFFF, hi = (int32_t)0x80000000;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (u64)gridDim.x * blockDim.x) {
-        const int32_t t = val_a[i];
-        lo = t < lo ? t : lo;
-        hi = t > hi ? t : hi;
+    // 16 bytes per lane over the aligned middle, the few values either side of it one by one
+    const u64 head = std::min<u64>(V, (u64)((16 - ((uintptr_t)val_a & 15)) & 15) / 4);
+    const u64 n4 = (V - head) / 4;
+    const int4 *__restrict__ body = (const int4 *)(val_a + head);
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (u64)gridDim.x * blockDim.x) {
+        const int4 t = body[i];
+        lo = min(min(lo, t.x), min(min(t.y, t.z), t.w));
+        hi = max(max(hi, t.x), max(max(t.y, t.z), t.w));
+    }
+    if (blockIdx.x == 0) {
+        for (u64 i = threadIdx.x; i < V - n4 * 4; i += blockDim.x) {
+            const int32_t t = val_a[i < head ? i : n4 * 4 + i];
+            lo = t < lo ? t : lo;
+            hi = t > hi ? t : hi;
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -219,39 +230,88 @@ __global__ void taxa_list_kernel(const u32 *__restrict__ bits, const u32 *__rest
     }
 }
 
-// MODE 0: LDS histogram of TX_LDS_SMALL rows, 1: of TX_LDS_BIG rows (1024 threads, one block per CU), 2: global
-template <int MODE>
+// dense path (the span of the ids fits the LDS rows): presence comes from the counted rows themselves
+__global__ void taxa_rows_present_kernel(const u64 *__restrict__ dm, u32 range, u32 *__restrict__ bits) {
+    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w * 32 >= range) return;
+    u32 b = 0;
+    for (u32 j = 0; j < 32 && w * 32 + j < range; j++) b |= (dm[w * 32 + j] != 0 ? 1u : 0u) << j;
+    bits[w] = b;
+}
+__global__ void taxa_rows_gather_kernel(const u64 *__restrict__ dm, const u64 *__restrict__ du, u32 range,
+                                        const u32 *__restrict__ bits, const u32 *__restrict__ prefix, u64 *__restrict__ match,
+                                        u64 *__restrict__ unique) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= range || dm[i] == 0) return;
+    const u32 idx = prefix[i >> 5] + __popc(bits[i >> 5] & ((1u << (i & 31)) - 1u));
+    match[idx] = dm[i];
+    unique[idx] = du[i];
+}
+
+// MODE 0: LDS histogram of TX_LDS_SMALL rows, 1: of TX_LDS_BIG rows (1024 threads, one block per CU), 2: global.
+// DIRECT: the whole span [min taxon, max taxon] fits the rows, so a value's row is taxon - min (match / unique are then
+// indexed by taxon - min too); otherwise the row is the taxon's rank (two dependent cached loads per value).
+// A thread takes TX_UNROLL k-mers per round: their offsets first, then their first values, then the counting, so
+// that several loads are in flight per lane (one block of 1024 per CU in MODE 1 leaves little else to hide latency).
+#ifndef TX_UNROLL
+#define TX_UNROLL 8
+#endif
+template <int MODE, bool DIRECT>
 __global__ __launch_bounds__(MODE == 1 ? 1024 : 256) void taxa_count_kernel(const u64 *__restrict__ val_off,
-                                                                            const int32_t *__restrict__ val_a, u64 U,
+                                                                            const int32_t *__restrict__ val_a, u64 U, u64 V,
                                                                             const u32 *__restrict__ bits,
-                                                                            const u32 *__restrict__ prefix, int32_t tmin, u32 nt,
+                                                                            const u32 *__restrict__ prefix, int32_t tmin, u32 rows,
                                                                             u64 *__restrict__ match, u64 *__restrict__ unique) {
     constexpr u32 ROWS = MODE == 0 ? TX_LDS_SMALL : (MODE == 1 ? TX_LDS_BIG : 1);
     __shared__ u32 s_match[ROWS];
     __shared__ u32 s_unique[ROWS];
     if (MODE != 2) {
-        for (u32 i = threadIdx.x; i < nt; i += blockDim.x) { s_match[i] = 0; s_unique[i] = 0; }
+        for (u32 i = threadIdx.x; i < rows; i += blockDim.x) { s_match[i] = 0; s_unique[i] = 0; }
         __syncthreads();
     }
-    for (u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += (u64)gridDim.x * blockDim.x) {
-        const u64 a = val_off[u], b = val_off[u + 1];
-        for (u64 v = a; v < b; v++) {
-            const u32 r = (u32)val_a[v] - (u32)tmin;
-            const u32 idx = prefix[r >> 5] + __popc(bits[r >> 5] & ((1u << (r & 31)) - 1u));
-            if (MODE != 2) {
-                atomicAdd(&s_match[idx], 1u);
-                if (b - a == 1) atomicAdd(&s_unique[idx], 1u);
-            } else {
-                atomicAdd(&match[idx], 1ull);
-                if (b - a == 1) atomicAdd(&unique[idx], 1ull);
-            }
+    auto add = [&](int32_t t, bool single) {
+        const u32 r = (u32)t - (u32)tmin;
+        const u32 idx = DIRECT ? r : prefix[r >> 5] + __popc(bits[r >> 5] & ((1u << (r & 31)) - 1u));
+        if (MODE != 2) {
+            atomicAdd(&s_match[idx], 1u);
+            if (single) atomicAdd(&s_unique[idx], 1u);
+        } else {
+            atomicAdd(&match[idx], 1ull);
+            if (single) atomicAdd(&unique[idx], 1ull);
+        }
+    };
+    const u64 step = (u64)blockDim.x * TX_UNROLL;
+    for (u64 base = (u64)blockIdx.x * step; base < U; base += (u64)gridDim.x * step) {
+        // (indices clamped instead of guarded: guarded loads compile to a branch and a wait apiece)
+        u64 a[TX_UNROLL], b[TX_UNROLL];
+        int32_t t0[TX_UNROLL], t1[TX_UNROLL];
+#pragma unroll
+        for (int j = 0; j < TX_UNROLL; j++) {
+            const u64 u = base + (u64)j * blockDim.x + threadIdx.x;
+            const u64 uc = u < U ? u : U - 1;
+            a[j] = val_off[uc];
+            b[j] = val_off[uc + 1];
+            if (u >= U) b[j] = a[j];
+        }
+#pragma unroll
+        for (int j = 0; j < TX_UNROLL; j++) {
+            t0[j] = val_a[a[j] < V ? a[j] : V - 1];
+            t1[j] = val_a[a[j] + 1 < V ? a[j] + 1 : V - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < TX_UNROLL; j++) {
+            const u64 n = b[j] - a[j];
+            if (n >= 1) add(t0[j], n == 1);
+            if (n >= 2) add(t1[j], false);
+            for (u64 v = a[j] + 2; v < b[j]; v++) add(val_a[v], false);
         }
     }
     if (MODE != 2) {
         // (a block's share of the values is far below 2^32: the u32 rows cannot wrap)
         __syncthreads();
-        for (u32 i = threadIdx.x; i < nt; i += blockDim.x) {
-            if (s_match[i]) atomicAdd(&match[i], (u64)s_match[i]);
+        for (u32 i = threadIdx.x; i < rows; i += blockDim.x) {
+            if (!s_match[i]) continue;
+            atomicAdd(&match[i], (u64)s_match[i]);
             if (s_unique[i]) atomicAdd(&unique[i], (u64)s_unique[i]);
         }
     }

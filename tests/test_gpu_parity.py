@@ -1133,6 +1133,25 @@ def test_taxacounts_many_taxa_and_the_whole_int32_range(ctx):
         ref.close()
 
 
+@pytest.mark.parametrize("n_taxa,stride", [(40, 1), (40, 100003), (3000, 5), (3000, 700001), (2049, 1), (16384, 1)])
+def test_taxacounts_row_addressing_modes(ctx, n_taxa, stride):
+    """TaxaCounts' LDS rows are addressed by taxon - min when the span of the ids fits them and by rank otherwise:
+    dense and sparse ids on both histogram sizes, and the sizes' edges, against the oracle."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    _, genomes = synth.random_genomes(500 + n_taxa, n_taxa, 150, shared_frac=0.3)
+    taxa = [-17 + i * stride for i in range(n_taxa)]
+    fa = synth.fasta_bytes(taxa, genomes)
+    ref = km.make_reference_db(ctx, fa, 25, 5)
+    o_ref = OracleDB(fa, 0, 25, 5, threads=8)
+    t, m, q = km.taxa_counts(ref)
+    ot, om, oq = o_ref.taxacounts()
+    assert len(t) == n_taxa and np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
+    assert int(m.sum()) == ref.n_values and (q < m).any()
+    ref.close()
+
+
 @pytest.mark.parametrize("k", [21, 25, 31])
 def test_cfg5_flavour_long_noisy_reads(ctx, k):
     """Config 5 in small: 10 kbp reads with 15 % substitutions and 0.5 % N, genome sizes spread over two orders of
