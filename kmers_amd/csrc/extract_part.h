@@ -298,6 +298,7 @@ __global__ __launch_bounds__(EP_BLOCK, 6) void extract_part_write_kernel(PartArg
     const bool dup = img[EP_IMG_FLAG] != 0;
     const u32 s_lo = a.tile_seq[tile];
     const u32 s_end = a.tile_end[tile];
+    const bool lds_only = !dup && s_end - s_lo < EP_SQCAP;             // every sequence of the tile is in sq_val / sq_neg
     u32 tbl0 = 0, tbl1 = 0;
     const u32 out_base = pa.out_base;
     if (tid < RS_DIGITS) {
@@ -395,26 +396,44 @@ __global__ __launch_bounds__(EP_BLOCK, 6) void extract_part_write_kernel(PartArg
             if (lp < tile_n) a.out_keys[lp + gdelta[sdig[lp]]] = stage[lp];
         }
         __syncthreads();
+        // payload of the window: the window's sequence = the tile's first + the sequence starts at or before p.
+        // Two copies of the loop behind a block-uniform test: the common one touches LDS only.  (A global load
+        // anywhere in the loop, even on a path no lane takes, puts a wait for ALL outstanding vector memory
+        // operations behind it -- the counter is shared with stores on gfx950 -- and the key stores just issued
+        // would have to drain before the first payload is built.)
+        if (lds_only) {
 #pragma unroll
-        for (int j = 0; j < EP_ROUNDS; j++) {
-            if ((imask >> j) & 1) {
-                // payload of the window (the sequence tables are tiny and cached: a tile spans few sequences)
-                const u32 p = pb + j * 64;
-                // the window's sequence = the tile's first + the sequence starts at or before p
-                u32 rel;
-                if (dup) rel = ep_seq_rel(a, s_lo, s_end, t0 + p);
-                else rel = wpre[p >> 5] + __popc(stb[p >> 5] >> (31 - (p & 31)));
-                u32 sv, neg;
-                if (rel < EP_SQCAP) { sv = sq_val[rel]; neg = sq_neg[rel]; }
-                else {
-                    const u64 sq = (u64)s_lo + rel;
-                    sv = a.kind == KMG_PAYLOAD_TAXON ? (u32)a.seq_id[sq] : (u32)a.read_index[sq];
-                    neg = (u32)(t0 - a.seq_off[sq]);
+            for (int j = 0; j < EP_ROUNDS; j++) {
+                if ((imask >> j) & 1) {
+                    const u32 p = pb + j * 64;
+                    const u32 rel = wpre[p >> 5] + __popc(stb[p >> 5] >> (31 - (p & 31)));
+                    const u32 sv = sq_val[rel], neg = sq_neg[rel];
+                    V v;
+                    if (a.kind == KMG_PAYLOAD_TAXON) v = (V)sv;
+                    else v = (V)(((u64)sv << a.pos_bits) | (u64)((p + neg) & a.pos_mask));
+                    reinterpret_cast<V *>(stage)[lpos[j]] = v;
                 }
-                V v;
-                if (a.kind == KMG_PAYLOAD_TAXON) v = (V)sv;
-                else v = (V)(((u64)sv << a.pos_bits) | (u64)((p + neg) & a.pos_mask));
-                reinterpret_cast<V *>(stage)[lpos[j]] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < EP_ROUNDS; j++) {
+                if ((imask >> j) & 1) {
+                    const u32 p = pb + j * 64;
+                    u32 rel;
+                    if (dup) rel = ep_seq_rel(a, s_lo, s_end, t0 + p);
+                    else rel = wpre[p >> 5] + __popc(stb[p >> 5] >> (31 - (p & 31)));
+                    u32 sv, neg;
+                    if (rel < EP_SQCAP) { sv = sq_val[rel]; neg = sq_neg[rel]; }
+                    else {
+                        const u64 sq = (u64)s_lo + rel;
+                        sv = a.kind == KMG_PAYLOAD_TAXON ? (u32)a.seq_id[sq] : (u32)a.read_index[sq];
+                        neg = (u32)(t0 - a.seq_off[sq]);
+                    }
+                    V v;
+                    if (a.kind == KMG_PAYLOAD_TAXON) v = (V)sv;
+                    else v = (V)(((u64)sv << a.pos_bits) | (u64)((p + neg) & a.pos_mask));
+                    reinterpret_cast<V *>(stage)[lpos[j]] = v;
+                }
             }
         }
         __syncthreads();

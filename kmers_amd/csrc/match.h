@@ -53,13 +53,26 @@ __device__ __forceinline__ void match_tile(const u64 *__restrict__ skeys, u64 q0
 #pragma unroll
         for (int j = 0; j < MT_ITEMS; j++) {
             const u64 i = q0 + (u64)j * MT_BLOCK + threadIdx.x;
-            key[j] = 0; res[j] = -1;
-            if (i < q1) { key[j] = skeys[i]; open |= 1u << j; }
+            res[j] = -1;
+            key[j] = skeys[i < q1 ? i : q1 - 1];            // (clamped, not guarded: guarded loads wait one by one)
+            if (i < q1) open |= 1u << j;
         }
         for (u64 c0 = 0; c0 < span; c0 += MT_RMAX) {
             const u32 cnt = (u32)(span - c0 < MT_RMAX ? span - c0 : MT_RMAX);
             if (c0) __syncthreads();                        // the previous piece's readers are done
-            for (u32 i = threadIdx.x; i < cnt; i += MT_BLOCK) sref[i] = rkeys[r_lo + c0 + i];
+            for (u32 b = 0; b < cnt; b += 4 * MT_BLOCK) {     // four loads in flight per lane
+                u64 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const u32 i = b + u * MT_BLOCK + threadIdx.x;
+                    t[u] = rkeys[r_lo + c0 + (i < cnt ? i : cnt - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const u32 i = b + u * MT_BLOCK + threadIdx.x;
+                    if (i < cnt) sref[i] = t[u];
+                }
+            }
             __syncthreads();
             const u64 last = sref[cnt - 1];
 #pragma unroll

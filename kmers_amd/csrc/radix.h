@@ -71,7 +71,24 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict
     for (int t = 0; t < tpb; t++) {
         const u32 base = (tile0 + t) * RS_TILE;
         if (base >= n) break;
-#pragma unroll 4
+        if (n - base >= RS_TILE) {
+            // full tile: all of a thread's loads leave before the first counter is touched (a load under
+            // `if (idx < n)` compiles to a branch with a wait behind it: one memory round trip per record)
+            if (src) {
+                V v[RS_ITEMS];
+#pragma unroll
+                for (int i = 0; i < RS_ITEMS; i++) v[i] = vals[base + i * RS_BLOCK + threadIdx.x];
+#pragma unroll
+                for (int i = 0; i < RS_ITEMS; i++) atomicAdd(&h[rs_digit<V>(0, v[i], shift, mask, src)][t], 1u);
+            } else {
+                u64 kk[RS_ITEMS];
+#pragma unroll
+                for (int i = 0; i < RS_ITEMS; i++) kk[i] = keys[base + i * RS_BLOCK + threadIdx.x];
+#pragma unroll
+                for (int i = 0; i < RS_ITEMS; i++) atomicAdd(&h[(u32)(kk[i] >> shift) & mask][t], 1u);
+            }
+            continue;
+        }
         for (int i = 0; i < RS_ITEMS; i++) {
             u32 idx = base + i * RS_BLOCK + threadIdx.x;
             if (idx < n) {
@@ -355,9 +372,13 @@ __device__ __forceinline__ void ls_sort_body(const u64 *__restrict__ keys_in, co
 #pragma unroll
     for (int j = 0; j < ROUNDS; j++) {
         const u32 li = wave_base + j * 64 + lane;
-        const bool valid = j < rounds && li < m;
-        key[j] = valid ? keys_in[s0 + li] : 0;
-        val[j] = valid ? vals_in[s0 + li] : (V)0;
+        const u32 lc = li < m ? li : m - 1;          // (clamped, not guarded: see ls_sortidx_body)
+        key[j] = keys_in[s0 + lc];
+        val[j] = vals_in[s0 + lc];
+    }
+#pragma unroll
+    for (int j = 0; j < ROUNDS; j++) {
+        if (wave_base + j * 64 + lane >= m) { key[j] = 0; val[j] = (V)0; }
     }
     if (lp.n == 0) {
 #pragma unroll
@@ -542,14 +563,24 @@ __device__ __forceinline__ void ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *_
 
     // Slots [m, rounds * 512) hold all-ones sentinels: they sort behind every record (stably, they are
     // loaded last), so no step below needs a per-lane validity branch.
+    // (loads at clamped indices, all issued before the first is used: a load under `if (valid)` compiles to a branch
+    // with a wait behind it, one memory round trip per round)
     u64 sw[ROUNDS];
     u32 rank[ROUNDS];
+    V vraw[ROUNDS];
 #pragma unroll
     for (int j = 0; j < ROUNDS; j++) {
         const u32 li = wave_base + j * 64 + lane;
-        const bool valid = j < rounds && li < m;
-        sw[j] = valid ? ((keys_in[s0 + li] << pbits) | li) : ~0ull;
-        if (valid) svals[li] = vals_in[s0 + li];
+        const u32 lc = li < m ? li : m - 1;
+        sw[j] = keys_in[s0 + lc];
+        vraw[j] = vals_in[s0 + lc];
+    }
+#pragma unroll
+    for (int j = 0; j < ROUNDS; j++) {
+        const u32 li = wave_base + j * 64 + lane;
+        const bool valid = li < m;
+        sw[j] = valid ? ((sw[j] << pbits) | li) : ~0ull;
+        if (valid) svals[li] = vraw[j];
     }
     *reinterpret_cast<uint2 *>(&wcnt[wave][4 * lane]) = make_uint2(0, 0);
     for (int p = 0; p < lp.n; p++) {

@@ -58,17 +58,22 @@ __global__ __launch_bounds__(RD_BLOCK) void rd_write_kernel(const u64 *__restric
     V vv[RD_ITEMS];
     u32 hk = 0, hv = 0;
     uint8_t prek[RD_ITEMS], prev[RD_ITEMS];
+    u64 kp[RD_ITEMS];
+    V vp[RD_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RD_ITEMS; r++) {          // every load first, at clamped indices: guarded loads wait one by one
+        const u32 idx = base + r * RD_BLOCK + tid;
+        const u32 ic = idx < n ? idx : n - 1, ip = ic ? ic - 1 : 0;
+        kk[r] = keys[ic];
+        vv[r] = vals[ic];
+        kp[r] = keys[ip];
+        if (IS_REF) vp[r] = vals[ip];
+    }
 #pragma unroll
     for (int r = 0; r < RD_ITEMS; r++) {
         const u32 idx = base + r * RD_BLOCK + tid;
-        bool h = false, h2 = false;
-        kk[r] = 0; vv[r] = 0;
-        if (idx < n) {
-            kk[r] = keys[idx];
-            vv[r] = vals[idx];
-            h = idx == 0 || kk[r] != keys[idx - 1];
-            if (IS_REF) h2 = h || vv[r] != vals[idx - 1];
-        }
+        const bool h = idx < n && (idx == 0 || kk[r] != kp[r]);
+        const bool h2 = IS_REF && idx < n && (h || vv[r] != vp[r]);
         const u64 bk = __ballot(h);
         prek[r] = (uint8_t)__popcll(bk & lt);
         hk |= (u32)h << r;
@@ -144,8 +149,8 @@ __global__ __launch_bounds__(RD_BLOCK) void rdk_count_kernel(const u64 *__restri
 #pragma unroll
     for (int r = 0; r < RDK_ROUNDS; r++) {
         const u32 idx = base + r * RD_BLOCK + threadIdx.x;
-        bool h = false;
-        if (idx < n) h = idx == 0 || keys[idx] != keys[idx - 1];
+        const u32 ic = idx < n ? idx : n - 1, ip = ic ? ic - 1 : 0;       // clamped, not guarded
+        const bool h = idx < n && (idx == 0 || keys[ic] != keys[ip]);
         c += __popcll(__ballot(h));       // wave-uniform count
     }
     u32 total;
@@ -161,13 +166,19 @@ __global__ __launch_bounds__(RD_BLOCK) void rdk_write_kernel(const u64 *__restri
     const u32 base = blockIdx.x * RDK_TILE;
     const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     u64 kk[RDK_ROUNDS];
+    u64 kp[RDK_ROUNDS];
     u32 hmask = 0, pre[RDK_ROUNDS];
 #pragma unroll
     for (int r = 0; r < RDK_ROUNDS; r++) {
         const u32 idx = base + r * RD_BLOCK + tid;
-        bool h = false;
-        kk[r] = 0;
-        if (idx < n) { kk[r] = keys[idx]; h = idx == 0 || kk[r] != keys[idx - 1]; }
+        const u32 ic = idx < n ? idx : n - 1, ip = ic ? ic - 1 : 0;
+        kk[r] = keys[ic];
+        kp[r] = keys[ip];
+    }
+#pragma unroll
+    for (int r = 0; r < RDK_ROUNDS; r++) {
+        const u32 idx = base + r * RD_BLOCK + tid;
+        const bool h = idx < n && (idx == 0 || kk[r] != kp[r]);
         const u64 bal = __ballot(h);
         pre[r] = __popcll(bal & lt);
         hmask |= (u32)h << r;
