@@ -157,6 +157,23 @@ int kmg_db_load_var(kmg_ctx *ctx, int k, int min_k, int key_len, int rc, int pay
  *   side (DB.java:134) before the exact join.  min_k <= length <= k of the source (DB.java:78-81 -> KMG_EINVAL); the
  *   result is a database of one length; the source stays valid. */
 int kmg_db_restrict(kmg_ctx *ctx, const kmg_db *db, int length, kmg_db **out);
+/* kmg_match_trie: DB.getNearestKmers' non-quick branch with maxDiff = 0 (Database/DB.java:83,139-184) for a search stream
+ *   of k-mers of several lengths -- what Matcher does on variable-length files when -k / -K are left at their defaults
+ *   (Matcher.java:147-148): per key a radix trie over the database's k-mers (Root.addKmer, Root.java:29-113) and
+ *   Root.closestKmers (:115-170) per search k-mer.  The trie's answer for a search k-mer t of T bases is the data object
+ *   of the node covering depth T on t's path, which -- because a split node shares its object with its tail (:79-80) and
+ *   k-mers merge into the nodes they pass from depth `shortest` on (:48-51,95-102) -- holds the summed counts of every
+ *   stored k-mer sharing the first max(min_k, L + 1) bases of x0, the first stored k-mer with prefix t, L = the bases x0
+ *   shares with its predecessor in the key.  Computed here in closed form, bit-exact against the literal restatement
+ *   (tests).  min_k = the search stream's declared shortest length (Root's `shortest`); the stream's lengths
+ *   must lie inside the database's (DB.java:78-81 -> KMG_EINVAL).  count_cap > 0: stored counts are cut to it before
+ *   they are added (255 = what a database file holds, CountDataType.java:40; 0 for handles loaded from files).
+ *   Out: hit_row[n_unique(search)] = row of the answer in *rows, or -1 (no stored k-mer has t as a prefix: no match
+ *   line); *rows = a taxon database whose row r (kmg_db_fetch: val_off / val_a / val_b) is answer r, taxa ascending --
+ *   its keys are row numbers, not k-mers.  The database searched is ONE file (the reference inserts the files of a set
+ *   one after the other, unmerged: not restated -> merge fails with KMG_EUNSUPPORTED for variable-length sets). */
+int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *db, int min_k, int count_cap, kmg_db **rows,
+                   int64_t *hit_row, uint64_t *n_hits);
 /* kmg_db_load : upload a decoded database (KmerFile.java:200-250 output) from host CSR arrays. */
 int kmg_db_load(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *keys,
                 uint64_t n_unique, const uint64_t *val_off, const int32_t *val_a, const int32_t *val_b,

@@ -341,6 +341,25 @@ def match_into(ctx, search, ref, out):
     return out
 
 
+def match_trie(search, ref, min_length=None, stored=False):
+    """DB.getNearestKmers' non-quick branch without differences (DB.java:83,139-184; Root.java:29-170) for a search
+    database of k-mers of several lengths (kmg_match_trie) -> (rows, hit): hit[i] = row of search k-mer i's answer in
+    the taxon database `rows`, -1 = no line.  min_length = the search stream's declared shortest length (default: the
+    search database's); stored = the handles were loaded from files (else counts are cut to the 255 a file holds
+    before they add up, as in match_lines)."""
+    if isinstance(ref, DB):
+        if len(ref.files) != 1:
+            raise KmersGpuError(_lib.KMG_EUNSUPPORTED, "a trie search over a database given as several files stays on the Java path")
+        ref = ref.files[0]
+    ctx = search.ctx
+    hit = np.empty(max(search.n_unique, 1), np.int64)
+    nh = C.c_uint64()
+    h = C.c_void_p()
+    ctx.check(ctx.lib.kmg_match_trie(ctx.h, search.h, ref.h, int(search.min_length if min_length is None else min_length),
+                                     0 if stored else 255, C.byref(h), _ptr(hit), C.byref(nh)))
+    return KmerDatabase(ctx, h), hit[:search.n_unique]
+
+
 def match_near(search, ref, max_diff):
     """Inexact search for k-mers of one length (kmg_match_near; DB.processNearestCommonKey, DB.java:139-184): every
     reference k-mer within Hamming distance max_diff of every search k-mer.  -> (pair_off[n_unique + 1], ref_index[],
@@ -451,7 +470,7 @@ def kmer_strings(keys, k):
     return [row.tobytes().decode() for row in _BASES[codes]]
 
 
-def match_lines(search, ref, hit, stored=False):
+def match_lines(search, ref, hit, stored=False, ref_stored=None):
     """One line per matched search k-mer, ascending (Matcher.java:247-249): KMER \\t r:p|r:p \\t -|TxC|TxC
     (ResultsDataType.java:15-35).  Matcher reads its databases from files, whose counts are bytes saturated at 255
     (CountDataType.java:40): for handles straight from a build the counts are capped here to what the file would
@@ -459,8 +478,11 @@ def match_lines(search, ref, hit, stored=False):
     longs, DB.java:99-109, and a line can show more than 255)."""
     s, r = search.fetch(), ref.fetch()
     cap = (1 << 31) if stored else 255
+    rcap = cap if ref_stored is None else ((1 << 31) if ref_stored else 255)     # (match_trie's rows hold sums: ref_stored=True)
     idx = np.nonzero(hit >= 0)[0]
     names = kmer_strings(s["keys"][idx], search.k)
+    if search.min_length != search.k:                    # k-mers of several lengths: zero-padded behind their own
+        names = [n[:l] for n, l in zip(names, search.lens()[idx].tolist())]
     lines = []
     for name, i in zip(names, idx.tolist()):
         a, b = int(s["val_off"][i]), int(s["val_off"][i + 1])
@@ -470,7 +492,7 @@ def match_lines(search, ref, hit, stored=False):
             left = "|".join("%dx%d" % (x, min(y, cap)) for x, y in zip(s["val_a"][a:b].tolist(), s["val_b"][a:b].tolist()))
         h = int(hit[i])
         c, d = int(r["val_off"][h]), int(r["val_off"][h + 1])
-        right = "|".join("%dx%d" % (x, min(y, cap)) for x, y in zip(r["val_a"][c:d].tolist(), r["val_b"][c:d].tolist()))
+        right = "|".join("%dx%d" % (x, min(y, rcap)) for x, y in zip(r["val_a"][c:d].tolist(), r["val_b"][c:d].tolist()))
         lines.append("%s\t%s\t-|%s" % (name, left, right))
     return lines
 

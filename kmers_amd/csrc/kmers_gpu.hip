@@ -1400,6 +1400,62 @@ extern "C" int kmg_db_restrict(kmg_ctx *ctx, const kmg_db *src, int length, kmg_
     return KMG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ trie search
+extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int min_k, int count_cap, kmg_db **rows,
+                              int64_t *hit_row, uint64_t *n_hits) {
+    if (!ctx || !search || !ref || !rows || (search->U && !hit_row)) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *rows = nullptr;
+    if (n_hits) *n_hits = 0;
+    if (search->ctx != ctx || ref->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
+    if (ref->kind != KMG_PAYLOAD_TAXON) return fail(ctx, KMG_EINVAL, "the database searched holds taxon counts");
+    if (search->key_len != ref->key_len) return fail(ctx, KMG_EINVAL, "key lengths differ");
+    // DB.java:78-81 on the search stream's declared lengths [min_k, search->k]
+    if (min_k < ref->min_k || search->k > ref->k || min_k > search->min_k || min_k < ref->key_len)
+        return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
+    KMG_HIP(hipSetDevice(ctx->device));
+    KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(ref)));
+    const u64 ns = search->U;
+    kmg_db *db = new (std::nothrow) kmg_db();
+    if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+    std::unique_ptr<kmg_db, void (*)(kmg_db *)> db_guard(db, db_release);
+    // the rows' "k-mer" is the row number in 32 bits: a database of 16-base keys as far as the merge pipeline cares
+    db->ctx = ctx; db->k = 16; db->min_k = 16; db->key_len = 1; db->rc = true; db->kind = KMG_PAYLOAD_TAXON;
+    PoolBuf first(ctx), found(ctx), nvals(ctx), row(ctx), dst(ctx), agg(ctx), k0(ctx), v0(ctx), k1(ctx), v1(ctx), totals(ctx), hit(ctx);
+    KMG_ALLOC(totals, 64);
+    KMG_HIP(hipMemsetAsync(totals.p, 0, 64, ctx->stream));
+    KMG_ALLOC(first, (ns + 1) * 8); KMG_ALLOC(found, (ns + 1) * 4); KMG_ALLOC(nvals, (ns + 1) * 4);
+    KMG_ALLOC(row, (ns + 2) * 8); KMG_ALLOC(dst, (ns + 2) * 8); KMG_ALLOC(hit, (ns + 1) * 8);
+    KMG_ALLOC(agg, (size_t)(div_up_u64(ns, SCAN_TILE) + 1) * 8);
+    u64 nrows = 0, nrec = 0;
+    if (ns) {
+        hipLaunchKernelGGL(trie_find_kernel, dim3(div_up_u64(ns, 256)), dim3(256), 0, ctx->stream, search->keys, search->lens, search->k,
+                           ns, ref->keys, ref->lens, ref->k, ref->bucket_off, ref->val_off, ref->key_len, min_k,
+                           first.as<long long>(), found.as<u32>(), nvals.as<u32>());
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, found.as<u32>(), row.as<u64>(), ns, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
+                                                    KP_SCAN)));
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, nvals.as<u32>(), dst.as<u64>(), ns, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
+                                                    KP_SCAN)));
+        KMG_HIP(read_back(ctx, &nrows, row.as<u64>() + ns, 8));
+        KMG_HIP(read_back(ctx, &nrec, dst.as<u64>() + ns, 8));
+    }
+    if (nrec >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 values in the answers of one call: search in key slices");
+    const u32 n = (u32)nrec;
+    KMG_ALLOC(k0, ((size_t)n + 1) * 8); KMG_ALLOC(v0, ((size_t)n + 1) * 8);
+    KMG_ALLOC(k1, ((size_t)n + 1) * 8); KMG_ALLOC(v1, ((size_t)n + 1) * 8);
+    if (ns)
+        hipLaunchKernelGGL(trie_expand_kernel, dim3(div_up_u64(ns, 256)), dim3(256), 0, ctx->stream, first.as<long long>(), nvals.as<u32>(),
+                           row.as<u64>(), dst.as<u64>(), ns, ref->val_off, ref->val_a, ref->val_b, count_cap, k0.as<u64>(), v0.as<u64>(),
+                           hit.as<long long>());
+    KMG_HIP(hipGetLastError());
+    if (ns) KMG_HIP(hipMemcpyAsync(hit_row, hit.p, ns * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_TRY(merge_records(ctx, db, k0, v0, k1, v1, n, totals));          // (ends with a stream synchronisation)
+    if (db->U != nrows) return fail(ctx, KMG_ESTATE, "trie search: rows and answered k-mers differ");
+    if (n_hits) *n_hits = nrows;
+    *rows = db_guard.release();
+    return KMG_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ match
 static int match_locked(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, long long *d_hit, u64 *d_nhits) {
     // databases of another context of the same device are fine (they are complete once their build has

@@ -1018,23 +1018,29 @@ int matcher(int argc, char **argv) {
         // reference stays loaded then and only the search side is walked in slices)
         if (max_diff > 0 && !ref_whole) ref_whole = ref_set.load(g);
         kmg_db *ref = max_diff > 0 ? ref_whole : ref_set.load(g, lo, hi), *search = search_set.load(g, lo, hi);
+        bool trie = false;
         // -k / -K default to the search file's lengths (Matcher.java:147-148).  One length L: both sides go through
         // KmerUtils.restrictedStream (KmerFile.allRestrictedKmers, Matcher.java:241; DB.java:134) -- kmg_db_restrict --
-        // and take the exact join.  A search over several lengths is the trie (DB.java:83): Java path.
+        // and take the exact join.  A search over several lengths is the trie (DB.java:83): kmg_match_trie.
         {
             const DbInfo s0 = db_info(search), r0 = db_info(ref);
             const int s_min = kmg_db_min_k(search), r_min = kmg_db_min_k(ref);
             const int want_min = a.geti('k', s_min), want_max = a.geti('K', s0.k);
-            if (want_min != want_max) throw Unsupported("a search over k-mers of several lengths (-k < -K) stays on the Java path");
             if (want_min < r_min || want_max > r0.k)                                                  // DB.java:78-81
                 throw std::runtime_error("InconsistentDataException: Search kmers contain kmers of a length inconsistent with the database");
-            if (s_min != s0.k || s0.k != want_min) {
+            if (want_min != want_max) {
+                // a search over several lengths: the trie (DB.java:83,139-184) in closed form -- kmg_match_trie
+                if (max_diff > 0) throw Unsupported("inexact search over k-mers of several lengths stays on the Java path");
+                if (want_min != s_min || want_max != s0.k)
+                    throw Unsupported("-k < -K other than the search file's own lengths stays on the Java path");
+                trie = true;
+            } else if (s_min != s0.k || s0.k != want_min) {
                 kmg_db *cut = nullptr;
                 g.check(kmg_db_restrict(g.ctx, search, want_min, &cut));
                 kmg_db_free(search);
                 search = cut;
             }
-            if (r_min != r0.k || r0.k != want_min) {
+            if (!trie && (r_min != r0.k || r0.k != want_min)) {
                 if (max_diff > 0) throw Unsupported("inexact search over a database of several k-mer lengths stays on the Java path");
                 kmg_db *cut = nullptr;
                 g.check(kmg_db_restrict(g.ctx, ref, want_min, &cut));
@@ -1049,6 +1055,7 @@ int matcher(int argc, char **argv) {
         uint64_t nh = 0;
         clk.lap("read + decode databases");
         // -n 1 | 2 [-j]: every reference k-mer within reach of every search k-mer (kmg_match_near), else the exact join
+        std::vector<uint8_t> slens;                  // lengths of the search k-mers when there are several
         std::vector<uint64_t> pair_off;
         std::vector<int64_t> pair_ref;
         std::vector<uint8_t> pair_dist;
@@ -1060,6 +1067,14 @@ int matcher(int argc, char **argv) {
             pair_dist.resize(np + 1);
             if (np) g.check(kmg_match_near(g.ctx, search, ref, max_diff, nullptr, pair_ref.data(), pair_dist.data(), np, &np));
             for (uint64_t i = 0; i < sd.U; i++) { hit[i] = pair_off[i + 1] > pair_off[i] ? 0 : -1; nh += hit[i] >= 0; }
+        } else if (trie) {
+            // the answers come as rows of a database of their own (counts already summed per taxon)
+            kmg_db *rows = nullptr;
+            g.check(kmg_match_trie(g.ctx, search, ref, kmg_db_min_k(search), 0, &rows, hit.data(), &nh));
+            kmg_db_free(ref);
+            ref = rows;
+            slens.resize(sd.U + 1);
+            g.check(kmg_db_fetch_lens(search, slens.data()));
         } else g.check(kmg_match(g.ctx, search, ref, hit.data(), &nh));
         const HostDb hs = fetch(g, search), hr = fetch(g, ref);
         if (ref != ref_whole) kmg_db_free(ref);
@@ -1078,7 +1093,8 @@ int matcher(int argc, char **argv) {
             s.reserve((hi_r - lo_r) * (size_t)(sd.k + 48));
             for (size_t r = lo_r; r < hi_r; r++) {
                 const uint64_t i = rows[r], key = hs.keys[i];
-                for (int p = 0; p < sd.k; p++) s.push_back("ACTG"[(key >> (62 - 2 * p)) & 3]);   // Sequence.java:117-134
+                const int len = trie ? (int)slens[i] : sd.k;
+                for (int p = 0; p < len; p++) s.push_back("ACTG"[(key >> (62 - 2 * p)) & 3]);   // Sequence.java:117-134
                 s.push_back('\t');
                 append_values(s, hs, i);
                 if (max_diff == 0) {

@@ -180,6 +180,83 @@ __global__ __launch_bounds__(MT_BLOCK) void match_runs_kernel(const u64 *__restr
     match_tile(skeys, mt.q0, mt.q1, rkeys, mt.r_lo, mt.r_hi, hit, nullptr);
 }
 
+// ---- search over k-mers of several lengths, no differences (Matcher on variable-length files with its default
+// -k / -K: DB.getNearestKmers' non-quick branch, DB.java:83,139-184, over Root.addKmer / closestKmers,
+// Root.java:29-170) ------------------------------------------------------------------------------------------------
+// What the reference's radix trie hands back for a search k-mer t of T bases, in closed form (derivation and the CPU
+// check against the literal restatement: DESIGN 6b, tools/exp/trie_closed_form.py).  The k-mers of one key enter the
+// trie in (zero-padded value, length) order, which is prefix-first lexicographic order, so every split happens on the
+// rightmost path and a data object is held by exactly one node of that path at a time.  The node that answers t is
+// the one covering depth T on t's path; it belongs to x0 = the first stored k-mer that has t as a prefix (none: no
+// line), and its data object has absorbed (Root.java:48-51,95-102; the object is shared between a split node and its
+// tail, :79-80) every stored k-mer that shares x0's first m = max(shortest, L + 1) bases, L = the bases x0 shares
+// with its predecessor in the key (0 for the key's first k-mer).  Those k-mers are the contiguous entries
+// [x0, first entry whose first m bases are larger).  So: two binary searches and one look at the predecessor.
+__global__ void trie_find_kernel(const u64 *__restrict__ skeys, const uint8_t *__restrict__ slens, int s_len_all, u64 ns,
+                                 const u64 *__restrict__ rkeys, const uint8_t *__restrict__ rlens, int r_len_all,
+                                 const u64 *__restrict__ rbucket, const u64 *__restrict__ rval_off, int key_len, int shortest,
+                                 long long *__restrict__ first, u32 *__restrict__ found, u32 *__restrict__ nvals) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const u64 t = skeys[i];
+    const int T = slens ? (int)slens[i] : s_len_all;
+    const u64 b = t >> (64 - 2 * key_len);
+    const u64 lo = rbucket[b], hi = rbucket[b + 1];
+    u64 l = lo, h = hi;
+    while (l < h) {                                // first entry >= (t, T) in (value, length) order
+        const u64 mid = (l + h) >> 1;
+        const u64 km = rkeys[mid];
+        const int lm = rlens ? (int)rlens[mid] : r_len_all;
+        if (km < t || (km == t && lm < T)) l = mid + 1; else h = mid;
+    }
+    first[i] = -1; found[i] = 0; nvals[i] = 0;
+    if (l == hi) return;
+    const u64 x0 = rkeys[l];
+    const int len0 = rlens ? (int)rlens[l] : r_len_all;
+    if (len0 < T || ((x0 ^ t) >> (64 - 2 * T)) != 0) return;      // t is not a prefix of it: of no stored k-mer then
+    int L = 0;
+    if (l > lo) {
+        const u64 p = rkeys[l - 1];
+        const int lp = rlens ? (int)rlens[l - 1] : r_len_all;
+        const u64 x = x0 ^ p;
+        const int c = x ? (int)(__clzll((long long)x) >> 1) : 32;
+        L = min(c, min(len0, lp));
+    }
+    const int m = max(shortest, L + 1);
+    const u64 top = m >= 32 ? x0 : (x0 | (~0ull >> (2 * m)));      // the largest value with x0's first m bases
+    u64 a = l + 1, e = hi;
+    while (a < e) {
+        const u64 mid = (a + e) >> 1;
+        if (rkeys[mid] <= top) a = mid + 1; else e = mid;
+    }
+    first[i] = (long long)l;
+    found[i] = 1;
+    const u64 nv = rval_off[a] - rval_off[l];
+    nvals[i] = nv > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)nv;         // (the host refuses totals beyond 2^32-16)
+}
+
+// the answers' values as (row, taxon, count) records for the merge pipeline (reduce.h, mg_*), which adds the counts
+// per taxon as TreeCountMap.addAll does.  row = rank of the search k-mer among the answered ones, in the records' key
+// field; cap > 0: every stored count is first cut to what its file byte holds (CountDataType.java:40).
+__global__ void trie_expand_kernel(const long long *__restrict__ first, const u32 *__restrict__ nvals, const u64 *__restrict__ row,
+                                   const u64 *__restrict__ dst, u64 ns, const u64 *__restrict__ rval_off,
+                                   const int32_t *__restrict__ rval_a, const int32_t *__restrict__ rval_b, int cap,
+                                   u64 *__restrict__ out_keys, u64 *__restrict__ out_vals, long long *__restrict__ hit) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    if (first[i] < 0) { hit[i] = -1; return; }
+    hit[i] = (long long)row[i];
+    const u64 key = row[i] << 32;
+    u64 o = dst[i];
+    const u64 v0 = rval_off[first[i]];
+    for (u64 v = v0; v < v0 + nvals[i]; v++, o++) {
+        int32_t c = rval_b[v];
+        if (cap > 0 && c > cap) c = cap;
+        out_keys[o] = key;
+        out_vals[o] = ((u64)((u32)rval_a[v] ^ 0x80000000u) << 32) | (u32)c;
+    }
+}
+
 // ---- TaxaCounts ----------------------------------------------------------------------------------------
 // The distinct taxa of a database come from a presence bitmap over [min taxon, max taxon] (at most 2^32 bits =
 // 512 MB; BASELINE's taxon ids span a few thousand): one pass marks, a popcount scan ranks the words, and the rank

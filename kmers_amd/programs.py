@@ -276,8 +276,8 @@ def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max
     """Matcher with -n 0: one line per matched search k-mer, ascending (Matcher.java:235-250); output is
     gzip at the default level unless plain (-Z x).  min_k / max_k = -k / -K, by default the search file's lengths
     (Matcher.java:147-148): with one length L both sides go through KmerUtils.restrictedStream (KmerFile.java:80-83,
-    DB.java:134; kmg_db_restrict) and take the exact join; a search over several lengths is the trie (DB.java:83),
-    which stays on the Java path.  limit = "start" or "start-end" (-L, Matcher.java:159-171): only
+    DB.java:134; kmg_db_restrict) and take the exact join; a search over several lengths -- the default on files built
+    with MakeDatabase's default -k 24 -K 32 -- is the trie (DB.java:83) in closed form (kmg_match_trie).  limit = "start" or "start-end" (-L, Matcher.java:159-171): only
     the search k-mers of keys start .. end; a k-mer and its match share their key, so the same slice of the
     reference is all that is loaded."""
     key_range = None
@@ -294,10 +294,27 @@ def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max
     searches = [open_database(ctx, f, key_range) for f in sfiles]
     min_k = searches[0].min_length if min_k is None else int(min_k)
     max_k = searches[0].max_length if max_k is None else int(max_k)
-    if min_k != max_k:
-        raise KmersGpuError(KMG_EUNSUPPORTED, "a search over k-mers of several lengths (-k < -K) stays on the Java path")
     if min_k < db.min_length or max_k > db.max_length:          # DB.java:78-81
         raise InconsistentDataException(KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database")
+    if min_k != max_k:
+        # a search over several lengths: the trie (DB.java:83,139-184) in closed form, kmg_match_trie
+        from .api import match_trie
+        if max_diff > 0:
+            raise KmersGpuError(KMG_EUNSUPPORTED, "inexact search over k-mers of several lengths stays on the Java path")
+        if len(searches) != 1 or len(db.files) != 1:
+            raise KmersGpuError(KMG_EUNSUPPORTED, "a search over several lengths takes one search file and one database file on the GPU path")
+        search = searches[0]
+        if (search.min_length, search.max_length) != (min_k, max_k):
+            raise KmersGpuError(KMG_EUNSUPPORTED, "-k < -K other than the search file's own lengths stays on the Java path")
+        if not db.files[0].rc:
+            raise ValueError("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included")
+        rows, hit = match_trie(search, db.files[0], min_k, stored=True)
+        lines = match_lines(search, rows, hit, stored=True)
+        rows.close()
+        text = "".join(l + "\n" for l in lines).encode()
+        with (open(output_path, "wb") if plain else gzip.open(output_path, "wb")) as f:
+            f.write(text)
+        return lines
     if any(s.min_length != s.max_length or s.k != min_k for s in searches):
         searches = [s.restrict(min_k) for s in searches]        # KmerFile.allRestrictedKmers (Matcher.java:241)
     if db.min_length != db.max_length or db.max_length != min_k:

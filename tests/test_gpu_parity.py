@@ -1401,6 +1401,81 @@ def test_restricted_match_matches_oracle(ctx, min_k, k, L, key_len, seed):
         ref.restrict(min_k - 1)
 
 
+def _trie_case(rng, alphabet, n_seq, seq_len, n_reads, read_len, taxa):
+    fa = _rand_fasta(rng, n_seq, seq_len, alphabet, taxa)
+    body = b"".join(l for l in fa.split(b"\n") if not l.startswith(b">"))
+    recs = []
+    for i in range(n_reads):
+        a = int(rng.integers(0, max(len(body) - read_len, 1)))
+        sq = bytearray(body[a:a + int(rng.integers(1, read_len + 1))])
+        if len(sq) and rng.random() < 0.3:                   # a changed base: suffixes / prefixes still match
+            sq[int(rng.integers(0, len(sq)))] = alphabet[int(rng.integers(0, len(alphabet)))]
+        recs.append(b"@q%d\n%s\n+\n%s\n" % (i, bytes(sq), b"I" * len(sq)))
+    return fa, b"".join(recs)
+
+
+@pytest.mark.parametrize("min_k,k,key_len,alphabet,seed", [
+    (3, 6, 2, b"AACCGTN", 61), (2, 9, 1, b"AC", 62), (1, 5, 1, b"AAAC", 63), (4, 8, 3, b"ACGT", 64), (3, 7, 2, b"AG", 65),
+    (20, 31, 3, b"ACGT" * 12 + b"N", 66), (24, 32, 6, b"ACGT" * 12 + b"N", 67), (24, 32, 6, b"ACGT", 68), (31, 32, 4, b"ACGT", 69)])
+def test_trie_search_matches_literal_trie(ctx, min_k, k, key_len, alphabet, seed):
+    """Matcher with its default -k / -K on variable-length files: DB.getNearestKmers' non-quick branch at maxDiff = 0
+    (DB.java:83,139-184) -- kmg_match_trie's closed form against the literal restatement of Root.addKmer / closestKmers
+    (oracle/slow_ref.py Root; shared data objects included), line by line.  Small alphabets force long shared prefixes
+    (answers summed over many stored k-mers); the search side also narrower than the database."""
+    import kmers_amd as km
+    from oracle import slow_ref as R
+    rng = np.random.default_rng(seed)
+    small = k <= 9
+    fa, fq = _trie_case(rng, alphabet, 12 if small else 30, 60 if small else 300, 40 if small else 200, 25 if small else 60,
+                        [11, 12, 13])
+    ref = km.make_reference_db(ctx, fa, k, key_len, min_k=min_k)
+    o_ref = R.build_ref_db(fa, k, key_len, min_k=min_k)
+    total = 0
+    for s_min, s_max in {(min_k, k), (min(min_k + 1, k), k), (min_k, max(k - 1, min_k)), (max(min_k, k - 2), k)}:
+        if key_len > s_min:
+            continue
+        rdb, _ = km.make_read_db(ctx, fq, s_max, key_len, min_k=s_min)
+        o_reads, _ = R.build_read_db(fq, s_max, key_len, min_k=s_min)
+        want = R.near_match_lines(o_reads, R.DB([o_ref]), 0, False)
+        rows, hit = km.match_trie(rdb, ref, s_min)
+        got = km.match_lines(rdb, rows, hit, ref_stored=True)
+        assert got == want, (s_min, s_max, len(got), len(want))
+        assert int((hit >= 0).sum()) == len(want) == rows.n_unique
+        total += len(want)
+        rows.close()
+        rdb.close()
+    assert total > 0
+    if min_k > key_len:
+        rdb, _ = km.make_read_db(ctx, fq, k, key_len, min_k=min_k)
+        with pytest.raises(km.InconsistentDataException):   # DB.java:78-81: search lengths outside the database's
+            km.match_trie(rdb, ref, min_k - 1)
+        rdb.close()
+    ref.close()
+
+
+def test_trie_search_counts_and_reference_search_side(ctx):
+    """Counts beyond a file's byte are cut to 255 BEFORE the trie adds them up (the reference reads them from the file,
+    CountDataType.java:40), and a reference database can be the search side (Matcher.java:182-210): `TxC` on both
+    sides of the line."""
+    import kmers_amd as km
+    from oracle import slow_ref as R
+    unit = b"ACGTTGCAAGGCTTAACCGGATAT"
+    fa = (b">7\n" + (unit + b"N") * 300 + b"\n>7\n" + (unit[:21] + b"GGGN") * 300 + b"\n>8\n" + unit + b"ACCA\n>9\n" +
+          unit[:20] + b"TTTTGG\n")
+    q = b">1\n" + unit + b"AC\n>2\n" + unit[:22] + b"\n"
+    min_k, k, l = 20, 24, 3
+    ref = km.make_reference_db(ctx, fa, k, l, min_k=min_k)
+    sdb = km.make_reference_db(ctx, q, k, l, min_k=min_k)
+    o_ref, o_s = R.build_ref_db(fa, k, l, min_k=min_k), R.build_ref_db(q, k, l, min_k=min_k)
+    want = R.near_match_lines(o_s, R.DB([o_ref]), 0, False)
+    rows, hit = km.match_trie(sdb, ref, min_k)
+    got = km.match_lines(sdb, rows, hit, ref_stored=True)
+    assert got == want
+    assert max(int(x.split("x")[-1]) for w in want for x in w.split("\t")[2].split("|")[1:]) > 255     # sums pass 255
+    for d in (rows, ref, sdb):
+        d.close()
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("KMERS_FUZZ_VAR_SEEDS", "12"))))
 def test_fuzz_variable_length_against_oracle(ctx, seed):
     """Random minK < maxK, key length, input shape, batch cuts, filters and key ranges; then Matcher -k L -K L at a

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Check on the CPU that the closed form the GPU trie search uses gives what the literal restatement of
+Root.addKmer / closestKmers gives at maxDiff = 0, on random variable-length databases with heavy prefix sharing.
+Test infrastructure: uses oracle/ only."""
+import random
+import sys
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+from oracle import slow_ref as R
+
+
+STATS = {'lines': 0, 'm_lt_T': 0, 'entries': 0}
+
+
+def closed_form_lines(search_blocks, ref_blocks):
+    min_k, max_k, key_len, ids, rc = R.parse_meta(search_blocks[-1])
+    kind = "read" if ids == R.READ_ID else "ref"
+    lines = []
+    for key in range(4 ** key_len):
+        group = R.decode_block(search_blocks.get(key, b""), kind)
+        ents = R.decode_block(ref_blocks.get(key, b""), "ref")      # (value, length) order
+        strs = [tuple(k.chars) for k, _ in ents]
+        for kmer, sdata in group:
+            t = tuple(kmer.chars)
+            T = len(t)
+            # first stored string >= t in prefix-first lexicographic order
+            i0 = None
+            for i, x in enumerate(strs):
+                if x >= t:        # python tuple order: prefix first, A = 0 smallest
+                    i0 = i
+                    break
+            if i0 is None or strs[i0][:T] != t:
+                continue
+            x0 = strs[i0]
+            L = 0
+            if i0 > 0:
+                p = strs[i0 - 1]
+                while L < min(len(p), len(x0)) and p[L] == x0[L]:
+                    L += 1
+            m = max(min_k, L + 1)
+            data = {}
+            STATS['lines'] += 1
+            STATS['m_lt_T'] += m < T
+            for x, (_, d) in zip(strs[i0:], ents[i0:]):
+                if x[:m] != x0[:m]:
+                    break
+                STATS['entries'] += 1
+                for tx, c in d.items():
+                    data[tx] = data.get(tx, 0) + c
+            if kind == "read":
+                s = "|".join("%d:%d" % (r_, p_) for r_, p_ in sorted(sdata))
+            else:
+                s = "|".join("%dx%d" % (tx, sdata[tx]) for tx in sorted(sdata))
+            lines.append("%s\t%s\t-|%s" % (kmer, s, "|".join("%dx%d" % (tx, data[tx]) for tx in sorted(data))))
+    return lines
+
+
+def main(seeds):
+    bad = 0
+    for seed in range(seeds):
+        rng = random.Random(seed)
+        alpha = rng.choice(["ACGT", "AC", "AAAC", "ACGTN", "AG"])
+        max_k = rng.randint(2, 9)
+        min_k = rng.randint(1, max_k)
+        key_len = rng.randint(1, min(min_k, 3))
+        fa = "".join(">%d\n%s\n" % (rng.randint(1, 5), "".join(rng.choice(alpha) for _ in range(rng.randint(0, 60)))) for _ in range(rng.randint(1, 6)))
+        fq = "".join("@r%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in
+                     enumerate("".join(rng.choice(alpha) for _ in range(rng.randint(0, 40))) for _ in range(rng.randint(1, 8))))
+        ref = R.build_ref_db(fa.encode(), max_k, key_len, min_k=min_k)
+        # the search side may be narrower than the database
+        s_min = rng.randint(min_k, max_k)
+        s_max = rng.randint(s_min, max_k)
+        if rng.random() < 0.5:
+            s_min, s_max = min_k, max_k
+        if key_len > s_min:
+            continue
+        reads, _ = R.build_read_db(fq.encode(), s_max, key_len, min_k=s_min)
+        if rng.random() < 0.3:
+            reads = R.build_ref_db(fq.replace("@", ">").encode(), s_max, key_len, min_k=s_min) if False else reads
+        db = R.DB([ref])
+        want = R.near_match_lines(reads, db, 0, False)
+        got = closed_form_lines(reads, ref)
+        if want != got:
+            bad += 1
+            print("seed", seed, "alpha", alpha, "k", min_k, max_k, "search", s_min, s_max, "key", key_len, "MISMATCH", len(want), len(got))
+            for a, b in zip(want, got):
+                if a != b:
+                    print("  want", a)
+                    print("  got ", b)
+                    break
+    print("seeds", seeds, "bad", bad, STATS)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 300) else 0)
