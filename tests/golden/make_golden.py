@@ -74,8 +74,12 @@ def main_var():
         assert cs.match_lines(cr, hit).decode().splitlines() == lines and len(lines) > 20, name
         t, m, q = c_ref.taxacounts()
         assert ["%d\t%d\t%d" % x for x in zip(t, m, q)] == counts, name
+        # Matcher with its default -k / -K (the files' own lengths): the literal trie, no differences
+        trie = R.near_match_lines(reads, db, 0, False)
+        assert len(trie) > 20 and len({len(x.split("\t")[0]) for x in trie}) > 1, name
         out = {
             "comment": "outputs of oracle/slow_ref.py (restatement of the reference), not of Kmers.jar; see make_golden.py",
+            "match_lines_trie": trie,
             "min_k": mn, "k": mx, "key_len": l, "restrict": L, "fasta": fa.decode(), "fastq": fq.decode(),
             "ref_blocks": {str(key): ref[key].hex() for key in sorted(ref)},
             "read_blocks": {str(key): reads[key].hex() for key in sorted(reads)},

@@ -133,6 +133,7 @@ def test_restatements_reproduce_variable_length_golden(path):
     assert ref[-1][0] == mn and ref[-1][1] == k
     db = R.DB([ref])
     assert R.match_lines(reads, db, min_k=L, max_k=L) == g["match_lines_restricted"] and R.taxa_counts(db) == g["taxa_counts"]
+    assert R.near_match_lines(reads, db, 0, False) == g["match_lines_trie"]          # the literal trie (Root.java)
     c_ref, c_reads = OracleDB(fa, 0, k, l, min_k=mn), OracleDB(fq, 1, k, l, min_k=mn)
     for c, want in ((c_ref, g["ref_blocks"]), (c_reads, g["read_blocks"])):
         blob, off = c.encode_blocks()
@@ -163,6 +164,9 @@ def test_gpu_reproduces_variable_length_golden(path):
     rr, rs = ref.restrict(L), reads.restrict(L)
     hit, nh = km.DB([rr]).get_nearest_kmers(rs)
     assert km.match_lines(rs, rr, hit) == g["match_lines_restricted"] and nh == len(g["match_lines_restricted"])
+    rows, thit = km.match_trie(reads, ref)                                           # Matcher's default -k / -K
+    assert km.match_lines(reads, rows, thit, ref_stored=True) == g["match_lines_trie"]
+    rows.close()
     # the same in two key ranges
     nkeys = 4 ** l
     for lo, hi in ((0, nkeys // 2), (nkeys // 2, nkeys)):

@@ -260,7 +260,7 @@ def test_native_cli_matches_python_drivers(tmp_path):
     # what is not on the GPU path exits with status 3 (wrapper falls back to Java)
     run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("x.db"), "-K", "32", "-k", "24", "-h", rc=3)
     run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-n", "3", rc=3)
-    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-k", str(k - 2), "-K", str(k), rc=3)      # the trie
+    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-k", str(k - 2), "-K", str(k), rc=1)      # DB.java:78-81: shorter than the database's k-mers
     # DB.java:78-81: search k-mers shorter than the database's -> InconsistentDataException
     run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-k", str(k - 2), "-K", str(k - 2), rc=1)
     run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("mk.txt"), "-Z", "x", "-k", str(k), "-K", str(k))
@@ -442,7 +442,8 @@ def _oracle_var_blocks(odb):
 def test_default_options_build_variable_length_databases(tmp_path):
     """`MakeDatabase -a -i x -o y` with no -K / -k is -K 32 -k 24 (MakeDatabase.java:106-107): k-mers of 24 .. 32 bases.
     Both drivers' unzipped files equal the oracle's byte for byte; `Matcher -k L -K L` restricts both files to one
-    length (KmerUtils.restrictedStream) and joins; TaxaCounts walks every stored k-mer."""
+    length (KmerUtils.restrictedStream) and joins; Matcher with its own defaults searches all nine lengths through the
+    trie (kmg_match_trie); TaxaCounts walks every stored k-mer."""
     import subprocess
     import kmers_amd as km
     from kmers_amd import synth
@@ -463,6 +464,8 @@ def test_default_options_build_variable_length_databases(tmp_path):
     want_ref, want_reads = str(tmp_path / "ref.want"), str(tmp_path / "reads.want")
     R.write_indexed_file(want_ref, _oracle_var_blocks(o_ref), None)
     R.write_indexed_file(want_reads, _oracle_var_blocks(o_reads), None)
+    want_trie = R.near_match_lines(_oracle_var_blocks(o_reads), R.DB([_oracle_var_blocks(o_ref)]), 0, False)
+    assert len(want_trie) > 1000 and len({len(w.split("\t")[0]) for w in want_trie}) == 9
     run = lambda *a: subprocess.run([kmg] + list(a), capture_output=True, text=True, timeout=300)
     for tag, drv in (("kmg", lambda *a: run(*a).returncode), ("py", lambda *a: cli(list(a)))):
         ref_db, reads_db = str(tmp_path / ("ref.%s.db" % tag)), str(tmp_path / ("reads.%s.db" % tag))
@@ -480,9 +483,17 @@ def test_default_options_build_variable_length_databases(tmp_path):
             cr, cs = o_ref.restrict(L), o_reads.restrict(L)
             hit, nh = cs.match(cr)
             assert open(out, "rb").read() == cs.match_lines(cr, hit) and nh > 100
-        # a search over several lengths is the trie: off the GPU path
+        # Matcher with ITS defaults (-k / -K = the search file's 24 / 32, Matcher.java:147-148) is the trie search
+        # (DB.java:83,139-184): the literal restatement's lines
+        out = str(tmp_path / ("trie.%s.txt" % tag))
+        assert drv("Database.Matcher", "-i", reads_db, "-d", ref_db, "-o", out, "-Z", "x") == 0
+        assert open(out).read().splitlines() == want_trie
+        assert drv("Database.Matcher", "-i", reads_db, "-d", ref_db, "-o", out + ".gz", "-k", "24", "-K", "32") == 0
+        assert gzip.open(out + ".gz", "rt").read().splitlines() == want_trie
         if tag == "kmg":
-            assert run("Database.Matcher", "-i", reads_db, "-d", ref_db, "-o", str(tmp_path / "x.txt"), "-Z", "x").returncode == 3
+            # still on the Java path: a length window other than the file's own, differences over several lengths, -h
+            assert run("Database.Matcher", "-i", reads_db, "-d", ref_db, "-o", str(tmp_path / "x.txt"), "-Z", "x", "-k", "25", "-K", "32").returncode == 3
+            assert run("Database.Matcher", "-i", reads_db, "-d", ref_db, "-o", str(tmp_path / "x.txt"), "-Z", "x", "-n", "1").returncode == 3
             assert run("Database.MakeDatabase", "-a", "-i", fa, "-o", str(tmp_path / "h.db"), "-h").returncode == 3
         counts = str(tmp_path / ("counts.%s.tsv" % tag))
         assert drv("Utils.TaxaCounts", "-d", ref_db, "-o", counts) == 0
