@@ -1533,8 +1533,28 @@ def test_fuzz_variable_length_against_oracle(ctx, seed):
     hit, nh = km.DB([rr]).get_nearest_kmers(rs)
     o_hit, o_nh = ors.match(orr)
     assert nh == o_nh and np.array_equal(hit, o_hit)
+    if len(fa) + len(fq) < 250000:
+        # ... and Matcher with its default -k / -K: all lengths at once through the trie (the literal restatement is
+        # Python over every stored k-mer, so only the smaller cases)
+        from oracle import slow_ref as R
+        want = R.near_match_lines(_oracle_var_blocks(o_reads), R.DB([_oracle_var_blocks(o_ref)]), 0, False)
+        rows, thit = km.match_trie(rdb, ref)
+        assert km.match_lines(rdb, rows, thit, ref_stored=True) == want
+        rows.close()
     for d in (ref, rdb, rr, rs):
         d.close()
+
+
+def _oracle_var_blocks(odb):
+    """The C oracle's database as the {key: block bytes, -1: meta} dict the Python restatement reads
+    (meta = [minK][maxK][keyLength][n ids][ids][rc], FileCreator.java:153-164)."""
+    blob, off = odb.encode_blocks()
+    ids = [2048] if odb.kind == 0 else [257, 2052]
+    blocks = {-1: bytes([odb.min_k, odb.k, odb.key_len]) + len(ids).to_bytes(4, "big") + b"".join(i.to_bytes(4, "big") for i in ids) +
+              bytes([1 if odb.kind == 0 else 0])}
+    for key in range(4 ** odb.key_len):
+        blocks[key] = blob[int(off[key]):int(off[key + 1])]
+    return blocks
 
 
 def test_exchange_under_the_c_abi_world_of_one(ctx):
