@@ -202,7 +202,22 @@ def main():
 
     ranges, comm = None, None
     if use_dist:
-        comm = kd.Comm(ctx)        # the library's own RCCL communicator (csrc/comm.h): the exchange runs under the C ABI
+        # the library's own RCCL communicator (csrc/comm.h): the exchange runs under the C ABI.  Should it not come up
+        # on some rank, every rank takes the torch.distributed form of the same exchange instead (kmers_amd/dist.py).
+        exchange = "kmg_match_sharded (grouped ncclSend/ncclRecv inside the library)"
+        try:
+            if os.environ.get("KMERS_BENCH_EXCHANGE") == "torch":          # rehearsal of the other path
+                raise RuntimeError("KMERS_BENCH_EXCHANGE=torch")
+            comm = kd.Comm(ctx)
+        except Exception as e:                  # noqa: BLE001 -- whatever it was, the ranks must agree on the path
+            sys.stderr.write("bench.py: rank %d: kmg_comm_create failed (%s)\n" % (rank, e))
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+            exchange = "torch.distributed all_to_all_single (the library's communicator did not come up)"
         # The partition of the key space is a property of the reference, planned once: balanced ranges from the bucket
         # histogram of one complete build (every rank holds the whole input, so all ranks find the same ranges).
         submit(ctx_ref, d_ref_bases, d_ref_off, d_ref_id, None, len(genomes), 0, 1)
@@ -374,7 +389,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload, "mode": headline, "k": K, "key_len": KEY_LEN, "scale": args.scale,
-                       "ref_windows": n_ref_win, "read_windows_per_gpu": n_read_win},
+                       "ref_windows": n_ref_win, "read_windows_per_gpu": n_read_win,
+                       **({"exchange": exchange} if use_dist else {})},
             "stages": stages,
             "verified": verified,
             "roofline": roofline,
@@ -390,6 +406,8 @@ def main():
                 assert (u_reads, hits_local) == (o_u, o_nh), ("GPU step vs oracle", u_reads, hits_local, o_u, o_nh)
                 out["verified"]["against"] = "oracle (cpu_baseline leg): distinct read k-mers and hit count equal"
         os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if comm is not None:
+        comm.close()
     ctx.close()
     ctx_ref.close()
     if use_dist:
