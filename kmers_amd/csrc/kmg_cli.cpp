@@ -1271,16 +1271,18 @@ int collect_by_read(int argc, char **argv) {
                 const char *t1 = (const char *)memchr(line, '\t', lend - line);
                 const char *t2 = t1 ? (const char *)memchr(t1 + 1, '\t', lend - t1 - 1) : nullptr;
                 if (!t2) throw std::runtime_error("bad match line");
-                if (k < 0) k = (int)(t1 - line);
-                if ((int)(t1 - line) != k || k < 1 || k > 32) { unsupported[c] = "k-mers of different lengths or longer than 32"; return; }
+                if (k == -1) k = (int)(t1 - line);
+                // k-mers of several lengths (Matcher's default on default databases) or beyond 32 bases: the k-mer only
+                // names the row here, so the line number stands in for it (k = -2; as read_classifier does throughout)
+                if ((int)(t1 - line) != k || k < 1 || k > 32) k = -2;
                 uint64_t v = 0;
-                for (const char *ch = line; ch < t1; ch++) {
+                for (const char *ch = line; k > 0 && ch < t1; ch++) {
                     int b;
                     switch (*ch) { case 'A': b = 0; break; case 'C': b = 1; break; case 'T': b = 2; break; case 'G': b = 3; break;
                                    default: throw std::runtime_error("bad k-mer in match line"); }
                     v = (v << 2) | (uint64_t)b;
                 }
-                j.keys.push_back(k == 32 ? v : v << (64 - 2 * k));
+                j.keys.push_back(k < 0 || k == 32 ? v : v << (64 - 2 * k));
                 for (const char *q = t1 + 1; q < t2;) {                       // r:p|r:p
                     char *en;
                     const long r = strtol(q, &en, 10);
@@ -1307,9 +1309,9 @@ int collect_by_read(int argc, char **argv) {
     int k = -1;
     for (size_t c = 0; c < nslice; c++) {
         if (!unsupported[c].empty()) throw Unsupported(unsupported[c]);
-        if (part_k[c] < 0) continue;
-        if (k < 0) k = part_k[c];
-        if (part_k[c] != k) throw Unsupported("k-mers of different lengths or longer than 32");
+        if (part_k[c] == -1) continue;
+        if (k == -1) k = part_k[c];
+        if (part_k[c] != k) k = -2;
     }
     {
         std::vector<uint64_t> kb(nslice + 1, 0), sb(nslice + 1, 0), rb(nslice + 1, 0);
@@ -1335,6 +1337,10 @@ int collect_by_read(int argc, char **argv) {
         });
         j.s_off[kb[nslice]] = sb[nslice];
         j.r_off[kb[nslice]] = rb[nslice];
+        if (k == -2) {                       // rows named by their line numbers, as 32-mers
+            for (size_t i = 0; i < j.keys.size(); i++) j.keys[i] = i;
+            k = 32;
+        }
         for (size_t c = 0; c < nslice; c++)
             for (auto &sp : special[c]) special_text.emplace(kb[c] + sp.first, std::move(sp.second));
     }

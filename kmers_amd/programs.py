@@ -379,6 +379,7 @@ def collect_by_read(ctx, input_path, output_path):
     keys, s_off, s_read, s_pos, r_off, r_tax, r_cnt = [], [0], [], [], [0], [], []
     special = {}
     k = None
+    mixed = False
     with _open_text(input_path) as f:
         for line in f:
             line = line.rstrip("\n")
@@ -387,7 +388,9 @@ def collect_by_read(ctx, input_path, output_path):
             kmer, reads_s, matches_s = line.split("\t", 2)
             ents = matches_s.split(" ")
             k = len(kmer) if k is None else k
-            keys.append(_kmer_key(kmer))
+            if len(kmer) != k or k > 32:
+                mixed = True         # several lengths (Matcher's default on default databases): line numbers name the rows
+            keys.append(0 if mixed else _kmer_key(kmer))
             for rp in reads_s.split("|"):
                 r, p = rp.split(":")
                 s_read.append(int(r))
@@ -414,6 +417,8 @@ def collect_by_read(ctx, input_path, output_path):
     if k is None:
         _write_text_blocks(output_path, {})
         return {}
+    if mixed:
+        keys, k = list(range(len(keys))), 32
     kl = min(k, 6)
     search = KmerDatabase.load(ctx, k, kl, False, PAYLOAD_READPOS, np.array(keys, np.uint64), np.array(s_off, np.uint64),
                                np.array(s_read, np.int32), np.array(s_pos, np.int32))

@@ -466,6 +466,9 @@ def test_default_options_build_variable_length_databases(tmp_path):
     R.write_indexed_file(want_reads, _oracle_var_blocks(o_reads), None)
     want_trie = R.near_match_lines(_oracle_var_blocks(o_reads), R.DB([_oracle_var_blocks(o_ref)]), 0, False)
     assert len(want_trie) > 1000 and len({len(w.split("\t")[0]) for w in want_trie}) == 9
+    want_cb = R.collect_by_read(want_trie)
+    want_calls = R.read_classifier(want_cb)
+    assert sum(len(v) for v in want_calls.values()) > 300
     run = lambda *a: subprocess.run([kmg] + list(a), capture_output=True, text=True, timeout=300)
     for tag, drv in (("kmg", lambda *a: run(*a).returncode), ("py", lambda *a: cli(list(a)))):
         ref_db, reads_db = str(tmp_path / ("ref.%s.db" % tag)), str(tmp_path / ("reads.%s.db" % tag))
@@ -490,6 +493,12 @@ def test_default_options_build_variable_length_databases(tmp_path):
         assert open(out).read().splitlines() == want_trie
         assert drv("Database.Matcher", "-i", reads_db, "-d", ref_db, "-o", out + ".gz", "-k", "24", "-K", "32") == 0
         assert gzip.open(out + ".gz", "rt").read().splitlines() == want_trie
+        # ... and on through CollectByRead and ReadClassifier, file to file, with their defaults too
+        by_read, calls = str(tmp_path / ("by_read.%s" % tag)), str(tmp_path / ("calls.%s" % tag))
+        assert drv("Utils.CollectByRead", "-i", out + ".gz", "-o", by_read) == 0
+        assert R.read_indexed_file(by_read) == want_cb
+        assert drv("Utils.ReadClassifier", "-i", by_read, "-o", calls) == 0
+        assert R.read_indexed_file(calls) == want_calls
         if tag == "kmg":
             # still on the Java path: a length window other than the file's own, differences over several lengths, -h
             assert run("Database.Matcher", "-i", reads_db, "-d", ref_db, "-o", str(tmp_path / "x.txt"), "-Z", "x", "-k", "25", "-K", "32").returncode == 3
