@@ -206,7 +206,10 @@ int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint64_t cap, ui
  *   + jar StreamUtils.mergeSortedStreams / groupAndReduceStream: k-way merge of the files' ascending k-mer
  *   streams, equal k-mers reduced with addAll -- per-taxon counts add (as long in Java; here int32, saturating),
  *   read-position sets unite).  Inputs must agree in datatype, k and key_len (DB.java:36-42,57-64 ->
- *   KMG_EINVAL); they stay valid.  Also the local step after a key-range exchange between GPUs. */
+ *   KMG_EINVAL); they stay valid.  Also the local step after a key-range exchange between GPUs.
+ *   Variable-length databases (minK < maxK): a set whose files share no key -- the sets MakeDatabase -S / -G write are
+ *   cut at key bounds -- is laid end to end in key order; files that share a key return KMG_EUNSUPPORTED (merge after
+ *   kmg_db_restrict, or on the Java path). */
 int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, kmg_db **out);
 
 /* ---- stage 3: match  (replaces DB.getNearestKmers quick branch, DB.java:76-90,129-137) -------

@@ -347,10 +347,7 @@ def match_trie(search, ref, min_length=None, stored=False):
     the taxon database `rows`, -1 = no line.  min_length = the search stream's declared shortest length (default: the
     search database's); stored = the handles were loaded from files (else counts are cut to the 255 a file holds
     before they add up, as in match_lines)."""
-    if isinstance(ref, DB):
-        if len(ref.files) != 1:
-            raise KmersGpuError(_lib.KMG_EUNSUPPORTED, "a trie search over a database given as several files stays on the Java path")
-        ref = ref.files[0]
+    ref = ref.merged if isinstance(ref, DB) else ref      # (a set's files must share no key: kmg_db_merge says so)
     ctx = search.ctx
     hit = np.empty(max(search.n_unique, 1), np.int64)
     nh = C.c_uint64()

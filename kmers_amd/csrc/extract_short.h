@@ -255,3 +255,37 @@ __global__ void rs_expand_kernel(const u64 *__restrict__ keys, const uint8_t *__
                                                 : (((u64)(u32)val_a[v] << 16) | (u64)((u32)val_b[v] & 0xFFFFu));
     }
 }
+
+// ---- a set of variable-length databases whose files share no key (what -S and -G write: sets cut at key bounds) laid
+// end to end in key order.  sum_boff / sum_voff[b] = sum over the files of their own offsets at bucket b = the merged
+// database's offsets (exclusive sums add); holders[b] = files with k-mers in bucket b.
+__global__ void vm_sum_kernel(const u64 *__restrict__ bucket_off, const u64 *__restrict__ val_off, u32 nbuckets,
+                              u64 *__restrict__ sum_boff, u64 *__restrict__ sum_voff, u32 *__restrict__ holders) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nbuckets) return;
+    const u64 o = bucket_off[b];
+    sum_boff[b] += o;
+    sum_voff[b] += val_off[o];
+    if (b < nbuckets && bucket_off[b + 1] > o) holders[b]++;
+}
+__global__ void vm_clash_kernel(const u32 *__restrict__ holders, u32 nbuckets, u32 *__restrict__ clash) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nbuckets && holders[b] > 1) *clash = 1;
+}
+__global__ void vm_place_kernel(const u64 *__restrict__ keys, const uint8_t *__restrict__ lens, int len_all,
+                                const u64 *__restrict__ val_off, const int32_t *__restrict__ val_a,
+                                const int32_t *__restrict__ val_b, const u64 *__restrict__ bucket_off, u64 n, int key_len,
+                                const u64 *__restrict__ sum_boff, const u64 *__restrict__ sum_voff, u64 *__restrict__ out_keys,
+                                uint8_t *__restrict__ out_lens, u64 *__restrict__ out_val_off, int32_t *__restrict__ out_a,
+                                int32_t *__restrict__ out_b) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 b = keys[i] >> (64 - 2 * key_len);
+    const u64 first = bucket_off[b];
+    const u64 dst = sum_boff[b] + (i - first);
+    u64 vdst = sum_voff[b] + (val_off[i] - val_off[first]);
+    out_keys[dst] = keys[i];
+    out_lens[dst] = lens ? lens[i] : (uint8_t)len_all;
+    out_val_off[dst] = vdst;
+    for (u64 v = val_off[i]; v < val_off[i + 1]; v++, vdst++) { out_a[vdst] = val_a[v]; out_b[vdst] = val_b[v]; }
+}

@@ -1308,6 +1308,65 @@ static int merge_records(kmg_ctx *ctx, kmg_db *db, PoolBuf &k0, PoolBuf &v0, Poo
 }
 
 // ------------------------------------------------------------------------------------------------ merge
+// Variable-length databases: a set whose files share no key (the sets MakeDatabase -S / -G write are cut at key
+// bounds) is laid end to end in key order; files that share a key would need a merge in (value, length) order.
+static int merge_disjoint_keys(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, kmg_db **out) {
+    const kmg_db *d0 = dbs[0];
+    const u32 nbuckets = 1u << (2 * d0->key_len);
+    u64 Ut = 0, Vt = 0;
+    int rc = 1;
+    for (int i = 0; i < n_dbs; i++) { Ut += dbs[i]->U; Vt += dbs[i]->V; rc &= dbs[i]->rc; }
+    KMG_HIP(hipSetDevice(ctx->device));
+    for (int i = 0; i < n_dbs; i++) KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(dbs[i])));
+    kmg_db *db = new (std::nothrow) kmg_db();
+    if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+    std::unique_ptr<kmg_db, void (*)(kmg_db *)> db_guard(db, db_release);
+    db->ctx = ctx; db->k = d0->k; db->min_k = d0->min_k; db->key_len = d0->key_len; db->rc = rc; db->kind = d0->kind;
+    db->U = Ut; db->V = Vt;
+    void *p;
+    if (ctx->pool.alloc(&p, (Ut + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->keys = (u64 *)p;
+    if (ctx->pool.alloc(&p, Ut + 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->lens = (uint8_t *)p;
+    if (ctx->pool.alloc(&p, (Ut + 2) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->val_off = (u64 *)p;
+    if (ctx->pool.alloc(&p, (Vt + 1) * 4) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->val_a = (int32_t *)p;
+    if (ctx->pool.alloc(&p, (Vt + 1) * 4) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->val_b = (int32_t *)p;
+    if (ctx->pool.alloc(&p, ((size_t)nbuckets + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    db->bucket_off = (u64 *)p;
+    PoolBuf sum_v(ctx), holders(ctx), clash(ctx);
+    KMG_ALLOC(sum_v, ((size_t)nbuckets + 1) * 8);
+    KMG_ALLOC(holders, ((size_t)nbuckets + 1) * 4);
+    KMG_ALLOC(clash, 64);
+    KMG_HIP(hipMemsetAsync(db->bucket_off, 0, ((size_t)nbuckets + 1) * 8, ctx->stream));
+    KMG_HIP(hipMemsetAsync(sum_v.p, 0, ((size_t)nbuckets + 1) * 8, ctx->stream));
+    KMG_HIP(hipMemsetAsync(holders.p, 0, ((size_t)nbuckets + 1) * 4, ctx->stream));
+    KMG_HIP(hipMemsetAsync(clash.p, 0, 64, ctx->stream));
+    const dim3 bgrid(div_up_u64((u64)nbuckets + 1, 256)), blk(256);
+    for (int i = 0; i < n_dbs; i++)
+        hipLaunchKernelGGL(vm_sum_kernel, bgrid, blk, 0, ctx->stream, dbs[i]->bucket_off, dbs[i]->val_off, nbuckets, db->bucket_off,
+                           sum_v.as<u64>(), holders.as<u32>());
+    hipLaunchKernelGGL(vm_clash_kernel, bgrid, blk, 0, ctx->stream, holders.as<u32>(), nbuckets, clash.as<u32>());
+    u32 h_clash = 0;
+    KMG_HIP(read_back(ctx, &h_clash, clash.p, 4));
+    if (h_clash)
+        return fail(ctx, KMG_EUNSUPPORTED, "databases of k-mers of several lengths that share a key: merged on the Java path (or after kmg_db_restrict)");
+    for (int i = 0; i < n_dbs; i++) {
+        const kmg_db *d = dbs[i];
+        if (d->U == 0) continue;
+        hipLaunchKernelGGL(vm_place_kernel, dim3(div_up_u64(d->U, 256)), blk, 0, ctx->stream, d->keys, d->lens, d->k, d->val_off, d->val_a,
+                           d->val_b, d->bucket_off, d->U, d->key_len, db->bucket_off, sum_v.as<u64>(), db->keys, db->lens, db->val_off,
+                           db->val_a, db->val_b);
+    }
+    KMG_HIP(hipMemcpyAsync(db->val_off + Ut, &Vt, 8, hipMemcpyHostToDevice, ctx->stream));
+    KMG_HIP(hipGetLastError());
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    *out = db_guard.release();
+    return KMG_OK;
+}
+
 extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, kmg_db **out) {
     if (!ctx || !dbs || !out || n_dbs < 1) return KMG_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
@@ -1319,12 +1378,12 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
         const kmg_db *d = dbs[i];
         if (!d || d->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
         if (d->kind != d0->kind) return fail(ctx, KMG_EINVAL, "Files contain different datatypes");          // DB.java:36-42
-        if (d->min_k != d->k) return fail(ctx, KMG_EUNSUPPORTED, "databases of k-mers of several lengths are merged after kmg_db_restrict");
-        if (d->k != d0->k || d->key_len != d0->key_len)                                                    // DB.java:57-64
+        if (d->k != d0->k || d->min_k != d0->min_k || d->key_len != d0->key_len)                           // DB.java:57-64
             return fail(ctx, KMG_EINVAL, "Files contains different kmer parameters (min/max length, key length or reverse complement included");
         Vt += d->V;
         rc &= d->rc;
     }
+    if (d0->min_k != d0->k) return merge_disjoint_keys(ctx, dbs, n_dbs, out);
     if (Vt >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 values in the merged database");
     KMG_HIP(hipSetDevice(ctx->device));
     const bool reads = d0->kind == KMG_PAYLOAD_READPOS;

@@ -301,14 +301,14 @@ def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max
         from .api import match_trie
         if max_diff > 0:
             raise KmersGpuError(KMG_EUNSUPPORTED, "inexact search over k-mers of several lengths stays on the Java path")
-        if len(searches) != 1 or len(db.files) != 1:
-            raise KmersGpuError(KMG_EUNSUPPORTED, "a search over several lengths takes one search file and one database file on the GPU path")
-        search = searches[0]
-        if (search.min_length, search.max_length) != (min_k, max_k):
+        if (searches[0].min_length, searches[0].max_length) != (min_k, max_k):
             raise KmersGpuError(KMG_EUNSUPPORTED, "-k < -K other than the search file's own lengths stays on the Java path")
-        if not db.files[0].rc:
+        # sets (name.1 .. name.N): files that share no key -- what -S / -G write -- are laid end to end (kmg_db_merge);
+        # the reference's trie takes one key's k-mers file by file, so files sharing a key stay on the Java path
+        search = searches[0] if len(searches) == 1 else merge_databases(searches)
+        if not db.merged.rc:
             raise ValueError("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included")
-        rows, hit = match_trie(search, db.files[0], min_k, stored=True)
+        rows, hit = match_trie(search, db.merged, min_k, stored=True)
         lines = match_lines(search, rows, hit, stored=True)
         rows.close()
         text = "".join(l + "\n" for l in lines).encode()

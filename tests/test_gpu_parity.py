@@ -1401,6 +1401,45 @@ def test_restricted_match_matches_oracle(ctx, min_k, k, L, key_len, seed):
         ref.restrict(min_k - 1)
 
 
+@pytest.mark.parametrize("min_k,k,key_len,seed", [(3, 6, 2, 81), (24, 32, 4, 82), (20, 31, 3, 83)])
+def test_variable_length_sets_cut_at_key_bounds_merge(ctx, min_k, k, key_len, seed):
+    """A set of variable-length files that share no key (what MakeDatabase -S / -G write: name.1 .. name.N cut at key
+    bounds) is one database again (kmg_db_merge lays the files end to end in key order; DB.kmers, DB.java:99-109):
+    equal to the whole build and to the oracle, for both payload kinds, and the trie search over the set gives the
+    whole database's lines.  Files that share a key are refused (the trie takes a key's k-mers file by file)."""
+    import kmers_amd as km
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(seed)
+    small = k <= 8
+    fa, fq = _trie_case(rng, b"AACCGTN" if small else b"ACGT" * 8 + b"N", 12 if small else 30, 60 if small else 300,
+                        40 if small else 150, 25 if small else 60, [3, 4, 5])
+    nkeys = 4 ** key_len
+    cuts = [0, nkeys // 5, nkeys // 5, nkeys // 2 + 1, nkeys]               # (one range is empty)
+    for kind, data, make in (("ref", fa, lambda kr: km.make_reference_db(ctx, fa, k, key_len, min_k=min_k, key_range=kr)),
+                             ("read", fq, lambda kr: km.make_read_db(ctx, fq, k, key_len, min_k=min_k, key_range=kr)[0])):
+        parts = [make((a, b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        whole = km.merge_databases(parts[::-1])                               # (the order of the files does not matter)
+        want = OracleDB(data, 0 if kind == "ref" else 1, k, key_len, min_k=min_k)
+        _same_var_db(whole, want)
+        if kind == "ref":
+            ref_set, ref_whole = km.DB(parts), whole
+        else:
+            rows, hit = km.match_trie(whole, ref_set)
+            got = km.match_lines(whole, rows, hit, ref_stored=True)
+            assert got == R.near_match_lines(R.build_read_db(fq, k, key_len, min_k=min_k)[0],
+                                             R.DB([R.build_ref_db(fa, k, key_len, min_k=min_k)]), 0, False) and len(got) > 10
+            t, m, q = km.taxa_counts(ref_set)
+            ot, om, oq = OracleDB(fa, 0, k, key_len, min_k=min_k).taxacounts()
+            assert np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
+            rows.close()
+            with pytest.raises(km.KmersGpuError):                             # two files holding the same keys
+                km.merge_databases([ref_whole, ref_whole])
+            whole.close()
+            for d in parts:
+                d.close()
+
+
 def _trie_case(rng, alphabet, n_seq, seq_len, n_reads, read_len, taxa):
     fa = _rand_fasta(rng, n_seq, seq_len, alphabet, taxa)
     body = b"".join(l for l in fa.split(b"\n") if not l.startswith(b">"))

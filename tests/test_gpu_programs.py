@@ -499,6 +499,14 @@ def test_default_options_build_variable_length_databases(tmp_path):
         assert R.read_indexed_file(by_read) == want_cb
         assert drv("Utils.ReadClassifier", "-i", by_read, "-o", calls) == 0
         assert R.read_indexed_file(calls) == want_calls
+        # the database as a set cut at key bounds (-G shares: name.1 .. name.3): the same lines, the same counts
+        for share in range(3):
+            assert drv("Database.MakeDatabase", "-a", "-i", fa, "-o", ref_db + ".set", "-G", "%d/3" % share) == 0
+        assert drv("Database.Matcher", "-i", reads_db, "-d", ref_db + ".set", "-o", out + ".set", "-Z", "x") == 0
+        assert open(out + ".set").read().splitlines() == want_trie
+        assert drv("Utils.TaxaCounts", "-d", ref_db + ".set", "-o", out + ".set.tsv") == 0
+        t, m, q = o_ref.taxacounts()
+        assert open(out + ".set.tsv").read().splitlines() == ["%d\t%d\t%d" % x for x in zip(t, m, q)]
         if tag == "kmg":
             # still on the Java path: a length window other than the file's own, differences over several lengths, -h
             assert run("Database.Matcher", "-i", reads_db, "-d", ref_db, "-o", str(tmp_path / "x.txt"), "-Z", "x", "-k", "25", "-K", "32").returncode == 3
