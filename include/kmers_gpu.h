@@ -246,7 +246,8 @@ int kmg_match_dev_noalloc(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref,
 /* kmg_match_near: inexact search for k-mers of one length (replaces DB.getNearestKmers' other branch ->
  *   processNearestCommonKey, DB.java:139-184, over Root.addKmers / closestKmers, Root.java:22-170, and
  *   KmerUtils.getCloseKeys, KmerUtils.java:18-47; Matcher -n 1 | 2): for every search k-mer ALL reference k-mers
- *   within Hamming distance max_diff (0 .. 2; more -> KMG_EUNSUPPORTED), as pairs (ref_index, dist) in ascending
+ *   within Hamming distance max_diff (any; up to 2 the neighbours are enumerated, beyond that the trie walk of
+ *   Root.closestKmers, Root.java:115-170, runs over the sorted array: cost grows as in the reference), as pairs (ref_index, dist) in ascending
  *   reference order -- the order the reference's trie hands them to ClosestInfoCollector.add -- with
  *   pair_off[i] .. pair_off[i + 1] the pairs of search k-mer i.  `-j` (only the best distance), the reverse-complement
  *   rule of ClosestInfoCollector.add (:30-50) and the KmerDiff text (KmerDiff.java:54-67) are cheap per-k-mer steps

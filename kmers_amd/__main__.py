@@ -31,8 +31,6 @@ def main(argv=None):
             ap.add_argument("-" + f)
         ap.add_argument("-j", action="store_true")
         a = ap.parse_args(rest)
-        if int(a.n or 0) > 2:
-            raise SystemExit("inexact search with more than 2 differences stays on the Java path")
         programs.matcher(Context(0), a.i, a.d, a.o, plain=a.Z is not None, limit=a.L, max_diff=int(a.n or 0), just=a.j,
                          min_k=a.k, max_k=a.K)
     elif prog == "TaxaCounts":

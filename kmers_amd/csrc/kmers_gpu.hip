@@ -1677,7 +1677,8 @@ extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     KMG_HIP(hipSetDevice(ctx->device));
     *n_pairs = 0;
     if (max_diff < 0) return fail(ctx, KMG_EINVAL, "max_diff must not be negative");
-    if (max_diff > 2) return fail(ctx, KMG_EUNSUPPORTED, "more than 2 differences are not supported on the GPU path");
+    // up to two differences: the neighbours are enumerated (near_kernel); more: the trie walk over the sorted array
+    const bool walk = max_diff > 2;
     if (search->ctx->device != ctx->device || ref->ctx->device != ctx->device)
         return fail(ctx, KMG_EINVAL, "database belongs to another device");
     if (search->k != ref->k || search->key_len != ref->key_len)      // DB.java:78-81
@@ -1711,7 +1712,7 @@ extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
         // one), so that the filling call places them instead of looking every neighbour up again; if the room does not
         // suffice, or cannot be had, that call falls back to the look-ups.
         NearLog log = {nullptr, nullptr, nullptr, 0, nullptr};
-        if (ref->U < 0xFFFFFFF0ull && U < 0xFFFFFFF0ull) {
+        if (!walk && ref->U < 0xFFFFFFF0ull && U < 0xFFFFFFF0ull) {
             const u64 cap = std::max<u64>(2 * U, 1024);
             void *a = nullptr, *b = nullptr, *c = nullptr;
             if (ctx->pool.alloc(&a, cap * 4) == KMG_OK && ctx->pool.alloc(&b, cap * 4) == KMG_OK && ctx->pool.alloc(&c, cap) == KMG_OK) {
@@ -1719,8 +1720,13 @@ extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
                 log = {sdb->near_log_s, sdb->near_log_ref, sdb->near_log_dist, cap, reinterpret_cast<unsigned long long *>(tot.as<u64>() + 1)};
             } else { ctx->pool.release(a); ctx->pool.release(b); ctx->pool.release(c); }
         }
-        hipLaunchKernelGGL((near_kernel<false>), grid, blk, 0, ctx->stream, search->keys, U, search->k, max_diff, ref->keys,
-                           ref->bucket_off, ref->key_len, cnt.as<u32>(), (const u64 *)nullptr, (long long *)nullptr, (uint8_t *)nullptr, log);
+        if (walk)
+            hipLaunchKernelGGL((near_walk_kernel<false>), dim3(div_up_u64(U, 128)), dim3(128), 0, ctx->stream, search->keys, U, search->k,
+                               std::min(max_diff, search->k), ref->keys, ref->U, ref->bucket_off, ref->key_len, cnt.as<u32>(),
+                               (const u64 *)nullptr, (long long *)nullptr, (uint8_t *)nullptr);
+        else
+            hipLaunchKernelGGL((near_kernel<false>), grid, blk, 0, ctx->stream, search->keys, U, search->k, max_diff, ref->keys,
+                               ref->bucket_off, ref->key_len, cnt.as<u32>(), (const u64 *)nullptr, (long long *)nullptr, (uint8_t *)nullptr, log);
         KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt.as<u32>(), sdb->near_off, U, OpSum(), 0ull, agg.as<u64>(),
                                                     tot.as<u64>(), true, KP_SCAN)));
         u64 t2[2] = {0, 0};
@@ -1737,7 +1743,11 @@ extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
         KMG_ALLOC(d_ref, n * 8);
         KMG_ALLOC(d_dist, n);
         KMG_HIP(hipMemsetAsync(cnt.p, 0, U * 4, ctx->stream));
-        if (sdb->near_log_s) {
+        if (walk) {
+            hipLaunchKernelGGL((near_walk_kernel<true>), dim3(div_up_u64(U, 128)), dim3(128), 0, ctx->stream, search->keys, U, search->k,
+                               std::min(max_diff, search->k), ref->keys, ref->U, ref->bucket_off, ref->key_len, cnt.as<u32>(), off_p,
+                               d_ref.as<long long>(), d_dist.as<uint8_t>());
+        } else if (sdb->near_log_s) {
             const NearLog log = {sdb->near_log_s, sdb->near_log_ref, sdb->near_log_dist, n, nullptr};
             hipLaunchKernelGGL(near_place_kernel, dim3(div_up_u64(n, 256)), blk, 0, ctx->stream, log, n, cnt.as<u32>(), off_p,
                                d_ref.as<long long>(), d_dist.as<uint8_t>());
@@ -1747,8 +1757,9 @@ extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
                                ref->bucket_off, ref->key_len, cnt.as<u32>(), off_p, d_ref.as<long long>(), d_dist.as<uint8_t>(), none);
         }
         near_log_release(ctx, sdb);                   // (stream-ordered: whoever gets the memory next runs after the kernel)
-        hipLaunchKernelGGL(near_sort_kernel, dim3(div_up_u64(U, 256)), blk, 0, ctx->stream, off_p, U, d_ref.as<long long>(),
-                           d_dist.as<uint8_t>());
+        if (!walk)                                    // (the walk hands its matches out in ascending order already)
+            hipLaunchKernelGGL(near_sort_kernel, dim3(div_up_u64(U, 256)), blk, 0, ctx->stream, off_p, U, d_ref.as<long long>(),
+                               d_dist.as<uint8_t>());
         KMG_HIP(hipGetLastError());
         KMG_HIP(hipMemcpyAsync(ref_index, d_ref.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         KMG_HIP(hipMemcpyAsync(dist, d_dist.p, n, hipMemcpyDeviceToHost, ctx->stream));

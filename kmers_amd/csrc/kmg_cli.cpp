@@ -12,7 +12,7 @@
 // Appendix A.1-A.3): header | gzip-member blocks | index block | footer; every key's block is its own gzip
 // member, so blocks are deflated / inflated on a thread pool and written in key order
 // (FileCreator.java:385-391 enforces that order with OrderedLatches).  Options outside the GPU path
-// (k > 32, -n > 2, a search over several k-mer lengths, -h with minK < maxK, -m, -N, -x ...) exit with status 3 so that a
+// (k > 32, -n > 0 over several k-mer lengths, -h with minK < maxK, -m, -N, -x ...) exit with status 3 so that a
 // wrapper can fall back to the Java program.  Plain C++17 + zlib; no HIP in this file.
 #include <stdint.h>
 #include <stdio.h>
@@ -986,7 +986,7 @@ int matcher(int argc, char **argv) {
     const Args a = parse_args(argc, argv, 2, "idozZntLPkK", "vj");
     const int max_diff = a.geti('n', 0);
     const bool just = a.has('j');
-    if (max_diff < 0 || max_diff > 2) throw Unsupported("inexact search with more than 2 differences stays on the Java path");
+    if (max_diff < 0) throw std::runtime_error("-n must not be negative");
     StageClock clk(a.has('v'));
     if (!a.has('i') || !a.has('d') || !a.has('o')) throw std::runtime_error("-i, -d and -o are required");
     g_threads = std::max(1, a.geti('t', g_threads));

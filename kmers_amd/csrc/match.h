@@ -557,6 +557,95 @@ __global__ __launch_bounds__(256) void near_kernel(const u64 *__restrict__ skeys
     }
 }
 
+// ---- any number of differences (Matcher -n > 2): the trie walk of Root.closestKmers (Root.java:115-170) over the sorted
+// array.  The stored k-mers that share a prefix are one contiguous range; a node of the walk = (range, depth, differences
+// so far); its four children split the range by the next base (three binary searches; above the key length the key
+// table gives the bounds), a child whose base differs from the search k-mer's costs one difference, empty ranges and
+// children beyond the budget are dropped.  Two short cuts end most paths early: a range of ONE k-mer is compared as a
+// whole (differing bases = popcount of the XOR folded to one bit per base), and with the budget spent the rest must
+// match exactly -- one binary search.  Children are taken in base order, so the matches come out in ascending k-mer
+// order, which is the order the trie hands them to ClosestInfoCollector.  One thread per search k-mer (the work per
+// k-mer is what the reference's walk does; it grows quickly with the number of differences, as there).
+#define NW_MAXK 32
+template <bool FILL>
+__global__ __launch_bounds__(128) void near_walk_kernel(const u64 *__restrict__ skeys, u64 ns, int k, int max_diff,
+                                                        const u64 *__restrict__ rkeys, u64 nr, const u64 *__restrict__ rbucket,
+                                                        int key_len, u32 *__restrict__ cnt, const u64 *__restrict__ off,
+                                                        long long *__restrict__ out_ref, uint8_t *__restrict__ out_dist) {
+    const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns || nr == 0) return;
+    const u64 key = skeys[s];
+    u64 found = 0;
+    const u64 base_out = FILL ? off[s] : 0;
+    auto emit = [&](u64 r, int d) {
+        if (FILL) { out_ref[base_out + found] = (long long)r; out_dist[base_out + found] = (uint8_t)d; }
+        found++;
+    };
+    auto bases_differing = [&](u64 a, u64 b) {
+        const u64 x = a ^ b;
+        return __popcll((x | (x >> 1)) & 0x5555555555555555ull);
+    };
+    // explicit stack: one frame per depth
+    u64 f_lo[NW_MAXK + 1], f_hi[NW_MAXK + 1];      // range of the node at this depth
+    u64 f_cur[NW_MAXK + 1];                        // start of the next child's range
+    uint8_t f_next[NW_MAXK + 1], f_diff[NW_MAXK + 1];
+    int d = 0;
+    f_lo[0] = 0; f_hi[0] = nr; f_cur[0] = 0; f_next[0] = 0; f_diff[0] = 0;
+    while (d >= 0) {
+        const u64 lo = f_lo[d], hi = f_hi[d];
+        const int used = f_diff[d];
+        if (f_next[d] == 0) {
+            // first visit of the node: the short cuts
+            if (hi - lo == 1) {
+                const int dist = bases_differing(rkeys[lo], key);
+                if (dist <= max_diff) emit(lo, dist);
+                d--;
+                continue;
+            }
+            if (used == max_diff) {
+                // (the node's k-mers share the first d bases of one variant of the search k-mer with `used` changes; the
+                // rest must be the search k-mer's own: that variant = the node's prefix + the search k-mer's tail)
+                const u64 pm = d == 0 ? 0ull : ~(~0ull >> (2 * d));
+                const u64 want = (rkeys[lo] & pm) | (key & ~pm);
+                const u64 at = near_lower(rkeys, lo, hi, want);
+                if (at < hi && rkeys[at] == want) emit(at, used);
+                d--;
+                continue;
+            }
+            f_cur[d] = lo;
+        }
+        if (f_next[d] == 4) { d--; continue; }
+        const int c = f_next[d]++;
+        // the child's range: the node's k-mers whose base at position d is c -- they follow the earlier children's
+        const u64 c_lo = f_cur[d];
+        u64 c_hi;
+        if (c == 3) c_hi = hi;
+        else if (d < key_len) {
+            // prefix of d + 1 bases -> first bucket of the next prefix
+            const u64 pre = (rkeys[lo] >> (64 - 2 * (d + 1)) & ~3ull) | (u64)c;          // (d + 1 bases, right-aligned)
+            c_hi = rbucket[(pre + 1) << (2 * (key_len - d - 1))];
+            c_hi = c_hi < c_lo ? c_lo : (c_hi > hi ? hi : c_hi);
+        } else {
+            const u64 pm = d + 1 >= 32 ? ~0ull : ~(~0ull >> (2 * (d + 1)));
+            const u64 pre = (rkeys[lo] & (d == 0 ? 0ull : ~(~0ull >> (2 * d)))) | ((u64)c << (62 - 2 * d));
+            const u64 last = pre | ~pm;                                                  // the largest k-mer with that prefix
+            c_hi = near_lower(rkeys, c_lo, hi, last);
+            if (c_hi < hi && rkeys[c_hi] == last) c_hi++;
+        }
+        f_cur[d] = c_hi;
+        if (c_hi == c_lo) continue;
+        const int cost = (int)((key >> (62 - 2 * d)) & 3) != c;
+        if (used + cost > max_diff) continue;
+        if (d + 1 == k) {                          // a whole k-mer: k-mers are distinct, the range holds one
+            emit(c_lo, used + cost);
+            continue;
+        }
+        d++;
+        f_lo[d] = c_lo; f_hi[d] = c_hi; f_next[d] = 0; f_diff[d] = (uint8_t)(used + cost);
+    }
+    if (!FILL) cnt[s] = (u32)(found > 0xFFFFFFFFull ? 0xFFFFFFFFull : found);
+}
+
 // every search k-mer's matches into ascending reference order (= ascending k-mer: the order the trie hands them out)
 __global__ void near_sort_kernel(const u64 *__restrict__ off, u64 ns, long long *__restrict__ ref, uint8_t *__restrict__ dist) {
     const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -335,7 +335,7 @@ def test_key_range_builds_are_slices_of_the_whole(ctx, k, l, cuts):
 
 @pytest.mark.parametrize("k,l,seed", [(9, 2, 5), (8, 2, 6), (31, 6, 8)])
 def test_inexact_search_matches_trie_restatement(ctx, k, l, seed):
-    """Matcher -n 1 | 2 [-j] for k-mers of one length: kmg_match_near + the per-k-mer steps of api.near_match_lines
+    """Matcher -n 1 | 2 | 3 | 5 [-j] for k-mers of one length: kmg_match_near + the per-k-mer steps of api.near_match_lines
     against the reference's radix trie restated in oracle/slow_ref.py (Root, ClosestInfoCollector,
     processNearestCommonKey) -- itself checked against an all-pairs search in tests/test_oracle_kat.py.  Three taxa a
     few bases apart, reads with errors, one database file and a set of two (merged on the GPU / inserted file by
@@ -353,7 +353,7 @@ def test_inexact_search_matches_trie_restatement(ctx, k, l, seed):
     refs = [km.make_reference_db(ctx, fa1, k, l), km.make_reference_db(ctx, fa2, k, l)]
     for nfiles in (1, 2):
         db = km.DB(refs[:nfiles])
-        for max_diff in (1, 2):
+        for max_diff in (1, 2, 3) + ((5,) if k < 31 else ()):       # (beyond two: the walk over the sorted array)
             for just in (False, True):
                 want = R.near_match_lines(o_reads, R.DB(o_files[:nfiles]), max_diff, just)
                 assert km.near_match_lines(reads, db, max_diff, just) == want, (nfiles, max_diff, just)
@@ -364,8 +364,6 @@ def test_inexact_search_matches_trie_restatement(ctx, k, l, seed):
         assert np.array_equal(np.diff(off.astype(np.int64)), (hit >= 0).astype(np.int64))
         if nfiles == 2:
             db.merged.close()
-    with pytest.raises(km.KmersGpuError):
-        km.match_near(reads, refs[0], 3)
     for d in refs + [reads]:
         d.close()
 
@@ -393,7 +391,7 @@ def test_inexact_search_pairs_against_all_pairs_distances(ctx, seed):
     ham = np.zeros(nz.shape, np.int32)
     for sh in range(0, 64, 2):
         ham += ((nz >> np.uint64(sh)) & np.uint64(1)).astype(np.int32)
-    for max_diff in (0, 1, 2):
+    for max_diff in (0, 1, 2, 3, 4, 7, k):
         off, idx, dist = km.match_near(rdb, ref, max_diff)
         rows, cols = np.nonzero(ham <= max_diff)                      # row-major: ascending reference index per row
         assert np.array_equal(np.diff(off.astype(np.int64)), np.bincount(rows, minlength=len(sk)))

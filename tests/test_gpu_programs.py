@@ -259,7 +259,6 @@ def test_native_cli_matches_python_drivers(tmp_path):
     assert open(p("f.db"), "rb").read() == open(p("f.want"), "rb").read()
     # what is not on the GPU path exits with status 3 (wrapper falls back to Java)
     run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("x.db"), "-K", "32", "-k", "24", "-h", rc=3)
-    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-n", "3", rc=3)
     run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-k", str(k - 2), "-K", str(k), rc=1)      # DB.java:78-81: shorter than the database's k-mers
     # DB.java:78-81: search k-mers shorter than the database's -> InconsistentDataException
     run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("x"), "-k", str(k - 2), "-K", str(k - 2), rc=1)
@@ -291,7 +290,7 @@ def test_native_cli_matches_python_drivers(tmp_path):
     run("Database.MakeDatabase", "-q", "-i", p("few.fq"), "-o", p("few.db"), "-r", p("few.map.gz"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z")
     o_few, _ = R.build_read_db(open(p("few.fq"), "rb").read(), k, l)
     o_set = R.DB([R.read_indexed_file(p("set.db.1")), R.read_indexed_file(p("set.db.2"))])
-    for n_, just in ((1, False), (2, True)):
+    for n_, just in ((1, False), (2, True), (3, False)):            # (-n 3: the walk over the sorted array)
         run("Database.Matcher", "-i", p("few.db"), "-d", p("set.db"), "-o", p("few.near.gz"), "-n", str(n_), *(["-j"] if just else []))
         near = R.near_match_lines(o_few, o_set, n_, just)
         assert gzip.open(p("few.near.gz"), "rt").read().splitlines() == near
