@@ -504,7 +504,55 @@ def _revcomp_key(key, k):
 
 
 def near_match_lines(search, ref, max_diff, just=False, stored=False):
-    """Matcher -n max_diff [-j] for k-mers of one length: one line per search k-mer that has a match within max_diff
+    """Matcher -n max_diff [-j]: the lines of _near_match_rows (k-mers of one length), or, for k-mers of several lengths,
+    of near_match_lines_var."""
+    one = ref.merged if isinstance(ref, DB) else ref
+    if search.min_length != search.k or one.min_length != one.k:
+        return near_match_lines_var(search, ref, max_diff, just, stored=stored)
+    return _near_match_rows(search, ref, max_diff, just, stored)[1]
+
+
+def near_match_lines_var(search, ref, max_diff, just=False, min_length=None, stored=False):
+    """Matcher -n max_diff [-j] over k-mers of several lengths (DB.processNearestCommonKey, DB.java:139-184, over the trie,
+    Root.java:29-170).  A search k-mer of T bases walks the trie to depth T, so what it can meet are the DISTINCT T-base
+    prefixes p of the stored k-mers of at least T bases, each within max_diff differences of it, and what it is handed
+    for p is the data object of the node covering depth T on p's path -- the closed form of kmg_match_trie,
+    asked for p itself.  Per length T: the prefixes = the database restricted to T (kmg_db_restrict), their answers =
+    kmg_match_trie with the prefixes as the search side, the neighbours = kmg_match_near of the search k-mers of that
+    length against the prefixes; the per-k-mer rules (-j, reverse complements, order, diff text) are _near_match_rows'.
+    Lines come out in the search stream's order."""
+    one = ref.merged if isinstance(ref, DB) else ref
+    ctx = search.ctx
+    shortest = int(search.min_length if min_length is None else min_length)
+    if shortest < one.min_length or search.k > one.k:                                # DB.java:78-81
+        raise InconsistentDataException(_lib.KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database")
+    s = search.fetch()
+    lens = search.lens() if search.min_length != search.k else np.full(search.n_unique, search.k, np.uint8)
+    out = []
+    for T in sorted(set(lens.tolist())):
+        sel = np.nonzero(lens == T)[0]
+        cnt = (s["val_off"][sel + 1] - s["val_off"][sel]).astype(np.int64)
+        voff = np.zeros(len(sel) + 1, np.uint64)
+        voff[1:] = np.cumsum(cnt)
+        take = np.concatenate([np.arange(int(a), int(b)) for a, b in zip(s["val_off"][sel], s["val_off"][sel + 1])]) if len(sel) else np.zeros(0, np.int64)
+        sub = KmerDatabase.load(ctx, T, search.key_length, search.rc, search.kind, s["keys"][sel], voff,
+                                np.ascontiguousarray(s["val_a"][take]), np.ascontiguousarray(s["val_b"][take]))
+        prefixes = one.restrict(T) if (one.min_length != one.k or one.k != T) else one
+        rows, row_of = match_trie(prefixes, one, shortest, stored=stored)
+        idx, lines = _near_match_rows(sub, prefixes, max_diff, just, stored, data_rows=rows, row_of=row_of)
+        out.extend(zip(sel[idx].tolist(), lines))
+        rows.close()
+        sub.close()
+        if prefixes is not one:
+            prefixes.close()
+    out.sort(key=lambda e: e[0])
+    return [l for _, l in out]
+
+
+def _near_match_rows(search, ref, max_diff, just=False, stored=False, data_rows=None, row_of=None):
+    """-> (indices of the search k-mers with a line, the lines).  data_rows / row_of: the values printed for reference
+    k-mer h are row row_of[h] of the database data_rows (sums: printed as they are) instead of h's own.
+    Matcher -n max_diff [-j] for k-mers of one length: one line per search k-mer that has a match within max_diff
     differences, `KMER \\t values \\t DIFF|TxC|TxC DIFF|TxC ...` (ResultsDataType.java:15-35).  The GPU hands over
     every reference k-mer within reach in ascending order (kmg_match_near); here, per search k-mer and on a handful
     of matches: -j keeps the best distance only (Root.java:144-148, DB.java:164-171), of a k-mer and its reverse
@@ -515,6 +563,7 @@ def near_match_lines(search, ref, max_diff, just=False, stored=False):
     cap = (1 << 31) if stored else 255            # see match_lines
     off, idx, dist = match_near(search, ref, max_diff)
     s, r = search.fetch(), ref.fetch()
+    vals, rcap = (r, cap) if data_rows is None else (data_rows.fetch(), 1 << 31)
     k = search.k
     rows = np.nonzero(off[1:] > off[:-1])[0]
     names = kmer_strings(s["keys"][rows], k)
@@ -550,9 +599,10 @@ def near_match_lines(search, ref, max_diff, just=False, stored=False):
             left = "|".join("%dx%d" % (x, min(y, cap)) for x, y in zip(s["val_a"][a0:a1].tolist(), s["val_b"][a0:a1].tolist()))
         parts = []
         for (_, diffs), h in entries:
-            c0, c1 = int(r["val_off"][h]), int(r["val_off"][h + 1])
+            h = h if row_of is None else int(row_of[h])
+            c0, c1 = int(vals["val_off"][h]), int(vals["val_off"][h + 1])
             text = "".join("%d%s" % (p, letters[b]) for p, b in diffs) if diffs else "-"
-            parts.append("%s|%s" % (text, "|".join("%dx%d" % (x, min(y, cap)) for x, y in
-                                                      zip(r["val_a"][c0:c1].tolist(), r["val_b"][c0:c1].tolist()))))
+            parts.append("%s|%s" % (text, "|".join("%dx%d" % (x, min(y, rcap)) for x, y in
+                                                      zip(vals["val_a"][c0:c1].tolist(), vals["val_b"][c0:c1].tolist()))))
         lines.append("%s\t%s\t%s" % (name, left, " ".join(parts)))
-    return lines
+    return rows, lines

@@ -12,7 +12,7 @@
 // Appendix A.1-A.3): header | gzip-member blocks | index block | footer; every key's block is its own gzip
 // member, so blocks are deflated / inflated on a thread pool and written in key order
 // (FileCreator.java:385-391 enforces that order with OrderedLatches).  Options outside the GPU path
-// (k > 32, -n > 0 over several k-mer lengths, -h with minK < maxK, -m, -N, -x ...) exit with status 3 so that a
+// (k > 32, -k a -K b windows other than the file's own, -h with minK < maxK, -m, -N, -x ...) exit with status 3 so that a
 // wrapper can fall back to the Java program.  Plain C++17 + zlib; no HIP in this file.
 #include <stdint.h>
 #include <stdio.h>
@@ -937,8 +937,11 @@ uint64_t revcomp_key(uint64_t key, int k) {
 // (ClosestInfoCollector.add, ClosestInfoCollector.java:30-50); entries are ordered by number of differences, then by
 // (position, base) in turn (KmerDiffComparaotr, :119-147); a difference prints as position + new base, none as "-"
 // (KmerDiff.java:54-67).
+// vals / row_of: the values printed for reference k-mer h are row row_of[h] of `vals` instead of h's own (the search over
+// several lengths: what the trie holds for a prefix, kmg_match_trie)
 void append_near(std::string &s, const HostDb &hs, const HostDb &hr, uint64_t i, int k, const std::vector<uint64_t> &off,
-                 const std::vector<int64_t> &ref, const std::vector<uint8_t> &dist, bool just) {
+                 const std::vector<int64_t> &ref, const std::vector<uint8_t> &dist, bool just, const HostDb *vals = nullptr,
+                 const std::vector<int64_t> *row_of = nullptr) {
     struct Kept { uint64_t key; int64_t h; int d; bool alive; };
     std::vector<Kept> kept;
     int best = 255;
@@ -978,7 +981,8 @@ void append_near(std::string &s, const HostDb &hs, const HostDb &hr, uint64_t i,
         if (en.diffs.empty()) s.push_back('-');
         for (auto &d : en.diffs) { append_int(s, d.first); s.push_back("ACTG"[d.second]); }
         s.push_back('|');
-        append_values(s, hr, (uint64_t)en.h);
+        if (vals) append_values(s, *vals, (uint64_t)(*row_of)[en.h]);
+        else append_values(s, hr, (uint64_t)en.h);
     }
 }
 
@@ -1030,7 +1034,6 @@ int matcher(int argc, char **argv) {
                 throw std::runtime_error("InconsistentDataException: Search kmers contain kmers of a length inconsistent with the database");
             if (want_min != want_max) {
                 // a search over several lengths: the trie (DB.java:83,139-184) in closed form -- kmg_match_trie
-                if (max_diff > 0) throw Unsupported("inexact search over k-mers of several lengths stays on the Java path");
                 if (want_min != s_min || want_max != s0.k)
                     throw Unsupported("-k < -K other than the search file's own lengths stays on the Java path");
                 trie = true;
@@ -1041,10 +1044,11 @@ int matcher(int argc, char **argv) {
                 search = cut;
             }
             if (!trie && (r_min != r0.k || r0.k != want_min)) {
-                if (max_diff > 0) throw Unsupported("inexact search over a database of several k-mer lengths stays on the Java path");
+                // (with differences too: the trie's data at depth L, shortest = L, is the sum over the k-mers sharing the
+                // L-base prefix -- DESIGN 6b with m = L -- which is what the restricted database holds)
                 kmg_db *cut = nullptr;
                 g.check(kmg_db_restrict(g.ctx, ref, want_min, &cut));
-                kmg_db_free(ref);
+                if (ref != ref_whole) kmg_db_free(ref);
                 ref = cut;
             }
         }
@@ -1059,7 +1063,54 @@ int matcher(int argc, char **argv) {
         std::vector<uint64_t> pair_off;
         std::vector<int64_t> pair_ref;
         std::vector<uint8_t> pair_dist;
-        if (max_diff > 0) {
+        std::vector<std::string> third;              // the lines' third field, where it is put together ahead of the formatting
+        if (max_diff > 0 && trie) {
+            // -n [-j] over several lengths (DB.java:139-184 over the trie): a search k-mer of T bases can meet the DISTINCT
+            // T-base prefixes of the stored k-mers of at least T bases, and is handed for each what the trie holds at depth
+            // T on that prefix's path.  Per length T: prefixes = the database restricted to T, their answers =
+            // kmg_match_trie with the prefixes as the search side, neighbours = kmg_match_near against the prefixes.
+            slens.resize(sd.U + 1);
+            g.check(kmg_db_fetch_lens(search, slens.data()));
+            HostDb hk;                               // (the search k-mers: only their keys are needed here)
+            hk.d = sd;
+            hk.keys.resize(sd.U + 1); hk.val_off.resize(sd.U + 1); hk.a.resize(sd.V + 1); hk.b.resize(sd.V + 1);
+            g.check(kmg_db_fetch(search, hk.keys.data(), hk.val_off.data(), hk.a.data(), hk.b.data(), nullptr));
+            third.assign(sd.U, std::string());
+            const int shortest = kmg_db_min_k(search);
+            for (int T = shortest; T <= sd.k; T++) {
+                std::vector<uint64_t> sel;
+                for (uint64_t i = 0; i < sd.U; i++) if (slens[i] == T) sel.push_back(i);
+                if (sel.empty()) continue;
+                HostDb sub;
+                sub.keys.resize(sel.size());
+                std::vector<uint64_t> voff(sel.size() + 1);
+                std::vector<int32_t> zero(sel.size() + 1, 0);
+                for (size_t j = 0; j < sel.size(); j++) { sub.keys[j] = hk.keys[sel[j]]; voff[j] = j; }
+                voff[sel.size()] = sel.size();
+                kmg_db *subdb = nullptr, *pre = ref, *rowsdb = nullptr;
+                g.check(kmg_db_load(g.ctx, T, sd.key_len, 0, KMG_PAYLOAD_READPOS, sub.keys.data(), sel.size(), voff.data(), zero.data(),
+                                    zero.data(), &subdb));
+                if (kmg_db_min_k(ref) != rd.k || rd.k != T) g.check(kmg_db_restrict(g.ctx, ref, T, &pre));
+                const DbInfo pd = db_info(pre);
+                std::vector<int64_t> row_of(pd.U + 1);
+                uint64_t nrow = 0, np = 0;
+                g.check(kmg_match_trie(g.ctx, pre, ref, shortest, 0, &rowsdb, row_of.data(), &nrow));
+                const HostDb hpre = fetch(g, pre), hrows = fetch(g, rowsdb);
+                std::vector<uint64_t> p_off(sel.size() + 1);
+                g.check(kmg_match_near(g.ctx, subdb, pre, max_diff, p_off.data(), nullptr, nullptr, 0, &np));
+                std::vector<int64_t> p_ref(np + 1);
+                std::vector<uint8_t> p_dist(np + 1);
+                if (np) g.check(kmg_match_near(g.ctx, subdb, pre, max_diff, nullptr, p_ref.data(), p_dist.data(), np, &np));
+                parallel_for((sel.size() + 4095) / 4096, [&](size_t c) {
+                    for (size_t j = c * 4096; j < std::min(sel.size(), (c + 1) * 4096); j++)
+                        if (p_off[j + 1] > p_off[j]) append_near(third[sel[j]], sub, hpre, j, T, p_off, p_ref, p_dist, just, &hrows, &row_of);
+                });
+                kmg_db_free(subdb);
+                kmg_db_free(rowsdb);
+                if (pre != ref) kmg_db_free(pre);
+            }
+            for (uint64_t i = 0; i < sd.U; i++) { hit[i] = third[i].empty() ? -1 : 0; nh += hit[i] >= 0; }
+        } else if (max_diff > 0) {
             uint64_t np = 0;
             pair_off.resize(sd.U + 1);
             g.check(kmg_match_near(g.ctx, search, ref, max_diff, pair_off.data(), nullptr, nullptr, 0, &np));
@@ -1100,6 +1151,9 @@ int matcher(int argc, char **argv) {
                 if (max_diff == 0) {
                     s += "\t-|";
                     append_values(s, hr, (uint64_t)hit[i]);
+                } else if (trie) {
+                    s.push_back('\t');
+                    s += third[i];
                 } else {
                     s.push_back('\t');
                     append_near(s, hs, hr, i, sd.k, pair_off, pair_ref, pair_dist, just);

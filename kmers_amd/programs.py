@@ -298,9 +298,7 @@ def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max
         raise InconsistentDataException(KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database")
     if min_k != max_k:
         # a search over several lengths: the trie (DB.java:83,139-184) in closed form, kmg_match_trie
-        from .api import match_trie
-        if max_diff > 0:
-            raise KmersGpuError(KMG_EUNSUPPORTED, "inexact search over k-mers of several lengths stays on the Java path")
+        from .api import match_trie, near_match_lines_var
         if (searches[0].min_length, searches[0].max_length) != (min_k, max_k):
             raise KmersGpuError(KMG_EUNSUPPORTED, "-k < -K other than the search file's own lengths stays on the Java path")
         # sets (name.1 .. name.N): files that share no key -- what -S / -G write -- are laid end to end (kmg_db_merge);
@@ -308,9 +306,12 @@ def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max
         search = searches[0] if len(searches) == 1 else merge_databases(searches)
         if not db.merged.rc:
             raise ValueError("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included")
-        rows, hit = match_trie(search, db.merged, min_k, stored=True)
-        lines = match_lines(search, rows, hit, stored=True)
-        rows.close()
+        if max_diff > 0:         # -n [-j]: per length, the stored k-mers' prefixes within reach (near_match_lines_var)
+            lines = near_match_lines_var(search, db.merged, max_diff, just, min_k, stored=True)
+        else:
+            rows, hit = match_trie(search, db.merged, min_k, stored=True)
+            lines = match_lines(search, rows, hit, stored=True)
+            rows.close()
         text = "".join(l + "\n" for l in lines).encode()
         with (open(output_path, "wb") if plain else gzip.open(output_path, "wb")) as f:
             f.write(text)

@@ -754,12 +754,18 @@ def kmer_diff_text(diffs):                       # KmerDiff.toString (KmerDiff.j
     return "".join("%d%s" % (p, _CODE2CHAR[b]) for p, b in diffs) if diffs else "-"
 
 
-def near_match_lines(search_blocks, db, max_diff, just):
-    """Matcher.doMatching with -n max_diff [-j] for k-mers of one length: DB.getNearestKmers' non-quick branch
+def near_match_lines(search_blocks, db, max_diff, just, min_k=None, max_k=None):
+    """Matcher.doMatching with -n max_diff [-j]; min_k / max_k = Matcher -k / -K (default: the search file's own lengths,
+    Matcher.java:147-148): the search stream is KmerFile.allRestrictedKmers(minK, maxK) (Matcher.java:241) and the trie
+    is built with those lengths (DB.java:86,154) over ALL the database's k-mers.  DB.getNearestKmers' non-quick branch
     (DB.java:83-90) -> processNearestCommonKey per group of search k-mers with a common key (DB.java:139-184): for
     every close key a Root over that key's k-mers of every file, closestKmers per search k-mer, the collectors
     combined as there; lines as match_lines, the diff text in place of "-"."""
-    min_k, max_k, key_len, ids, rc = parse_meta(search_blocks[-1])
+    f_min, f_max, key_len, ids, rc = parse_meta(search_blocks[-1])
+    min_k = f_min if min_k is None else min_k
+    max_k = f_max if max_k is None else max_k
+    if min_k < db.min_k or max_k > db.max_k:      # DB.java:78-81
+        raise InconsistentDataException("Search kmers contain kmers of a length inconsistent with the database")
     kind = "read" if ids == READ_ID else "ref"
     lines = []
     roots = {}
@@ -774,7 +780,7 @@ def near_match_lines(search_blocks, db, max_diff, just):
         return roots[key]
 
     for key in range(4 ** key_len):
-        group = decode_block(search_blocks.get(key, b""), kind)
+        group = restricted_stream(decode_block(search_blocks.get(key, b""), kind), f_min, f_max, min_k, max_k, kind)
         if not group:
             continue
         close = get_close_keys(group[0][0].chars[:key_len], max_diff)

@@ -1480,6 +1480,12 @@ def test_trie_search_matches_literal_trie(ctx, min_k, k, key_len, alphabet, seed
         assert int((hit >= 0).sum()) == len(want) == rows.n_unique
         total += len(want)
         rows.close()
+        # ... and with differences allowed (-n 1 | 2 [-j]): every T-base prefix of a stored k-mer within reach, each with
+        # what the trie holds at depth T on its path
+        for max_diff, just in ((1, False), (2, True)) + (((3, False),) if small else ()):
+            near = R.near_match_lines(o_reads, R.DB([o_ref]), max_diff, just)
+            assert km.near_match_lines_var(rdb, ref, max_diff, just, min_length=s_min) == near, (s_min, s_max, max_diff, just)
+            assert len(near) >= len(want)
         rdb.close()
     assert total > 0
     if min_k > key_len:

@@ -465,6 +465,16 @@ def test_default_options_build_variable_length_databases(tmp_path):
     R.write_indexed_file(want_reads, _oracle_var_blocks(o_reads), None)
     want_trie = R.near_match_lines(_oracle_var_blocks(o_reads), R.DB([_oracle_var_blocks(o_ref)]), 0, False)
     assert len(want_trie) > 1000 and len({len(w.split("\t")[0]) for w in want_trie}) == 9
+    few_fq = str(tmp_path / "few.fq")
+    few_b = b"@" + b"@".join(fq_b.split(b"@")[1:41])
+    open(few_fq, "wb").write(few_b)
+    o_few = _oracle_var_blocks(OracleDB(few_b, 1, 32, 6, min_k=24))
+    o_db = R.DB([_oracle_var_blocks(o_ref)])
+    want_near1, want_near2j = R.near_match_lines(o_few, o_db, 1, False), R.near_match_lines(o_few, o_db, 2, True)
+    assert len(want_near1) > 100 and any(" " in w.split("\t")[2] for w in want_near1)
+    # -n 1 -k 27 -K 27: the search file restricted to 27 bases (Matcher.java:241), the trie over the WHOLE database
+    want_near27 = R.near_match_lines(o_few, o_db, 1, False, 27, 27)
+    assert len(want_near27) > 50
     want_cb = R.collect_by_read(want_trie)
     want_calls = R.read_classifier(want_cb)
     assert sum(len(v) for v in want_calls.values()) > 300
@@ -506,10 +516,17 @@ def test_default_options_build_variable_length_databases(tmp_path):
         assert drv("Utils.TaxaCounts", "-d", ref_db + ".set", "-o", out + ".set.tsv") == 0
         t, m, q = o_ref.taxacounts()
         assert open(out + ".set.tsv").read().splitlines() == ["%d\t%d\t%d" % x for x in zip(t, m, q)]
+        # differences over all nine lengths (-n 1, -n 2 -j) on a few reads, and at one length (-n 1 -k 27 -K 27)
+        few_db = str(tmp_path / ("few.%s.db" % tag))
+        assert drv("Database.MakeDatabase", "-q", "-i", few_fq, "-o", few_db, "-r", str(tmp_path / ("few.%s.map" % tag)), "-Z") == 0
+        for n_, flags, want_near in ((1, [], want_near1), (2, ["-j"], want_near2j)):
+            assert drv("Database.Matcher", "-i", few_db, "-d", ref_db, "-o", out + ".near", "-Z", "x", "-n", str(n_), *flags) == 0
+            assert open(out + ".near").read().splitlines() == want_near
+        assert drv("Database.Matcher", "-i", few_db, "-d", ref_db, "-o", out + ".near27", "-Z", "x", "-n", "1", "-k", "27", "-K", "27") == 0
+        assert open(out + ".near27").read().splitlines() == want_near27
         if tag == "kmg":
-            # still on the Java path: a length window other than the file's own, differences over several lengths, -h
+            # still on the Java path: a length window other than the file's own, -h
             assert run("Database.Matcher", "-i", reads_db, "-d", ref_db, "-o", str(tmp_path / "x.txt"), "-Z", "x", "-k", "25", "-K", "32").returncode == 3
-            assert run("Database.Matcher", "-i", reads_db, "-d", ref_db, "-o", str(tmp_path / "x.txt"), "-Z", "x", "-n", "1").returncode == 3
             assert run("Database.MakeDatabase", "-a", "-i", fa, "-o", str(tmp_path / "h.db"), "-h").returncode == 3
         counts = str(tmp_path / ("counts.%s.tsv" % tag))
         assert drv("Utils.TaxaCounts", "-d", ref_db, "-o", counts) == 0
