@@ -157,6 +157,12 @@ int kmg_db_load_var(kmg_ctx *ctx, int k, int min_k, int key_len, int rc, int pay
  *   side (DB.java:134) before the exact join.  min_k <= length <= k of the source (DB.java:78-81 -> KMG_EINVAL); the
  *   result is a database of one length; the source stays valid. */
 int kmg_db_restrict(kmg_ctx *ctx, const kmg_db *db, int length, kmg_db **out);
+/* kmg_db_restrict_range: the same stream function with min_length < max_length (Matcher -k a -K b on the search side,
+ *   Matcher.java:224,241): k-mers shorter than min_length dropped, longer than max_length cut to it and folded, the
+ *   others untouched; the result is a variable-length database declared [min_length, max_length] (the declared lengths
+ *   are what the trie is built with, DB.java:86,154), whatever lengths it holds.  key_len <= min_length <=
+ *   max_length <= 32. */
+int kmg_db_restrict_range(kmg_ctx *ctx, const kmg_db *db, int min_length, int max_length, kmg_db **out);
 /* kmg_match_trie: DB.getNearestKmers' non-quick branch with maxDiff = 0 (Database/DB.java:83,139-184) for a search stream
  *   of k-mers of several lengths -- what Matcher does on variable-length files when -k / -K are left at their defaults
  *   (Matcher.java:147-148): per key a radix trie over the database's k-mers (Root.addKmer, Root.java:29-113) and

@@ -120,10 +120,14 @@ class KmerDatabase:
         self.ctx.check(self.ctx.lib.kmg_db_fetch_lens(self.h, _ptr(out)))
         return out[:self.n_unique]
 
-    def restrict(self, length):
-        """KmerUtils.restrictedStream(.., length, length, ..) over the whole database (kmg_db_restrict)."""
+    def restrict(self, length, max_length=None):
+        """KmerUtils.restrictedStream(.., length, length, ..) over the whole database (kmg_db_restrict); with max_length
+        > length the stream function with two lengths (kmg_db_restrict_range)."""
         h = C.c_void_p()
-        self.ctx.check(self.ctx.lib.kmg_db_restrict(self.ctx.h, self.h, int(length), C.byref(h)))
+        if max_length is None or int(max_length) == int(length):
+            self.ctx.check(self.ctx.lib.kmg_db_restrict(self.ctx.h, self.h, int(length), C.byref(h)))
+        else:
+            self.ctx.check(self.ctx.lib.kmg_db_restrict_range(self.ctx.h, self.h, int(length), int(max_length), C.byref(h)))
         return KmerDatabase(self.ctx, h)
 
     @classmethod

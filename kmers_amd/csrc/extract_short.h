@@ -289,3 +289,28 @@ __global__ void vm_place_kernel(const u64 *__restrict__ keys, const uint8_t *__r
     out_val_off[dst] = vdst;
     for (u64 v = val_off[i]; v < val_off[i + 1]; v++, vdst++) { out_a[vdst] = val_a[v]; out_b[vdst] = val_b[v]; }
 }
+
+// ---- KmerUtils.restrictedStream with minLength < maxLength: the entries of lo <= length < hi stay as they are
+__global__ void vr_flag_kernel(const uint8_t *__restrict__ lens, int len_all, const u64 *__restrict__ val_off, u64 n, int lo, int hi,
+                               u32 *__restrict__ keep, u32 *__restrict__ nvals) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int len = lens ? (int)lens[i] : len_all;
+    const bool k = len >= lo && len < hi;
+    keep[i] = k;
+    nvals[i] = k ? (u32)(val_off[i + 1] - val_off[i]) : 0u;
+}
+__global__ void vr_gather_kernel(const u64 *__restrict__ keys, const uint8_t *__restrict__ lens, int len_all,
+                                 const u64 *__restrict__ val_off, const int32_t *__restrict__ val_a, const int32_t *__restrict__ val_b,
+                                 u64 n, const u32 *__restrict__ keep, const u64 *__restrict__ dstk, const u64 *__restrict__ dstv,
+                                 u64 *__restrict__ out_keys, uint8_t *__restrict__ out_lens, u64 *__restrict__ out_val_off,
+                                 int32_t *__restrict__ out_a, int32_t *__restrict__ out_b) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const u64 o = dstk[i];
+    u64 v = dstv[i];
+    out_keys[o] = keys[i];
+    out_lens[o] = lens ? lens[i] : (uint8_t)len_all;
+    out_val_off[o] = v;
+    for (u64 s = val_off[i]; s < val_off[i + 1]; s++, v++) { out_a[v] = val_a[s]; out_b[v] = val_b[s]; }
+}

@@ -819,8 +819,9 @@ static int interleave_dbs(kmg_ctx *ctx, kmg_db *X, kmg_db *Y, kmg_db *out) {
     if (Y->U)
         hipLaunchKernelGGL((il_place_kernel<false>), dim3(div_up_u64(Y->U, 256)), dim3(256), 0, ctx->stream, Y->keys, Y->lens, Y->k,
                            Y->val_off, Y->U, X->keys, X->U, out->keys, out->lens, cnt.as<u32>(), py.as<u64>());
-    KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt.as<u32>(), out->val_off, U, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
-                                                KP_SCAN)));
+    if (U)
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt.as<u32>(), out->val_off, U, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
+                                                    KP_SCAN)));
     if (X->U)
         hipLaunchKernelGGL(il_values_kernel, dim3(div_up_u64(X->U, 256)), dim3(256), 0, ctx->stream, X->val_off, X->val_a, X->val_b,
                            X->U, px.as<u64>(), out->val_off, out->val_a, out->val_b);
@@ -1415,6 +1416,8 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
 }
 
 // ------------------------------------------------------------------------------------------------ restrict
+static int restrict_locked(kmg_ctx *ctx, const kmg_db *src, int length, kmg_db **out);
+
 extern "C" int kmg_db_restrict(kmg_ctx *ctx, const kmg_db *src, int length, kmg_db **out) {
     if (!ctx || !src || !out) return KMG_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
@@ -1423,6 +1426,79 @@ extern "C" int kmg_db_restrict(kmg_ctx *ctx, const kmg_db *src, int length, kmg_
     if (length < src->min_k || length > src->k)                                                     // DB.java:78-81
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
     if (length < src->key_len) return fail(ctx, KMG_EINVAL, "length below the key length");
+    return restrict_locked(ctx, src, length, out);
+}
+
+// KmerUtils.restrictedStream(stream, minLength, maxLength, dataType) with minLength < maxLength (KmerUtils.java:59-74):
+// the k-mers of at least maxLength bases, cut and folded, are a database of one length (restrict_locked); those of
+// minLength .. maxLength - 1 bases stay as they are; the two interleave by rank as the length classes of a build do.
+extern "C" int kmg_db_restrict_range(kmg_ctx *ctx, const kmg_db *src, int min_length, int max_length, kmg_db **out) {
+    if (!ctx || !src || !out) return KMG_EINVAL;
+    if (min_length == max_length) return kmg_db_restrict(ctx, src, min_length, out);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *out = nullptr;
+    if (src->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
+    if (min_length > max_length || min_length < src->key_len || max_length > 32)
+        return fail(ctx, KMG_EINVAL, "key length <= min_length <= max_length <= 32");
+    KMG_HIP(hipSetDevice(ctx->device));
+    KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(src)));
+    const int cut = std::min(max_length, src->k);          // (nothing is longer than src->k: nothing else is cut)
+    std::unique_ptr<kmg_db, void (*)(kmg_db *)> Y(nullptr, db_release), X(new (std::nothrow) kmg_db(), db_release),
+        res(new (std::nothrow) kmg_db(), db_release);
+    if (!X || !res) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+    if (cut >= min_length) {
+        kmg_db *y = nullptr;
+        KMG_TRY(restrict_locked(ctx, src, cut, &y));
+        Y.reset(y);
+    } else {                                               // every stored k-mer is shorter than min_length: nothing stays
+        Y.reset(new (std::nothrow) kmg_db());
+        if (!Y) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+        Y->ctx = ctx; Y->k = src->k; Y->min_k = src->k; Y->key_len = src->key_len; Y->rc = src->rc; Y->kind = src->kind;
+    }
+    // X: the entries of min_length <= length < cut
+    const u64 U = src->U;
+    X->ctx = ctx; X->k = src->k; X->min_k = src->min_k; X->key_len = src->key_len; X->rc = src->rc; X->kind = src->kind;
+    PoolBuf keep(ctx), nv(ctx), dk(ctx), dv(ctx), agg(ctx);
+    KMG_ALLOC(keep, (U + 1) * 4); KMG_ALLOC(nv, (U + 1) * 4);
+    KMG_ALLOC(dk, (U + 2) * 8); KMG_ALLOC(dv, (U + 2) * 8);
+    KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
+    u64 xu = 0, xv = 0;
+    if (U && cut > min_length) {
+        hipLaunchKernelGGL(vr_flag_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, src->lens, src->k, src->val_off, U, min_length,
+                           cut, keep.as<u32>(), nv.as<u32>());
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, keep.as<u32>(), dk.as<u64>(), U, OpSum(), 0ull, agg.as<u64>(), nullptr, true, KP_SCAN)));
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, nv.as<u32>(), dv.as<u64>(), U, OpSum(), 0ull, agg.as<u64>(), nullptr, true, KP_SCAN)));
+        KMG_HIP(read_back(ctx, &xu, dk.as<u64>() + U, 8));
+        KMG_HIP(read_back(ctx, &xv, dv.as<u64>() + U, 8));
+    }
+    void *p;
+    if (ctx->pool.alloc(&p, (xu + 1) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    X->keys = (u64 *)p;
+    if (ctx->pool.alloc(&p, xu + 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    X->lens = (uint8_t *)p;
+    if (ctx->pool.alloc(&p, (xu + 2) * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    X->val_off = (u64 *)p;
+    if (ctx->pool.alloc(&p, (xv + 1) * 4) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    X->val_a = (int32_t *)p;
+    if (ctx->pool.alloc(&p, (xv + 1) * 4) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+    X->val_b = (int32_t *)p;
+    X->U = xu; X->V = xv;
+    if (xu)
+        hipLaunchKernelGGL(vr_gather_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, src->keys, src->lens, src->k, src->val_off,
+                           src->val_a, src->val_b, U, keep.as<u32>(), dk.as<u64>(), dv.as<u64>(), X->keys, X->lens, X->val_off, X->val_a,
+                           X->val_b);
+    KMG_HIP(hipMemcpyAsync(X->val_off + xu, &xv, 8, hipMemcpyHostToDevice, ctx->stream));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));            // (xv is on this frame)
+    res->ctx = ctx; res->k = max_length; res->min_k = min_length; res->key_len = src->key_len; res->rc = src->rc; res->kind = src->kind;
+    KMG_TRY(interleave_dbs(ctx, X.get(), Y.get(), res.get()));
+    KMG_TRY(db_make_buckets(ctx, res.get()));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    KMG_HIP(hipGetLastError());
+    *out = res.release();
+    return KMG_OK;
+}
+
+static int restrict_locked(kmg_ctx *ctx, const kmg_db *src, int length, kmg_db **out) {
     KMG_HIP(hipSetDevice(ctx->device));
     KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(src)));
     const bool reads = src->kind == KMG_PAYLOAD_READPOS;

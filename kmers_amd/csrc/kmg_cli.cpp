@@ -12,7 +12,7 @@
 // Appendix A.1-A.3): header | gzip-member blocks | index block | footer; every key's block is its own gzip
 // member, so blocks are deflated / inflated on a thread pool and written in key order
 // (FileCreator.java:385-391 enforces that order with OrderedLatches).  Options outside the GPU path
-// (k > 32, -k a -K b windows other than the file's own, -h with minK < maxK, -m, -N, -x ...) exit with status 3 so that a
+// (k > 32, -h with minK < maxK, -m, -N, -x ...) exit with status 3 so that a
 // wrapper can fall back to the Java program.  Plain C++17 + zlib; no HIP in this file.
 #include <stdint.h>
 #include <stdio.h>
@@ -1034,8 +1034,12 @@ int matcher(int argc, char **argv) {
                 throw std::runtime_error("InconsistentDataException: Search kmers contain kmers of a length inconsistent with the database");
             if (want_min != want_max) {
                 // a search over several lengths: the trie (DB.java:83,139-184) in closed form -- kmg_match_trie
-                if (want_min != s_min || want_max != s0.k)
-                    throw Unsupported("-k < -K other than the search file's own lengths stays on the Java path");
+                if (want_min != s_min || want_max != s0.k) {               // KmerFile.allRestrictedKmers (Matcher.java:241)
+                    kmg_db *cut = nullptr;
+                    g.check(kmg_db_restrict_range(g.ctx, search, want_min, want_max, &cut));
+                    kmg_db_free(search);
+                    search = cut;
+                }
                 trie = true;
             } else if (s_min != s0.k || s0.k != want_min) {
                 kmg_db *cut = nullptr;

@@ -299,8 +299,8 @@ def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max
     if min_k != max_k:
         # a search over several lengths: the trie (DB.java:83,139-184) in closed form, kmg_match_trie
         from .api import match_trie, near_match_lines_var
-        if (searches[0].min_length, searches[0].max_length) != (min_k, max_k):
-            raise KmersGpuError(KMG_EUNSUPPORTED, "-k < -K other than the search file's own lengths stays on the Java path")
+        if any((s_.min_length, s_.max_length) != (min_k, max_k) for s_ in searches):
+            searches = [s_.restrict(min_k, max_k) for s_ in searches]       # KmerFile.allRestrictedKmers (Matcher.java:241)
         # sets (name.1 .. name.N): files that share no key -- what -S / -G write -- are laid end to end (kmg_db_merge);
         # the reference's trie takes one key's k-mers file by file, so files sharing a key stay on the Java path
         search = searches[0] if len(searches) == 1 else merge_databases(searches)

@@ -1496,6 +1496,50 @@ def test_trie_search_matches_literal_trie(ctx, min_k, k, key_len, alphabet, seed
     ref.close()
 
 
+@pytest.mark.parametrize("min_k,k,key_len,alphabet,seed", [(3, 8, 2, b"AACCGTN", 91), (2, 9, 1, b"AC", 92), (24, 32, 4, b"ACGT", 93)])
+def test_length_windows_other_than_the_files_own(ctx, min_k, k, key_len, alphabet, seed):
+    """Matcher -k a -K b with a < b: the search side goes through KmerUtils.restrictedStream(a, b) (KmerUtils.java:59-74;
+    kmg_db_restrict_range: shorter dropped, longer cut and folded, the rest untouched), the trie is built with (a, b) over
+    the whole database.  The restricted database entry by entry against the restated stream function, then the lines
+    with and without differences against the literal trie."""
+    import kmers_amd as km
+    from oracle import slow_ref as R
+    rng = np.random.default_rng(seed)
+    small = k <= 9
+    fa, fq = _trie_case(rng, alphabet, 12 if small else 30, 60 if small else 300, 40 if small else 150, 25 if small else 60, [6, 7])
+    ref = km.make_reference_db(ctx, fa, k, key_len, min_k=min_k)
+    rdb, _ = km.make_read_db(ctx, fq, k, key_len, min_k=min_k)
+    o_ref, (o_reads, _) = R.build_ref_db(fa, k, key_len, min_k=min_k), R.build_read_db(fq, k, key_len, min_k=min_k)
+    windows = {(min_k, k - 1), (min_k + 1, k), (min_k + 1, k - 1), (max(min_k, key_len), min_k + 1)}
+    for a, b in sorted(w for w in windows if key_len <= w[0] < w[1] <= k):
+        for db, blocks, kind in ((ref, o_ref, "ref"), (rdb, o_reads, "read")):
+            cut = db.restrict(a, b)
+            assert (cut.min_length, cut.max_length) == (a, b)
+            want = []
+            for key in range(4 ** key_len):
+                want.extend(R.restricted_stream(R.decode_block(blocks.get(key, b""), kind), min_k, k, a, b, kind))
+            got, lens = cut.fetch(), cut.lens()
+            assert cut.n_unique == len(want)
+            names = km.kmer_strings(got["keys"], 32)
+            assert [n[:l] for n, l in zip(names, lens.tolist())] == [str(kk) for kk, _ in want]
+            for i in rng.integers(0, max(len(want), 1), size=min(len(want), 200)).tolist():
+                c0, c1 = int(got["val_off"][i]), int(got["val_off"][i + 1])
+                vals = list(zip(got["val_a"][c0:c1].tolist(), got["val_b"][c0:c1].tolist()))
+                assert vals == (sorted(want[i][1].items()) if kind == "ref" else sorted(want[i][1])), (a, b, kind, i)
+            if kind == "read":
+                for n_, just in ((0, False), (1, False), (2, True)):
+                    lines = R.near_match_lines(o_reads, R.DB([o_ref]), n_, just, a, b)
+                    if n_ == 0:
+                        rows, hit = km.match_trie(cut, ref, a)
+                        assert km.match_lines(cut, rows, hit, ref_stored=True) == lines and len(lines) > 5
+                        rows.close()
+                    else:
+                        assert km.near_match_lines_var(cut, ref, n_, just, min_length=a) == lines
+            cut.close()
+    ref.close()
+    rdb.close()
+
+
 def test_trie_search_counts_and_reference_search_side(ctx):
     """Counts beyond a file's byte are cut to 255 BEFORE the trie adds them up (the reference reads them from the file,
     CountDataType.java:40), and a reference database can be the search side (Matcher.java:182-210): `TxC` on both

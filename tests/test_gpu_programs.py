@@ -474,6 +474,8 @@ def test_default_options_build_variable_length_databases(tmp_path):
     assert len(want_near1) > 100 and any(" " in w.split("\t")[2] for w in want_near1)
     # -n 1 -k 27 -K 27: the search file restricted to 27 bases (Matcher.java:241), the trie over the WHOLE database
     want_near27 = R.near_match_lines(o_few, o_db, 1, False, 27, 27)
+    want_win = R.near_match_lines(o_few, o_db, 0, False, 26, 30)
+    assert len(want_win) > 100 and {len(w.split("\t")[0]) for w in want_win} == {26, 27, 28, 29, 30}
     assert len(want_near27) > 50
     want_cb = R.collect_by_read(want_trie)
     want_calls = R.read_classifier(want_cb)
@@ -524,9 +526,11 @@ def test_default_options_build_variable_length_databases(tmp_path):
             assert open(out + ".near").read().splitlines() == want_near
         assert drv("Database.Matcher", "-i", few_db, "-d", ref_db, "-o", out + ".near27", "-Z", "x", "-n", "1", "-k", "27", "-K", "27") == 0
         assert open(out + ".near27").read().splitlines() == want_near27
+        # a length window other than the file's own (-k 26 -K 30): the search side through restrictedStream(26, 30)
+        assert drv("Database.Matcher", "-i", few_db, "-d", ref_db, "-o", out + ".win", "-Z", "x", "-k", "26", "-K", "30") == 0
+        assert open(out + ".win").read().splitlines() == want_win
         if tag == "kmg":
-            # still on the Java path: a length window other than the file's own, -h
-            assert run("Database.Matcher", "-i", reads_db, "-d", ref_db, "-o", str(tmp_path / "x.txt"), "-Z", "x", "-k", "25", "-K", "32").returncode == 3
+            # still on the Java path: -h with several lengths
             assert run("Database.MakeDatabase", "-a", "-i", fa, "-o", str(tmp_path / "h.db"), "-h").returncode == 3
         counts = str(tmp_path / ("counts.%s.tsv" % tag))
         assert drv("Utils.TaxaCounts", "-d", ref_db, "-o", counts) == 0
