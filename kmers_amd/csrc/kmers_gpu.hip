@@ -256,10 +256,10 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     // from the upper bound: any plan is correct, a tight one fills the local sort's segments)
     const u64 short_by = std::min<u64>(nbases, nseq * (u64)(ctx->k - 1));
     const u64 expect = std::max<u64>(nbases - short_by, nbases / 16) * (ctx->rc ? 2 : 1);
-    // (a variable-length build takes the window-order extractor: its short k-mers add to the build state after the
-    // full windows, so the state snapshot of the fused path would be stale)
+    // (a variable-length build's full windows take the same path; its shorter k-mers are counted before the reads are
+    // numbered and before the state snapshot below, and written into buffers of their own afterwards)
     const bool var = ctx->min_k < ctx->k;
-    const int plan = (ctx->n_adds == 0 && !var) ? choose_pbits(expect, 2 * ctx->k) : 0;
+    const int plan = ctx->n_adds == 0 ? choose_pbits(expect, 2 * ctx->k) : 0;
     const bool part = plan > 0 && plan <= 32 && nbases < 0xFFFFFFF0ull / 2;   // (<= 32: the partition digit lies in the key's upper word)
     ctx->prepart = part;
     ctx->plan_pbits = plan;
@@ -987,7 +987,17 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     ctx->pool.release(ctx->rec_keys);
     ctx->pool.release(ctx->rec_vals);
     ctx->rec_keys = nullptr; ctx->rec_vals = nullptr; ctx->rec_cap = 0; ctx->rec_upper = 0; ctx->compact_pb = 0;
-    if (r == KMG_OK && ctx->min_k < ctx->k) r = finish_variable(ctx, db_guard, payload);
+    if (r == KMG_OK && ctx->min_k < ctx->k) {
+        // the shorter k-mers carry (read << 16 | pos) in 64 bits whatever form the full windows took
+        std::vector<SortPass> payload_short = payload;
+        if (reads && st[ST_DUP_READS] && pos_bits != 16) {
+            payload_short.clear();
+            int bits = 16;
+            while (bits < 16 + 32 && (st[ST_READ_BASE] >> (bits - 16)) != 0) bits++;
+            for (int shift = 0; shift < bits; shift += RS_BITS) payload_short.push_back({shift, std::min(RS_BITS, bits - shift), RS_SRC_VAL64});
+        }
+        r = finish_variable(ctx, db_guard, payload_short);
+    }
     ctx->pool.release(ctx->sh_keys); ctx->pool.release(ctx->sh_vals); ctx->pool.release(ctx->sh_len);
     ctx->sh_keys = nullptr; ctx->sh_vals = nullptr; ctx->sh_len = nullptr; ctx->sh_n = 0; ctx->sh_cap = 0;
     if (r != KMG_OK) return r;
