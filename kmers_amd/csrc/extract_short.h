@@ -183,17 +183,27 @@ __global__ __launch_bounds__(256) void short_hist_kernel(const uint8_t *__restri
     __syncthreads();
     if (threadIdx.x < 64 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
-// flag[i] = record i has length L (input of the exclusive scan that places the class, in record order: stable)
-__global__ void short_flag_kernel(const uint8_t *__restrict__ len, u64 n, int L, u32 *__restrict__ flag) {
+// Up to four consecutive lengths L0 .. L1-1 are sorted as ONE class: a k-mer of at most 31 bases leaves the two lowest
+// bits of its 64-bit form free, and with length - L0 there the plain 64-bit order is (zero-padded value, length) --
+// Sequence.compareTo -- so the class sorts and reduces as a build of 32-mers; short_split_kernel takes the tag off again.
+// flag[i] = record i belongs to the class (input of the exclusive scan that places it, in record order: stable)
+__global__ void short_flag_kernel(const uint8_t *__restrict__ len, u64 n, int L0, int L1, u32 *__restrict__ flag) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = len[i] == L;
+    if (i < n) flag[i] = len[i] >= L0 && len[i] < L1;
 }
 template <typename V>
-__global__ void short_gather_kernel(const uint8_t *__restrict__ len, const u32 *__restrict__ dst, u64 n, int L,
+__global__ void short_gather_kernel(const uint8_t *__restrict__ len, const u32 *__restrict__ dst, u64 n, int L0, int L1,
                                     const u64 *__restrict__ keys, const V *__restrict__ vals, u64 *__restrict__ out_keys,
                                     V *__restrict__ out_vals) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && len[i] == L) { out_keys[dst[i]] = keys[i]; out_vals[dst[i]] = vals[i]; }
+    if (i < n && len[i] >= L0 && len[i] < L1) { out_keys[dst[i]] = keys[i] | (u64)(len[i] - L0); out_vals[dst[i]] = vals[i]; }
+}
+__global__ void short_split_kernel(u64 *__restrict__ keys, u64 n, int L0, uint8_t *__restrict__ lens) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 k = keys[i];
+    lens[i] = (uint8_t)(L0 + (int)(k & 3));
+    keys[i] = k & ~3ull;
 }
 
 // ---- interleaving two databases by rank ---------------------------------------------------------------------------

@@ -873,38 +873,48 @@ static int finish_variable(kmg_ctx *ctx, std::unique_ptr<kmg_db, void (*)(kmg_db
         KMG_ALLOC(flag, ns * 4);
         KMG_ALLOC(dst, (ns + 1) * 4);
         KMG_ALLOC(agg, (size_t)(div_up_u64(ns, SCAN_TILE) + 1) * 8);
-        for (int L = ctx->min_k; L < ctx->k; L++) {
-            const u32 n = hist[L];
-            if (!n) continue;
+        for (int L0 = ctx->min_k; L0 < ctx->k; L0 += 4) {
+            const int L1 = std::min(L0 + 4, ctx->k);             // the class: lengths L0 .. L1 - 1 (all below 32)
+            u64 n64 = 0;
+            for (int L = L0; L < L1; L++) n64 += hist[L];
+            if (!n64) continue;
+            const u32 n = (u32)n64;
             PoolBuf ck(ctx), cv(ctx);
             KMG_ALLOC(ck, (size_t)n * 8);
             KMG_ALLOC(cv, (size_t)n * vb);
             const dim3 grid(div_up_u64(ns, 256)), blk(256);
-            hipLaunchKernelGGL(short_flag_kernel, grid, blk, 0, ctx->stream, ctx->sh_len, ns, L, flag.as<u32>());
+            hipLaunchKernelGGL(short_flag_kernel, grid, blk, 0, ctx->stream, ctx->sh_len, ns, L0, L1, flag.as<u32>());
             KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, flag.as<u32>(), dst.as<u32>(), ns, OpSum(), 0u, agg.as<u32>(), nullptr,
                                                         false, KP_SCAN)));
             if (vb == 4)
-                hipLaunchKernelGGL((short_gather_kernel<u32>), grid, blk, 0, ctx->stream, ctx->sh_len, dst.as<u32>(), ns, L, ctx->sh_keys,
+                hipLaunchKernelGGL((short_gather_kernel<u32>), grid, blk, 0, ctx->stream, ctx->sh_len, dst.as<u32>(), ns, L0, L1, ctx->sh_keys,
                                    (const u32 *)ctx->sh_vals, ck.as<u64>(), cv.as<u32>());
             else
-                hipLaunchKernelGGL((short_gather_kernel<u64>), grid, blk, 0, ctx->stream, ctx->sh_len, dst.as<u32>(), ns, L, ctx->sh_keys,
+                hipLaunchKernelGGL((short_gather_kernel<u64>), grid, blk, 0, ctx->stream, ctx->sh_len, dst.as<u32>(), ns, L0, L1, ctx->sh_keys,
                                    (const u64 *)ctx->sh_vals, ck.as<u64>(), cv.as<u64>());
             KMG_HIP(hipGetLastError());
             kmg_db *c = new (std::nothrow) kmg_db();
             if (!c) return fail(ctx, KMG_ENOMEM, "host allocation failed");
             std::unique_ptr<kmg_db, void (*)(kmg_db *)> cls(c, db_release);
-            c->ctx = ctx; c->k = L; c->min_k = L; c->key_len = ctx->key_len; c->rc = ctx->rc; c->kind = ctx->kind;
+            // (sorted as 32-mers: the length tag in the two lowest bits takes part in the order and in the runs)
+            c->ctx = ctx; c->k = 32; c->min_k = 32; c->key_len = ctx->key_len; c->rc = ctx->rc; c->kind = ctx->kind;
             void *vals = cv.detach();
             const u64 n_dense = ctx->ranged ? (u64)n * (1u << (2 * ctx->key_len)) / std::max<u32>(ctx->range_hi - ctx->range_lo, 1u) : n;
-            int r = sort_reduce_class(ctx, ck.as<u64>(), vals, n, false, 16, payload, choose_pbits(n_dense, 2 * L), false, c, nullptr);
+            int r = sort_reduce_class(ctx, ck.as<u64>(), vals, n, false, 16, payload, choose_pbits(n_dense, 64), false, c, nullptr);
             ctx->pool.release(vals);
             KMG_TRY(r);
+            void *lp;
+            if (ctx->pool.alloc(&lp, c->U + 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+            c->lens = (uint8_t *)lp;
+            if (c->U)
+                hipLaunchKernelGGL(short_split_kernel, dim3(div_up_u64(c->U, 256)), blk, 0, ctx->stream, c->keys, c->U, L0, c->lens);
+            c->k = L1 - 1; c->min_k = L0;
             if (!acc) acc = std::move(cls);
             else {
                 kmg_db *m = new (std::nothrow) kmg_db();
                 if (!m) return fail(ctx, KMG_ENOMEM, "host allocation failed");
                 std::unique_ptr<kmg_db, void (*)(kmg_db *)> merged(m, db_release);
-                m->ctx = ctx; m->k = L; m->min_k = acc->min_k; m->key_len = ctx->key_len; m->rc = ctx->rc; m->kind = ctx->kind;
+                m->ctx = ctx; m->k = L1 - 1; m->min_k = acc->min_k; m->key_len = ctx->key_len; m->rc = ctx->rc; m->kind = ctx->kind;
                 KMG_TRY(interleave_dbs(ctx, acc.get(), c, m));
                 acc = std::move(merged);
             }
