@@ -232,14 +232,34 @@ __global__ void il_place_kernel(const u64 *__restrict__ keys, const uint8_t *__r
     out_lens[at] = lens ? lens[i] : (uint8_t)len_all;
     out_cnt[at] = (u32)(val_off[i + 1] - val_off[i]);
 }
-// the values of every entry to their place in the interleaved value arrays
-__global__ void il_values_kernel(const u64 *__restrict__ val_off, const int32_t *__restrict__ val_a,
-                                 const int32_t *__restrict__ val_b, u64 n, const u64 *__restrict__ place,
-                                 const u64 *__restrict__ out_off, int32_t *__restrict__ out_a, int32_t *__restrict__ out_b) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u64 o = out_off[place[i]];
-    for (u64 v = val_off[i]; v < val_off[i + 1]; v++, o++) { out_a[o] = val_a[v]; out_b[o] = val_b[v]; }
+// the values of every entry to their place in the interleaved value arrays.  A block takes 256 consecutive entries: their
+// values are one contiguous piece of the source, walked by all lanes side by side (coalesced reads, and writes that
+// only break where an entry of the other database goes in between); the entry a value belongs to is found by a binary
+// search over the block's 257 offsets in LDS.
+#define ILV_BLOCK 256
+__global__ __launch_bounds__(ILV_BLOCK) void il_values_kernel(const u64 *__restrict__ val_off, const int32_t *__restrict__ val_a,
+                                                               const int32_t *__restrict__ val_b, u64 n,
+                                                               const u64 *__restrict__ place, const u64 *__restrict__ out_off,
+                                                               int32_t *__restrict__ out_a, int32_t *__restrict__ out_b) {
+    __shared__ u64 s_off[ILV_BLOCK + 1];
+    __shared__ u64 s_dst[ILV_BLOCK];
+    const u64 e0 = (u64)blockIdx.x * ILV_BLOCK;
+    const u32 cnt = (u32)(n - e0 < ILV_BLOCK ? n - e0 : ILV_BLOCK);
+    if (threadIdx.x <= cnt) s_off[threadIdx.x] = val_off[e0 + threadIdx.x];
+    if (threadIdx.x == 0 && cnt == ILV_BLOCK) s_off[ILV_BLOCK] = val_off[e0 + ILV_BLOCK];
+    if (threadIdx.x < cnt) s_dst[threadIdx.x] = out_off[place[e0 + threadIdx.x]];
+    __syncthreads();
+    const u64 v0 = s_off[0], v1 = s_off[cnt];
+    for (u64 v = v0 + threadIdx.x; v < v1; v += ILV_BLOCK) {
+        u32 lo = 0, hi = cnt;                      // last entry whose offset is <= v (entries without values are skipped over)
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (s_off[mid] <= v) lo = mid; else hi = mid;
+        }
+        const u64 o = s_dst[lo] + (v - s_off[lo]);
+        out_a[o] = val_a[v];
+        out_b[o] = val_b[v];
+    }
 }
 
 // ---- KmerUtils.restrictedStream (Kmers/KmerUtils.java:59-74) ---------------------------------------------------------

@@ -823,10 +823,10 @@ static int interleave_dbs(kmg_ctx *ctx, kmg_db *X, kmg_db *Y, kmg_db *out) {
         KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt.as<u32>(), out->val_off, U, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
                                                     KP_SCAN)));
     if (X->U)
-        hipLaunchKernelGGL(il_values_kernel, dim3(div_up_u64(X->U, 256)), dim3(256), 0, ctx->stream, X->val_off, X->val_a, X->val_b,
+        hipLaunchKernelGGL(il_values_kernel, dim3(div_up_u64(X->U, ILV_BLOCK)), dim3(ILV_BLOCK), 0, ctx->stream, X->val_off, X->val_a, X->val_b,
                            X->U, px.as<u64>(), out->val_off, out->val_a, out->val_b);
     if (Y->U)
-        hipLaunchKernelGGL(il_values_kernel, dim3(div_up_u64(Y->U, 256)), dim3(256), 0, ctx->stream, Y->val_off, Y->val_a, Y->val_b,
+        hipLaunchKernelGGL(il_values_kernel, dim3(div_up_u64(Y->U, ILV_BLOCK)), dim3(ILV_BLOCK), 0, ctx->stream, Y->val_off, Y->val_a, Y->val_b,
                            Y->U, py.as<u64>(), out->val_off, out->val_a, out->val_b);
     KMG_HIP(hipGetLastError());
     out->U = U;
