@@ -26,76 +26,56 @@ struct ShortArgs {
     int min_k;
     uint8_t *out_len;     // length of every short record
     u64 out_base;         // records already in the buffers (earlier batches)
+    u32 *jw_count;        // [tile][round][wave]: records of 64 consecutive positions (count pass -> write pass)
 };
 
-// Calls emit(key, len, pos_in_sequence, is_rc) for every short record of thread position p, in the order the reference
-// hands them out (situation B before C, longest first, forward before reverse complement).  Returns the number of
-// forward k-mers the mapper saw (before the -D / -R filters and the key range): > 0 numbers the read.
-template <typename Emit>
-__device__ __forceinline__ u32 short_records(const ShortArgs &sa, const u32 *pk, const u32 *inv, const u32 *stb,
-                                             const u32 *seqrel, u32 s_lo, u64 t0, u32 p, Emit emit) {
+// What position p of a tile hands out, as a list of items (one per length, in the order the reference hands them out:
+// situation B before C, longest first); item i is evaluated by lane i of the wave that owns p, so the eight lengths
+// of a read's end cost one step of 8 busy lanes instead of eight steps of one (a lane walking its own lengths one after
+// the other was two thirds of the first version's time).  At most 2 x 31 items.
+struct ShortSite {
+    u64 win;          // 32 bases from p, first in the top bits
+    u64 seq_start;
+    u32 seq;          // sequence of p
+    int n;            // bases the suffixes are cut from (W, or the whole of a sequence shorter than W)
+    int d, nB;        // first nB items: lengths d, d - 1, ...
+    int top, nC;      // next nC items: lengths top, top - 1, ...
+};
+__device__ __forceinline__ ShortSite short_site(const ShortArgs &sa, const u32 *pk, const u32 *inv, const u32 *stb,
+                                                const u32 *seqrel, u32 s_lo, u64 t0, u32 p) {
     const ExtractArgs &a = sa.e;
     const int W = a.k, m = sa.min_k;
+    ShortSite x;
+    x.nB = x.nC = 0; x.d = x.top = 0; x.n = W; x.win = 0; x.seq_start = 0; x.seq = 0;
     const u64 gp = t0 + p;
-    if (gp >= a.nbases) return 0;
+    if (gp >= a.nbases) return x;
     const u32 w = p >> 4, r = p & 15;
     const u64 hi = ((u64)pk[w] << 32) | pk[w + 1];
-    const u64 win = (hi << (2 * r)) | ((u64)pk[w + 2] >> (32 - 2 * r));     // 32 bases from p, first in the top bits
+    x.win = (hi << (2 * r)) | ((u64)pk[w + 2] >> (32 - 2 * r));
     const u32 w2 = p >> 5, r2 = p & 31;
     const u64 bad = (((u64)inv[w2] << 32) | inv[w2 + 1]) << r2;             // bit 63 - i: base p + i is invalid
     const u64 st = (((u64)stb[w2] << 32) | stb[w2 + 1]) << r2;              // bit 63 - i: a sequence starts at p + i
-    const u32 s = s_lo + seqrel[p];
-    u32 seen = 0;
-
-    // one suffix of length L of the n bases that start at p (n = W for a full window)
-    auto one = [&](int n, int L) {
-        const u64 maskn = n == 32 ? ~0ull : ~(~0ull >> (2 * n));
-        const u64 key = (win & maskn) << (2 * (n - L));
-        seen++;
-        if (a.runofsame >= 0 && !runofsame_keep(key, L, a.runofsame)) return;
-        if (a.dust >= 0 && !dust_keep(key, L, a.dust)) return;
-        const u32 pos = (u32)(gp + (u64)(n - L) - a.seq_off[s]);
-        bool ok = true;
-        if (a.ranged) {
-            const u32 fb = (u32)(key >> a.range_shift);
-            ok = fb >= a.range_lo && fb < a.range_hi;
-        }
-        if (ok) emit(key, L, pos, false);
-        if (a.rc) {
-            const u64 maskL = ~(~0ull >> (2 * L));                          // L < 32 here
-            const u64 rev = revpairs64(key >> (64 - 2 * L));
-            if (((L & 1) == 0) && rev == key) return;                        // Kmer.isOwnRC: a palindrome of even length
-            const u64 rk = rev ^ (0xAAAAAAAAAAAAAAAAull & maskL);
-            if (a.ranged) {
-                const u32 rb = (u32)(rk >> a.range_shift);
-                if (rb < a.range_lo || rb >= a.range_hi) return;
-            }
-            emit(rk, L, pos, true);
-        }
-    };
-
+    x.seq = s_lo + seqrel[p];
+    x.seq_start = a.seq_off[x.seq];
     const bool inside = (W == 1 || ((st << 1) >> (65 - W)) == 0) && gp + (u64)W <= a.nbases;
     if (inside) {
         const u64 badW = bad >> (64 - W);
-        const int d = badW ? __ffsll((long long)badW) - 1 : W;               // valid bases in a row at the window's end
-        if (badW && d >= m)                                                  // (B): lengths d .. m
-            for (int L = d; L >= m; L--) one(W, L);
+        x.d = badW ? __ffsll((long long)badW) - 1 : W;                       // valid bases in a row at the window's end
+        if (badW && x.d >= m) x.nB = x.d - m + 1;                            // (B): lengths d .. m
         const bool last = gp + (u64)W == a.nbases || ((st >> (63 - W)) & 1);
-        if (last) {                                                          // (C), sequence of n >= W bases
-            const int top = d < W - 1 ? d : W - 1;
-            for (int L = top; L >= m; L--) one(W, L);
-        }
-    } else if (a.seq_off[s] == gp) {
+        x.top = x.d < W - 1 ? x.d : W - 1;
+        if (last && x.top >= m) x.nC = x.top - m + 1;                        // (C), sequence of n >= W bases
+    } else if (x.seq_start == gp) {
         // a sequence of fewer than W bases starts here: its (C), if it has at least m bases
-        const u64 n64 = a.seq_off[s + 1] - gp;
+        const u64 n64 = a.seq_off[x.seq + 1] - gp;
         if (n64 >= (u64)m && n64 < (u64)W) {
-            const int n = (int)n64;
-            const u64 badn = bad >> (64 - n);
-            const int d = badn ? __ffsll((long long)badn) - 1 : n;
-            for (int L = d; L >= m; L--) one(n, L);
+            x.n = (int)n64;
+            const u64 badn = bad >> (64 - x.n);
+            x.d = badn ? __ffsll((long long)badn) - 1 : x.n;
+            if (x.d >= m) x.nB = x.d - m + 1;
         }
     }
-    return seen;
+    return x;
 }
 
 #define ES_STAGE 1024                    // short records of a tile staged in LDS before they are stored
@@ -105,41 +85,34 @@ __global__ __launch_bounds__(EX_BLOCK) void extract_short_kernel(ShortArgs sa) {
     __shared__ u32 inv[EX_TILE / 32 + 2];
     __shared__ u32 stb[EX_TILE / 32 + 2];
     __shared__ u32 seqrel[EX_TILE + EX_EXT];
-    __shared__ u32 wave_cnt[EX_ROUNDS][EX_BLOCK / 64];
+    __shared__ u32 wave_cnt[EX_ROUNDS][EX_BLOCK / 64];     // records of (round, wave): 64 consecutive positions, in position order
     __shared__ u32 scan_smem[4];
-    __shared__ u32 blk_total;
+    __shared__ u32 blk_total, blk_fwd;
+    __shared__ u32 cand[EX_TILE / 32];
     __shared__ u64 st_key[WRITE ? ES_STAGE : 1], st_val[WRITE ? ES_STAGE : 1];
     __shared__ uint8_t st_len[WRITE ? ES_STAGE : 1];
     const ExtractArgs &a = sa.e;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 t0 = (u64)blockIdx.x * EX_TILE;
     const u32 s_lo = ex_load_tile(a, blockIdx.x, pk, inv, stb, seqrel, scan_smem);
+    const int W = a.k;
 
-    // records per thread and round, exclusive over the lanes of the wave
-    u32 cnt[EX_ROUNDS], before[EX_ROUNDS];
-    u32 nfwd = 0;
-#pragma unroll
-    for (int j = 0; j < EX_ROUNDS; j++) {
-        const u32 p = j * EX_BLOCK + tid;
-        u32 c = 0, f = 0;
-        const u32 seen = short_records(sa, pk, inv, stb, seqrel, s_lo, t0, p,
-                                       [&](u64, int, u32, bool is_rc) { c++; f += is_rc ? 0u : 1u; });
-        // reads are numbered by the mapper, which runs when the k-mer is built: before the filters
-        if (!WRITE && seen && a.has_kmer) a.has_kmer[s_lo + seqrel[p]] = 1;
-        cnt[j] = c;
-        nfwd += f;
-        u32 inc = c;
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-            const u32 o = __shfl_up(inc, dd, 64);
-            if (lane >= dd) inc += o;
-        }
-        before[j] = inc - c;
-        if (lane == 63) wave_cnt[j][wave] = inc;
+    // Positions that can hand out a short k-mer at all, 32 per thread and bit-parallel (a superset; short_site decides):
+    // a window with an invalid base, a window that ends where a sequence ends, a sequence start (a sequence of fewer
+    // than W bases), the tile's first position.  On reads that is one position in a hundred.
+    if (tid < EX_TILE / 32) {
+        const u64 B = ((u64)inv[tid] << 32) | inv[tid + 1];
+        const u64 S = ((u64)stb[tid] << 32) | stb[tid + 1];
+        u32 c = (u32)(ep_or_span(B, W) >> 32) | (u32)(S >> 32) | (u32)((S << W) >> 32);       // (W <= 32: bit p + W lies inside S)
+        const long long eoi = (long long)a.nbases - W - (long long)t0 - 32ll * tid;             // the window that ends the input
+        if (eoi >= 0 && eoi < 32) c |= 0x80000000u >> (u32)eoi;
+        if (tid == 0) c |= 0x80000000u;
+        cand[tid] = c;
     }
-    __syncthreads();
-    if (tid < 64) {
-        const u32 v = wave_cnt[tid >> 2][tid & 3];
+    if (tid == 0) blk_fwd = 0;
+    if (WRITE && tid < EX_ROUNDS * (EX_BLOCK / 64)) {
+        // the count pass left the records of every (round, wave): their exclusive scan places them
+        const u32 v = sa.jw_count[(u64)blockIdx.x * (EX_ROUNDS * (EX_BLOCK / 64)) + tid];
         u32 inc = v;
 #pragma unroll
         for (int dd = 1; dd < 64; dd <<= 1) {
@@ -150,38 +123,92 @@ __global__ __launch_bounds__(EX_BLOCK) void extract_short_kernel(ShortArgs sa) {
         if (tid == 63) blk_total = inc;
     }
     __syncthreads();
+    const u64 tile_base = WRITE ? sa.out_base + a.tile_off[blockIdx.x] : 0;
+    const bool staged = WRITE && blk_total <= ES_STAGE;
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    u32 wave_fwd = 0;
+    for (int j = 0; j < EX_ROUNDS; j++) {
+        const u32 p0 = j * EX_BLOCK + wave * 64;
+        const u32 pl = p0 + lane;
+        u64 todo = __ballot((cand[pl >> 5] >> (31 - (pl & 31))) & 1u);
+        u32 running = 0;
+        const u32 base = WRITE ? wave_cnt[j][wave] : 0;
+        while (todo) {
+            const u32 p = p0 + (u32)(__ffsll((long long)todo) - 1);
+            todo &= todo - 1;
+            const ShortSite x = short_site(sa, pk, inv, stb, seqrel, s_lo, t0, p);          // (the same for all lanes)
+            const int T = x.nB + x.nC;
+            if (T == 0) continue;
+            // reads are numbered by the mapper, which runs when the k-mer is built: before the filters
+            if (!WRITE && a.has_kmer && lane == 0) a.has_kmer[x.seq] = 1;
+            // item `lane`: one suffix of length L of the n bases that start at p
+            bool ef = false, er = false;
+            u64 key = 0, rk = 0;
+            int L = 0;
+            if (lane < T) {
+                L = lane < x.nB ? x.d - lane : x.top - (lane - x.nB);
+                const u64 maskn = x.n == 32 ? ~0ull : ~(~0ull >> (2 * x.n));
+                key = (x.win & maskn) << (2 * (x.n - L));
+                bool keep = true;
+                if (a.runofsame >= 0 && !runofsame_keep(key, L, a.runofsame)) keep = false;
+                if (keep && a.dust >= 0 && !dust_keep(key, L, a.dust)) keep = false;
+                if (keep) {
+                    ef = true;
+                    if (a.ranged) {
+                        const u32 fb = (u32)(key >> a.range_shift);
+                        ef = fb >= a.range_lo && fb < a.range_hi;
+                    }
+                    if (a.rc) {
+                        const u64 maskL = ~(~0ull >> (2 * L));                          // L < 32 here
+                        const u64 rev = revpairs64(key >> (64 - 2 * L));
+                        er = !(((L & 1) == 0) && rev == key);                            // Kmer.isOwnRC: a palindrome of even length
+                        rk = rev ^ (0xAAAAAAAAAAAAAAAAull & maskL);
+                        if (er && a.ranged) {
+                            const u32 rb = (u32)(rk >> a.range_shift);
+                            er = rb >= a.range_lo && rb < a.range_hi;
+                        }
+                    }
+                }
+            }
+            const u64 bf = __ballot(ef), br = __ballot(er);
+            if (WRITE && (ef || er)) {
+                u32 local = base + running + (u32)__popcll(bf & lt) + (u32)__popcll(br & lt);
+                const u32 pos = (u32)(t0 + p + (u64)(x.n - L) - x.seq_start);
+                const u64 val = a.kind == KMG_PAYLOAD_TAXON ? (u64)(u32)a.seq_id[x.seq]
+                                                            : (((u64)(u32)a.read_index[x.seq] << 16) | (u64)(pos & 0xFFFFu));
+                for (int half = 0; half < 2; half++) {
+                    if (!(half ? er : ef)) continue;
+                    const u64 kk = half ? rk : key;
+                    if (staged) { st_key[local] = kk; st_val[local] = val; st_len[local] = (uint8_t)L; }
+                    else {
+                        const u64 slot = tile_base + local;
+                        a.out_keys[slot] = kk;
+                        sa.out_len[slot] = (uint8_t)L;
+                        if (a.kind == KMG_PAYLOAD_TAXON) reinterpret_cast<u32 *>(a.out_vals)[slot] = (u32)val;
+                        else reinterpret_cast<u64 *>(a.out_vals)[slot] = val;
+                    }
+                    local++;
+                }
+            }
+            running += (u32)__popcll(bf) + (u32)__popcll(br);
+            wave_fwd += (u32)__popcll(bf);
+        }
+        if (!WRITE && lane == 0) sa.jw_count[(u64)blockIdx.x * (EX_ROUNDS * (EX_BLOCK / 64)) + j * (EX_BLOCK / 64) + wave] = running;
+        if (!WRITE && lane == 0) wave_cnt[j][wave] = running;
+    }
     if (!WRITE) {
-        u32 tot;
-        block_scan_inclusive(nfwd, OpSum(), scan_smem, &tot);
-        if (tid == 0) {
-            a.tile_count[blockIdx.x] = blk_total;
-            a.tile_fwd[blockIdx.x] = tot;
+        if (lane == 0 && wave_fwd) atomicAdd(&blk_fwd, wave_fwd);
+        __syncthreads();
+        if (tid < 64) {
+            u32 v = wave_cnt[tid >> 2][tid & 3];
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) v += __shfl_xor(v, dd, 64);
+            if (tid == 0) {
+                a.tile_count[blockIdx.x] = v;
+                a.tile_fwd[blockIdx.x] = blk_fwd;
+            }
         }
         return;
-    }
-    const u64 tile_base = sa.out_base + a.tile_off[blockIdx.x];
-    // The records of a tile (a few hundred: eight lengths at every sequence end) are put together in LDS and leave in
-    // coalesced stores; a lane storing its own eight records one after the other costs a store instruction per record
-    // and lane (measured: 0.96 of the kernel's 2.5 ms).  Tiles with more records than the staging area holds store directly.
-    const bool staged = blk_total <= ES_STAGE;
-#pragma unroll
-    for (int j = 0; j < EX_ROUNDS; j++) {
-        if (cnt[j] == 0) continue;
-        const u32 p = j * EX_BLOCK + tid;
-        const u32 s = s_lo + seqrel[p];
-        u32 local = wave_cnt[j][wave] + before[j];
-        short_records(sa, pk, inv, stb, seqrel, s_lo, t0, p, [&](u64 key, int L, u32 pos, bool) {
-            const u64 val = a.kind == KMG_PAYLOAD_TAXON ? (u64)(u32)a.seq_id[s] : (((u64)(u32)a.read_index[s] << 16) | (u64)(pos & 0xFFFFu));
-            if (staged) { st_key[local] = key; st_val[local] = val; st_len[local] = (uint8_t)L; }
-            else {
-                const u64 slot = tile_base + local;
-                a.out_keys[slot] = key;
-                sa.out_len[slot] = (uint8_t)L;
-                if (a.kind == KMG_PAYLOAD_TAXON) reinterpret_cast<u32 *>(a.out_vals)[slot] = (u32)val;
-                else reinterpret_cast<u64 *>(a.out_vals)[slot] = val;
-            }
-            local++;
-        });
     }
     if (!staged) return;
     __syncthreads();

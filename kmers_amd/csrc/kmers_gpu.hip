@@ -318,13 +318,15 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     }
     // variable-length build: count the k-mers shorter than k (extract_short.h) -- before the reads are numbered,
     // because a read gets its index at its first k-mer of ANY length
-    PoolBuf sh_count(ctx), sh_fwd(ctx), sh_off(ctx);
+    PoolBuf sh_count(ctx), sh_fwd(ctx), sh_off(ctx), sh_jw(ctx);
     ShortArgs sa;
     memset(&sa, 0, sizeof sa);
     if (var) {
         KMG_ALLOC(sh_count, (size_t)ntiles * 4);
         KMG_ALLOC(sh_fwd, (size_t)ntiles * 4);
         KMG_ALLOC(sh_off, (size_t)(ntiles + 1) * 8);
+        KMG_ALLOC(sh_jw, (size_t)ntiles * (EX_ROUNDS * (EX_BLOCK / 64)) * 4);
+        sa.jw_count = sh_jw.as<u32>();
         sa.e = a;
         sa.min_k = ctx->min_k;
         sa.e.tile_count = sh_count.as<u32>(); sa.e.tile_fwd = sh_fwd.as<u32>(); sa.e.tile_off = sh_off.as<u64>();
