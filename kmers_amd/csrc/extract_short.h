@@ -260,26 +260,68 @@ __global__ void short_split_kernel(u64 *__restrict__ keys, u64 n, int L0, uint8_
 // k-mers than Y throughout, both ascending: X_i goes before Y_j iff key(X_i) <= key(Y_j).  Hence
 //   place(X_i) = i + #{ j : key(Y_j) <  key(X_i) }          place(Y_j) = j + #{ i : key(X_i) <= key(Y_j) }.
 // FROM_X: the entries of X are placed (lower bound in Y's keys), else those of Y (upper bound in X's keys).
-template <bool FROM_X>
-__global__ void il_place_kernel(const u64 *__restrict__ keys, const uint8_t *__restrict__ lens, int len_all,
-                                const u64 *__restrict__ val_off, u64 n, const u64 *__restrict__ other, u64 n_other,
-                                u64 *__restrict__ out_keys, uint8_t *__restrict__ out_lens, u32 *__restrict__ out_cnt,
-                                u64 *__restrict__ place) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u64 key = keys[i];
+// Tile-wise (the two sides are ascending, so the entries of the other side that a tile of ILP_TILE
+// consecutive entries can land between are one contiguous piece -- il_bounds_kernel finds it, one thread per tile -- and
+// the piece is searched in LDS instead of through the whole array; pieces beyond ILP_CAP entries are searched in place).
+#define ILP_TILE 1024
+#define ILP_CAP 3072
+__global__ void il_bounds_kernel(const u64 *__restrict__ keys, u64 n, const u64 *__restrict__ other, u64 n_other,
+                                 u64 *__restrict__ lo_out, u64 *__restrict__ hi_out) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t * ILP_TILE >= n) return;
+    const u64 first = keys[t * ILP_TILE], last = keys[min(n, (t + 1) * ILP_TILE) - 1];
     u64 lo = 0, hi = n_other;
-    while (lo < hi) {
-        const u64 mid = (lo + hi) >> 1;
-        const u64 o = other[mid];
-        if (FROM_X ? o < key : o <= key) lo = mid + 1; else hi = mid;
-    }
-    const u64 at = i + lo;
-    place[i] = at;
-    out_keys[at] = key;
-    out_lens[at] = lens ? lens[i] : (uint8_t)len_all;
-    out_cnt[at] = (u32)(val_off[i + 1] - val_off[i]);
+    while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (other[mid] < first) lo = mid + 1; else hi = mid; }
+    lo_out[t] = lo;
+    hi = n_other;
+    u64 l2 = lo;
+    while (l2 < hi) { const u64 mid = (l2 + hi) >> 1; if (other[mid] <= last) l2 = mid + 1; else hi = mid; }
+    hi_out[t] = l2;
 }
+template <bool FROM_X>
+__global__ __launch_bounds__(256) void il_place_tiled_kernel(const u64 *__restrict__ keys, const uint8_t *__restrict__ lens, int len_all,
+                                                             const u64 *__restrict__ val_off, u64 n, const u64 *__restrict__ other,
+                                                             const u64 *__restrict__ t_lo, const u64 *__restrict__ t_hi,
+                                                             u64 *__restrict__ out_keys, uint8_t *__restrict__ out_lens,
+                                                             u32 *__restrict__ out_cnt, u64 *__restrict__ place) {
+    __shared__ u64 s_other[ILP_CAP];
+    const u64 olo = t_lo[blockIdx.x], ohi = t_hi[blockIdx.x];
+    const u32 span = (u32)(ohi - olo <= ILP_CAP ? ohi - olo : 0);
+    const bool in_lds = ohi - olo <= ILP_CAP;
+    for (u32 i = threadIdx.x; i < span; i += 256) s_other[i] = other[olo + i];
+    __syncthreads();
+    const u64 i0 = (u64)blockIdx.x * ILP_TILE;
+#pragma unroll
+    for (int r = 0; r < ILP_TILE / 256; r++) {
+        const u64 i = i0 + r * 256 + threadIdx.x;
+        if (i >= n) break;
+        const u64 key = keys[i];
+        u64 lo;
+        if (in_lds) {
+            u32 a = 0, b = span;
+            while (a < b) {
+                const u32 mid = (a + b) >> 1;
+                const u64 o = s_other[mid];
+                if (FROM_X ? o < key : o <= key) a = mid + 1; else b = mid;
+            }
+            lo = olo + a;
+        } else {
+            u64 a = olo, b = ohi;
+            while (a < b) {
+                const u64 mid = (a + b) >> 1;
+                const u64 o = other[mid];
+                if (FROM_X ? o < key : o <= key) a = mid + 1; else b = mid;
+            }
+            lo = a;
+        }
+        const u64 at = i + lo;
+        place[i] = at;
+        out_keys[at] = key;
+        out_lens[at] = lens ? lens[i] : (uint8_t)len_all;
+        out_cnt[at] = (u32)(val_off[i + 1] - val_off[i]);
+    }
+}
+
 // the values of every entry to their place in the interleaved value arrays.  A block takes 256 consecutive entries: their
 // values are one contiguous piece of the source, walked by all lanes side by side (coalesced reads, and writes that
 // only break where an entry of the other database goes in between); the entry a value belongs to is found by a binary

@@ -815,12 +815,23 @@ static int interleave_dbs(kmg_ctx *ctx, kmg_db *X, kmg_db *Y, kmg_db *out) {
     KMG_ALLOC(px, (X->U + 1) * 8);
     KMG_ALLOC(py, (Y->U + 1) * 8);
     KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
-    if (X->U)
-        hipLaunchKernelGGL((il_place_kernel<true>), dim3(div_up_u64(X->U, 256)), dim3(256), 0, ctx->stream, X->keys, X->lens, X->k,
-                           X->val_off, X->U, Y->keys, Y->U, out->keys, out->lens, cnt.as<u32>(), px.as<u64>());
-    if (Y->U)
-        hipLaunchKernelGGL((il_place_kernel<false>), dim3(div_up_u64(Y->U, 256)), dim3(256), 0, ctx->stream, Y->keys, Y->lens, Y->k,
-                           Y->val_off, Y->U, X->keys, X->U, out->keys, out->lens, cnt.as<u32>(), py.as<u64>());
+    // (tile-wise: the piece of the other side a tile can land in is found first and searched in LDS)
+    PoolBuf blo(ctx), bhi(ctx);
+    const u64 xt = div_up_u64(X->U, ILP_TILE), yt = div_up_u64(Y->U, ILP_TILE);
+    KMG_ALLOC(blo, (std::max(xt, yt) + 1) * 8);
+    KMG_ALLOC(bhi, (std::max(xt, yt) + 1) * 8);
+    if (X->U) {
+        hipLaunchKernelGGL(il_bounds_kernel, dim3(div_up_u64(xt, 256)), dim3(256), 0, ctx->stream, X->keys, X->U, Y->keys, Y->U,
+                           blo.as<u64>(), bhi.as<u64>());
+        hipLaunchKernelGGL((il_place_tiled_kernel<true>), dim3(xt), dim3(256), 0, ctx->stream, X->keys, X->lens, X->k, X->val_off, X->U,
+                           Y->keys, blo.as<u64>(), bhi.as<u64>(), out->keys, out->lens, cnt.as<u32>(), px.as<u64>());
+    }
+    if (Y->U) {
+        hipLaunchKernelGGL(il_bounds_kernel, dim3(div_up_u64(yt, 256)), dim3(256), 0, ctx->stream, Y->keys, Y->U, X->keys, X->U,
+                           blo.as<u64>(), bhi.as<u64>());
+        hipLaunchKernelGGL((il_place_tiled_kernel<false>), dim3(yt), dim3(256), 0, ctx->stream, Y->keys, Y->lens, Y->k, Y->val_off, Y->U,
+                           X->keys, blo.as<u64>(), bhi.as<u64>(), out->keys, out->lens, cnt.as<u32>(), py.as<u64>());
+    }
     if (U)
         KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, cnt.as<u32>(), out->val_off, U, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
                                                     KP_SCAN)));
