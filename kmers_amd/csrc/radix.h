@@ -23,11 +23,12 @@
 // the same digit and `total` = number of such lanes in the whole wave.  Per digit bit: the bit sign-extended
 // to a 0 / ~0 word B (one v_bfe_i32), its ballot, and "keep the lanes whose bit equals mine" folded into the
 // running mask as m & ~(ballot ^ B) (one three-input bit-op per half).
+template <int BITS = RS_BITS>
 __device__ __forceinline__ void wave_match(u32 d, bool valid, u32 &below, u32 &total) {
     const u64 v = __ballot(valid);
     u32 mlo = (u32)v, mhi = (u32)(v >> 32);
 #pragma unroll
-    for (int b = 0; b < RS_BITS; b++) {
+    for (int b = 0; b < BITS; b++) {
         int B = ((int)(d << (31 - b))) >> 31;
         asm("" : "+v"(B));                     // keep B a value of its own: the ballot is one compare of it
         const u64 bal = __ballot(B != 0);
