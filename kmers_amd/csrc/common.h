@@ -136,6 +136,8 @@ enum {
     ST_HAVE_CARRY,    // 0 until some read has produced a k-mer
     ST_ID_OR,         // OR / AND of every (taxon ^ 0x80000000): constant value bits skip sort passes
     ST_ID_AND,
+    ST_ID_MIN,        // smallest / largest (taxon ^ 0x80000000) of the sequences handed over: bounds of the database's taxa
+    ST_ID_MAX,
     ST_DUP_READS,     // 1 once two sequences shared a read index (equal neighbouring headers)
     ST_TMP0,          // scratch totals written by scans
     ST_TMP1,
@@ -202,6 +204,8 @@ struct kmg_db {
     int k = 0, key_len = 0, rc = 0, kind = 0;
     int min_k = 0;              // shortest k-mer (== k: every k-mer has k bases and lens is null)
     uint8_t *lens = nullptr;    // U: length of every k-mer of a variable-length database, ascending inside equal keys
+    bool tax_bounds = false;    // taxon databases: every taxon lies in [tax_lo, tax_hi] (known from the build's sequence ids)
+    int32_t tax_lo = 0, tax_hi = 0;
     u64 U = 0, V = 0;
     u64 *keys = nullptr;        // U; zero-padded to k bases: (keys, lens) ascending == Sequence.compareTo order
     u64 *val_off = nullptr;     // U + 1

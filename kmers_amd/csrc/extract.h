@@ -342,20 +342,27 @@ __global__ __launch_bounds__(256) void sum_u32_kernel(const u32 *__restrict__ in
 
 // OR / AND of (taxon ^ sign bit) over a batch: value bits that never vary need no sort pass.
 __global__ void id_bits_kernel(const int32_t *__restrict__ ids, u64 n, u64 *state) {
-    u32 o = 0, an = 0xFFFFFFFFu;
+    u32 o = 0, an = 0xFFFFFFFFu, mn = 0xFFFFFFFFu, mx = 0;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
         u32 v = (u32)ids[i] ^ 0x80000000u;
         o |= v;
         an &= v;
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         o |= __shfl_down(o, d, 64);
         an &= __shfl_down(an, d, 64);
+        const u32 omn = __shfl_down(mn, d, 64), omx = __shfl_down(mx, d, 64);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
     }
     if ((threadIdx.x & 63) == 0) {
         atomicOr(&state[ST_ID_OR], (u64)o);
         atomicAnd(&state[ST_ID_AND], (u64)an);
+        atomicMin((unsigned long long *)&state[ST_ID_MIN], (unsigned long long)mn);
+        atomicMax((unsigned long long *)&state[ST_ID_MAX], (unsigned long long)mx);
     }
 }
 

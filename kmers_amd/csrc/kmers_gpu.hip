@@ -121,6 +121,7 @@ extern "C" int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int pay
     // stream-ordered, no host round trip
     KMG_HIP(hipMemsetAsync(ctx->d_state, 0, ST_WORDS * sizeof(u64), ctx->stream));
     hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state + ST_ID_AND, (u64)0xFFFFFFFFull);
+    hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state + ST_ID_MIN, (u64)0xFFFFFFFFull);
     KMG_HIP(hipGetLastError());
     ctx->building = true;
     return KMG_OK;
@@ -1025,6 +1026,12 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     ctx->sh_keys = nullptr; ctx->sh_vals = nullptr; ctx->sh_len = nullptr; ctx->sh_n = 0; ctx->sh_cap = 0;
     if (r != KMG_OK) return r;
     db = db_guard.get();
+    if (!reads && st[ST_ID_MIN] <= st[ST_ID_MAX]) {
+        // every taxon of the database is some sequence's id: TaxaCounts need not look for the span
+        db->tax_bounds = true;
+        db->tax_lo = (int32_t)((u32)st[ST_ID_MIN] ^ 0x80000000u);
+        db->tax_hi = (int32_t)((u32)st[ST_ID_MAX] ^ 0x80000000u);
+    }
     if (ctx->prof_on)
     {
         ctx->prof[KP_REDUCE_WRITE].bytes += db->U * (heads_done ? (8 + vb) + 16 : 16) + (reads ? 0 : db->V * 8);
@@ -2040,11 +2047,13 @@ extern "C" int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, in
     PoolBuf mm(ctx), bits(ctx), cnt(ctx), prefix(ctx), agg(ctx), total(ctx), taxa(ctx), cm(ctx), cu(ctx);
     KMG_ALLOC(mm, 64);
     KMG_ALLOC(total, 64);
-    hipLaunchKernelGGL(taxa_minmax_init_kernel, dim3(1), dim3(64), 0, ctx->stream, mm.as<int32_t>());
     const u32 vgrid = std::min<u32>(div_up_u64(V, 1024), 4096);
-    hipLaunchKernelGGL(taxa_minmax_kernel, dim3(vgrid), dim3(256), 0, ctx->stream, db->val_a, V, mm.as<int32_t>());
-    int32_t h_mm[2] = {0, 0};
-    KMG_HIP(read_back(ctx, h_mm, mm.p, 8));
+    int32_t h_mm[2] = {db->tax_lo, db->tax_hi};
+    if (!db->tax_bounds) {                      // (a database built here knows the span of its taxa from the sequence ids)
+        hipLaunchKernelGGL(taxa_minmax_init_kernel, dim3(1), dim3(64), 0, ctx->stream, mm.as<int32_t>());
+        hipLaunchKernelGGL(taxa_minmax_kernel, dim3(vgrid), dim3(256), 0, ctx->stream, db->val_a, V, mm.as<int32_t>());
+        KMG_HIP(read_back(ctx, h_mm, mm.p, 8));
+    }
     const int32_t tmin = h_mm[0];
     const u64 range = (u64)((long long)h_mm[1] - (long long)tmin) + 1;      // <= 2^32
     const u64 nwords = (range + 31) / 32;
