@@ -560,10 +560,16 @@ __device__ __forceinline__ void ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *_
                                                 uint16_t (*wcnt)[RS_DIGITS], uint16_t (*wbase)[RS_DIGITS], u64 *swords, V *svals) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int rounds = ROUNDS;
-    const u32 wave_base = wave * 64 * rounds;
+    // The segment's ceil(m / 64) wave-rounds dealt out evenly: every wave takes ROUNDS - 1 of them, the first `extra`
+    // waves one more -- in slot order, so (wave, round, lane) still reads the records in their order.  A wave without
+    // the last round skips it (wave-uniform): on average half a block-round of all-sentinel work less per pass.
+    const u32 extra = ((m + 63) >> 6) - (ROUNDS - 1) * LS_WAVES;          // 1 .. LS_WAVES
+    const bool last = (u32)wave < extra;
+    const u32 wave_base = 64u * ((u32)wave * (ROUNDS - 1) + ((u32)wave < extra ? (u32)wave : extra));
+#define LS_ACT(j) ((j) < ROUNDS - 1 || last)
 
-    // Slots [m, rounds * 512) hold all-ones sentinels: they sort behind every record (stably, they are
-    // loaded last), so no step below needs a per-lane validity branch.
+    // Slots from m to the end of m's wave-round hold all-ones sentinels: they sort behind every record (stably, they
+    // are loaded last), so no step below needs a per-lane validity branch.
     // (loads at clamped indices, all issued before the first is used: a load under `if (valid)` compiles to a branch
     // with a wait behind it, one memory round trip per round)
     u64 sw[ROUNDS];
@@ -579,7 +585,7 @@ __device__ __forceinline__ void ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *_
 #pragma unroll
     for (int j = 0; j < ROUNDS; j++) {
         const u32 li = wave_base + j * 64 + lane;
-        const bool valid = li < m;
+        const bool valid = li < m && LS_ACT(j);
         sw[j] = valid ? ((sw[j] << pbits) | li) : ~0ull;
         if (valid) svals[li] = vraw[j];
     }
@@ -589,12 +595,13 @@ __device__ __forceinline__ void ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *_
         const u32 mask = (1u << lp.bits[p]) - 1u;
 #pragma unroll
         for (int j = 0; j < ROUNDS; j++) {
+            if (!LS_ACT(j)) continue;
             const u32 d = (u32)(sw[j] >> shift) & mask;
             u32 below, total;
             wave_match(d, true, below, total);
             const u32 before = wcnt[wave][d];
             rank[j] = before + below;
-            if (below == 0) wcnt[wave][d] = before + total;
+            wcnt[wave][d] = before + total;      // every lane of the digit stores the same sum: no branch around the store
         }
         __syncthreads();
         if (wave == 0) {
@@ -626,16 +633,16 @@ __device__ __forceinline__ void ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *_
         u32 pos[ROUNDS];
 #pragma unroll
         for (int j = 0; j < ROUNDS; j++)
-            if (j < rounds) pos[j] = wbase[wave][(u32)(sw[j] >> shift) & mask] + rank[j];
+            if (LS_ACT(j)) pos[j] = wbase[wave][(u32)(sw[j] >> shift) & mask] + rank[j];
 #pragma unroll
         for (int j = 0; j < ROUNDS; j++)
-            if (j < rounds) swords[pos[j]] = sw[j];
+            if (LS_ACT(j)) swords[pos[j]] = sw[j];
         __syncthreads();
         *reinterpret_cast<uint2 *>(&wcnt[wave][4 * lane]) = make_uint2(0, 0);
         if (p + 1 < lp.n) {
 #pragma unroll
             for (int j = 0; j < ROUNDS; j++)
-                if (j < rounds) sw[j] = swords[wave_base + j * 64 + lane];
+                if (LS_ACT(j)) sw[j] = swords[wave_base + j * 64 + lane];
         }
     }
     const u64 seg_prefix = pbits > 0 ? ((u64)blockIdx.x << (64 - pbits)) : 0ull;
@@ -692,6 +699,8 @@ __device__ __forceinline__ void ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *_
     const u32 nheads = __shfl(inc, 63, 64);
     if (tid == 0) ucount[blockIdx.x] = nheads;
 }
+
+#undef LS_ACT
 
 template <typename V, bool HEADS>
 __global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *keys_in, V *vals_in, u64 *__restrict__ keys_out,
