@@ -16,7 +16,7 @@ def main(argv=None):
     prog, rest = argv[0].split(".")[-1], argv[1:]
     ap = argparse.ArgumentParser(prog=prog, add_help=False)
     if prog == "MakeDatabase":
-        for f in "ioKklzrDRPLG":
+        for f in "ioKklzrDRPLGm":
             ap.add_argument("-" + f)
         for f in "aqpZvh":
             ap.add_argument("-" + f, action="store_true")
@@ -25,7 +25,7 @@ def main(argv=None):
         programs.make_database(ctx, a.i, a.o, "a" if a.a else ("p" if a.p else "q"), int(a.K or 32), int(a.k or 24), int(a.l or 6),
                                None if a.Z else int(a.z or 5), a.r, None if a.D is None else int(a.D),
                                None if a.R is None else int(a.R), hr=a.h, passes=int(a.P or 1), limit=a.L,
-                               share=None if a.G is None else tuple(int(x) for x in a.G.split("/")))
+                               share=None if a.G is None else tuple(int(x) for x in a.G.split("/")), id_map_path=a.m)
     elif prog == "Matcher":
         for f in "idozZnLkK":
             ap.add_argument("-" + f)

@@ -12,6 +12,7 @@
 
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -108,7 +109,8 @@ extern "C" {
 
 typedef struct kmh_batch kmh_batch;
 
-// mode 0 = FASTA (KmersFromFileStateChanger.getFAinstance), 1 = FASTQ (getFQinstance).
+// mode 0 = FASTA (KmersFromFileStateChanger.getFAinstance), 1 = FASTQ (getFQinstance), 2 = FASTA whose header ids
+// are kept as strings (tokens + names, as for FASTQ) for kmh_apply_id_map (MakeDatabase -m).
 // k is only used for the no-trailing-newline quirk, FASTA only: when the file ends
 // inside a sequence line right after a base, the reference emits the last k-mer twice; this appends
 // the last k characters as one more sequence with the same id, which yields exactly that extra k-mer
@@ -117,6 +119,8 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
     Batch *b = new Batch();
     int8_t trans[3][256];
     memset(trans, -1, sizeof trans);
+    const bool named = mode == 2;
+    if (named) mode = 0;
     if (mode == 0) {
         trans[S_ID][' '] = S_OTHER; trans[S_ID]['\n'] = S_KMER; trans[S_OTHER]['\n'] = S_KMER;
         trans[S_KMER]['\n'] = S_OTHER; trans[S_OTHER]['>'] = S_ID;
@@ -133,9 +137,11 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
     auto finish_id = [&]() {
         if (id_done) return;
         id_done = true;
-        if (mode == 0) {
+        if (mode == 0 && !named) {
             cur_ok = parse_java_int(data + id_start, id_len, &cur_id) ? 1 : 0;
             if (!cur_ok) cur_id = 0;
+        } else if (named) {
+            cur_tok = intern.intern(data + id_start, id_len, b->names, b->name_off);
         } else {
             cur_tok = intern.intern(data + id_start, id_len, b->names, b->name_off);
             if (id_len == 0) b->empty_header = 1;
@@ -173,7 +179,7 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
                 finish_id();
                 // open a new sequence (pos = 0, KmersFromFile.java:137-139)
                 in_seq = true;
-                if (mode == 0) { b->seq_id.push_back(cur_id); b->id_ok.push_back(cur_ok); }
+                if (mode == 0 && !named) { b->seq_id.push_back(cur_id); b->id_ok.push_back(cur_ok); }
                 else b->seq_tok.push_back(cur_tok);
             }
             i++;
@@ -236,11 +242,53 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
             for (int j = 0; j < k; j++) out[b->nbases + j] = out[from + j];
             b->nbases += (uint64_t)k;
             b->seq_off.push_back(b->nbases);
-            b->seq_id.push_back(b->seq_id.back());
-            b->id_ok.push_back(b->id_ok.back());
+            if (named) b->seq_tok.push_back(b->seq_tok.back());
+            else {
+                b->seq_id.push_back(b->seq_id.back());
+                b->id_ok.push_back(b->id_ok.back());
+            }
         }
     }
     return (kmh_batch *)b;
+}
+
+// MakeDatabase -m (MakeDatabase.java:138-147): `map` = the text of the map file, one "<sequence id>\t<taxon id>" per
+// line (BufferedReader.lines: \n, \r\n or \r end a line; String.split("\t") -> parts[0], Integer.parseInt(parts[1]);
+// a later line replaces an earlier one with the same id, HashMap.put).  For a batch parsed in mode 2 this fills seq_id /
+// id_ok as mode 0 does: id_ok = 0 where the header is not in the map (KmersFromFile.java:46 hands out null there).
+// Returns 0, or the 1-based number of the first line the reference would throw on (no tab, or not an int).
+uint64_t kmh_apply_id_map(kmh_batch *h, const uint8_t *map, uint64_t n) {
+    Batch *b = (Batch *)h;
+    std::unordered_map<std::string, int32_t> ids;
+    uint64_t line = 0, i = 0;
+    while (i < n) {
+        uint64_t e = i;
+        while (e < n && map[e] != '\n' && map[e] != '\r') e++;
+        line++;
+        const uint8_t *t1 = (const uint8_t *)memchr(map + i, '\t', e - i);
+        if (!t1) return line;                              // parts[1]: ArrayIndexOutOfBoundsException
+        const uint8_t *t2 = (const uint8_t *)memchr(t1 + 1, '\t', (map + e) - (t1 + 1));
+        const uint8_t *vend = t2 ? t2 : map + e;
+        int32_t v = 0;
+        if (!parse_java_int(t1 + 1, (size_t)(vend - (t1 + 1)), &v)) return line;   // (an empty parts[1] included)
+        ids[std::string((const char *)map + i, (size_t)(t1 - (map + i)))] = v;
+        i = e;
+        if (i < n) i += (map[i] == '\r' && i + 1 < n && map[i + 1] == '\n') ? 2 : 1;
+    }
+    const size_t ntok = b->name_off.size() - 1, nseq = b->seq_tok.size();
+    std::vector<int32_t> tok_id(ntok, 0);
+    std::vector<uint8_t> tok_ok(ntok, 0);
+    for (size_t t = 0; t < ntok; t++) {
+        auto it = ids.find(b->names.substr(b->name_off[t], b->name_off[t + 1] - b->name_off[t]));
+        if (it != ids.end()) { tok_id[t] = it->second; tok_ok[t] = 1; }
+    }
+    b->seq_id.resize(nseq);
+    b->id_ok.resize(nseq);
+    for (size_t s2 = 0; s2 < nseq; s2++) {
+        b->seq_id[s2] = tok_id[b->seq_tok[s2]];
+        b->id_ok[s2] = tok_ok[b->seq_tok[s2]];
+    }
+    return 0;
 }
 
 void kmh_free(kmh_batch *h) { delete (Batch *)h; }

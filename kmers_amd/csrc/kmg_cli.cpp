@@ -1,18 +1,18 @@
 // kmg_cli.cpp -- native (C++) host side of the hot path: the three reference programs that sit on it, driven
 // through the C ABI of libkmers_gpu.so, plus the on-disk container they read and write.
 //
-//   kmg Database.MakeDatabase -a|-q|-p -i in -o out [-K maxK -k minK] [-l keylen] [-z level | -Z] [-h] [-S maxsize] [-r readmap] [-D n] [-R n] [-L a-b] [-t threads] [-P passes] [-G r/n]
-//   kmg Database.Matcher      -i search.db -d ref.db -o out [-Z x] [-n 0|1|2 [-j]] [-k L -K L] [-L a-b] [-t threads]
+//   kmg Database.MakeDatabase -a|-q|-p -i in -o out [-K maxK -k minK] [-l keylen] [-z level | -Z] [-h] [-S maxsize] [-r readmap] [-m idmap] [-D n] [-R n] [-L a-b] [-t threads] [-P passes] [-G r/n]
+//   kmg Database.Matcher      -i search.db -d ref.db -o out [-Z x] [-n N [-j]] [-k a -K b] [-L a-b] [-t threads]
 //   kmg Utils.TaxaCounts      -d ref.db -o out
 //   kmg Utils.CollectByRead / Utils.ReadClassifier -i in -o out;  kmg Pipeline.ReadCalls -q reads.fq -d ref.db -o calls
 //
 // Mirrors Database/MakeDatabase.java:100-185 (option letters and defaults: -K 32 -k 24 -l 6 -z 5),
-// Database/Matcher.java:60-250 (exact join; -n 1 | 2 for k-mers of one length), Utils/TaxaCounts.java:100-150
+// Database/Matcher.java:60-250 (exact join, the trie search over several lengths, -n N), Utils/TaxaCounts.java:100-150
 // (default mode).  The container is jar IndexedFiles.* (SURVEY.md
 // Appendix A.1-A.3): header | gzip-member blocks | index block | footer; every key's block is its own gzip
 // member, so blocks are deflated / inflated on a thread pool and written in key order
 // (FileCreator.java:385-391 enforces that order with OrderedLatches).  Options outside the GPU path
-// (k > 32, -h with minK < maxK, -m, -N, -x ...) exit with status 3 so that a
+// (k > 32, -h with minK < maxK, TaxaCounts' taxonomy modes -x / -s / -P / -N ...) exit with status 3 so that a
 // wrapper can fall back to the Java program.  Plain C++17 + zlib; no HIP in this file.
 #include <stdint.h>
 #include <stdio.h>
@@ -38,6 +38,7 @@ extern "C" {
 typedef struct kmh_batch kmh_batch;
 kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k);
 void kmh_free(kmh_batch *);
+uint64_t kmh_apply_id_map(kmh_batch *, const uint8_t *map, uint64_t n);
 uint64_t kmh_nseq(const kmh_batch *);
 uint64_t kmh_nbases(const kmh_batch *);
 const uint8_t *kmh_bases(const kmh_batch *);
@@ -756,11 +757,18 @@ int make_database_preprocessed(const Args &a, int k, int min_k, int key_len, int
 kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int key_len, bool filters, int dust, int runofsame,
                         const std::string &read_map, uint64_t *n_reads, uint64_t *nwin, StageClock &clk, int passes = 1,
                         const std::function<void(kmg_db *, size_t, size_t)> &per_pass = nullptr, int share = 0, int shares = 1,
-                        int min_k = 0) {
+                        int min_k = 0, const std::string &id_map = "") {
     if (min_k <= 0) min_k = k;
     const std::string data = read_input(path);
     clk.lap("read input");
-    const std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch(kmh_parse((const uint8_t *)data.data(), data.size(), reads ? 1 : 0, k), kmh_free);
+    // id_map (-m, FASTA only; MakeDatabase.java:138-147): headers are names looked up in the map file, not ints
+    const bool named = !reads && !id_map.empty();
+    const std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch(kmh_parse((const uint8_t *)data.data(), data.size(), reads ? 1 : (named ? 2 : 0), k), kmh_free);
+    if (named) {
+        const std::string map = read_input(id_map);
+        const uint64_t bad = kmh_apply_id_map(batch.get(), (const uint8_t *)map.data(), map.size());
+        if (bad) throw std::runtime_error("line " + std::to_string(bad) + " of the id map is not <sequence id><tab><int>");
+    }
     const kmh_batch *b = batch.get();
     const uint64_t nseq = kmh_nseq(b);
     const uint64_t *off = kmh_seq_off(b);
@@ -779,7 +787,7 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
         const uint8_t *ok = kmh_id_ok(b);
         for (uint64_t s = 0; s < nseq; s++)   // Integer.parseInt throws at the sequence's first k-mer
             if (!ok[s] && off[s + 1] - off[s] >= (uint64_t)min_k)
-                throw std::runtime_error("NumberFormatException: FASTA header of sequence " + std::to_string(s) + " is not an int");
+                throw std::runtime_error("FASTA header of sequence " + std::to_string(s) + (named ? " is not in the id map" : " is not an int"));
     }
     clk.lap("split records (host)");
     std::vector<int32_t> ridx(reads ? nseq : 0);
@@ -837,7 +845,7 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
 int make_database(int argc, char **argv) {
     const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmNPLG", "aqpZvh");
     if (a.has('L') && !a.has('p')) throw std::runtime_error("-L limits the input indexes of a preprocessed file (-p)");
-    for (char c : std::string("mN")) if (a.has(c)) throw Unsupported(std::string("option -") + c + " is not on the GPU path");
+    for (char c : std::string("N")) if (a.has(c)) throw Unsupported(std::string("option -") + c + " is not on the GPU path");
     const int k = a.geti('K', 32), min_k = a.geti('k', 24), key_len = a.geti('l', 6);     // MakeDatabase.java:106-109
     const int level = a.has('Z') ? -1 : a.geti('z', 5);
     g_threads = std::max(1, a.geti('t', g_threads));
@@ -875,7 +883,8 @@ int make_database(int argc, char **argv) {
         w.add(part, lo, hi);
     };
     kmg_db *db = build_from_text(g, a.get('i'), reads, k, key_len, a.has('D') || a.has('R'), a.geti('D', -1), a.geti('R', -1),
-                                 reads && share == 0 ? a.get('r') : "", nullptr, &nwin, clk, passes, emit, share, shares, min_k);
+                                 reads && share == 0 ? a.get('r') : "", nullptr, &nwin, clk, passes, emit, share, shares, min_k,
+                                 a.has('m') && !reads ? a.get('m') : "");
     if (db) {
         emit(db, 0, (size_t)1 << (2 * key_len));
         kmg_db_free(db);

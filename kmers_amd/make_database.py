@@ -24,16 +24,17 @@ def _check_eof(pf, mode, k, min_k):
                             "on the GPU path for FASTQ input or with minK < maxK")
 
 
-def make_reference_db(ctx, fasta, k=32, key_length=6, dust=None, runofsame=None, key_range=None, min_k=None):
-    """MakeDatabase -a -K k -k min_k -l key_length [-D dust] [-R runofsame] (min_k: default k).  -> KmerDatabase
-    fasta: the file's bytes, or what parse.parse made of them (a build in key ranges parses once)."""
+def make_reference_db(ctx, fasta, k=32, key_length=6, dust=None, runofsame=None, key_range=None, min_k=None, id_map=None):
+    """MakeDatabase -a -K k -k min_k -l key_length [-D dust] [-R runofsame] [-m id_map] (min_k: default k).  -> KmerDatabase
+    fasta: the file's bytes, or what parse.parse made of them (a build in key ranges parses once).
+    id_map: the bytes of the -m file (sequence id <tab> taxon id); headers are then names, not ints."""
     min_k = k if min_k is None else min_k
-    pf = fasta if isinstance(fasta, parse.ParsedFile) else parse.parse(fasta, parse.FASTA, k)
+    pf = fasta if isinstance(fasta, parse.ParsedFile) else parse.parse(fasta, parse.FASTA, k, id_map=id_map)
     _check_eof(pf, parse.FASTA, k, min_k)
     lens = np.diff(pf.batch.seq_off.astype(np.int64))
     bad = np.nonzero((pf.id_ok == 0) & (lens >= min_k))[0]
-    if bad.size:   # Integer.parseInt throws NumberFormatException at the sequence's first k-mer
-        raise ValueError("NumberFormatException: FASTA header of sequence %d is not an int" % int(bad[0]))
+    if bad.size:   # Integer.parseInt throws NumberFormatException at the sequence's first k-mer (with -m: map.get is null)
+        raise ValueError("FASTA header of sequence %d is not %s" % (int(bad[0]), "in the id map" if pf.named else "an int"))
     fc = FileCreator(ctx, key_length, k, "ref", rc=True, dust=dust, runofsame=runofsame, key_range=key_range)
     fc.add_kmers(pf.batch, min_length=min_k, max_length=k)
     db = fc.create()

@@ -26,6 +26,8 @@ def _load():
         lib.kmh_parse.argtypes = [C.c_char_p, u64, C.c_int, C.c_int]
         lib.kmh_free.argtypes = [vp]
         lib.kmh_free.restype = None
+        lib.kmh_apply_id_map.restype = u64
+        lib.kmh_apply_id_map.argtypes = [vp, C.c_char_p, u64]
         for n in ("nseq", "nbases", "ntok"):
             f = getattr(lib, "kmh_" + n)
             f.restype, f.argtypes = u64, [vp]
@@ -65,8 +67,9 @@ def maybe_gunzip(data: bytes) -> bytes:
 
 
 class ParsedFile:
-    def __init__(self, batch, names, id_ok, eof_in_kmer, high_bytes=0, empty_header=0):
+    def __init__(self, batch, names, id_ok, eof_in_kmer, high_bytes=0, empty_header=0, named=False):
         self.batch = batch
+        self.named = named            # FASTA: headers were looked up in an id map (-m), not read as ints
         self.names = names            # FASTQ: header string of every token
         self.id_ok = id_ok            # FASTA: header parsed as a Java int
         self.eof_in_kmer = eof_in_kmer
@@ -74,18 +77,26 @@ class ParsedFile:
         self.high_bytes = high_bytes  # a sequence line held a byte >= 128 (Sequence.java:15-33 reads those differently)
 
 
-def parse(data: bytes, mode: int, k: int) -> ParsedFile:
+def parse(data: bytes, mode: int, k: int, id_map: bytes = None) -> ParsedFile:
+    """id_map (FASTA only): the text of MakeDatabase's -m file, "<sequence id>\\t<taxon id>" per line
+    (MakeDatabase.java:138-147); headers are looked up in it instead of being read as ints."""
     lib = _load()
     data = maybe_gunzip(data)
-    h = lib.kmh_parse(data, len(data), mode, k)
+    h = lib.kmh_parse(data, len(data), 2 if (mode == FASTA and id_map is not None) else mode, k)
     try:
+        if mode == FASTA and id_map is not None:
+            id_map = maybe_gunzip(id_map)
+            bad = lib.kmh_apply_id_map(h, id_map, len(id_map))
+            if bad:
+                raise ValueError("line %d of the id map is not <sequence id><tab><int>" % bad)
         nseq, nb = lib.kmh_nseq(h), lib.kmh_nbases(h)
         bases = _arr(lib.kmh_bases(h), nb, np.uint8)
         off = _arr(lib.kmh_seq_off(h), nseq + 1, np.uint64)
         if mode == FASTA:
             ids = _arr(lib.kmh_seq_id(h), nseq, np.int32)
             ok = _arr(lib.kmh_id_ok(h), nseq, np.uint8)
-            return ParsedFile(SequenceBatch(bases, off, seq_id=ids), None, ok, lib.kmh_eof_in_kmer(h), lib.kmh_high_bytes(h))
+            return ParsedFile(SequenceBatch(bases, off, seq_id=ids), None, ok, lib.kmh_eof_in_kmer(h), lib.kmh_high_bytes(h),
+                              named=id_map is not None)
         tok = _arr(lib.kmh_seq_tok(h), nseq, np.int64)
         nt = lib.kmh_ntok(h)
         noff = _arr(lib.kmh_name_off(h), nt + 1, np.uint64)

@@ -202,7 +202,7 @@ def read_preprocessed(path, packed=False, limit=None):
 
 
 def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length=6, zip_level=5, read_map_path=None,
-                  dust=None, runofsame=None, hr=False, passes=1, limit=None, share=None):
+                  dust=None, runofsame=None, hr=False, passes=1, limit=None, share=None, id_map_path=None):
     """MakeDatabase -a (mode 'a') / -q (mode 'q') / -p (mode 'p', preprocessed input).  Defaults as the reference's
     (-K 32 -k 24 -l 6 -z 5, MakeDatabase.java:106-109); min_k < k builds k-mers of every length min_k .. k.
     passes > 1 (-P, no counterpart in the reference; modes 'a' and 'q'): the database is built and written in that many
@@ -214,11 +214,14 @@ def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length
         raise ValueError("-k (shortest k-mer) above -K (longest)")
     if hr and min_k != k:
         raise KmersGpuError(KMG_EUNSUPPORTED, "human-readable databases (-h) hold k-mers of one length on the GPU path")
+    # -m (with -a only, MakeDatabase.java:136-147): sequence id -> taxon id, tab separated, gzip or plain (ZipOrNot)
+    id_map = open(id_map_path, "rb").read() if (id_map_path is not None and mode == "a") else None
     if (passes > 1 or share is not None) and mode in ("a", "q"):
         from . import parse
         if mode == "q" and read_map_path is None:
             raise ValueError("-r <read map file> is required with -q")
-        pf = parse.parse(open(input_path, "rb").read(), parse.FASTA if mode == "a" else parse.FASTQ, k)
+        pf = parse.parse(open(input_path, "rb").read(), parse.FASTA if mode == "a" else parse.FASTQ, k,
+                         id_map=id_map if mode == "a" else None)
         nkeys = 4 ** key_length
         r, n = share if share is not None else (0, 1)
         r_lo, r_hi = nkeys * r // n, nkeys * (r + 1) // n
@@ -258,7 +261,7 @@ def make_database(ctx, input_path, output_path, mode, k=32, min_k=24, key_length
         return db
     data = open(input_path, "rb").read()
     if mode == "a":
-        db = make_reference_db(ctx, data, k, key_length, dust, runofsame, min_k=min_k)
+        db = make_reference_db(ctx, data, k, key_length, dust, runofsame, min_k=min_k, id_map=id_map)
     elif mode == "q":
         if read_map_path is None:      # new File(null) -> NullPointerException in the reference (:172-173)
             raise ValueError("-r <read map file> is required with -q")

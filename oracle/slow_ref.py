@@ -1153,11 +1153,32 @@ def filter_stream(kwds, dust=None, runofsame=None):
 
 
 # --------------------------------------------------------------------- convenience pipelines
-def build_ref_db(fasta_bytes, k, key_length, min_k=None, rc=True, dust=None, runofsame=None):
-    """MakeDatabase -a (MakeDatabase.java:127-163): FASTA -> reference DB blocks."""
+def read_id_map(text):
+    """MakeDatabase -m (MakeDatabase.java:140-145): br.lines().forEach(line -> { parts = line.split("\\t");
+    map.put(parts[0], Integer.parseInt(parts[1])); }).  `text`: the file's bytes (already gunzipped)."""
+    import re
+    lines = re.split("\r\n|\n|\r", text.decode("latin-1"))
+    if lines and lines[-1] == "":
+        lines.pop()                                # BufferedReader.lines: no empty line after the last terminator
+    m = {}
+    for line in lines:
+        parts = line.split("\t")
+        while parts and parts[-1] == "":           # String.split drops trailing empty strings
+            parts.pop()
+        v = parts[1]                               # IndexError ~ ArrayIndexOutOfBoundsException
+        if not re.fullmatch("[+-]?[0-9]+", v) or not -2 ** 31 <= int(v) < 2 ** 31:
+            raise ValueError("NumberFormatException: " + v)
+        m[parts[0]] = int(v)
+    return m
+
+
+def build_ref_db(fasta_bytes, k, key_length, min_k=None, rc=True, dust=None, runofsame=None, id_map=None):
+    """MakeDatabase -a (MakeDatabase.java:127-163): FASTA -> reference DB blocks.  id_map: the dict of -m
+    (KmersFromFile.java:44-47: the mapper is map.get(header id) instead of Integer.parseInt)."""
     min_k = k if min_k is None else min_k
     fc = FileCreator(key_length, "ref", rc)
-    kw = kmers_from_file(fasta_bytes, fa_state_changer(), min_k, k, fa_to_refdb_mapper)
+    mapper = fa_to_refdb_mapper if id_map is None else (lambda id_str, pos: id_map[id_str])   # KeyError ~ the null's NPE
+    kw = kmers_from_file(fasta_bytes, fa_state_changer(), min_k, k, mapper)
     fc.add_kmers(filter_stream(kw, dust, runofsame), min_k, k)
     return fc.create()
 

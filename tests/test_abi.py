@@ -58,7 +58,7 @@ def test_native_cli_builds_and_refuses_what_is_off_the_gpu_path():
     assert run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y", "-h").returncode == 3    # -h with minK < maxK
     r = run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y", "-K", "20", "-k", "24")
     assert r.returncode == 1 and "above" in r.stderr
-    assert run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y", "-K", "31", "-k", "31", "-m", "5").returncode == 3
+    assert run("Database.MakeDatabase", "-a", "-i", "x", "-o", "y", "-K", "31", "-k", "31", "-m", "5").returncode == 1   # -m is on the path: missing input
     assert run("Database.Matcher", "-i", "a", "-d", "b", "-o", "c", "-n", "3").returncode == 1          # any -n runs on the GPU: missing input
     assert run("Database.Matcher", "-i", "a", "-d", "b", "-o", "c", "-x", "t").returncode == 3          # taxonomy: Java path
     r = run("Database.MakeDatabase", "-a", "-q", "-i", "x", "-o", "y", "-K", "31", "-k", "31")

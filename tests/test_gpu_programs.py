@@ -635,3 +635,62 @@ def test_counts_saturate_at_255_when_written_and_add_when_merged(tmp_path):
             km.make_read_db(c2, b"@r1\nACGTACGT\n+\nIIIIIIII\n@r2\nACGTAC", 4, 2)
         finally:
             c2.close()
+
+
+def test_sequence_id_to_taxon_map(tmp_path):
+    """MakeDatabase -a -m map (MakeDatabase.java:138-147, KmersFromFile.java:44-47): FASTA headers are names looked up in
+    a tab-separated map file (gzip or plain) instead of ints.  Both drivers' files equal the literal restatement's byte
+    for byte; a name that is not in the map, or a map line without an int, ends the run (status 1)."""
+    import subprocess
+    import kmers_amd as km
+    from kmers_amd import synth
+    from kmers_amd.__main__ import main as cli
+    from oracle import slow_ref as R
+    kmg = os.path.join(os.path.dirname(km.__file__), "kmg")
+    taxa, genomes = synth.random_genomes(171, 7, 1500, first_taxon=50, shared_frac=0.3)
+    genomes = [g if isinstance(g, bytes) else bytes(np.asarray(g, np.uint8).tobytes()) for g in genomes]
+    names = ["NC_%06d.%d" % (1000 + 7 * i, i % 3) for i in range(len(genomes))]
+    fa_b = b"".join(b">" + nm.encode() + (b" some description %d" % i if i % 2 else b"") + b"\n" + g + b"\n"
+                    for i, (nm, g) in enumerate(zip(names, genomes)))
+    fa_b += b">short\nACGT\n"                                       # not in the map, and too short to hand out a k-mer
+    # two names share a taxon; one line is replaced by a later one; \r\n and a third column are fine
+    tax = [int(t) for t in taxa]
+    tax[3] = tax[2]
+    map_b = b"".join(b"%s\t%d%s" % (nm.encode(), (999 if i == 4 else t), (b"\textra\r\n" if i % 2 else b"\n"))
+                     for i, (nm, t) in enumerate(zip(names, tax)))
+    map_b += b"%s\t%d\n" % (names[4].encode(), tax[4]) + b"unused\t-5\n"
+    fa, mp, mpz = str(tmp_path / "ref.fa"), str(tmp_path / "ids.tsv"), str(tmp_path / "ids.tsv.gz")
+    open(fa, "wb").write(fa_b)
+    open(mp, "wb").write(map_b)
+    open(mpz, "wb").write(gzip.compress(map_b))
+    k, mk, l = 28, 25, 4
+    id_map = R.read_id_map(map_b)
+    assert id_map[names[4]] == tax[4] and id_map["unused"] == -5 and len(id_map) == len(names) + 1
+    want = str(tmp_path / "want.db")
+    R.write_indexed_file(want, R.build_ref_db(fa_b, k, l, min_k=mk, id_map=id_map), None)
+    as_ints = b"".join(b">%d\n" % t + g + b"\n" for t, g in zip(tax, genomes))
+    R.write_indexed_file(str(tmp_path / "ints.db"), R.build_ref_db(as_ints, k, l, min_k=mk), None)
+    assert open(want, "rb").read() == open(str(tmp_path / "ints.db"), "rb").read()
+    run = lambda *a: subprocess.run([kmg] + list(a), capture_output=True, text=True, timeout=120)
+    common = ["-K", str(k), "-k", str(mk), "-l", str(l), "-Z"]
+    for tag, drv in (("kmg", lambda *a: run(*a).returncode), ("py", lambda *a: cli(list(a)))):
+        for m in (mp, mpz):
+            out = str(tmp_path / ("ref.%s.db" % tag))
+            assert drv("Database.MakeDatabase", "-a", "-i", fa, "-o", out, "-m", m, *common) == 0
+            assert open(out, "rb").read() == open(want, "rb").read()
+        # in key ranges (-P) the same file
+        assert drv("Database.MakeDatabase", "-a", "-i", fa, "-o", out + ".p", "-m", mp, "-P", "3", *common) == 0
+        assert open(out + ".p", "rb").read() == open(want, "rb").read()
+    # a sequence that hands out k-mers under a name the map does not hold; a map line without an int
+    bad_fa, bad_map = str(tmp_path / "bad.fa"), str(tmp_path / "bad.tsv")
+    open(bad_fa, "wb").write(fa_b + b">missing\n" + genomes[0][:200] + b"\n")
+    open(bad_map, "wb").write(map_b + b"name only\n")
+    for f, m in ((bad_fa, mp), (fa, bad_map)):
+        r = run("Database.MakeDatabase", "-a", "-i", f, "-o", str(tmp_path / "x.db"), "-m", m, *common)
+        assert r.returncode == 1, r.stderr
+        with pytest.raises(ValueError):
+            cli(["Database.MakeDatabase", "-a", "-i", f, "-o", str(tmp_path / "y.db"), "-m", m] + common)
+    with pytest.raises((KeyError, IndexError)):
+        R.build_ref_db(open(bad_fa, "rb").read(), k, l, min_k=mk, id_map=id_map)
+    with pytest.raises(IndexError):
+        R.read_id_map(open(bad_map, "rb").read())

@@ -87,3 +87,39 @@ def test_gzip_input_is_sniffed():
     a = parse.parse(gzip.compress(fa), parse.FASTA, 4)
     b = parse.parse(fa, parse.FASTA, 4)
     assert np.array_equal(a.batch.bases, b.batch.bases) and np.array_equal(a.batch.seq_off, b.batch.seq_off)
+
+
+CASES_NAMED = [
+    (b">chr1\nACGTNACGTA\n", b"chr1\t7\n"),
+    (b">chr1 the first\nACGTA",  b"chr1\t7"),                                     # neither file ends with a newline
+    (b">a|b\nACGTA\nCCCCC\nGGGGG\n>c\nTTTTTT\n", b"a|b\t-4\r\nc\t12\textra\r\nc\t13\n"),   # \r\n, third column, a line replaced
+    (b"\n>x\nacgtacgt\n>y\n\n>x\nAC GT\tACG\n", b"y\t1\rx\t2\r"),                 # \r alone ends a line; an id used twice
+    (b">9\nACGTACGTAC\n>10\nAC\n", b"9\t100\n"),                                  # 10 is not in the map but hands out nothing
+]
+
+
+@pytest.mark.parametrize("fa,idmap", CASES_NAMED)
+@pytest.mark.parametrize("k", [3, 5])
+def test_fasta_with_id_map_matches_oracle(fa, idmap, k):
+    """MakeDatabase -m (MakeDatabase.java:138-147): headers looked up in a map file instead of read as ints."""
+    m = R.read_id_map(idmap)
+    want = [(str(km), d) for km, d in R.kmers_from_file(fa, R.fa_state_changer(), k, k, lambda s, i: m[s])]
+    pf = parse.parse(fa, parse.FASTA, k, id_map=idmap)
+    assert pf.named
+    got, _ = windows_from_batch(pf.batch, k, False)
+    assert got == want
+    lens = np.diff(pf.batch.seq_off.astype(np.int64))
+    assert not np.any((pf.id_ok == 0) & (lens >= k))
+
+
+@pytest.mark.parametrize("idmap", [b"a\n", b"a\t\n", b"a\t1\n\nb\t2\n", b"a\t1x\n", b"a\t99999999999\n", b"a 1\n"])
+def test_id_map_lines_the_reference_throws_on(idmap):
+    with pytest.raises((IndexError, ValueError)):
+        R.read_id_map(idmap)
+    with pytest.raises(ValueError):
+        parse.parse(b">a\nACGT\n", parse.FASTA, 3, id_map=idmap)
+
+
+def test_id_map_missing_name_is_flagged():
+    pf = parse.parse(b">a\nACGTAC\n>b\nACGTAC\n", parse.FASTA, 3, id_map=b"a\t1\n")
+    assert pf.id_ok.tolist() == [1, 0]
