@@ -27,6 +27,7 @@ struct Batch {
     std::vector<int64_t> seq_tok;    // FASTQ: token of the header string (equal <=> equal strings)
     std::vector<uint64_t> name_off;  // token t's header = names[name_off[t] .. name_off[t+1])
     std::string names;
+    bool per_seq_names = false;      // a stream's piece: names / name_off go by sequence, not by token
     int eof_in_kmer = 0;             // file ended inside a sequence line whose last char was a base
     int high_bytes = 0;              // a sequence character >= 128 was seen (see kmh_high_bytes)
     int empty_header = 0;            // FASTQ: a record with an empty header line was seen (see kmh_empty_header)
@@ -109,13 +110,23 @@ extern "C" {
 
 typedef struct kmh_batch kmh_batch;
 
-// mode 0 = FASTA (KmersFromFileStateChanger.getFAinstance), 1 = FASTQ (getFQinstance), 2 = FASTA whose header ids
-// are kept as strings (tokens + names, as for FASTQ) for kmh_apply_id_map (MakeDatabase -m).
-// k is only used for the no-trailing-newline quirk (SURVEY App. C.7), FASTA only: when the file ends
-// inside a sequence line right after a base, the reference emits the last k-mer twice; this appends
-// the last k characters as one more sequence with the same id, which yields exactly that extra k-mer
-// when (and only when) the last window is valid.
-kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
+}  // extern "C"
+
+namespace {
+// What a stream keeps between its pieces (kmh_stream_*): header strings -> tokens over the WHOLE input, so that equal
+// tokens mean equal strings across pieces (read numbering compares a read with the last one that handed out a k-mer).
+struct Stream {
+    int mode = 1;
+    NameTable intern;
+    std::string names;
+    std::vector<uint64_t> name_off{0};
+    std::string carry;           // input from the last header start on that the previous piece left unparsed
+};
+
+// The splitter proper.  Whole input: `st` = NULL, tokens index b->names / b->name_off.  One piece of a stream: tokens come
+// from st's table, b->names / b->name_off hold the header text PER SEQUENCE (name_off has nseq + 1 entries), and unless
+// `final` everything from the last header start on is rolled back and left to the next piece: *consumed = its offset.
+Batch *parse_core(const uint8_t *data, uint64_t n, int mode, int k, Stream *st, bool final, uint64_t *consumed) {
     Batch *b = new Batch();
     int8_t trans[3][256];
     memset(trans, -1, sizeof trans);
@@ -128,8 +139,16 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
         trans[S_OTHER]['@'] = S_ID; trans[S_KMER]['@'] = S_ID; trans[S_ID]['\n'] = S_KMER;
         trans[S_KMER]['+'] = S_OTHER;
     }
-    NameTable intern;
+    NameTable own_table;
+    b->per_seq_names = st != nullptr;
+    NameTable &intern = st ? st->intern : own_table;
+    std::string &tnames = st ? st->names : b->names;
+    std::vector<uint64_t> &tname_off = st ? st->name_off : b->name_off;
     b->name_off.push_back(0);
+    // the last header start and what the batch held then (stream pieces are cut there)
+    uint64_t cut_i = 0, cut_nout = 0;
+    size_t cut_nseq = 0, cut_names = 0;
+    bool cut_in_seq = false, have_cut = false;
     int state = S_OTHER;
     uint64_t id_start = 0, id_len = 0;
     int32_t cur_id = 0; uint8_t cur_ok = 0; int64_t cur_tok = -1;
@@ -141,11 +160,17 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
             cur_ok = parse_java_int(data + id_start, id_len, &cur_id) ? 1 : 0;
             if (!cur_ok) cur_id = 0;
         } else if (named) {
-            cur_tok = intern.intern(data + id_start, id_len, b->names, b->name_off);
+            cur_tok = intern.intern(data + id_start, id_len, tnames, tname_off);
         } else {
-            cur_tok = intern.intern(data + id_start, id_len, b->names, b->name_off);
+            cur_tok = intern.intern(data + id_start, id_len, tnames, tname_off);
             if (id_len == 0) b->empty_header = 1;
         }
+    };
+    // stream pieces: the header text of the sequence being opened, one entry per sequence
+    auto note_name = [&]() {
+        if (!st || (mode == 0 && !named)) return;
+        b->names.append((const char *)data + id_start, id_len);
+        b->name_off.push_back(b->names.size());
     };
     b->seq_off.push_back(0);   // seq_off = [0, end_0, end_1, ...]: a sequence is opened/closed in turn
     // bases are written through a raw pointer into a buffer sized for the whole input (it can only shrink)
@@ -174,9 +199,16 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
             if (state == S_KMER) close_seq_fast();
             state = ns;
             last_was_base = false;
-            if (state == S_ID) { id_start = i + 1; id_len = 0; id_done = false; }
+            if (state == S_ID) {
+                id_start = i + 1; id_len = 0; id_done = false;
+                if (st) {      // (a sequence is closed by now: leaving S_KMER closed it)
+                    have_cut = true; cut_i = i; cut_nout = nout; cut_nseq = b->seq_off.size(); cut_names = b->names.size();
+                    cut_in_seq = in_seq;
+                }
+            }
             else if (state == S_KMER) {
                 finish_id();
+                note_name();
                 // open a new sequence (pos = 0, KmersFromFile.java:137-139)
                 in_seq = true;
                 if (mode == 0 && !named) { b->seq_id.push_back(cur_id); b->id_ok.push_back(cur_ok); }
@@ -227,6 +259,20 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
         }
         i = j;
     }
+    if (st && !final) {
+        // leave the record that was being read to the next piece
+        if (!have_cut) { *consumed = 0; b->seq_off.assign(1, 0); b->seq_id.clear(); b->id_ok.clear(); b->seq_tok.clear();
+                         b->names.clear(); b->name_off.assign(1, 0); b->nbases = 0; return b; }
+        (void)cut_in_seq;
+        b->seq_off.resize(cut_nseq);
+        const size_t ns = cut_nseq - 1;
+        if (mode == 0 && !named) { b->seq_id.resize(ns); b->id_ok.resize(ns); }
+        else { b->seq_tok.resize(ns); b->names.resize(cut_names); b->name_off.resize(ns + 1); }
+        b->nbases = cut_nout;
+        *consumed = cut_i;
+        return b;
+    }
+    if (consumed) *consumed = n;
     b->nbases = nout;
     auto close_seq = [&]() {
         if (in_seq) { b->seq_off.push_back(b->nbases); in_seq = false; }
@@ -242,15 +288,64 @@ kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
             for (int j = 0; j < k; j++) out[b->nbases + j] = out[from + j];
             b->nbases += (uint64_t)k;
             b->seq_off.push_back(b->nbases);
-            if (named) b->seq_tok.push_back(b->seq_tok.back());
-            else {
+            if (named) {
+                b->seq_tok.push_back(b->seq_tok.back());
+                if (st) {
+                    const size_t q = b->name_off.size();
+                    b->names.append(b->names, b->name_off[q - 2], b->name_off[q - 1] - b->name_off[q - 2]);
+                    b->name_off.push_back(b->names.size());
+                }
+            } else {
                 b->seq_id.push_back(b->seq_id.back());
                 b->id_ok.push_back(b->id_ok.back());
             }
         }
     }
+    return b;
+}
+}  // namespace
+
+extern "C" {
+
+// mode 0 = FASTA (KmersFromFileStateChanger.getFAinstance), 1 = FASTQ (getFQinstance), 2 = FASTA whose header ids
+// are kept as strings (tokens + names, as for FASTQ) for kmh_apply_id_map (MakeDatabase -m).
+// k is only used for the no-trailing-newline quirk (SURVEY App. C.7), FASTA only: when the file ends
+// inside a sequence line right after a base, the reference emits the last k-mer twice; this appends
+// the last k characters as one more sequence with the same id, which yields exactly that extra k-mer
+// when (and only when) the last window is valid.
+kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k) {
+    return (kmh_batch *)parse_core(data, n, mode, k, nullptr, true, nullptr);
+}
+
+// The same input in pieces of any size (inputs that should not sit in memory whole, and readers that overlap the file
+// with the GPU): kmh_stream_next parses what the previous piece left plus `data`, up to the last header start it sees
+// (all of it when `final`), and returns the sequences of that part as a batch of their own.  Tokens are equal across
+// pieces iff the header strings are; kmh_name_off / kmh_names of such a batch hold the header text PER SEQUENCE
+// (kmh_nseq + 1 offsets), not per token.  The batches of a stream, one after the other, are the sequences kmh_parse
+// finds in the whole input (tests/test_host_parse.py cuts every case at every size).
+typedef struct kmh_stream kmh_stream;
+kmh_stream *kmh_stream_open(int mode) {
+    Stream *st = new Stream();
+    st->mode = mode;
+    return (kmh_stream *)st;
+}
+void kmh_stream_close(kmh_stream *h) { delete (Stream *)h; }
+kmh_batch *kmh_stream_next(kmh_stream *h, const uint8_t *data, uint64_t n, int final, int k) {
+    Stream *st = (Stream *)h;
+    uint64_t used = 0;
+    Batch *b;
+    if (st->carry.empty()) {
+        b = parse_core(data, n, st->mode, k, st, final != 0, &used);
+        if (!final) st->carry.assign((const char *)data + used, n - used);
+    } else {
+        st->carry.append((const char *)data, n);
+        b = parse_core((const uint8_t *)st->carry.data(), st->carry.size(), st->mode, k, st, final != 0, &used);
+        if (!final) st->carry.erase(0, used); else st->carry.clear();
+    }
     return (kmh_batch *)b;
 }
+// bytes the stream holds back for its next piece (a reader sizes its next read by it)
+uint64_t kmh_stream_pending(const kmh_stream *h) { return ((const Stream *)h)->carry.size(); }
 
 // MakeDatabase -m (MakeDatabase.java:138-147): `map` = the text of the map file, one "<sequence id>\t<taxon id>" per
 // line (BufferedReader.lines: \n, \r\n or \r end a line; String.split("\t") -> parts[0], Integer.parseInt(parts[1]);
@@ -275,7 +370,7 @@ uint64_t kmh_apply_id_map(kmh_batch *h, const uint8_t *map, uint64_t n) {
         i = e;
         if (i < n) i += (map[i] == '\r' && i + 1 < n && map[i + 1] == '\n') ? 2 : 1;
     }
-    const size_t ntok = b->name_off.size() - 1, nseq = b->seq_tok.size();
+    const size_t ntok = b->name_off.size() - 1, nseq = b->seq_tok.size();   // (a stream's piece: one name per sequence)
     std::vector<int32_t> tok_id(ntok, 0);
     std::vector<uint8_t> tok_ok(ntok, 0);
     for (size_t t = 0; t < ntok; t++) {
@@ -285,8 +380,9 @@ uint64_t kmh_apply_id_map(kmh_batch *h, const uint8_t *map, uint64_t n) {
     b->seq_id.resize(nseq);
     b->id_ok.resize(nseq);
     for (size_t s2 = 0; s2 < nseq; s2++) {
-        b->seq_id[s2] = tok_id[b->seq_tok[s2]];
-        b->id_ok[s2] = tok_ok[b->seq_tok[s2]];
+        const size_t t = b->per_seq_names ? s2 : (size_t)b->seq_tok[s2];
+        b->seq_id[s2] = tok_id[t];
+        b->id_ok[s2] = tok_ok[t];
     }
     return 0;
 }

@@ -23,9 +23,12 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -39,6 +42,10 @@ typedef struct kmh_batch kmh_batch;
 kmh_batch *kmh_parse(const uint8_t *data, uint64_t n, int mode, int k);
 void kmh_free(kmh_batch *);
 uint64_t kmh_apply_id_map(kmh_batch *, const uint8_t *map, uint64_t n);
+typedef struct kmh_stream kmh_stream;
+kmh_stream *kmh_stream_open(int mode);
+void kmh_stream_close(kmh_stream *);
+kmh_batch *kmh_stream_next(kmh_stream *, const uint8_t *data, uint64_t n, int final, int k);
 uint64_t kmh_nseq(const kmh_batch *);
 uint64_t kmh_nbases(const kmh_batch *);
 const uint8_t *kmh_bases(const kmh_batch *);
@@ -1568,16 +1575,84 @@ int read_classifier(int argc, char **argv) {
     return 0;
 }
 
-// Pipeline.ReadCalls -q reads.fq (-d database | -a reference.fa) -o calls [-K k -l key_length -r read_map.gz]
+// Pipeline.ReadCalls -q reads.fq (-d database | -a reference.fa) -o calls [-K k -l key_length -r read_map.gz -C seqs -B bytes]
 // The file the chain MakeDatabase -q | Matcher | CollectByRead | ReadClassifier ends with, byte for byte, without the
 // three files in between: both databases stay on the GPU, the join feeds kmg_classify_reads_hits and only the
 // `read \t call` lines leave.  No counterpart program in the reference.
 int read_calls(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "qdaoKlrtC", "v");
+    const Args a = parse_args(argc, argv, 2, "qdaoKlrtCB", "v");
     if (!a.has('q') || !a.has('o') || a.has('d') == a.has('a'))
         throw std::runtime_error("-q, -o and exactly one of -d (database) / -a (FASTA reference) are required");
     g_threads = std::max(1, a.geti('t', g_threads));
     StageClock clk(a.has('v'));
+    // The reads come in pieces of the file (-B bytes, default 16 MiB): a reader thread inflates and splits piece i + 1
+    // while the GPU builds, joins and classifies piece i, and neither the text nor the sequences of the whole input are
+    // ever in memory.  A call depends on its own read only.  Reads number on across pieces as ReadIDMapping would: the
+    // sequences that share a piece's LAST read index may have more of their kind behind the cut, so they are carried
+    // over and lead the next build -- they hand out k-mers, so the numbering there starts as it would have gone on.
+    // -C n: at most n sequences of a piece per build.
+    const uint64_t piece_bytes = a.has('B') ? std::max<uint64_t>(1, size_from_human(a.get('B'))) : (16ull << 20);
+    // (the reader starts before the GPU context and the database are up -- FASTQ splitting needs neither -- and may run
+    // ahead by 256 MiB of input)
+    const size_t queue_cap = (size_t)std::max<uint64_t>(2, (256ull << 20) / piece_bytes);
+    const uint64_t chunk_seqs = a.has('C') ? (uint64_t)std::max(1, a.geti('C', 1)) : 0;
+    struct Piece { std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch{nullptr, kmh_free}; bool last = false; std::string err; };
+    std::deque<Piece> ready;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool stop = false;
+    std::thread reader([&]() {
+        kmh_stream *st = kmh_stream_open(1);
+        gzFile z = gzopen(a.get('q').c_str(), "rb");
+        auto push = [&](Piece &&p) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return stop || ready.size() < queue_cap; });
+            if (!stop) ready.push_back(std::move(p));
+            cv.notify_all();
+        };
+        if (!z) {
+            Piece p; p.last = true; p.err = "cannot open " + a.get('q');
+            push(std::move(p));
+        } else {
+            gzbuffer(z, 1 << 20);
+            auto fill = [&](std::vector<uint8_t> &buf) {      // up to piece_bytes, grown as the file delivers
+                buf.clear();
+                uint64_t got = 0;
+                while (got < piece_bytes) {
+                    const uint64_t want = std::min<uint64_t>(piece_bytes - got, 16u << 20);
+                    buf.resize(got + want);
+                    const int n = gzread(z, buf.data() + got, (unsigned)want);
+                    if (n <= 0) break;
+                    got += (uint64_t)n;
+                }
+                buf.resize(got);
+            };
+            try {
+                std::vector<uint8_t> cur, nxt;
+                fill(cur);
+                for (;;) {
+                    fill(nxt);                               // (what follows decides whether `cur` is the last piece)
+                    Piece p;
+                    p.last = nxt.empty();
+                    p.batch.reset(kmh_stream_next(st, cur.data(), cur.size(), p.last ? 1 : 0, 0));
+                    const bool last = p.last;
+                    push(std::move(p));
+                    { std::lock_guard<std::mutex> lk(mu); if (stop) break; }
+                    if (last) break;
+                    cur.swap(nxt);
+                }
+            } catch (const std::exception &e) {
+                Piece p; p.last = true; p.err = std::string("reading ") + a.get('q') + ": " + e.what();
+                push(std::move(p));
+            }
+            gzclose(z);
+        }
+        kmh_stream_close(st);
+    });
+    struct StopReader {      // whatever ends the consumer, the reader is told and joined
+        std::thread &t; std::mutex &mu; std::condition_variable &cv; bool &stop;
+        ~StopReader() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); }
+    } stop_reader{reader, mu, cv, stop};
     Gpu g;
     clk.lap("GPU context");
     int k = a.geti('K', 32), key_len = a.geti('l', 6);
@@ -1590,22 +1665,6 @@ int read_calls(int argc, char **argv) {
     } else ref = build_from_text(g, a.get('a'), false, k, key_len, false, -1, -1, "", nullptr, nullptr, clk);
     if (!db_info(ref).rc)   // DB.java:57-64
         throw std::runtime_error("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included");
-    // The reads go through in chunks of sequences (-C n, default: what keeps a chunk's windows inside one build): a
-    // call depends on its own read only.  Reads number on across chunks as ReadIDMapping would: the sequences
-    // that share a chunk's LAST read index may have more of their kind behind the cut, so that index is left to the
-    // next chunk, which starts at its first sequence -- an emitting one, so the numbering there starts as it would
-    // have gone on.
-    const std::string data = read_input(a.get('q'));
-    clk.lap("read input");
-    const std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch(kmh_parse((const uint8_t *)data.data(), data.size(), 1, k), kmh_free);
-    const kmh_batch *b = batch.get();
-    if (kmh_high_bytes(b)) throw Unsupported("sequence lines hold bytes >= 128: not supported on the GPU path");
-    if (kmh_empty_header(b)) throw Unsupported("a FASTQ record with an empty header: not supported on the GPU path");
-    if (kmh_eof_in_kmer(b)) throw Unsupported("input ends inside a sequence line (no final newline): not supported on the GPU path for FASTQ input");
-    const uint64_t nseq = kmh_nseq(b);
-    const uint64_t *off = kmh_seq_off(b);
-    const int64_t *tok = kmh_seq_tok(b);
-    clk.lap("split records (host)");
     gzFile zmap = nullptr;
     if (a.has('r')) {
         zmap = gzopen(a.get('r').c_str(), "wb");
@@ -1613,61 +1672,104 @@ int read_calls(int argc, char **argv) {
     }
     std::vector<int32_t> call;
     std::vector<uint8_t> seen;
-    uint64_t chunk_seqs = a.has('C') ? (uint64_t)std::max(1, a.geti('C', 1)) : 0;
-    uint64_t s0 = 0;
-    while (s0 < nseq) {
-        uint64_t s1;
-        if (chunk_seqs) s1 = std::min(nseq, s0 + chunk_seqs);
-        else {      // as many sequences as hold at most 3 G bases (every base can start a window)
-            s1 = std::upper_bound(off + s0, off + nseq + 1, off[s0] + 3000000000ull) - off - 1;
-            s1 = std::max(s1, s0 + 1);
-        }
-        std::vector<uint64_t> loff(s1 - s0 + 1);
-        for (uint64_t i = 0; i <= s1 - s0; i++) loff[i] = off[s0 + i] - off[s0];
-        std::vector<int32_t> ridx(s1 - s0, -1);
+    // sequences carried over from the build before (those of its last read index)
+    std::vector<uint8_t> left_bases;
+    std::vector<uint64_t> left_off{0};
+    std::vector<int64_t> left_tok;
+    std::vector<std::string> left_names;
+    auto run_build = [&](const kmh_batch *b, uint64_t s0, uint64_t s1, bool last_of_input) {
+        const uint64_t *off = kmh_seq_off(b);
+        const int64_t *tok = kmh_seq_tok(b);
+        const uint64_t *noff = kmh_name_off(b);
+        const char *names = kmh_names(b);
+        const uint64_t nl = left_tok.size(), np = s1 - s0;
+        if (nl + np == 0) return;
+        std::vector<int32_t> ridx(nl + np, -1);
         g.check(kmg_build_begin(g.ctx, k, key_len, 0, KMG_PAYLOAD_READPOS));
-        g.check(kmg_build_add(g.ctx, kmh_bases(b) + off[s0], loff.back(), loff.data(), nullptr, tok + s0, s1 - s0, ridx.data()));
+        if (nl) g.check(kmg_build_add(g.ctx, left_bases.data(), left_bases.size(), left_off.data(), nullptr, left_tok.data(), nl, ridx.data()));
+        std::vector<uint64_t> loff(np + 1);
+        if (np) {
+            for (uint64_t i = 0; i <= np; i++) loff[i] = off[s0 + i] - off[s0];
+            g.check(kmg_build_add(g.ctx, kmh_bases(b) + off[s0], loff.back(), loff.data(), nullptr, tok + s0, np, ridx.data() + nl));
+        }
         kmg_db *reads = nullptr;
         g.check(kmg_build_finish(g.ctx, &reads, nullptr));
         int32_t top = -1;
         for (int32_t r : ridx) top = std::max(top, r);
         const uint64_t n_local = (uint64_t)(top + 1);
-        uint64_t keep = n_local, next = s1;
-        if (s1 < nseq && n_local > 0) {
+        uint64_t keep = n_local, next = nl + np;
+        if (!last_of_input && n_local > 0) {
             keep = n_local - 1;
-            next = s0;
-            while (ridx[next - s0] != top) next++;
-            if (next == s0) {               // one read index fills the whole chunk: take a longer one
-                kmg_db_free(reads);
-                chunk_seqs = (s1 - s0) * 2;
-                continue;
-            }
+            next = 0;
+            while (ridx[next] != top) next++;
         }
-        std::vector<int32_t> c(std::max<uint64_t>(n_local, 1), -1);
-        std::vector<uint8_t> h(std::max<uint64_t>(n_local, 1), 0);
-        g.check(kmg_classify_reads_hits(g.ctx, reads, ref, n_local, c.data(), h.data()));
+        if (keep) {
+            std::vector<int32_t> c(n_local, -1);
+            std::vector<uint8_t> h(n_local, 0);
+            g.check(kmg_classify_reads_hits(g.ctx, reads, ref, n_local, c.data(), h.data()));
+            call.insert(call.end(), c.begin(), c.begin() + keep);
+            seen.insert(seen.end(), h.begin(), h.begin() + keep);
+        }
         kmg_db_free(reads);
-        call.insert(call.end(), c.begin(), c.begin() + keep);
-        seen.insert(seen.end(), h.begin(), h.begin() + keep);
         if (zmap) {
-            const uint64_t *noff = kmh_name_off(b);
-            const char *names = kmh_names(b);
             int32_t last = -1;
-            for (uint64_t s = s0; s < s1; s++) {
-                const int32_t r = ridx[s - s0];
+            for (uint64_t s = 0; s < nl + np; s++) {
+                const int32_t r = ridx[s];
                 if (r >= 0 && r != last && (uint64_t)r < keep) {
-                    gzwrite(zmap, names + noff[tok[s]], (unsigned)(noff[tok[s] + 1] - noff[tok[s]]));
+                    if (s < nl) gzwrite(zmap, left_names[s].data(), (unsigned)left_names[s].size());
+                    else gzwrite(zmap, names + noff[s0 + s - nl], (unsigned)(noff[s0 + s - nl + 1] - noff[s0 + s - nl]));
                     gzwrite(zmap, "\n", 1);
                 }
                 if (r >= 0) last = r;
             }
         }
-        s0 = next;
+        // what is carried over: the combined sequences [next, nl + np)
+        std::vector<uint8_t> nb;
+        std::vector<uint64_t> no{0};
+        std::vector<int64_t> nt;
+        std::vector<std::string> nn;
+        for (uint64_t s = next; s < nl + np; s++) {
+            if (s < nl) {
+                nb.insert(nb.end(), left_bases.begin() + left_off[s], left_bases.begin() + left_off[s + 1]);
+                nt.push_back(left_tok[s]);
+                nn.push_back(left_names[s]);
+            } else {
+                const uint64_t q = s0 + s - nl;
+                nb.insert(nb.end(), kmh_bases(b) + off[q], kmh_bases(b) + off[q + 1]);
+                nt.push_back(tok[q]);
+                nn.emplace_back(names + noff[q], noff[q + 1] - noff[q]);
+            }
+            no.push_back(nb.size());
+        }
+        left_bases.swap(nb); left_off.swap(no); left_tok.swap(nt); left_names.swap(nn);
+    };
+    for (bool done = false; !done;) {
+        Piece p;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !ready.empty(); });
+            p = std::move(ready.front());
+            ready.pop_front();
+        }
+        cv.notify_all();
+        if (!p.err.empty()) throw std::runtime_error(p.err);
+        const kmh_batch *b = p.batch.get();
+        if (kmh_high_bytes(b)) throw Unsupported("sequence lines hold bytes >= 128: not supported on the GPU path");
+        if (kmh_empty_header(b)) throw Unsupported("a FASTQ record with an empty header: not supported on the GPU path");
+        if (p.last && kmh_eof_in_kmer(b)) throw Unsupported("input ends inside a sequence line (no final newline): not supported on the GPU path for FASTQ input");
+        const uint64_t nseq = kmh_nseq(b);
+        const uint64_t step = chunk_seqs ? chunk_seqs : std::max<uint64_t>(nseq, 1);
+        for (uint64_t s0 = 0; s0 < nseq || (s0 == 0 && p.last); s0 += step) {
+            const uint64_t s1 = std::min(nseq, s0 + step);
+            run_build(b, s0, s1, p.last && s1 == nseq);
+            if (nseq == 0) break;
+        }
+        done = p.last;
     }
     if (zmap) gzclose(zmap);
     kmg_db_free(ref);
     const uint64_t n_reads = call.size();
-    clk.lap("build + join + classify (GPU)");
+    clk.lap("read + split (reader thread) alongside build + join + classify (GPU)");
     // one block per (read / 1000) * 1000 that holds a read with a matched k-mer (CollectByRead.java:105-124 writes no
     // other); inside, the reads that have a call (ReadClassifier.java:140-160)
     std::vector<std::pair<int, std::string>> blocks;

@@ -26,6 +26,14 @@ def _load():
         lib.kmh_parse.argtypes = [C.c_char_p, u64, C.c_int, C.c_int]
         lib.kmh_free.argtypes = [vp]
         lib.kmh_free.restype = None
+        lib.kmh_stream_open.restype = vp
+        lib.kmh_stream_open.argtypes = [C.c_int]
+        lib.kmh_stream_close.restype = None
+        lib.kmh_stream_close.argtypes = [vp]
+        lib.kmh_stream_next.restype = vp
+        lib.kmh_stream_next.argtypes = [vp, C.c_char_p, u64, C.c_int, C.c_int]
+        lib.kmh_stream_pending.restype = u64
+        lib.kmh_stream_pending.argtypes = [vp]
         lib.kmh_apply_id_map.restype = u64
         lib.kmh_apply_id_map.argtypes = [vp, C.c_char_p, u64]
         for n in ("nseq", "nbases", "ntok"):
@@ -106,6 +114,42 @@ def parse(data: bytes, mode: int, k: int, id_map: bytes = None) -> ParsedFile:
                           lib.kmh_empty_header(h))
     finally:
         lib.kmh_free(h)
+
+
+def parse_pieces(pieces, mode: int, k: int, id_map: bytes = None):
+    """The input handed over in pieces (kmh_stream_*): yields one ParsedFile per piece, whose sequences, one piece after
+    the other, are those of parse() on the whole input.  FASTQ / named FASTA: .names holds the header of every SEQUENCE of
+    the piece, and tokens are equal across pieces iff the headers are."""
+    lib = _load()
+    named = mode == FASTA and id_map is not None
+    st = lib.kmh_stream_open(2 if named else mode)
+    try:
+        pieces = list(pieces)
+        for i, data in enumerate(pieces):
+            h = lib.kmh_stream_next(st, data, len(data), 1 if i == len(pieces) - 1 else 0, k)
+            try:
+                if named:
+                    bad = lib.kmh_apply_id_map(h, id_map, len(id_map))
+                    if bad:
+                        raise ValueError("line %d of the id map is not <sequence id><tab><int>" % bad)
+                nseq, nb = lib.kmh_nseq(h), lib.kmh_nbases(h)
+                bases = _arr(lib.kmh_bases(h), nb, np.uint8)
+                off = _arr(lib.kmh_seq_off(h), nseq + 1, np.uint64)
+                flags = (lib.kmh_eof_in_kmer(h), lib.kmh_high_bytes(h))
+                if mode == FASTA:
+                    ids = _arr(lib.kmh_seq_id(h), nseq, np.int32)
+                    ok = _arr(lib.kmh_id_ok(h), nseq, np.uint8)
+                    yield ParsedFile(SequenceBatch(bases, off, seq_id=ids), None, ok, *flags, named=named)
+                else:
+                    tok = _arr(lib.kmh_seq_tok(h), nseq, np.int64)
+                    noff = _arr(lib.kmh_name_off(h), nseq + 1, np.uint64)
+                    raw = _arr(lib.kmh_names(h), int(noff[-1]) if nseq else 0, np.uint8).tobytes()
+                    names = [raw[int(noff[j]):int(noff[j + 1])].decode("latin-1") for j in range(nseq)]
+                    yield ParsedFile(SequenceBatch(bases, off, seq_tok=tok), names, None, *flags, lib.kmh_empty_header(h))
+            finally:
+                lib.kmh_free(h)
+    finally:
+        lib.kmh_stream_close(st)
 
 
 def decode_blocks(data: bytes, kind: int, with_lens=False):

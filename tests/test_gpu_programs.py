@@ -206,6 +206,14 @@ def test_native_cli_matches_python_drivers(tmp_path):
         run("Pipeline.ReadCalls", "-q", p("paired.fq"), "-d", p("ref.db"), "-o", p("pc." + c), "-r", p("pc.map.gz"), "-C", c)
         assert open(p("pc." + c), "rb").read() == open(p("pc.whole"), "rb").read(), c
         assert gzip.open(p("pc.map.gz"), "rb").read() == gzip.open(p("pc.whole.map.gz"), "rb").read(), c
+    # the file itself in pieces (-B bytes: a reader thread inflates and splits the next piece while the GPU works on this
+    # one): cut inside headers, sequence and quality lines, with and without -C, gzipped or not -- the same two files
+    open(p("paired.fq.gz"), "wb").write(gzip.compress(open(p("paired.fq"), "rb").read()))
+    for src, b, c in ((p("paired.fq"), "97", None), (p("paired.fq"), "1000", "7"), (p("paired.fq.gz"), "4k", None),
+                      (p("paired.fq.gz"), "37000", "64"), (p("paired.fq"), "1m", None)):
+        run("Pipeline.ReadCalls", "-q", src, "-d", p("ref.db"), "-o", p("pb"), "-r", p("pb.map.gz"), "-B", b, *(["-C", c] if c else []))
+        assert open(p("pb"), "rb").read() == open(p("pc.whole"), "rb").read(), (b, c)
+        assert gzip.open(p("pb.map.gz"), "rb").read() == gzip.open(p("pc.whole.map.gz"), "rb").read(), (b, c)
     open(p("none.fq"), "wb").write(b"@r\nNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN\n+\n" + b"I" * 40 + b"\n")
     run("Pipeline.ReadCalls", "-q", p("none.fq"), "-d", p("ref.db"), "-o", p("calls.none"))
     assert R.read_indexed_file(p("calls.none")) == {}

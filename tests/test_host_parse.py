@@ -123,3 +123,48 @@ def test_id_map_lines_the_reference_throws_on(idmap):
 def test_id_map_missing_name_is_flagged():
     pf = parse.parse(b">a\nACGTAC\n>b\nACGTAC\n", parse.FASTA, 3, id_map=b"a\t1\n")
     assert pf.id_ok.tolist() == [1, 0]
+
+
+def _whole_and_pieces(data, mode, k, size, id_map=None):
+    whole = parse.parse(data, mode, k, id_map=id_map)
+    cuts = [data[i:i + size] for i in range(0, len(data), size)] or [b""]
+    return whole, list(parse.parse_pieces(cuts, mode, k, id_map=id_map))
+
+
+@pytest.mark.parametrize("size", [1, 2, 3, 5, 7, 11, 16, 1000])
+def test_input_in_pieces_gives_the_sequences_of_the_whole(size):
+    """kmh_stream_*: the splitter over an input cut anywhere -- inside a header, a sequence line, a quality line that
+    holds '@', between \\r and \\n -- finds the sequences it finds in the whole input, tokens consistent across pieces."""
+    for mode, cases in ((parse.FASTA, [(c, None) for c in CASES_FA] + CASES_NAMED), (parse.FASTQ, [(c, None) for c in CASES_FQ])):
+        for data, idmap in cases:
+            for k in (3, 5):
+                if mode == parse.FASTA and idmap is None and b"junk" in data:
+                    pass
+                whole, parts = _whole_and_pieces(data, mode, k, size, idmap)
+                bases = np.concatenate([p.batch.bases for p in parts]) if parts else np.zeros(0, np.uint8)
+                lens = np.concatenate([np.diff(p.batch.seq_off.astype(np.int64)) for p in parts])
+                assert bases.tobytes() == whole.batch.bases.tobytes(), (data, size)
+                assert lens.tolist() == np.diff(whole.batch.seq_off.astype(np.int64)).tolist(), (data, size)
+                assert parts[-1].eof_in_kmer == whole.eof_in_kmer
+                if mode == parse.FASTA:
+                    assert np.concatenate([p.batch.seq_id for p in parts]).tolist() == whole.batch.seq_id.tolist()
+                    assert np.concatenate([p.id_ok for p in parts]).tolist() == whole.id_ok.tolist()
+                else:
+                    names = [nm for p in parts for nm in p.names]
+                    toks = np.concatenate([p.batch.seq_tok for p in parts]).tolist()
+                    wtok = whole.batch.seq_tok.tolist()
+                    assert names == [whole.names[t] for t in wtok]
+                    # equal tokens <=> equal names, over the whole stream
+                    assert len(set(zip(toks, names))) == len(set(toks)) == len(set(names))
+
+
+def test_pieces_of_a_larger_fastq():
+    from kmers_amd import synth
+    taxa, genomes = synth.random_genomes(5, 3, 3000)
+    reads = synth.random_reads(6, genomes, 400, 100, 0.01, n_rate=0.01)
+    fq = synth.fastq_bytes(reads)
+    for size in (977, 4096, 50000):
+        whole, parts = _whole_and_pieces(fq, parse.FASTQ, 31, size)
+        assert np.concatenate([p.batch.bases for p in parts]).tobytes() == whole.batch.bases.tobytes()
+        assert [nm for p in parts for nm in p.names] == [whole.names[t] for t in whole.batch.seq_tok.tolist()]
+        assert sum(p.batch.nseq for p in parts) == whole.batch.nseq
