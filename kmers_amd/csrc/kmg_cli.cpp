@@ -1,7 +1,7 @@
 // kmg_cli.cpp -- native (C++) host side of the hot path: the three reference programs that sit on it, driven
 // through the C ABI of libkmers_gpu.so, plus the on-disk container they read and write.
 //
-//   kmg Database.MakeDatabase -a|-q|-p -i in -o out [-K maxK -k minK] [-l keylen] [-z level | -Z] [-h] [-S maxsize] [-r readmap] [-m idmap] [-D n] [-R n] [-L a-b] [-t threads] [-P passes] [-G r/n]
+//   kmg Database.MakeDatabase -a|-q|-p -i in -o out [-K maxK -k minK] [-l keylen] [-z level | -Z] [-h] [-S maxsize] [-r readmap] [-m idmap] [-D n] [-R n] [-L a-b] [-t threads] [-P passes] [-G r/n] [-B bytes]
 //   kmg Database.Matcher      -i search.db -d ref.db -o out [-Z x] [-n N [-j]] [-k a -K b] [-L a-b] [-t threads]
 //   kmg Utils.TaxaCounts      -d ref.db -o out
 //   kmg Utils.CollectByRead / Utils.ReadClassifier -i in -o out;  kmg Pipeline.ReadCalls -q reads.fq -d ref.db -o calls
@@ -756,6 +756,98 @@ int make_database_preprocessed(const Args &a, int k, int min_k, int key_len, int
     return 0;
 }
 
+// A sequence file read, inflated and split into records piece by piece on a thread of its own (kmh_stream_*): the
+// consumer takes the pieces' batches in order while the next ones are being made.  Neither the text nor the sequences
+// of the whole input are in memory at any time; the reader runs ahead by at most ~256 MiB of input.
+struct Piece {
+    std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch{nullptr, kmh_free};
+    bool last = false;
+    std::string err;
+};
+class PieceReader {
+  public:
+    // mode: 0 FASTA, 1 FASTQ (kmh_parse's); k: for the FASTA repeated-last-k-mer rule at the end of the input
+    PieceReader(const std::string &path, int mode, int k, uint64_t piece_bytes)
+        : path_(path), mode_(mode), k_(k), piece_bytes_(std::max<uint64_t>(1, piece_bytes)),
+          cap_((size_t)std::max<uint64_t>(2, (256ull << 20) / std::max<uint64_t>(1, piece_bytes))), th_([this] { run(); }) {}
+    ~PieceReader() {      // whatever ends the consumer, the reader is told and joined
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    Piece next() {
+        Piece p;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return !ready_.empty(); });
+            p = std::move(ready_.front());
+            ready_.pop_front();
+        }
+        cv_.notify_all();
+        if (!p.err.empty()) throw std::runtime_error(p.err);
+        return p;
+    }
+
+  private:
+    void push(Piece &&p) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || ready_.size() < cap_; });
+        if (!stop_) ready_.push_back(std::move(p));
+        cv_.notify_all();
+    }
+    void fill(gzFile z, std::vector<uint8_t> &buf) {      // up to piece_bytes, grown as the file delivers
+        buf.clear();
+        uint64_t got = 0;
+        while (got < piece_bytes_) {
+            const uint64_t want = std::min<uint64_t>(piece_bytes_ - got, 16u << 20);
+            buf.resize(got + want);
+            const int n = gzread(z, buf.data() + got, (unsigned)want);
+            if (n <= 0) break;
+            got += (uint64_t)n;
+        }
+        buf.resize(got);
+    }
+    void run() {
+        kmh_stream *st = kmh_stream_open(mode_);
+        gzFile z = gzopen(path_.c_str(), "rb");      // (jar Zip.ZipOrNot: gzip or not, sniffed; gzread does the same)
+        if (!z) {
+            Piece p; p.last = true; p.err = "cannot open " + path_;
+            push(std::move(p));
+        } else {
+            gzbuffer(z, 1 << 20);
+            try {
+                std::vector<uint8_t> cur, nxt;
+                fill(z, cur);
+                for (;;) {
+                    fill(z, nxt);                            // (what follows decides whether `cur` is the last piece)
+                    Piece p;
+                    p.last = nxt.empty();
+                    p.batch.reset(kmh_stream_next(st, cur.data(), cur.size(), p.last ? 1 : 0, k_));
+                    const bool last = p.last;
+                    push(std::move(p));
+                    { std::lock_guard<std::mutex> lk(mu_); if (stop_) break; }
+                    if (last) break;
+                    cur.swap(nxt);
+                }
+            } catch (const std::exception &e) {
+                Piece p; p.last = true; p.err = "reading " + path_ + ": " + e.what();
+                push(std::move(p));
+            }
+            gzclose(z);
+        }
+        kmh_stream_close(st);
+    }
+    const std::string path_;
+    const int mode_, k_;
+    const uint64_t piece_bytes_;
+    const size_t cap_;
+    std::deque<Piece> ready_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+    std::thread th_;      // (last: it starts in the constructor and uses the members above)
+};
+
 // FASTA (reference) or FASTQ (reads) text -> database on the GPU; for reads also the read-name map file
 // (ReadIDMapping.geNext prints a header each time a new index is handed out: gzip text, one per line) unless
 // read_map is empty, and the number of read indices.
@@ -764,12 +856,96 @@ int make_database_preprocessed(const Args &a, int k, int min_k, int key_len, int
 kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int key_len, bool filters, int dust, int runofsame,
                         const std::string &read_map, uint64_t *n_reads, uint64_t *nwin, StageClock &clk, int passes = 1,
                         const std::function<void(kmg_db *, size_t, size_t)> &per_pass = nullptr, int share = 0, int shares = 1,
-                        int min_k = 0, const std::string &id_map = "") {
+                        int min_k = 0, const std::string &id_map = "", uint64_t piece_bytes = 16ull << 20) {
     if (min_k <= 0) min_k = k;
-    const std::string data = read_input(path);
-    clk.lap("read input");
     // id_map (-m, FASTA only; MakeDatabase.java:138-147): headers are names looked up in the map file, not ints
     const bool named = !reads && !id_map.empty();
+    if (!named) {
+        // The input in pieces (PieceReader): piece i + 1 is read, inflated and split while piece i is copied in and its
+        // k-mers extracted; one kmg_build_add per piece, the read numbering runs on from add to add.  A build in key
+        // ranges (-P) reads the file once per range.
+        const size_t nkeys = (size_t)1 << (2 * key_len);
+        const size_t r_lo = nkeys * (size_t)share / (size_t)shares, r_hi = nkeys * ((size_t)share + 1) / (size_t)shares;
+        const bool ranged = passes > 1 || shares > 1;
+        passes = (int)std::max<size_t>(1, std::min<size_t>((size_t)passes, std::max<size_t>(r_hi - r_lo, 1)));
+        uint64_t windows = 0;
+        kmg_db *db = nullptr;
+        int32_t top = -1;
+        bool map_done = false;
+        for (int ps = 0; ps < passes; ps++) {
+            const size_t lo = r_lo + (r_hi - r_lo) * ps / passes, hi = r_lo + (r_hi - r_lo) * (ps + 1) / passes;
+            if (hi <= lo) continue;
+            PieceReader rd(path, reads ? 1 : 0, k, piece_bytes);
+            g.check(kmg_build_begin(g.ctx, k, key_len, reads ? 0 : 1, reads ? KMG_PAYLOAD_READPOS : KMG_PAYLOAD_TAXON));
+            if (filters) g.check(kmg_build_set_filters(g.ctx, dust, runofsame));
+            if (min_k != k) g.check(kmg_build_set_min_k(g.ctx, min_k));
+            if (ranged) g.check(kmg_build_set_key_range(g.ctx, (uint32_t)lo, (uint32_t)hi));
+            gzFile z = nullptr;
+            if (reads && !read_map.empty() && !map_done) {
+                z = gzopen(read_map.c_str(), "wb");
+                if (!z) throw std::runtime_error("cannot create " + read_map);
+            }
+            struct CloseZ { gzFile &z; ~CloseZ() { if (z) gzclose(z); } } close_z{z};
+            int32_t last = -1;
+            uint64_t seq_base = 0;
+            for (bool done = false; !done;) {
+                Piece pc = rd.next();
+                const kmh_batch *b = pc.batch.get();
+                const uint64_t nseq = kmh_nseq(b);
+                const uint64_t *off = kmh_seq_off(b);
+                // Sequence.java:15-33 decides by the sign of a window's first byte: windows made of bytes >= 128 only are
+                // k-mers of garbage codes there, invalid here -- refused rather than built differently
+                if (kmh_high_bytes(b)) throw Unsupported("sequence lines hold bytes >= 128: not supported on the GPU path");
+                // ReadIDMapping starts with curReadS = "" (ReadIDMapping.java:10-16): a first emitting read with an empty
+                // header gets index -1 and no name line there
+                if (reads && kmh_empty_header(b)) throw Unsupported("a FASTQ record with an empty header: not supported on the GPU path");
+                // A file that ends inside a sequence line: the reference hands its last k-mer out twice
+                // (KmersFromFile.java:115-123,193-200).  For FASTA with k-mers of one length the record splitter reproduces
+                // that; a FASTQ cut there, or any such file with minK < maxK, is refused rather than built differently.
+                if (pc.last && kmh_eof_in_kmer(b) && (reads || min_k != k))
+                    throw Unsupported("input ends inside a sequence line (no final newline): not supported on the GPU path for FASTQ input or with minK < maxK");
+                if (!reads) {
+                    const uint8_t *ok = kmh_id_ok(b);
+                    for (uint64_t q = 0; q < nseq; q++)   // Integer.parseInt throws at the sequence's first k-mer
+                        if (!ok[q] && off[q + 1] - off[q] >= (uint64_t)min_k)
+                            throw std::runtime_error("FASTA header of sequence " + std::to_string(seq_base + q) + " is not an int");
+                }
+                std::vector<int32_t> ridx(reads ? nseq : 0);
+                if (nseq)
+                    g.check(kmg_build_add(g.ctx, kmh_bases(b), kmh_nbases(b), off, reads ? nullptr : kmh_seq_id(b),
+                                          reads ? kmh_seq_tok(b) : nullptr, nseq, reads ? ridx.data() : nullptr));
+                if (reads) {
+                    const uint64_t *noff = kmh_name_off(b);      // (a stream's piece: one name per sequence)
+                    const char *names = kmh_names(b);
+                    for (uint64_t q = 0; q < nseq; q++) {
+                        top = std::max(top, ridx[q]);
+                        if (z && ridx[q] >= 0 && ridx[q] != last) {
+                            gzwrite(z, names + noff[q], (unsigned)(noff[q + 1] - noff[q]));
+                            gzwrite(z, "\n", 1);
+                            last = ridx[q];
+                        }
+                    }
+                }
+                seq_base += nseq;
+                done = pc.last;
+            }
+            if (z) map_done = true;
+            uint64_t w = 0;
+            g.check(kmg_build_finish(g.ctx, &db, &w));
+            windows += w;
+            if (ranged) {
+                per_pass(db, lo, hi);
+                kmg_db_free(db);
+                db = nullptr;
+            }
+        }
+        if (nwin) *nwin = windows;
+        if (reads && n_reads) *n_reads = (uint64_t)(top + 1);
+        clk.lap(ranged ? "read + split alongside copy in + build (GPU), encode + write, per pass" : "read + split alongside copy in + build (GPU)");
+        return db;
+    }
+    const std::string data = read_input(path);
+    clk.lap("read input");
     const std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch(kmh_parse((const uint8_t *)data.data(), data.size(), reads ? 1 : (named ? 2 : 0), k), kmh_free);
     if (named) {
         const std::string map = read_input(id_map);
@@ -850,7 +1026,7 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
 }
 
 int make_database(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmNPLG", "aqpZvh");
+    const Args a = parse_args(argc, argv, 2, "ioKklzrDRtcSmNPLGB", "aqpZvh");
     if (a.has('L') && !a.has('p')) throw std::runtime_error("-L limits the input indexes of a preprocessed file (-p)");
     for (char c : std::string("N")) if (a.has(c)) throw Unsupported(std::string("option -") + c + " is not on the GPU path");
     const int k = a.geti('K', 32), min_k = a.geti('k', 24), key_len = a.geti('l', 6);     // MakeDatabase.java:106-109
@@ -891,7 +1067,8 @@ int make_database(int argc, char **argv) {
     };
     kmg_db *db = build_from_text(g, a.get('i'), reads, k, key_len, a.has('D') || a.has('R'), a.geti('D', -1), a.geti('R', -1),
                                  reads && share == 0 ? a.get('r') : "", nullptr, &nwin, clk, passes, emit, share, shares, min_k,
-                                 a.has('m') && !reads ? a.get('m') : "");
+                                 a.has('m') && !reads ? a.get('m') : "",
+                                 a.has('B') ? size_from_human(a.get('B')) : (16ull << 20));    // -B: bytes of input per piece
     if (db) {
         emit(db, 0, (size_t)1 << (2 * key_len));
         kmg_db_free(db);
@@ -1592,67 +1769,9 @@ int read_calls(int argc, char **argv) {
     // over and lead the next build -- they hand out k-mers, so the numbering there starts as it would have gone on.
     // -C n: at most n sequences of a piece per build.
     const uint64_t piece_bytes = a.has('B') ? std::max<uint64_t>(1, size_from_human(a.get('B'))) : (16ull << 20);
-    // (the reader starts before the GPU context and the database are up -- FASTQ splitting needs neither -- and may run
-    // ahead by 256 MiB of input)
-    const size_t queue_cap = (size_t)std::max<uint64_t>(2, (256ull << 20) / piece_bytes);
+    // (the reader starts before the GPU context and the database are up -- FASTQ splitting needs neither)
     const uint64_t chunk_seqs = a.has('C') ? (uint64_t)std::max(1, a.geti('C', 1)) : 0;
-    struct Piece { std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch{nullptr, kmh_free}; bool last = false; std::string err; };
-    std::deque<Piece> ready;
-    std::mutex mu;
-    std::condition_variable cv;
-    bool stop = false;
-    std::thread reader([&]() {
-        kmh_stream *st = kmh_stream_open(1);
-        gzFile z = gzopen(a.get('q').c_str(), "rb");
-        auto push = [&](Piece &&p) {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return stop || ready.size() < queue_cap; });
-            if (!stop) ready.push_back(std::move(p));
-            cv.notify_all();
-        };
-        if (!z) {
-            Piece p; p.last = true; p.err = "cannot open " + a.get('q');
-            push(std::move(p));
-        } else {
-            gzbuffer(z, 1 << 20);
-            auto fill = [&](std::vector<uint8_t> &buf) {      // up to piece_bytes, grown as the file delivers
-                buf.clear();
-                uint64_t got = 0;
-                while (got < piece_bytes) {
-                    const uint64_t want = std::min<uint64_t>(piece_bytes - got, 16u << 20);
-                    buf.resize(got + want);
-                    const int n = gzread(z, buf.data() + got, (unsigned)want);
-                    if (n <= 0) break;
-                    got += (uint64_t)n;
-                }
-                buf.resize(got);
-            };
-            try {
-                std::vector<uint8_t> cur, nxt;
-                fill(cur);
-                for (;;) {
-                    fill(nxt);                               // (what follows decides whether `cur` is the last piece)
-                    Piece p;
-                    p.last = nxt.empty();
-                    p.batch.reset(kmh_stream_next(st, cur.data(), cur.size(), p.last ? 1 : 0, 0));
-                    const bool last = p.last;
-                    push(std::move(p));
-                    { std::lock_guard<std::mutex> lk(mu); if (stop) break; }
-                    if (last) break;
-                    cur.swap(nxt);
-                }
-            } catch (const std::exception &e) {
-                Piece p; p.last = true; p.err = std::string("reading ") + a.get('q') + ": " + e.what();
-                push(std::move(p));
-            }
-            gzclose(z);
-        }
-        kmh_stream_close(st);
-    });
-    struct StopReader {      // whatever ends the consumer, the reader is told and joined
-        std::thread &t; std::mutex &mu; std::condition_variable &cv; bool &stop;
-        ~StopReader() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); }
-    } stop_reader{reader, mu, cv, stop};
+    PieceReader reader(a.get('q'), 1, 0, piece_bytes);
     Gpu g;
     clk.lap("GPU context");
     int k = a.geti('K', 32), key_len = a.geti('l', 6);
@@ -1744,15 +1863,7 @@ int read_calls(int argc, char **argv) {
         left_bases.swap(nb); left_off.swap(no); left_tok.swap(nt); left_names.swap(nn);
     };
     for (bool done = false; !done;) {
-        Piece p;
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return !ready.empty(); });
-            p = std::move(ready.front());
-            ready.pop_front();
-        }
-        cv.notify_all();
-        if (!p.err.empty()) throw std::runtime_error(p.err);
+        Piece p = reader.next();
         const kmh_batch *b = p.batch.get();
         if (kmh_high_bytes(b)) throw Unsupported("sequence lines hold bytes >= 128: not supported on the GPU path");
         if (kmh_empty_header(b)) throw Unsupported("a FASTQ record with an empty header: not supported on the GPU path");

@@ -222,6 +222,20 @@ def test_native_cli_matches_python_drivers(tmp_path):
     assert R.read_indexed_file(p("by_read.empty")) == {}
     run("Utils.ReadClassifier", "-i", p("by_read.empty"), "-o", p("calls.empty"))
     assert R.read_indexed_file(p("calls.empty")) == {}
+    # MakeDatabase reads its input in pieces too (-B bytes per piece; one kmg_build_add per piece): the same files
+    for b in ("61", "3k", "100k"):
+        run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("ref.b.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z", "-B", b)
+        assert open(p("ref.b.db"), "rb").read() == open(p("ref.want"), "rb").read(), b
+        run("Database.MakeDatabase", "-q", "-i", fq, "-o", p("reads.b.db"), "-r", p("map.b.gz"), "-K", str(k), "-k", str(k), "-l", str(l),
+            "-B", b, *(["-P", "3"] if b == "3k" else []))
+        assert R.read_indexed_file(p("reads.b.db")) == R.read_indexed_file(p("reads.want")), b
+        assert gzip.open(p("map.b.gz"), "rt").read().splitlines() == o_reads.names, b
+    run("Database.MakeDatabase", "-q", "-i", p("paired.fq"), "-o", p("paired.db"), "-r", p("paired.map.gz"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z")
+    run("Database.MakeDatabase", "-q", "-i", p("paired.fq"), "-o", p("paired.b.db"), "-r", p("paired.b.map.gz"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z", "-B", "150")
+    assert open(p("paired.b.db"), "rb").read() == open(p("paired.db"), "rb").read()
+    assert gzip.open(p("paired.b.map.gz"), "rb").read() == gzip.open(p("paired.map.gz"), "rb").read()
+    o_paired = OracleDB(open(p("paired.fq"), "rb").read(), 1, k, l)
+    assert gzip.open(p("paired.map.gz"), "rt").read().splitlines() == o_paired.names
     # -P: the database built and written in key ranges, one after the other -- the same file
     run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("ref.p5.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z", "-P", "5")
     assert open(p("ref.p5.db"), "rb").read() == open(p("ref.want"), "rb").read()
