@@ -702,6 +702,20 @@ __device__ __forceinline__ void ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *_
 
 #undef LS_ACT
 
+// Oversize segments: their records to and from one compact array, a chunk of a segment per workgroup.
+#define BIG_CHUNK 4096u
+struct BigChunk { u32 slice, compact, count; };      // first record in the segmented array, in the compact array, records
+template <typename V, bool GATHER>
+__global__ __launch_bounds__(256) void big_copy_kernel(const BigChunk *__restrict__ chunks, const u64 *__restrict__ ks,
+                                                       const V *__restrict__ vs, u64 *__restrict__ kd, V *__restrict__ vd) {
+    const BigChunk c = chunks[blockIdx.x];
+    const u32 from = GATHER ? c.slice : c.compact, to = GATHER ? c.compact : c.slice;
+    for (u32 i = threadIdx.x; i < c.count; i += 256) {
+        kd[to + i] = ks[from + i];
+        vd[to + i] = vs[from + i];
+    }
+}
+
 template <typename V, bool HEADS>
 __global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *keys_in, V *vals_in, u64 *__restrict__ keys_out,
                                                                V *__restrict__ vals_out, const u32 *__restrict__ seg_off,
@@ -801,9 +815,11 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
         }
     }
     // Segments that do not fit one workgroup's LDS (skew: poly-A, low-complexity repeats pile into a few
-    // prefixes).  A handful of them are sorted one by one with global passes restricted to the segment's
-    // slice (its records already agree on the prefix, so only the remaining digits are needed); if there
-    // are many, or they hold most of the data, the whole array takes the plain LSD path below.
+    // prefixes -- with sequencing errors into a few hundred).  Their records are gathered into one array, that array is
+    // sorted by plain LSD passes on the whole key (stable, so it keeps the segments in their order and each segment's
+    // records end up where its slice expects them), and copied back into the slices: the passes run over the few per
+    // cent of the records that need them, in a handful of launches however many such segments there are.  If they hold
+    // most of the data, the whole array takes the plain LSD path below.
     std::vector<std::pair<u32, u32>> big;   // (first record, size)
     bool local_ok = rest.size() <= LS_MAX_PASSES;
     if (local_ok && h_max > LS_MAX) {
@@ -815,7 +831,7 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
             const u32 sz = h_seg[sgi + 1] - h_seg[sgi];
             if (sz > LS_MAX) { big.push_back({h_seg[sgi], sz}); total_big += sz; }
         }
-        if (big.size() > 64 || total_big > (u64)n / 2) local_ok = false;
+        if (total_big > (u64)n / 2) local_ok = false;
     }
     if (local_ok) {
         LocalPasses lp;
@@ -855,14 +871,44 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
                 hipLaunchKernelGGL((ls_sort_kernel<V>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp);
             KMG_HIP(hipGetLastError());
         }
-        for (const auto &bs : big) {
-            bool slice_in_b = false;
-            KMG_TRY(radix_sort_records<V>(ctx, ka + bs.first, va + bs.first, kb + bs.first, vb + bs.first, bs.second, rest,
-                                          table, agg, &slice_in_b));
-            if (!slice_in_b) {   // even number of passes: the slice ended up in the source buffer
-                KMG_HIP(hipMemcpyAsync(kb + bs.first, ka + bs.first, (size_t)bs.second * 8, hipMemcpyDeviceToDevice, ctx->stream));
-                KMG_HIP(hipMemcpyAsync(vb + bs.first, va + bs.first, (size_t)bs.second * sizeof(V), hipMemcpyDeviceToDevice, ctx->stream));
+        if (!big.empty()) {
+            std::vector<BigChunk> chunks;
+            u64 total_big = 0;
+            for (const auto &bs : big) {
+                for (u32 c = 0; c < bs.second; c += BIG_CHUNK)
+                    chunks.push_back({bs.first + c, (u32)total_big + c, std::min<u32>(BIG_CHUNK, bs.second - c)});
+                total_big += bs.second;
             }
+            void *d_chunks = nullptr, *ck0 = nullptr, *ck1 = nullptr, *cv0 = nullptr, *cv1 = nullptr;
+            int rc = ctx->pool.alloc(&d_chunks, chunks.size() * sizeof(BigChunk));
+            if (rc == KMG_OK) rc = ctx->pool.alloc(&ck0, total_big * 8);
+            if (rc == KMG_OK) rc = ctx->pool.alloc(&ck1, total_big * 8);
+            if (rc == KMG_OK) rc = ctx->pool.alloc(&cv0, total_big * sizeof(V));
+            if (rc == KMG_OK) rc = ctx->pool.alloc(&cv1, total_big * sizeof(V));
+            auto give_back = [&]() {      // (behind the launches: the pool's blocks are reused on this stream only)
+                for (void *q : {d_chunks, ck0, ck1, cv0, cv1}) if (q) ctx->pool.release(q);
+            };
+            if (rc != KMG_OK) { give_back(); return rc; }
+            hipError_t he = hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(BigChunk), hipMemcpyHostToDevice, ctx->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);      // `chunks` is pageable host memory
+            if (he != hipSuccess) { give_back(); return KMG_EDEVICE; }
+            {
+                ProfScope ps(ctx, KP_SORT_SEGMENTS, 0);
+                hipLaunchKernelGGL((big_copy_kernel<V, true>), dim3((u32)chunks.size()), dim3(256), 0, ctx->stream,
+                                   (const BigChunk *)d_chunks, (const u64 *)ka, (const V *)va, (u64 *)ck0, (V *)cv0);
+            }
+            std::vector<SortPass> all = rest;
+            for (const SortPass &p : prefix) all.push_back(p);
+            bool in_c1 = false;
+            rc = radix_sort_records<V>(ctx, (u64 *)ck0, (V *)cv0, (u64 *)ck1, (V *)cv1, (u32)total_big, all, table, agg, &in_c1);
+            if (rc != KMG_OK) { give_back(); return rc; }
+            {
+                ProfScope ps(ctx, KP_SORT_SEGMENTS, 0);
+                hipLaunchKernelGGL((big_copy_kernel<V, false>), dim3((u32)chunks.size()), dim3(256), 0, ctx->stream,
+                                   (const BigChunk *)d_chunks, (const u64 *)(in_c1 ? ck1 : ck0), (const V *)(in_c1 ? cv1 : cv0), kb, vb);
+            }
+            give_back();
+            KMG_HIP(hipGetLastError());
         }
         *result_in_1 = !in1;
         return KMG_OK;

@@ -92,3 +92,31 @@ def cfg1(scale=1.0):
     taxa, genomes = random_genomes(1, 10, glen)
     reads = random_reads(2, genomes, nreads, 150, 0.01)
     return taxa, genomes, reads
+
+
+def cfg5(scale=1.0, n_taxa=40):
+    """BASELINE config 5 (long-read stress): genome sizes Zipf(s = 1.2) from 50 Mbp x scale down to 10 kbp, 5 % of the
+    bases in homopolymer / dinucleotide tracts of 100-250 bases (a few key prefixes hold most of those k-mers), and
+    10 kbp reads with 15 % substitutions and 0.5 % N (40 000 x scale of them, drawn from a uniformly random taxon: the
+    small genomes are covered hundreds of times, the large ones hardly).  -> (taxa, genomes, reads[n, 10000])"""
+    rng = np.random.Generator(np.random.PCG64(7))
+    sizes = [max(10_000, int(50_000_000 * scale / (i + 1) ** 1.2)) for i in range(n_taxa)]
+    genomes = []
+    for n in sizes:
+        g = _ACGT[rng.integers(0, 4, size=n, dtype=np.uint8)]
+        n_tracts = max(1, int(n * 0.05 / 175))
+        starts = rng.integers(0, max(1, n - 250), size=n_tracts)
+        lens = rng.integers(100, 250, size=n_tracts)
+        kinds = rng.integers(0, 4, size=(n_tracts, 3))
+        for s, ln, (mono, a, b) in zip(starts.tolist(), lens.tolist(), kinds.tolist()):
+            e = min(n, s + ln)
+            if mono < 2:
+                g[s:e] = _ACGT[a]
+            else:
+                g[s:e:2] = _ACGT[a]
+                g[s + 1:e:2] = _ACGT[b]
+        genomes.append(g)
+    n_reads = max(20, int(40_000 * scale))
+    reads = np.concatenate([random_reads(700 + c, genomes, min(2000, n_reads - c), 10_000, 0.15, n_rate=0.005)
+                            for c in range(0, n_reads, 2000)])
+    return list(range(9000, 9000 + n_taxa)), genomes, reads
