@@ -315,12 +315,18 @@ int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, int64_t *matc
  * kmg_classify_reads_hits: the same, and has_hit[r] = 1 if read r has at least one matched k-mer -- what decides
  *   whether the reference's output holds a block for (r / 1000) * 1000 at all (ReadClassifier.java:157-160 writes
  *   one block per block of CollectByRead's output, and CollectByRead.java:105-124 one per group of reads with a
- *   record), so a caller can write ReadClassifier's file straight from two databases. */
+ *   record), so a caller can write ReadClassifier's file straight from two databases.
+ * kmg_classify_reads_rows: the same calls from answers found by another search -- `rows` and hit_row as
+ *   kmg_match_trie hands them out for `search` (the non-quick branch of DB.getNearestKmers, DB.java:139-184: what
+ *   Matcher does with its defaults on default databases), hit_row a host array of n_kmers(search) entries: the
+ *   taxa of search k-mer i are those of row hit_row[i], -1 = no match line.  KMG_EINVAL for an index outside the rows. */
 int kmg_collect_by_read(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t *n_out, int32_t *read,
                         int32_t *pos, int64_t *ref_index);
 int kmg_classify_reads(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t n_reads, int32_t *call);
 int kmg_classify_reads_hits(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t n_reads, int32_t *call,
                             uint8_t *has_hit);
+int kmg_classify_reads_rows(kmg_ctx *ctx, const kmg_db *search, const kmg_db *rows, const int64_t *hit_row,
+                            uint64_t n_reads, int32_t *call, uint8_t *has_hit);
 
 /* ---- measurement hook (bench.py) --------------------------------------------------------------
  * Total device time in ms, measured with HIP events on kmg_stream(), of the launches of one

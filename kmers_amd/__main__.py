@@ -44,11 +44,11 @@ def main(argv=None):
         a = ap.parse_args(rest)
         (programs.collect_by_read if prog == "CollectByRead" else programs.read_classifier)(Context(0), a.i, a.o)
     elif prog == "ReadCalls":
-        for f in "qdaoKlr":
+        for f in "qdaoKklr":
             ap.add_argument("-" + f)
         a = ap.parse_args(rest)
         programs.read_calls(Context(0), a.q, a.o, db_path=a.d, fasta_path=a.a, k=int(a.K or 32), key_length=int(a.l or 6),
-                            read_map_path=a.r)
+                            read_map_path=a.r, min_k=None if a.k is None else int(a.k))
     else:
         raise SystemExit("unknown program %s" % argv[0])
     return 0

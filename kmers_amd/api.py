@@ -448,6 +448,17 @@ def classify_reads(search, ref, n_reads, with_hits=False):
     return call[:n_reads], seen[:n_reads]
 
 
+def classify_reads_rows(search, rows, hit, n_reads):
+    """The same calls from answers found by another search (kmg_classify_reads_rows): `rows`, `hit` as match_trie
+    hands them out -- Matcher's search over several lengths.  -> (call, has_hit)"""
+    ctx = search.ctx
+    call = np.empty(max(n_reads, 1), np.int32)
+    seen = np.zeros(max(n_reads, 1), np.uint8)
+    hit = np.ascontiguousarray(hit, np.int64)
+    ctx.check(ctx.lib.kmg_classify_reads_rows(ctx.h, search.h, rows.h, _ptr(hit) if hit.size else None, n_reads, _ptr(call), _ptr(seen)))
+    return call[:n_reads], seen[:n_reads]
+
+
 def read_call_blocks(call, has_hit):
     """The blocks of ReadClassifier's output file from per-read calls: one block per (read / 1000) * 1000 that
     holds a read with a matched k-mer (CollectByRead.java:105-124 writes no other), lines `read \t call \n` for

@@ -129,6 +129,12 @@ __global__ void rc_call_kernel(const int2 *__restrict__ mm, const u32 *__restric
     call[r] = (m.x == m.y && m.x >= 0 && !bad[r]) ? m.x : -1;
 }
 
+// flag[0] = 1 if any hit index is neither -1 nor one of the n_rows rows
+__global__ void hit_range_kernel(const long long *__restrict__ hit, u64 n, long long n_rows, u32 *__restrict__ flag) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (hit[i] < -1 || hit[i] >= n_rows)) flag[0] = 1u;
+}
+
 __global__ void rc_init_kernel(int2 *mm, u64 n) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) mm[i] = make_int2(0x7FFFFFFF, (int)0x80000000);

@@ -1975,12 +1975,22 @@ extern "C" int kmg_collect_by_read(kmg_ctx *ctx, const kmg_db *search, const kmg
     return KMG_OK;
 }
 
+// the per-read calls from a finished join: d_hit[i] = index of search k-mer i's answer among `ref`'s k-mers (its taxa
+// are ref->val_a[ref->val_off[..]]), -1 = none
+static int classify_from_hits(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, const long long *d_hit_index, uint64_t n_reads,
+                              int32_t *call, uint8_t *has_hit);
+
 static int classify_locked(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, uint64_t n_reads, int32_t *call,
                            uint8_t *has_hit) {
     KMG_HIP(hipSetDevice(ctx->device));
     if (n_reads >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "too many reads");
     PoolBuf d_hit(ctx);
     KMG_TRY(join_for_reads(ctx, search, ref, d_hit));
+    return classify_from_hits(ctx, search, ref, d_hit.as<long long>(), n_reads, call, has_hit);
+}
+
+static int classify_from_hits(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, const long long *d_hit_index, uint64_t n_reads,
+                              int32_t *call, uint8_t *has_hit) {
     if (n_reads == 0) {
         if (search->V) return fail(ctx, KMG_EINVAL, "read index outside n_reads");
         return KMG_OK;
@@ -2003,9 +2013,9 @@ static int classify_locked(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref
         // two passes over the join: offsets + hit per search k-mer, one read index per occurrence (+ the hit k-mers'
         // taxa, cache-resident), per-read words updated in place
         ProfScope ps(ctx, KP_CLASSIFY, 2 * (U * 16 + search->V * 4) + n_reads * 16);
-        hipLaunchKernelGGL(rc_single_kernel, gk, b, 0, ctx->stream, search->val_off, search->val_a, d_hit.as<long long>(), U,
+        hipLaunchKernelGGL(rc_single_kernel, gk, b, 0, ctx->stream, search->val_off, search->val_a, d_hit_index, U,
                            ref->val_off, ref->val_a, n_reads, mm.as<int2>(), err, seen.as<uint8_t>());
-        hipLaunchKernelGGL(rc_check_kernel, gk, b, 0, ctx->stream, search->val_off, search->val_a, d_hit.as<long long>(), U,
+        hipLaunchKernelGGL(rc_check_kernel, gk, b, 0, ctx->stream, search->val_off, search->val_a, d_hit_index, U,
                            ref->val_off, ref->val_a, n_reads, mm.as<int2>(), bad.as<u32>());
     }
     hipLaunchKernelGGL(rc_call_kernel, gr, b, 0, ctx->stream, mm.as<int2>(), bad.as<u32>(), n_reads, d_call.as<int32_t>());
@@ -2029,6 +2039,37 @@ extern "C" int kmg_classify_reads_hits(kmg_ctx *ctx, const kmg_db *search, const
     if (!ctx || !search || !ref || (n_reads && (!call || !has_hit))) return KMG_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
     return classify_locked(ctx, search, ref, n_reads, call, has_hit);
+}
+
+// The calls from answers found elsewhere: `rows` and hit_row as kmg_match_trie hands them out (or any database of taxon
+// values with, per search k-mer, the index of its entry there or -1).
+extern "C" int kmg_classify_reads_rows(kmg_ctx *ctx, const kmg_db *search, const kmg_db *rows, const int64_t *hit_row,
+                                       uint64_t n_reads, int32_t *call, uint8_t *has_hit) {
+    if (!ctx || !search || !rows || (search->U && !hit_row) || (n_reads && (!call || !has_hit))) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    if (n_reads >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "too many reads");
+    if (search->kind != KMG_PAYLOAD_READPOS || rows->kind != KMG_PAYLOAD_TAXON)
+        return fail(ctx, KMG_EINVAL, "per-read aggregation joins a read database against taxon values");
+    if (search->ctx != ctx || rows->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
+    if (search->V >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 read occurrences");
+    const u64 U = search->U;
+    PoolBuf d_hit(ctx), d_bad(ctx);
+    KMG_ALLOC(d_hit, (U + 1) * 8);
+    KMG_ALLOC(d_bad, 64);
+    KMG_HIP(hipMemsetAsync(d_bad.p, 0, 64, ctx->stream));
+    if (U) {
+        KMG_HIP(hipMemcpyAsync(d_hit.p, hit_row, U * 8, hipMemcpyHostToDevice, ctx->stream));
+        // every index must name one of the rows (the kernels below follow it)
+        hipLaunchKernelGGL(hit_range_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, d_hit.as<long long>(), U,
+                           (long long)rows->U, d_bad.as<u32>());
+        u32 h_bad = 0;
+        KMG_HIP(read_back(ctx, &h_bad, d_bad.p, 4));      // (also: hit_row may be pageable -- it has been read by now)
+        if (h_bad) return fail(ctx, KMG_EINVAL, "hit_row holds an index outside the rows");
+    }
+    KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(search)));
+    KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(rows)));
+    return classify_from_hits(ctx, search, rows, d_hit.as<long long>(), n_reads, call, has_hit);
 }
 
 extern "C" int kmg_taxacounts(kmg_ctx *ctx, const kmg_db *db, int32_t *taxon, int64_t *match, int64_t *unique,

@@ -1752,12 +1752,12 @@ int read_classifier(int argc, char **argv) {
     return 0;
 }
 
-// Pipeline.ReadCalls -q reads.fq (-d database | -a reference.fa) -o calls [-K k -l key_length -r read_map.gz -C seqs -B bytes]
+// Pipeline.ReadCalls -q reads.fq (-d database | -a reference.fa) -o calls [-K maxK -k minK -l key_length -r read_map.gz -C seqs -B bytes]
 // The file the chain MakeDatabase -q | Matcher | CollectByRead | ReadClassifier ends with, byte for byte, without the
 // three files in between: both databases stay on the GPU, the join feeds kmg_classify_reads_hits and only the
 // `read \t call` lines leave.  No counterpart program in the reference.
 int read_calls(int argc, char **argv) {
-    const Args a = parse_args(argc, argv, 2, "qdaoKlrtCB", "v");
+    const Args a = parse_args(argc, argv, 2, "qdaoKklrtCB", "v");
     if (!a.has('q') || !a.has('o') || a.has('d') == a.has('a'))
         throw std::runtime_error("-q, -o and exactly one of -d (database) / -a (FASTA reference) are required");
     g_threads = std::max(1, a.geti('t', g_threads));
@@ -1775,13 +1775,20 @@ int read_calls(int argc, char **argv) {
     Gpu g;
     clk.lap("GPU context");
     int k = a.geti('K', 32), key_len = a.geti('l', 6);
+    int min_k = a.geti('k', k);
+    if (min_k > k) throw std::runtime_error("-k (shortest k-mer) above -K (longest)");
     kmg_db *ref = nullptr;
     if (a.has('d')) {
         ref = open_database_set(g, a.get('d'));
         const DbInfo rd = db_info(ref);
         k = rd.k; key_len = rd.key_len;
+        min_k = kmg_db_min_k(ref);       // the reads are built with the database's lengths, as MakeDatabase -q -K -k would
         clk.lap("read + decode database");
-    } else ref = build_from_text(g, a.get('a'), false, k, key_len, false, -1, -1, "", nullptr, nullptr, clk);
+    } else ref = build_from_text(g, a.get('a'), false, k, key_len, false, -1, -1, "", nullptr, nullptr, clk, 1, nullptr, 0, 1, min_k);
+    // k-mers of several lengths (the reference's defaults, -K 32 -k 24): Matcher's search is then the trie's
+    // (DB.java:83,139-184 -> kmg_match_trie) and the calls come from its answers (kmg_classify_reads_rows)
+    const bool several = min_k != k;
+    const int count_cap = a.has('d') ? 0 : 255;
     if (!db_info(ref).rc)   // DB.java:57-64
         throw std::runtime_error("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included");
     gzFile zmap = nullptr;
@@ -1805,6 +1812,7 @@ int read_calls(int argc, char **argv) {
         if (nl + np == 0) return;
         std::vector<int32_t> ridx(nl + np, -1);
         g.check(kmg_build_begin(g.ctx, k, key_len, 0, KMG_PAYLOAD_READPOS));
+        if (several) g.check(kmg_build_set_min_k(g.ctx, min_k));
         if (nl) g.check(kmg_build_add(g.ctx, left_bases.data(), left_bases.size(), left_off.data(), nullptr, left_tok.data(), nl, ridx.data()));
         std::vector<uint64_t> loff(np + 1);
         if (np) {
@@ -1825,7 +1833,15 @@ int read_calls(int argc, char **argv) {
         if (keep) {
             std::vector<int32_t> c(n_local, -1);
             std::vector<uint8_t> h(n_local, 0);
-            g.check(kmg_classify_reads_hits(g.ctx, reads, ref, n_local, c.data(), h.data()));
+            if (several) {
+                kmg_db *rows = nullptr;
+                std::vector<int64_t> hit_row(db_info(reads).U + 1);
+                g.check(kmg_match_trie(g.ctx, reads, ref, min_k, count_cap, &rows, hit_row.data(), nullptr));
+                const int rc2 = kmg_classify_reads_rows(g.ctx, reads, rows, hit_row.data(), n_local, c.data(), h.data());
+                kmg_db_free(rows);
+                g.check(rc2);
+            } else
+                g.check(kmg_classify_reads_hits(g.ctx, reads, ref, n_local, c.data(), h.data()));
             call.insert(call.end(), c.begin(), c.begin() + keep);
             seen.insert(seen.end(), h.begin(), h.begin() + keep);
         }

@@ -495,29 +495,38 @@ def read_classifier(ctx, input_path, output_path):
     return blocks
 
 
-def read_calls(ctx, reads_path, output_path, db_path=None, fasta_path=None, k=32, key_length=6, read_map_path=None):
+def read_calls(ctx, reads_path, output_path, db_path=None, fasta_path=None, k=32, key_length=6, read_map_path=None, min_k=None):
     """FASTQ reads + a reference (database file set -d, or FASTA -a) -> the file the reference's four-stage chain
     MakeDatabase -q | Matcher | CollectByRead | ReadClassifier ends with, byte for byte, without the three files in
     between (a 1M-read sample's match text alone is ~600 MB gzipped): both databases stay on the GPU, the join
     feeds kmg_classify_reads_hits, and only `read \t call` lines leave.  No counterpart program in the reference."""
     if (db_path is None) == (fasta_path is None):
         raise ValueError("exactly one of -d (database) / -a (FASTA reference)")
+    min_k = k if min_k is None else min_k
     if fasta_path is not None:
-        ref = make_reference_db(ctx, open(fasta_path, "rb").read(), k, key_length)
+        ref = make_reference_db(ctx, open(fasta_path, "rb").read(), k, key_length, min_k=min_k)
     else:
         files = container.file_set(db_path)
         if not files:
             raise FileNotFoundError(db_path)
         ref = DB([open_database(ctx, f) for f in files]).merged
-        k, key_length = ref.k, ref.key_length
+        k, key_length, min_k = ref.k, ref.key_length, ref.min_length
     if not ref.rc:       # DB.java:57-64
         raise ValueError("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included")
-    rdb, names = make_read_db(ctx, open(reads_path, "rb").read(), k, key_length)
+    # the reads are built with the database's lengths, as MakeDatabase -q with the same -K / -k would build them
+    rdb, names = make_read_db(ctx, open(reads_path, "rb").read(), k, key_length, min_k=min_k)
     if read_map_path is not None:
         with gzip.open(read_map_path, "wt") as g:
             for nm in names:
                 g.write(nm + "\n")
-    call, seen = classify_reads(rdb, ref, len(names), with_hits=True)
+    if min_k != k:
+        # k-mers of several lengths: Matcher's search is the trie's (DB.java:83,139-184), the calls come from its answers
+        from .api import classify_reads_rows, match_trie
+        rows, hit = match_trie(rdb, ref, min_k, stored=db_path is not None)
+        call, seen = classify_reads_rows(rdb, rows, hit, len(names))
+        rows.close()
+    else:
+        call, seen = classify_reads(rdb, ref, len(names), with_hits=True)
     blocks = read_call_blocks(call, seen)
     rdb.close()
     ref.close()

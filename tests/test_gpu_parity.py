@@ -1041,6 +1041,17 @@ def test_collect_by_read_and_classifier_match_oracle(ctx, k, l, n_reads, rlen, p
         km.classify_reads(rdb, ref, len(names) - 1)                  # a read index outside n_reads
     with pytest.raises(km.InconsistentDataException):
         km.collect_by_read(ref, ref)                                 # not a read database
+    # kmg_classify_reads_rows: the calls from answers found elsewhere -- here the exact join's own hit list against the
+    # reference's own values, which must give kmg_classify_reads_hits' result; an index outside the rows is refused
+    hit_all, _ = km.DB([ref]).get_nearest_kmers(rdb)
+    call3, seen3 = km.classify_reads_rows(rdb, ref, hit_all, len(names))
+    assert np.array_equal(call3, call) and np.array_equal(seen3, seen)
+    none3, seen_none = km.classify_reads_rows(rdb, ref, np.full(rdb.n_unique, -1, np.int64), len(names))
+    assert np.all(none3 == -1) and not seen_none.any()
+    bad_hit = hit_all.copy()
+    bad_hit[len(bad_hit) // 2] = ref.n_unique
+    with pytest.raises(km.InconsistentDataException):
+        km.classify_reads_rows(rdb, ref, bad_hit, len(names))
     ref.close()
     rdb.close()
 

@@ -532,6 +532,19 @@ def test_default_options_build_variable_length_databases(tmp_path):
         assert R.read_indexed_file(by_read) == want_cb
         assert drv("Utils.ReadClassifier", "-i", by_read, "-o", calls) == 0
         assert R.read_indexed_file(calls) == want_calls
+        # ... and the four stages in one process (Pipeline.ReadCalls: reads built with the database's lengths, the trie
+        # search's answers straight into the per-read calls, kmg_classify_reads_rows): the same calls file
+        fused = str(tmp_path / ("calls.fused.%s" % tag))
+        assert drv("Pipeline.ReadCalls", "-q", fq, "-d", ref_db, "-o", fused, "-r", str(tmp_path / ("map.fused.%s.gz" % tag))) == 0
+        assert R.read_indexed_file(fused) == want_calls
+        assert open(fused, "rb").read() == open(calls, "rb").read()
+        assert gzip.open(str(tmp_path / ("map.fused.%s.gz" % tag)), "rt").read().splitlines() == o_reads.names
+        assert drv("Pipeline.ReadCalls", "-q", fq, "-a", fa, "-o", fused + ".fa", "-k", "24") == 0       # (-K 32 is the default)
+        assert R.read_indexed_file(fused + ".fa") == want_calls
+        if tag == "kmg":      # the reads in pieces / several builds
+            for extra in (["-B", "2k"], ["-C", "37"], ["-B", "700", "-C", "5"]):
+                assert drv("Pipeline.ReadCalls", "-q", fq, "-d", ref_db, "-o", fused + ".p", *extra) == 0
+                assert open(fused + ".p", "rb").read() == open(calls, "rb").read(), extra
         # the database as a set cut at key bounds (-G shares: name.1 .. name.3): the same lines, the same counts
         for share in range(3):
             assert drv("Database.MakeDatabase", "-a", "-i", fa, "-o", ref_db + ".set", "-G", "%d/3" % share) == 0
