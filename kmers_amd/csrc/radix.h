@@ -364,8 +364,12 @@ __device__ __forceinline__ void ls_sort_body(const u64 *__restrict__ keys_in, co
                                              u64 *__restrict__ keys_out, V *__restrict__ vals_out, const LocalPasses &lp, u32 s0, u32 m,
                                              uint16_t (*wcnt)[RS_DIGITS], uint16_t (*wbase)[RS_DIGITS], u64 *skeys, V *svals) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int rounds = ROUNDS;
-    const u32 wave_base = wave * 64 * rounds;
+    // (the segment's wave-rounds dealt out evenly over the waves, a wave without the last round skips it: as in
+    // ls_sortidx_body)
+    const u32 extra = ((m + 63) >> 6) - (ROUNDS - 1) * LS_WAVES;          // 1 .. LS_WAVES
+    const bool last = (u32)wave < extra;
+    const u32 wave_base = 64u * ((u32)wave * (ROUNDS - 1) + ((u32)wave < extra ? (u32)wave : extra));
+#define LS_ACT(j) ((j) < ROUNDS - 1 || last)
 
     u64 key[ROUNDS];
     V val[ROUNDS];
@@ -379,13 +383,13 @@ __device__ __forceinline__ void ls_sort_body(const u64 *__restrict__ keys_in, co
     }
 #pragma unroll
     for (int j = 0; j < ROUNDS; j++) {
-        if (wave_base + j * 64 + lane >= m) { key[j] = 0; val[j] = (V)0; }
+        if (wave_base + j * 64 + lane >= m || !LS_ACT(j)) { key[j] = 0; val[j] = (V)0; }
     }
     if (lp.n == 0) {
 #pragma unroll
         for (int j = 0; j < ROUNDS; j++) {
             const u32 li = wave_base + j * 64 + lane;
-            if (j < rounds && li < m) { keys_out[s0 + li] = key[j]; vals_out[s0 + li] = val[j]; }
+            if (LS_ACT(j) && li < m) { keys_out[s0 + li] = key[j]; vals_out[s0 + li] = val[j]; }
         }
         return;
     }
@@ -400,7 +404,7 @@ __device__ __forceinline__ void ls_sort_body(const u64 *__restrict__ keys_in, co
         const u32 mask = (1u << nbits) - 1u;
 #pragma unroll
         for (int j = 0; j < ROUNDS; j++) {
-            if (j < rounds) {
+            if (LS_ACT(j)) {
                 const u32 li = wave_base + j * 64 + lane;
                 const bool valid = li < m;
                 const u32 d = rs_digit<V>(key[j], val[j], shift, mask, src);
@@ -439,7 +443,7 @@ __device__ __forceinline__ void ls_sort_body(const u64 *__restrict__ keys_in, co
 #pragma unroll
         for (int j = 0; j < ROUNDS; j++) {
             const u32 li = wave_base + j * 64 + lane;
-            if (j < rounds && li < m) {
+            if (LS_ACT(j) && li < m) {
                 const u32 d = rs_digit<V>(key[j], val[j], shift, mask, src);
                 const u32 pos = wbase[wave][d] + rank[j];
                 skeys[pos] = key[j];
@@ -466,7 +470,7 @@ __device__ __forceinline__ void ls_sort_body(const u64 *__restrict__ keys_in, co
             for (int j = 0; j < ROUNDS; j++) {
                 const u32 li = wave_base + j * 64 + lane;
                 npos[j] = li;
-                if (j < rounds && li < m) {
+                if (LS_ACT(j) && li < m) {
                     const u64 x = skeys[li];
                     const V xv = svals[li];
                     const u64 px = x >> lp.cmp_shift;
@@ -499,7 +503,7 @@ __device__ __forceinline__ void ls_sort_body(const u64 *__restrict__ keys_in, co
 #pragma unroll
                 for (int j = 0; j < ROUNDS; j++) {
                     const u32 li = wave_base + j * 64 + lane;
-                    if (j < rounds && li < m) { skeys[npos[j]] = key[j]; svals[npos[j]] = val[j]; }
+                    if (LS_ACT(j) && li < m) { skeys[npos[j]] = key[j]; svals[npos[j]] = val[j]; }
                 }
                 __syncthreads();
                 break;
@@ -509,7 +513,7 @@ __device__ __forceinline__ void ls_sort_body(const u64 *__restrict__ keys_in, co
 #pragma unroll
         for (int j = 0; j < ROUNDS; j++) {
             const u32 li = wave_base + j * 64 + lane;
-            if (j < rounds && li < m) { key[j] = skeys[li]; val[j] = svals[li]; }
+            if (LS_ACT(j) && li < m) { key[j] = skeys[li]; val[j] = svals[li]; }
         }
         // the next pass's first barrier orders these reads before its LDS writes
     }
@@ -518,6 +522,7 @@ __device__ __forceinline__ void ls_sort_body(const u64 *__restrict__ keys_in, co
         vals_out[s0 + i] = svals[i];
     }
 }
+#undef LS_ACT
 
 template <typename V>
 __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
