@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""BASELINE config 5 at size on one MI355X (run ON the GPU box): python tools/cfg5_bench.py [scale] > gpurun_out/cfg5.json
+"""BASELINE config 5 at size on one MI355X (run ON the GPU box; not collected by pytest -- it lives under tests/ because
+with `check` it calls the oracle, which is a checker): python tests/cfg5_bench.py [scale [check]] > gpurun_out/cfg5.json
 Long, noisy reads (10 kbp, 15 % substitutions, 0.5 % N), genome sizes over three orders of magnitude, 5 % of the bases in
 low-complexity tracts (a few key prefixes hold most of those k-mers: the oversize-segment paths of the sort), k = 21, 25,
 31.  Per k: reference build, read build, join -- wall clock from host buffers (PCIe included), the kernels' own time from
