@@ -151,8 +151,9 @@ __device__ __forceinline__ u32 ex_load_tile(const ExtractArgs &a, const u32 tile
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             u32 c = (q[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            u32 up = c & 0xDFu;                    // Base.fromCharacterByte accepts both cases
-            u32 ok = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
+            // Base.fromCharacterByte accepts both cases; A C G T = 0x41 + {0, 2, 6, 19}: one look into a 32-bit set
+            const u32 t = (c & 0xDFu) - 0x41u;
+            const u32 ok = (0x00080045u >> (t < 31u ? t : 31u)) & 1u;
             word = (word << 2) | ((c >> 1) & 3u);  // 'A'>>1&3=0 'C'=1 'T'=2 'G'=3
             bad = (bad << 1) | (ok ^ 1u);
         }

@@ -138,8 +138,9 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             u32 c = (q[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            u32 up = c & 0xDFu;
-            u32 ok = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
+            // A C G T (either case) = 0x41 + {0, 2, 6, 19}: one look into a 32-bit set instead of four compares
+            const u32 t = (c & 0xDFu) - 0x41u;
+            const u32 ok = (0x00080045u >> (t < 31u ? t : 31u)) & 1u;
             word = (word << 2) | ((c >> 1) & 3u);
             bad = (bad << 1) | (ok ^ 1u);
         }
@@ -191,12 +192,28 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
     __syncthreads();
     if (tid < EX_TILE / 32) inv[tid] = vw;
     __syncthreads();
+    const bool dup = s_dup != 0;
+    // A sequence's first k-mer (of this tile) sits behind a window that is none: a window across its start (k > 1), one
+    // with an invalid base, or the tile's edge -- marking there marks every sequence that has a k-mer.  Those windows
+    // are one in a read's length: the threads that hold the validity words walk their few set bits, and the window loop
+    // below carries none of this.
+    if (a.has_kmer && tid < EX_TILE / 32) {
+        u32 fw = vw;
+        if (k > 1) fw &= ~((vw >> 1) | (tid ? (inv[tid - 1] << 31) : 0u));
+        while (fw) {
+            const u32 b = (u32)__clz((int)fw), p = 32u * tid + b;
+            u32 rel;
+            if (dup) rel = ep_seq_rel(a, s_lo, s_end, t0 + p);
+            else rel = wpre[p >> 5] + __popc(stb[p >> 5] >> (31 - (p & 31)));
+            a.has_kmer[s_lo + rel] = 1;
+            fw &= ~(0x80000000u >> b);
+        }
+    }
 
     // ---- 3. windows: a wave owns positions wave*512 .. +511, round j covers 64 consecutive ones ------
     const u64 kmask = k == 32 ? ~0ull : ~(~0ull >> (2 * k));
     const u64 rcx = 0xAAAAAAAAAAAAAAAAull & kmask;
     const u32 pbase = wave * (64 * EP_ROUNDS) + lane;
-    const bool dup = s_dup != 0;
     u32 vmask = 0, rmask = 0, nfwd = 0, nrc = 0;
 #pragma unroll
     for (int j = 0; j < EP_ROUNDS; j++) {
@@ -204,14 +221,6 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
         // (without reverse complements or filters only the digit is needed here: the upper word)
         const u64 key = (RC || FILT) ? ep_window(pk, p, kmask) : ((u64)ep_window_hi(pk, p, kmask) << 32);
         bool ok = (inv[p >> 5] >> (31 - (p & 31))) & 1u;
-        // a sequence's first k-mer (of this tile) sits behind a window that is none: a window across its start (k > 1),
-        // one with an invalid base, or the tile's edge -- marking there marks every sequence that has a k-mer
-        if (ok && a.has_kmer && (k == 1 || p == 0 || !((inv[(p - 1) >> 5] >> (31 - ((p - 1) & 31))) & 1u))) {
-            u32 rel;
-            if (dup) rel = ep_seq_rel(a, s_lo, s_end, t0 + p);
-            else rel = wpre[p >> 5] + __popc(stb[p >> 5] >> (31 - (p & 31)));
-            a.has_kmer[s_lo + rel] = 1;
-        }
         if (FILT) {
             if (ok && a.runofsame >= 0) ok = runofsame_keep(key, k, a.runofsame);
             if (ok && a.dust >= 0) ok = dust_keep(key, k, a.dust);
