@@ -148,7 +148,7 @@ Batch *parse_core(const uint8_t *data, uint64_t n, int mode, int k, Stream *st, 
     // the last header start and what the batch held then (stream pieces are cut there)
     uint64_t cut_i = 0, cut_nout = 0;
     size_t cut_nseq = 0, cut_names = 0;
-    bool cut_in_seq = false, have_cut = false;
+    bool have_cut = false;
     int state = S_OTHER;
     uint64_t id_start = 0, id_len = 0;
     int32_t cur_id = 0; uint8_t cur_ok = 0; int64_t cur_tok = -1;
@@ -203,7 +203,6 @@ Batch *parse_core(const uint8_t *data, uint64_t n, int mode, int k, Stream *st, 
                 id_start = i + 1; id_len = 0; id_done = false;
                 if (st) {      // (a sequence is closed by now: leaving S_KMER closed it)
                     have_cut = true; cut_i = i; cut_nout = nout; cut_nseq = b->seq_off.size(); cut_names = b->names.size();
-                    cut_in_seq = in_seq;
                 }
             }
             else if (state == S_KMER) {
@@ -263,7 +262,6 @@ Batch *parse_core(const uint8_t *data, uint64_t n, int mode, int k, Stream *st, 
         // leave the record that was being read to the next piece
         if (!have_cut) { *consumed = 0; b->seq_off.assign(1, 0); b->seq_id.clear(); b->id_ok.clear(); b->seq_tok.clear();
                          b->names.clear(); b->name_off.assign(1, 0); b->nbases = 0; return b; }
-        (void)cut_in_seq;
         b->seq_off.resize(cut_nseq);
         const size_t ns = cut_nseq - 1;
         if (mode == 0 && !named) { b->seq_id.resize(ns); b->id_ok.resize(ns); }
