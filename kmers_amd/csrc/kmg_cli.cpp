@@ -802,7 +802,15 @@ class PieceReader {
             const uint64_t want = std::min<uint64_t>(piece_bytes_ - got, 16u << 20);
             buf.resize(got + want);
             const int n = gzread(z, buf.data() + got, (unsigned)want);
-            if (n <= 0) break;
+            if (n < 0) throw std::runtime_error("read error (a damaged gzip stream?)");
+            if (n == 0) {
+                // (a gzip stream that stops short hands out what it has and reports Z_BUF_ERROR: the reference's
+                // GZIPInputStream throws EOFException there)
+                int errnum = Z_OK;
+                (void)gzerror(z, &errnum);
+                if (errnum != Z_OK && errnum != Z_STREAM_END) throw std::runtime_error("unexpected end of the gzip stream");
+                break;
+            }
             got += (uint64_t)n;
         }
         buf.resize(got);
