@@ -97,9 +97,11 @@ std::string read_input(const std::string &path) {
     std::vector<char> buf(1 << 20);
     int n;
     while ((n = gzread(z, buf.data(), (unsigned)buf.size())) > 0) s.append(buf.data(), (size_t)n);
-    const bool bad = n < 0;
+    int errnum = Z_OK;
+    (void)gzerror(z, &errnum);       // (a gzip stream that stops short: Z_BUF_ERROR after the last bytes it could hand out)
+    const bool bad = n < 0 || (errnum != Z_OK && errnum != Z_STREAM_END);
     gzclose(z);
-    if (bad) throw std::runtime_error("read error in " + path);
+    if (bad) throw std::runtime_error("read error in " + path + " (a damaged or truncated gzip stream?)");
     return s;
 }
 
