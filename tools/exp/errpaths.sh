@@ -25,4 +25,22 @@ run $K Database.MakeDatabase -q -i $T/nonexistent.fq -o $T/x.db -r $T/x.map -K 3
 run $K Database.MakeDatabase -q -i $T/empty.fq -o $T/e.db -r $T/e.map -K 31 -k 31 -l 4
 run $K Database.MakeDatabase -q -i $T/trunc.fq.gz -o $T/t.db -r $T/t.map -K 31 -k 31 -l 4
 run $K Database.MakeDatabase -a -i $T/empty.fq -o $T/ea.db -K 31 -k 31 -l 4
+run $K Database.MakeDatabase -q -i $T/r.fq -o $T/r.db -r $T/r.map -K 31 -k 31 -l 4
+run $K Database.Matcher -i $T/r.db -d $T/ref.db -o $T/m.gz
+run $K Database.Matcher -i $T/nonexistent.db -d $T/ref.db -o $T/m2.gz
+run $K Database.Matcher -i $T/e.db -d $T/ref.db -o $T/m3.gz
+run $K Database.Matcher -i $T/r.db -d $T/r.db -o $T/m4.gz
+run $K Database.Matcher -i $T/r.db -d $T/ref.db -o $T/m5.gz -n 2 -j
+run $K Utils.TaxaCounts -d $T/ref.db -o $T/tc.tsv
+run $K Utils.TaxaCounts -d $T/r.db -o $T/tc2.tsv
+run $K Utils.TaxaCounts -d $T/nonexistent.db -o $T/tc3.tsv
+run $K Utils.CollectByRead -i $T/m.gz -o $T/cb
+run $K Utils.CollectByRead -i $T/nonexistent.gz -o $T/cb2
+run $K Utils.CollectByRead -i $T/ref.fa -o $T/cb3
+run $K Utils.ReadClassifier -i $T/cb -o $T/calls
+run $K Utils.ReadClassifier -i $T/ref.db -o $T/calls2
+run $K Utils.ReadClassifier -i $T/nonexistent -o $T/calls3
+head -c 300 $T/ref.db > $T/cut.db
+run $K Utils.TaxaCounts -d $T/cut.db -o $T/tc4.tsv
+run $K Database.Matcher -i $T/r.db -d $T/cut.db -o $T/m6.gz
 rm -rf $T
