@@ -76,6 +76,8 @@ void *kmg_stream(kmg_ctx *ctx);
  * kmg_build_add_dev: the same with every pointer a DEVICE pointer on this context's GPU (inputs
  *                   already resident in HBM); asynchronous on kmg_stream(); the buffers must stay
  *                   valid until kmg_build_finish returns.  read_index_out is a device pointer.
+ *                   The offsets are the caller's to get right here (kmg_build_add checks them on the host,
+ *                   KMG_EINVAL): seq_off[0] = 0, non-decreasing, seq_off[nseq] = nbases.
  * kmg_build_finish: FileCreator.create's compute (MakeAndWriteKey.call, FileCreator.java:271-347):
  *                   sort by k-mer, deduplicate, reduce.  Reference DB: per k-mer the ascending
  *                   taxon list with occurrence counts (TreeCountMap; counts are NOT saturated
