@@ -61,10 +61,14 @@ static RcclApi *rccl_api() {
     return api.ok ? &api : nullptr;
 }
 
+#define COMM_MAX_COLS 3     // count columns of an exchange (k-mers, values) + the status column
 struct kmg_comm {
     kmg_ctx *ctx = nullptr;
     int nranks = 0, rank = 0;
     kmg_nccl_comm comm = nullptr;
+    // device words of the count exchange (mine: nranks x COMM_MAX_COLS, all: nranks times that), allocated when the
+    // communicator is made: nothing that can fail locally stands between a call's checks and its first collective
+    u64 *d_mine = nullptr, *d_all = nullptr;
 };
 
 #define KMG_NCCL(expr)                                                                        \
@@ -99,9 +103,18 @@ extern "C" int kmg_comm_create(kmg_ctx *ctx, int nranks, int rank, const uint8_t
     c->ctx = ctx; c->nranks = nranks; c->rank = rank;
     kmg_nccl_id u;
     memcpy(u.internal, id, sizeof u.internal);
+    const size_t per = (size_t)nranks * COMM_MAX_COLS;
+    void *pm = nullptr, *pa = nullptr;
+    if (ctx->pool.alloc(&pm, per * 8) != KMG_OK || ctx->pool.alloc(&pa, per * nranks * 8) != KMG_OK) {
+        ctx->pool.release(pm);
+        delete c;
+        return fail(ctx, KMG_ENOMEM, "device allocation failed");
+    }
+    c->d_mine = (u64 *)pm; c->d_all = (u64 *)pa;
     const int e = api->CommInitRank(&c->comm, nranks, u, rank);
     if (e != 0) {
         ctx->err = std::string("ncclCommInitRank: ") + api->GetErrorString(e);
+        ctx->pool.release(pm); ctx->pool.release(pa);
         delete c;
         return KMG_EDEVICE;
     }
@@ -116,6 +129,8 @@ extern "C" void kmg_comm_destroy(kmg_comm *c) {
         (void)hipSetDevice(c->ctx->device);
         (void)hipStreamSynchronize(c->ctx->stream);
         if (c->comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
+        c->ctx->pool.release(c->d_mine);
+        c->ctx->pool.release(c->d_all);
     }
     delete c;
 }
@@ -141,18 +156,39 @@ static int comm_cuts(kmg_ctx *ctx, const kmg_db *db, const uint32_t *bounds, int
 }
 
 // Every rank's `ncols` send counts to every rank: m[(src * nranks + dst) * ncols + col] on the host of every rank.
-static int comm_counts(kmg_comm *c, const std::vector<u64> &mine, int ncols, std::vector<u64> &m) {
+// The same all-gather carries every rank's verdict on its own checks (`my_status`, 0 = fine): a rank whose arguments or
+// local preparation failed still takes part -- with zero counts -- and EVERY rank leaves the call with an error, instead
+// of one rank returning early while its peers wait in the collective.
+static int comm_counts(kmg_comm *c, const std::vector<u64> &mine, int ncols, int my_status, std::vector<u64> &m) {
     kmg_ctx *ctx = c->ctx;
-    const size_t per = (size_t)c->nranks * ncols;
-    if (c->nranks == 1) { m = mine; return KMG_OK; }
-    PoolBuf d_mine(ctx), d_all(ctx);
-    KMG_ALLOC(d_mine, per * 8);
-    KMG_ALLOC(d_all, per * c->nranks * 8);
-    KMG_HIP(hipMemcpyAsync(d_mine.p, mine.data(), per * 8, hipMemcpyHostToDevice, ctx->stream));
-    KMG_NCCL(rccl_api()->AllGather(d_mine.p, d_all.p, per, KMG_NCCL_UINT64, c->comm, ctx->stream));
-    m.assign(per * c->nranks, 0);
-    KMG_HIP(hipMemcpyAsync(m.data(), d_all.p, per * c->nranks * 8, hipMemcpyDeviceToHost, ctx->stream));
+    const int n = c->nranks;
+    if (n == 1) { m = mine; return my_status; }
+    const int cols = ncols + 1;                       // + status
+    const size_t per = (size_t)n * cols;
+    std::vector<u64> row(per, 0), all(per * n, 0);
+    for (int r = 0; r < n; r++) {
+        if (my_status == KMG_OK)
+            for (int col = 0; col < ncols; col++) row[(size_t)r * cols + col] = mine[(size_t)r * ncols + col];
+        row[(size_t)r * cols + ncols] = (u64)(uint32_t)(-my_status);
+    }
+    const std::string own_err = ctx->err;
+    // (a failure of these two copies is a device failure: the peers cannot be told)
+    KMG_HIP(hipMemcpyAsync(c->d_mine, row.data(), per * 8, hipMemcpyHostToDevice, ctx->stream));
+    KMG_NCCL(rccl_api()->AllGather(c->d_mine, c->d_all, per, KMG_NCCL_UINT64, c->comm, ctx->stream));
+    KMG_HIP(hipMemcpyAsync(all.data(), c->d_all, per * n * 8, hipMemcpyDeviceToHost, ctx->stream));
     KMG_HIP(hipStreamSynchronize(ctx->stream));
+    m.assign((size_t)n * n * ncols, 0);
+    int first_bad = -1;
+    for (int s = 0; s < n; s++)
+        for (int r = 0; r < n; r++) {
+            for (int col = 0; col < ncols; col++) m[((size_t)s * n + r) * ncols + col] = all[((size_t)s * n + r) * cols + col];
+            if (all[((size_t)s * n + r) * cols + ncols] != 0 && first_bad < 0) first_bad = s;
+        }
+    if (my_status != KMG_OK) { ctx->err = own_err; return my_status; }
+    if (first_bad >= 0) {
+        ctx->err = "rank " + std::to_string(first_bad) + " failed its checks before the exchange: nothing was exchanged";
+        return KMG_ESTATE;
+    }
     return KMG_OK;
 }
 
@@ -170,14 +206,34 @@ static int comm_alltoallv(kmg_comm *c, const void *send, const std::vector<u64> 
     }
     if (c->nranks == 1) return KMG_OK;
     KMG_NCCL(api->GroupStart());
-    for (int g = 0; g < c->nranks; g++) {
+    // (an error between GroupStart and GroupEnd must not leave the communicator inside an open group)
+    int bad = 0;
+    const char *what = "ncclSend";
+    for (int g = 0; g < c->nranks && !bad; g++) {
         if (g == c->rank) continue;
         const u64 ns = soff[g + 1] - soff[g], nr = roff[g + 1] - roff[g];
-        if (ns) KMG_NCCL(api->Send((const char *)send + soff[g] * elem, ns, dtype, g, c->comm, ctx->stream));
-        if (nr) KMG_NCCL(api->Recv((char *)recv + roff[g] * elem, nr, dtype, g, c->comm, ctx->stream));
+        if (ns) bad = api->Send((const char *)send + soff[g] * elem, ns, dtype, g, c->comm, ctx->stream);
+        if (nr && !bad) { bad = api->Recv((char *)recv + roff[g] * elem, nr, dtype, g, c->comm, ctx->stream); if (bad) what = "ncclRecv"; }
     }
-    KMG_NCCL(api->GroupEnd());
+    std::string msg;
+    if (bad) msg = std::string(what) + ": " + api->GetErrorString(bad);
+    const int end = api->GroupEnd();
+    if (bad) { ctx->err = msg; return KMG_EDEVICE; }
+    if (end != 0) { ctx->err = std::string("ncclGroupEnd: ") + api->GetErrorString(end); return KMG_EDEVICE; }
     return KMG_OK;
+}
+
+// the checks of kmg_match_sharded that need no other rank; the cut points come out with them
+static int match_sharded_checks(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref_shard, const uint32_t *bounds, int n,
+                                const int64_t *d_hit_index, std::vector<u64> &cut) {
+    if (search->ctx->device != ctx->device || ref_shard->ctx->device != ctx->device)
+        return fail(ctx, KMG_EINVAL, "database belongs to another device");
+    if (search->k != ref_shard->k || search->key_len != ref_shard->key_len)                          // DB.java:78-81
+        return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
+    if (search->min_k != search->k || ref_shard->min_k != ref_shard->k)
+        return fail(ctx, KMG_EUNSUPPORTED, "k-mers of several lengths: restrict the databases to one length first");
+    if (search->U && !d_hit_index) return fail(ctx, KMG_EINVAL, "null hit_index");
+    return comm_cuts(ctx, search, bounds, n, cut);
 }
 
 extern "C" int kmg_match_sharded(kmg_comm *c, const kmg_db *search, const kmg_db *ref_shard, const uint32_t *bounds,
@@ -186,21 +242,17 @@ extern "C" int kmg_match_sharded(kmg_comm *c, const kmg_db *search, const kmg_db
     kmg_ctx *ctx = c->ctx;
     std::lock_guard<std::mutex> g(ctx->mu);
     KMG_HIP(hipSetDevice(ctx->device));
-    if (search->ctx->device != ctx->device || ref_shard->ctx->device != ctx->device)
-        return fail(ctx, KMG_EINVAL, "database belongs to another device");
-    if (search->k != ref_shard->k || search->key_len != ref_shard->key_len)                          // DB.java:78-81
-        return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
-    if (search->min_k != search->k || ref_shard->min_k != ref_shard->k)
-        return fail(ctx, KMG_EUNSUPPORTED, "k-mers of several lengths: restrict the databases to one length first");
-    if (search->U && !d_hit_index) return fail(ctx, KMG_EINVAL, "null hit_index");
     const int n = c->nranks;
-    std::vector<u64> cut, mine(n), all;
-    KMG_TRY(comm_cuts(ctx, search, bounds, n, cut));
-    for (int r = 0; r < n; r++) mine[r] = cut[r + 1] - cut[r];
-    KMG_TRY(comm_counts(c, mine, 1, all));
+    std::vector<u64> cut(n + 1, 0), mine(n, 0), all;
+    // a rank whose checks fail still meets its peers in the count exchange, and every rank returns an error
+    const int st = match_sharded_checks(ctx, search, ref_shard, bounds, n, d_hit_index, cut);
+    if (st == KMG_OK) for (int r = 0; r < n; r++) mine[r] = cut[r + 1] - cut[r];
+    KMG_TRY(comm_counts(c, mine, 1, st, all));
     std::vector<u64> roff(n + 1, 0);
     for (int s = 0; s < n; s++) roff[s + 1] = roff[s] + all[(size_t)s * n + c->rank];
     const u64 nrecv = roff[n];
+    // (from here on a local failure -- out of device memory -- leaves the peers waiting in the grouped exchange: the
+    // receive buffers can only be sized once the counts are known)
     PoolBuf rkeys(ctx), rhits(ctx);
     KMG_ALLOC(rkeys, (nrecv + 1) * 8);
     KMG_ALLOC(rhits, (nrecv + 1) * 8);
@@ -237,15 +289,19 @@ extern "C" int kmg_db_exchange_by_key_range(kmg_comm *c, const kmg_db *local, co
     {
         std::lock_guard<std::mutex> g(ctx->mu);
         KMG_HIP(hipSetDevice(ctx->device));
-        if (local->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
-        if (local->min_k != local->k) return fail(ctx, KMG_EUNSUPPORTED, "databases of k-mers of several lengths are not exchanged");
-        KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(local)));
-        std::vector<u64> cut, vcut(n + 1), mine(2 * (size_t)n), all;
-        KMG_TRY(comm_cuts(ctx, local, bounds, n, cut));
-        for (int r = 0; r <= n; r++) KMG_HIP(hipMemcpyAsync(&vcut[r], local->val_off + cut[r], 8, hipMemcpyDeviceToHost, ctx->stream));
-        KMG_HIP(hipStreamSynchronize(ctx->stream));
-        for (int r = 0; r < n; r++) { mine[2 * r] = cut[r + 1] - cut[r]; mine[2 * r + 1] = vcut[r + 1] - vcut[r]; }
-        KMG_TRY(comm_counts(c, mine, 2, all));
+        std::vector<u64> cut(n + 1, 0), vcut(n + 1, 0), mine(2 * (size_t)n, 0), all;
+        // the checks and preparation that need no other rank; their verdict travels with the counts (comm_counts)
+        const int st = [&]() -> int {
+            if (local->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
+            if (local->min_k != local->k) return fail(ctx, KMG_EUNSUPPORTED, "databases of k-mers of several lengths are not exchanged");
+            KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(local)));
+            KMG_TRY(comm_cuts(ctx, local, bounds, n, cut));
+            for (int r = 0; r <= n; r++) KMG_HIP(hipMemcpyAsync(&vcut[r], local->val_off + cut[r], 8, hipMemcpyDeviceToHost, ctx->stream));
+            KMG_HIP(hipStreamSynchronize(ctx->stream));
+            return KMG_OK;
+        }();
+        if (st == KMG_OK) for (int r = 0; r < n; r++) { mine[2 * r] = cut[r + 1] - cut[r]; mine[2 * r + 1] = vcut[r + 1] - vcut[r]; }
+        KMG_TRY(comm_counts(c, mine, 2, st, all));
         std::vector<u64> koff(n + 1, 0), voff(n + 1, 0);
         for (int s = 0; s < n; s++) {
             koff[s + 1] = koff[s] + all[((size_t)s * n + c->rank) * 2];
