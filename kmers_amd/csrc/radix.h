@@ -229,7 +229,7 @@ struct SortPass {
 #define LS_ITEMS 5
 #endif
 #ifndef LS_MINWAVES
-#define LS_MINWAVES 6
+#define LS_MINWAVES 8
 #endif
 #define LS_MAX (LS_BLOCK * LS_ITEMS)   // 2560 records per segment at most (48 KB of LDS: 3 blocks per CU)
 
@@ -559,8 +559,85 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
 // (the body is compiled once per number of rounds -- ROUNDS x 512 slots cover the segment -- so that every loop over a
 // thread's records is straight-line code: the rounds' ballot chains and counter look-ups overlap instead of queueing
 // behind one scalar branch per round)
+// One stable counting pass of the one-word-per-record local sort: the wave's words (registers) -> dst[] in digit order,
+// and, if `reload`, back into the registers in the new order.  Round j of this wave holds slots iff j < ALWAYS (known
+// at compile time) or j < nact (wave-uniform).  Three barriers; wcnt rows must be zero on entry and are zero on exit.
+template <int R, int ALWAYS>
+__device__ __forceinline__ void ls_word_pass(u64 (&w)[R], u32 nact, int shift, u32 mask, uint16_t (*wcnt)[RS_DIGITS],
+                                             uint16_t (*wbase)[RS_DIGITS], u64 *dst, u32 wave_base, bool reload) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define LSW_ACT(j) ((j) < ALWAYS || (u32)(j) < nact)
+    u32 rank[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        if (!LSW_ACT(j)) continue;
+        const u32 d = (u32)(w[j] >> shift) & mask;
+        u32 below, total;
+        wave_match(d, true, below, total);
+        const u32 before = wcnt[wave][d];
+        rank[j] = before + below;
+        wcnt[wave][d] = before + total;      // every lane of the digit stores the same sum: no branch around the store
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // One wave turns the 8 x 256 per-wave counts into per-wave slot bases; lane owns digits 4*lane .. +3.
+        // Counts are 16-bit and every partial sum stays <= LS_MAX, so four of them are added at once as two
+        // 32-bit words without carries between the halves.
+        uint2 run = make_uint2(0, 0), pre[LS_WAVES];
+#pragma unroll
+        for (int wv = 0; wv < LS_WAVES; wv++) {
+            const uint2 c = *reinterpret_cast<const uint2 *>(&wcnt[wv][4 * lane]);
+            pre[wv] = run;
+            run.x += c.x; run.y += c.y;
+        }
+        const u32 t0 = run.x & 0xFFFFu, t1 = run.x >> 16, t2 = run.y & 0xFFFFu, t3 = run.y >> 16;
+        const u32 s4 = t0 + t1 + t2 + t3;
+        u32 inc = s4;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const u32 o = __shfl_up(inc, dd, 64);
+            if (lane >= dd) inc += o;
+        }
+        const u32 b0 = inc - s4, b1 = b0 + t0, b2 = b1 + t1, b3 = b2 + t2;
+        const uint2 start = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+#pragma unroll
+        for (int wv = 0; wv < LS_WAVES; wv++)
+            *reinterpret_cast<uint2 *>(&wbase[wv][4 * lane]) = make_uint2(start.x + pre[wv].x, start.y + pre[wv].y);
+    }
+    __syncthreads();
+    u32 pos[R];
+#pragma unroll
+    for (int j = 0; j < R; j++)
+        if (LSW_ACT(j)) pos[j] = wbase[wave][(u32)(w[j] >> shift) & mask] + rank[j];
+#pragma unroll
+    for (int j = 0; j < R; j++)
+        if (LSW_ACT(j)) dst[pos[j]] = w[j];
+    __syncthreads();
+    *reinterpret_cast<uint2 *>(&wcnt[wave][4 * lane]) = make_uint2(0, 0);
+    if (reload) {
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if (LSW_ACT(j)) w[j] = dst[wave_base + j * 64 + lane];
+    }
+#undef LSW_ACT
+}
+
+// Read sets are deep: at 30-fold coverage two thirds of a segment's records are copies of a k-mer that is already
+// there.  FOLD (HEADS only): after the two lowest digit passes equal k-mers stand next to each other (records that
+// agree on those 16 bits and differ above them are rare), so the runs of equal words are found there -- "groups" -- and
+// only one word per group takes the remaining passes; the records then move to their group's final place in one step.
+// A k-mer whose copies were split into several groups by a stranger with the same low digits is put together again by
+// the stable group passes (the groups end up adjacent, in their order), and the distinct k-mers are told apart on the
+// sorted groups.  Segments of mostly distinct k-mers (> 5/8 groups per record, long reads with many errors) carry on
+// with the plain passes: what the check costs them is one neighbour look per record.
+#ifndef LS_FOLD
+#define LS_FOLD 1
+#endif
+#define LS_FOLD_AFTER 2          // passes before the groups are looked for
+#define LS_GROUPS_MAX 1024       // two group words per thread; a 12-bit group number
+
 template <typename V, bool HEADS, int ROUNDS>
-__device__ __forceinline__ void ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *__restrict__ keys_out, V *__restrict__ vals_out,
+__device__ __forceinline__ u32 ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *__restrict__ keys_out, V *__restrict__ vals_out,
                                                 const LocalPasses &lp, int pbits, u32 *__restrict__ ucount, u32 s0, u32 m,
                                                 uint16_t (*wcnt)[RS_DIGITS], uint16_t (*wbase)[RS_DIGITS], u64 *swords, V *svals) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -570,6 +647,7 @@ __device__ __forceinline__ void ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *_
     // the last round skips it (wave-uniform): on average half a block-round of all-sentinel work less per pass.
     const u32 extra = ((m + 63) >> 6) - (ROUNDS - 1) * LS_WAVES;          // 1 .. LS_WAVES
     const bool last = (u32)wave < extra;
+    const u32 nact = (u32)(ROUNDS - 1) + (last ? 1u : 0u);
     const u32 wave_base = 64u * ((u32)wave * (ROUNDS - 1) + ((u32)wave < extra ? (u32)wave : extra));
 #define LS_ACT(j) ((j) < ROUNDS - 1 || last)
 
@@ -578,7 +656,6 @@ __device__ __forceinline__ void ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *_
     // (loads at clamped indices, all issued before the first is used: a load under `if (valid)` compiles to a branch
     // with a wait behind it, one memory round trip per round)
     u64 sw[ROUNDS];
-    u32 rank[ROUNDS];
     V vraw[ROUNDS];
 #pragma unroll
     for (int j = 0; j < ROUNDS; j++) {
@@ -595,69 +672,74 @@ __device__ __forceinline__ void ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *_
         if (valid) svals[li] = vraw[j];
     }
     *reinterpret_cast<uint2 *>(&wcnt[wave][4 * lane]) = make_uint2(0, 0);
+    const u64 seg_prefix = pbits > 0 ? ((u64)blockIdx.x << (64 - pbits)) : 0ull;
     for (int p = 0; p < lp.n; p++) {
-        const int shift = lp.shift[p] + pbits;
-        const u32 mask = (1u << lp.bits[p]) - 1u;
+        ls_word_pass<ROUNDS, ROUNDS - 1>(sw, nact, lp.shift[p] + pbits, (1u << lp.bits[p]) - 1u, wcnt, wbase, swords, wave_base, p + 1 < lp.n);
+        if (LS_FOLD && HEADS && p + 1 == LS_FOLD_AFTER && lp.n >= LS_FOLD_AFTER + 2) {
+            // ---- groups: runs of equal words (the index bits aside) in the order of the two lowest digits -------------
+            u32 *wtot = reinterpret_cast<u32 *>(&wbase[0][0]);   // heads per wave-round, in slot order (wbase is free between passes)
+            u32 gbelow[ROUNDS];
+            u32 ghead = 0;
+            // opaque copy of the slot base: keeps this block's address arithmetic out of the pass loop's registers
+            // (hoisted, it sat in a dozen registers across every pass: 61 -> 80 and a wave per SIMD less)
+            u32 wb = wave_base;
+            asm volatile("" : "+v"(wb));
 #pragma unroll
-        for (int j = 0; j < ROUNDS; j++) {
-            if (!LS_ACT(j)) continue;
-            const u32 d = (u32)(sw[j] >> shift) & mask;
-            u32 below, total;
-            wave_match(d, true, below, total);
-            const u32 before = wcnt[wave][d];
-            rank[j] = before + below;
-            wcnt[wave][d] = before + total;      // every lane of the digit stores the same sum: no branch around the store
-        }
-        __syncthreads();
-        if (wave == 0) {
-            // One wave turns the 8 x 256 per-wave counts into per-wave slot bases; lane owns digits 4*lane .. +3.
-            // Counts are 16-bit and every partial sum stays <= LS_MAX, so four of them are added at once as two
-            // 32-bit words without carries between the halves.
-            uint2 run = make_uint2(0, 0), pre[LS_WAVES];
-#pragma unroll
-            for (int w = 0; w < LS_WAVES; w++) {
-                const uint2 c = *reinterpret_cast<const uint2 *>(&wcnt[w][4 * lane]);
-                pre[w] = run;
-                run.x += c.x; run.y += c.y;
+            for (int j = 0; j < ROUNDS; j++) {
+                if (!LS_ACT(j)) continue;
+                const u32 q = wb + j * 64 + lane;
+                const u64 prev = swords[q ? q - 1 : 0];
+                const bool head = q < m && (q == 0 || ((prev ^ sw[j]) >> 12) != 0);
+                const u64 hb = __ballot(head);
+                if (lane == 0) wtot[q >> 6] = __popcll(hb);
+                gbelow[j] = __builtin_amdgcn_mbcnt_hi((u32)(hb >> 32), __builtin_amdgcn_mbcnt_lo((u32)hb, 0u));
+                ghead |= (u32)head << j;
             }
-            const u32 t0 = run.x & 0xFFFFu, t1 = run.x >> 16, t2 = run.y & 0xFFFFu, t3 = run.y >> 16;
-            const u32 s4 = t0 + t1 + t2 + t3;
-            u32 inc = s4;
+            __syncthreads();
+            const u32 nwr = (m + 63) >> 6;                        // wave-rounds of the segment (<= 40)
+            const u32 c = (u32)lane < nwr ? wtot[lane] : 0u;
+            u32 inc = c;
 #pragma unroll
             for (int dd = 1; dd < 64; dd <<= 1) {
                 const u32 o = __shfl_up(inc, dd, 64);
                 if (lane >= dd) inc += o;
             }
-            const u32 b0 = inc - s4, b1 = b0 + t0, b2 = b1 + t1, b3 = b2 + t2;
-            const uint2 start = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+            const u32 G = __shfl(inc, 63, 64);
+            if (G < LS_GROUPS_MAX && 8 * G <= 5 * m) {       // (G + 1 group starts must end below the records' numbers)
+                u64 *gbuf = swords;                                              // [G] group words: key bits | group number
+                uint16_t *gstart = reinterpret_cast<uint16_t *>(swords + LS_GROUPS_MAX);   // [G + 1] first slot of every group
+                // (the barrier above ordered every wave's reads of swords before these stores into it; wtot is not
+                // written over before the group passes' first barrier)
+                // per record, in the order of the slots: group number << 12 | load index -- in the upper half of swords, which
+                // neither the group words (<= 8 KB + 2 KB of group starts) nor 32-bit payloads in final order (<= 10 KB) reach
+                u32 *recs = reinterpret_cast<u32 *>(swords + LS_MAX / 2);
+                const u32 exc = inc - c;
 #pragma unroll
-            for (int w = 0; w < LS_WAVES; w++)
-                *reinterpret_cast<uint2 *>(&wbase[w][4 * lane]) = make_uint2(start.x + pre[w].x, start.y + pre[w].y);
-        }
-        __syncthreads();
-        u32 pos[ROUNDS];
-#pragma unroll
-        for (int j = 0; j < ROUNDS; j++)
-            if (LS_ACT(j)) pos[j] = wbase[wave][(u32)(sw[j] >> shift) & mask] + rank[j];
-#pragma unroll
-        for (int j = 0; j < ROUNDS; j++)
-            if (LS_ACT(j)) swords[pos[j]] = sw[j];
-        __syncthreads();
-        *reinterpret_cast<uint2 *>(&wcnt[wave][4 * lane]) = make_uint2(0, 0);
-        if (p + 1 < lp.n) {
-#pragma unroll
-            for (int j = 0; j < ROUNDS; j++)
-                if (LS_ACT(j)) sw[j] = swords[wave_base + j * 64 + lane];
+                for (int j = 0; j < ROUNDS; j++) {
+                    if (!LS_ACT(j)) continue;
+                    const u32 q = wb + j * 64 + lane;
+                    const u32 base = __shfl(exc, q >> 6, 64);
+                    const bool head = (ghead >> j) & 1;
+                    const u32 gid = base + gbelow[j] - (head ? 0u : 1u);
+                    recs[q] = (gid << 12) | ((u32)sw[j] & 0xFFFu);
+                    if (head) {
+                        gbuf[gid] = (sw[j] & ~0xFFFull) | gid;
+                        gstart[gid] = (uint16_t)q;
+                    }
+                }
+                if (tid == 0) gstart[G] = (uint16_t)m;
+                return G;          // the rest happens once for all round counts: ls_fold_tail
+            }
+            // (wtot lies in wbase, which the next pass writes behind its first barrier: every wave has read it by then)
         }
     }
-    const u64 seg_prefix = pbits > 0 ? ((u64)blockIdx.x << (64 - pbits)) : 0ull;
     if (!HEADS) {
         for (u32 i = tid; i < m; i += LS_BLOCK) {
             const u64 w = swords[i];
             keys_out[s0 + i] = seg_prefix | ((w & ~0xFFFull) >> pbits);
             vals_out[s0 + i] = svals[(u32)w & 0xFFFu];
         }
-        return;
+        return 0;
     }
     // the last pass's closing barrier ordered every load of this block's input slice before these stores
     u32 *wtot = reinterpret_cast<u32 *>(&wbase[0][0]);   // head counts per (round, wave), in record order
@@ -703,6 +785,131 @@ __device__ __forceinline__ void ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *_
     }
     const u32 nheads = __shfl(inc, 63, 64);
     if (tid == 0) ucount[blockIdx.x] = nheads;
+    return 0;
+}
+
+// The second half of the fold (see ls_sortidx_body): G group words in swords[0 .. G), the groups' first slots behind
+// them, every record's (group number << 12 | load index) in the upper half of swords.  Compiled once, behind the
+// switch over the round counts: nothing of the body's registers is live here.
+template <typename V>
+__device__ __forceinline__ void ls_fold_tail(u64 *keys_in, V *vals_in, V *__restrict__ vals_out, const LocalPasses &lp, int pbits,
+                                             u32 *__restrict__ ucount, u32 s0, u32 m, u32 G, uint16_t (*wcnt)[RS_DIGITS],
+                                             uint16_t (*wbase)[RS_DIGITS], u64 *swords, V *svals) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u64 *gbuf = swords;
+    uint16_t *gstart = reinterpret_cast<uint16_t *>(swords + LS_GROUPS_MAX);
+    uint16_t *delta = reinterpret_cast<uint16_t *>(&wbase[0][0]);    // [G] final place - place now (mod 2^16)
+    u32 *recs = reinterpret_cast<u32 *>(swords + LS_MAX / 2);
+    const u64 seg_prefix = pbits > 0 ? ((u64)blockIdx.x << (64 - pbits)) : 0ull;
+    __syncthreads();
+    // ---- the remaining passes over one word per group --------------------------------------------------------
+    const u32 gwr = (G + 63) >> 6;                                   // 1 .. 16 wave-rounds
+    const u32 grounds = (gwr + LS_WAVES - 1) / LS_WAVES;             // 1 or 2 per wave
+    const u32 gextra = gwr - (grounds - 1) * LS_WAVES;
+    const u32 gnact = (grounds - 1) + ((u32)wave < gextra ? 1u : 0u);
+    const u32 gwave_base = 64u * ((u32)wave * (grounds - 1) + ((u32)wave < gextra ? (u32)wave : gextra));
+    u64 gw[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const u32 i = gwave_base + j * 64 + lane;
+        gw[j] = ((u32)j < gnact && i < G) ? gbuf[i] : ~0ull;
+    }
+    // The group words are all different (their group numbers are), and their order as plain 64-bit numbers -- key bits,
+    // then group number -- is the order wanted: groups of one k-mer keep the order they were found in.  So no stable
+    // pass per digit is needed here: ONE counting pass on the top eight bits leaves buckets of a few words each, and
+    // a word's place inside its bucket is the number of smaller words there (a short walk through LDS).  Five barriers
+    // instead of twelve for the four passes this replaces: with a few hundred words per segment a pass is all latency.
+    ls_word_pass<2, 0>(gw, gnact, 56, 0xFFu, wcnt, wbase, gbuf, gwave_base, true);
+    u32 npos[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        npos[j] = 0;
+        if ((u32)j < gnact) {
+            const u64 w = gw[j];
+            const u32 d = (u32)(w >> 56);
+            const u32 bs = wbase[0][d];                                   // wave 0's slot base of a digit = the bucket's start
+            const u32 be = d == 255u ? gwr * 64u : (u32)wbase[0][d + 1];  // (the last bucket ends with the sentinels)
+            u32 smaller = 0;
+            for (u32 t = bs; t < be; t += 4) {
+                // (four reads in flight, at clamped slots; a word is not smaller than itself)
+                const u64 x0 = gbuf[t], x1 = gbuf[min(t + 1, be - 1)], x2 = gbuf[min(t + 2, be - 1)], x3 = gbuf[min(t + 3, be - 1)];
+                smaller += (x0 < w) + (t + 1 < be && x1 < w) + (t + 2 < be && x2 < w) + (t + 3 < be && x3 < w);
+            }
+            npos[j] = bs + smaller;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+        if ((u32)j < gnact && gw[j] != ~0ull) gbuf[npos[j]] = gw[j];
+    __syncthreads();
+    // ---- sorted groups -> their first slots (scan of the sizes) and the distinct k-mers -------------------------
+    u32 *wsum = reinterpret_cast<u32 *>(&wbase[LS_WAVES / 2][0]);    // (wbase: delta in its first half, this behind it)
+    u64 x[2];
+    u32 v[2], gg[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const u32 i = 2 * tid + e;
+        v[e] = 0; gg[e] = 0; x[e] = 0;
+        if (i < G) {
+            x[e] = gbuf[i];
+            gg[e] = (u32)x[e] & 0xFFFu;
+            const u64 pv = i ? gbuf[i - 1] : ~x[e];
+            const u32 distinct = ((pv ^ x[e]) >> 12) != 0;
+            v[e] = ((u32)gstart[gg[e] + 1] - (u32)gstart[gg[e]]) | (distinct << 16);
+        }
+    }
+    const u32 both = v[0] + v[1];
+    u32 winc = both;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const u32 o = __shfl_up(winc, dd, 64);
+        if (lane >= dd) winc += o;
+    }
+    if (lane == 63) wsum[wave] = winc;
+    __syncthreads();
+    u32 wpre = 0, tot = 0;
+#pragma unroll
+    for (int wv = 0; wv < LS_WAVES; wv++) {
+        const u32 t = wsum[wv];
+        if (wv < wave) wpre += t;
+        tot += t;
+    }
+    u32 ex = wpre + winc - both;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const u32 i = 2 * tid + e;
+        if (i < G) {
+            const u32 first = ex & 0xFFFFu;
+            delta[gg[e]] = (uint16_t)(first - (u32)gstart[gg[e]]);
+            if (v[e] >> 16) {
+                const u32 slot = s0 + (ex >> 16);
+                keys_in[slot] = seg_prefix | ((x[e] & ~0xFFFull) >> pbits);
+                vals_in[slot] = (V)(s0 + first);
+            }
+        }
+        ex += v[e];
+    }
+    if (tid == 0) ucount[blockIdx.x] = tot >> 16;
+    __syncthreads();
+    // ---- every record to its group's final place ------------------------------------------------------------------
+    if (sizeof(V) == 4) {
+        // through LDS (the lower half of swords: the group words are done with), then out in order
+        V *fvals = reinterpret_cast<V *>(swords);
+        for (u32 q = tid; q < m; q += LS_BLOCK) {
+            const u32 rec = recs[q];
+            fvals[(q + delta[rec >> 12]) & 0xFFFFu] = svals[rec & 0xFFFu];
+        }
+        __syncthreads();
+        for (u32 i = tid; i < m; i += LS_BLOCK) vals_out[s0 + i] = fvals[i];
+    } else {
+        // (64-bit payloads in final order would not fit beside the records' group numbers: straight to memory,
+        // a group's records side by side)
+        for (u32 q = tid; q < m; q += LS_BLOCK) {
+            const u32 rec = recs[q];
+            vals_out[s0 + ((q + delta[rec >> 12]) & 0xFFFFu)] = svals[rec & 0xFFFu];
+        }
+    }
 }
 
 #undef LS_ACT
@@ -736,13 +943,15 @@ __global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *
         if (HEADS && threadIdx.x == 0) ucount[blockIdx.x] = 0;   // (the host never asks for HEADS with oversize segments)
         return;
     }
+    u32 G = 0;
     switch ((m + LS_BLOCK - 1) / LS_BLOCK) {
-        case 1: ls_sortidx_body<V, HEADS, 1>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
-        case 2: ls_sortidx_body<V, HEADS, 2>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
-        case 3: ls_sortidx_body<V, HEADS, 3>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
-        case 4: ls_sortidx_body<V, HEADS, 4>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
-        default: ls_sortidx_body<V, HEADS, 5>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        case 1: G = ls_sortidx_body<V, HEADS, 1>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        case 2: G = ls_sortidx_body<V, HEADS, 2>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        case 3: G = ls_sortidx_body<V, HEADS, 3>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        case 4: G = ls_sortidx_body<V, HEADS, 4>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        default: G = ls_sortidx_body<V, HEADS, 5>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
     }
+    if (LS_FOLD && HEADS && G) ls_fold_tail<V>(keys_in, vals_in, vals_out, lp, pbits, ucount, s0, m, G, wcnt, wbase, swords, svals);
 }
 
 // Gathers what ls_sortidx_kernel<.., true> left per segment into the DB arrays: one block per segment.
