@@ -20,6 +20,7 @@ are the same in both modes.
 
 `--config 3` is the secondary line: BASELINE config 3 at full size on one GPU (1 Gbp / 10 k taxa reference, 100 M
 reads streamed in chunks against the resident reference, TaxaCounts) -- see bench_config3().
+`--config 4`: one rank's share of BASELINE config 4 (8 GPUs) on one GPU -- see bench_config4.py.
 
 Adds "roofline" (dominant kernel, algorithmic bytes / HIP-event time measured live on the library's stream) and, on
 rank 0 at N = 1, "cpu_baseline" (the C restatement of the reference's algorithm timed on this box's host cores).
@@ -46,7 +47,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="BASELINE config: 2 = headline, 3 = 1 Gbp + 100 M reads + TaxaCounts (one GPU)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),
+                    help="BASELINE config: 2 = headline, 3 = 1 Gbp + 100 M reads + TaxaCounts (one GPU), 4 = one rank's share of the "
+                         "8-GPU config (30 Gbp scanned for an eighth of the key buckets, 125 M reads) on one GPU")
     ap.add_argument("--scale", type=float, default=1.0, help="scale factor on config sizes (1.0 = the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calib", action="store_true", help="also launch the known-traffic copy kernel (PMC calibration)")
@@ -133,11 +136,11 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if args.config == 3:
+    if args.config in (3, 4):
         if world != 1:
-            sys.stderr.write("bench.py: --config 3 is a one-GPU line\n")
+            sys.stderr.write("bench.py: --config %d is a one-GPU line\n" % args.config)
             sys.exit(2)
-        out = bench_config3(args, dev)
+        out = bench_config3(args, dev) if args.config == 3 else bench_config4(args, dev)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
         return
     # KMERS_BENCH_FORCE_DIST=1: run the collective code path with a single rank too (rehearsal on a 1-GPU box)
@@ -522,6 +525,11 @@ def cpu_baseline(synth, taxa, genomes, reads):
 def bench_config3(args, dev):
     import bench_config3 as b3
     return b3.run(args, dev)
+
+
+def bench_config4(args, dev):
+    import bench_config4 as b4
+    return b4.run(args, dev)
 
 
 if __name__ == "__main__":

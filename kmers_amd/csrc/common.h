@@ -84,10 +84,16 @@ struct DevPool {
         void *p = nullptr;
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
-            // give everything cached back and retry once
+            // give everything cached back and retry once.  The failed call leaves hipErrorOutOfMemory as the
+            // runtime's last error: taken off here, or the next hipGetLastError() behind a kernel launch would
+            // report an allocation failure that was recovered from
+            (void)hipGetLastError();
             trim();
             e = hipMalloc(&p, bytes);
-            if (e != hipSuccess) return KMG_ENOMEM;
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return KMG_ENOMEM;
+            }
         }
         total += bytes;
         live[p] = bytes;
