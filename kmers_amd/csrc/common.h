@@ -191,6 +191,11 @@ struct kmg_ctx {
     uint8_t *sh_len = nullptr;
     u64 sh_n = 0, sh_cap = 0;
     u64 *match_scratch = nullptr; // this device's copy of the file-scope bounds array (kmg_match_dev_noalloc)
+    // single-pass (chained) scans and their relatives, scan.h: tile status words, two control words, the launch epoch
+    u64 *scan_status = nullptr;
+    size_t scan_status_cap = 0;
+    u32 *scan_ctl = nullptr;
+    u32 scan_epoch = 0;
 
     // profiling
     bool prof_on = false;

@@ -17,6 +17,7 @@
 //      exclusive-scanned offsets, in window order (the later stable sort relies on that order).
 #pragma once
 #include "common.h"
+#include "scan.h"
 
 #define EX_BLOCK 256
 #define EX_ROUNDS 16
@@ -368,45 +369,118 @@ __global__ void id_bits_kernel(const int32_t *__restrict__ ids, u64 n, u64 *stat
 }
 
 // ---- read numbering (ReadIDMapping.geNext, OtherFiles/ReadIDMapping.java:14-23) ----------------------
-// emit_idx[i] = i if sequence i produced a k-mer else -1          (input of the exclusive max-scan)
-__global__ void number_emit_kernel(const uint8_t *__restrict__ has_kmer, int32_t *__restrict__ emit_idx, u64 n) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) emit_idx[i] = has_kmer[i] ? (int32_t)i : -1;
-}
-// is_new[i] = sequence i produced a k-mer and its header differs from the last one that did
-__global__ void number_new_kernel(const uint8_t *__restrict__ has_kmer, const int32_t *__restrict__ prev_emit,
-                                  const int64_t *__restrict__ tok, u64 *__restrict__ state,
-                                  u32 *__restrict__ is_new, u64 n) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 nw = 0;
-    if (has_kmer[i]) {
-        int32_t p = prev_emit[i];
-        if (p >= 0) nw = tok[i] != tok[p];
-        else nw = !(state[ST_HAVE_CARRY] && (int64_t)state[ST_CARRY_TOK] == tok[i]);
-        // two sequences now share a read index: their (read, pos) pairs are no longer generated in
-        // ascending order, so the sort must also order the payload (rare; costs extra passes)
-        if (!nw) state[ST_DUP_READS] = 1;
+// A sequence that produced a k-mer gets the next read index unless its header token equals that of the last sequence
+// that produced one (the carried state across batches: ST_CARRY_TOK / ST_HAVE_CARRY / ST_READ_BASE).  One launch: a
+// tile of NR_TILE sequences finds each emitter's predecessor (inside the tile by a max-scan; the tile's first emitter
+// walks back through the flags before the tile, 64 a step -- one step unless reads without a k-mer pile up there),
+// counts the emitters whose token differs from their predecessor's, and takes its offset from the tiles before it
+// through the chained look-back of scan.h.  The tile that finishes last advances the carried state.
+#define NR_BLOCK 256
+#ifndef NR_ITEMS
+#define NR_ITEMS 8
+#endif
+#define NR_TILE (NR_BLOCK * NR_ITEMS)
+
+// last sequence at or before `from` that produced a k-mer, or -1 (called by every lane of one wave)
+__device__ __forceinline__ long long nr_walk_back(const uint8_t *__restrict__ has_kmer, long long from) {
+    const int lane = threadIdx.x & 63;
+    for (long long hi = from; hi >= 0; hi -= 64) {
+        const long long i = hi - lane;
+        const u64 b = __ballot(i >= 0 && has_kmer[i >= 0 ? i : 0] != 0);
+        if (b) return hi - (long long)(__ffsll((unsigned long long)b) - 1);
     }
-    is_new[i] = nw;
+    return -1;
 }
-// read_index[i] = base + (#new up to and including i) - 1, or -1; then advance the carried state.
-__global__ void number_final_kernel(const uint8_t *__restrict__ has_kmer, const u32 *__restrict__ incl_new,
-                                    int32_t *__restrict__ read_index, u64 n, const u64 *__restrict__ state) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    read_index[i] = has_kmer[i] ? (int32_t)(state[ST_READ_BASE] + incl_new[i]) - 1 : -1;
-}
-__global__ void number_carry_kernel(const int32_t *__restrict__ prev_emit, const uint8_t *__restrict__ has_kmer,
-                                    const u32 *__restrict__ incl_new, const int64_t *__restrict__ tok, u64 n,
-                                    u64 *state) {
-    if (threadIdx.x != 0 || blockIdx.x != 0 || n == 0) return;
-    int64_t last = has_kmer[n - 1] ? (int64_t)(n - 1) : (int64_t)prev_emit[n - 1];
-    if (last >= 0) {
-        state[ST_CARRY_TOK] = (u64)tok[last];
-        state[ST_HAVE_CARRY] = 1;
+
+__global__ __launch_bounds__(NR_BLOCK) void number_reads_kernel(const uint8_t *__restrict__ has_kmer, const int64_t *__restrict__ tok,
+                                                                 u64 n, int32_t *__restrict__ read_index, u64 *state,
+                                                                 u64 *__restrict__ status, u32 *__restrict__ ctl, u32 epoch, u32 ntiles) {
+    __shared__ long long smax[4];
+    __shared__ long long line[NR_BLOCK];
+    __shared__ u32 ssum[4];
+    __shared__ u32 s_tile;
+    __shared__ u64 s_excl;
+    __shared__ long long s_prev;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u32 tile = cs_take_tile(ctl, &s_tile);
+    // the carried state as the batch found it (only the tile that finishes last writes it, after every tile has read)
+    const u64 read_base = state[ST_READ_BASE], have_carry = state[ST_HAVE_CARRY];
+    const int64_t carry_tok = (int64_t)state[ST_CARRY_TOK];
+    const u64 t0 = (u64)tile * NR_TILE, i0 = t0 + (u64)tid * NR_ITEMS;
+    if (tid < 64) {
+        const long long p = t0 ? nr_walk_back(has_kmer, (long long)t0 - 1) : -1;
+        if (lane == 0) s_prev = p;
     }
-    state[ST_READ_BASE] += incl_new[n - 1];
+    // (every load of the thread asked for up front, at clamped indices: a load under `if (h[i])` compiles to a branch
+    // with a wait behind it, one memory round trip per sequence)
+    bool h[NR_ITEMS];
+    int64_t tk[NR_ITEMS];
+    long long last = -1;
+#pragma unroll
+    for (int i = 0; i < NR_ITEMS; i++) {
+        const u64 ic = i0 + i < n ? i0 + i : n - 1;
+        h[i] = has_kmer[ic] != 0;
+        tk[i] = tok[ic];
+    }
+#pragma unroll
+    for (int i = 0; i < NR_ITEMS; i++) {
+        h[i] = h[i] && i0 + i < n;
+        if (h[i]) last = (long long)(i0 + i);
+    }
+    long long tot_unused;
+    line[tid] = block_scan_inclusive<long long, OpMax, NR_BLOCK / 64>(last, OpMax(), smax, &tot_unused);
+    __syncthreads();
+    long long prev = tid ? line[tid - 1] : -1;       // last emitter of the tile before this thread's sequences
+    if (prev < 0) prev = s_prev;
+    u32 nw = 0, cnt = 0;
+    bool dup = false;
+    int64_t prev_tok = prev >= 0 ? tok[prev] : 0;
+#pragma unroll
+    for (int i = 0; i < NR_ITEMS; i++) {
+        if (h[i]) {
+            const int64_t t = tk[i];
+            const bool is_new = prev >= 0 ? t != prev_tok : !(have_carry && carry_tok == t);
+            // two sequences that share a read index: their (read, pos) pairs are no longer generated in ascending
+            // order, so the sort must also order the payload (rare; costs extra passes)
+            dup = dup || !is_new;
+            nw |= (u32)is_new << i;
+            cnt += is_new;
+            prev = (long long)(i0 + i);
+            prev_tok = t;
+        }
+    }
+    if (dup) state[ST_DUP_READS] = 1;
+    u32 total;
+    const u32 inc = block_scan_inclusive<u32, OpSum, NR_BLOCK / 64>(cnt, OpSum(), ssum, &total);
+    if (tid < 64) {
+        const u64 e = cs_lookback(status, epoch, tile, (u64)total);
+        if (lane == 0) s_excl = e;
+    }
+    __syncthreads();
+    u64 run = read_base + s_excl + inc - cnt;
+#pragma unroll
+    for (int i = 0; i < NR_ITEMS; i++) {
+        if (i0 + i < n) {
+            run += (nw >> i) & 1u;
+            read_index[i0 + i] = h[i] ? (int32_t)run - 1 : -1;
+        }
+    }
+    if (tid < 64) {
+        int fin = 0;
+        if (lane == 0) fin = cs_tile_done(ctl, ntiles) ? 1 : 0;
+        if (__shfl(fin, 0, 64)) {
+            // every tile is done: the batch's total is the last tile's inclusive prefix
+            const u64 w = __hip_atomic_load(&status[ntiles - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long lastem = nr_walk_back(has_kmer, (long long)n - 1);
+            if (lane == 0) {
+                if (lastem >= 0) {
+                    state[ST_CARRY_TOK] = (u64)tok[lastem];
+                    state[ST_HAVE_CARRY] = 1;
+                }
+                state[ST_READ_BASE] = read_base + (w & CS_VAL_MASK);
+            }
+        }
+    }
 }
 
 

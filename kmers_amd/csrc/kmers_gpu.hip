@@ -91,6 +91,8 @@ extern "C" void kmg_destroy(kmg_ctx *ctx) {
     prof_drain(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->pool.destroy();
+    if (ctx->scan_status) (void)hipFree(ctx->scan_status);
+    if (ctx->scan_ctl) (void)hipFree(ctx->scan_ctl);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->h_snap) (void)hipHostFree(ctx->h_snap);
     if (ctx->ev_len) (void)hipEventDestroy(ctx->ev_len);
@@ -220,7 +222,7 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     if (!exact) KMG_TRY(ensure_record_capacity(ctx, upper));
 
     const u32 ntiles = div_up_u64(nbases, EX_TILE);
-    PoolBuf tile_seq(ctx), tile_count(ctx), tile_fwd(ctx), tile_off(ctx), agg(ctx), has_kmer(ctx), read_index(ctx), tmp_a(ctx), tmp_b(ctx);
+    PoolBuf tile_seq(ctx), tile_count(ctx), tile_fwd(ctx), tile_off(ctx), agg(ctx), has_kmer(ctx), read_index(ctx);
     KMG_ALLOC(tile_seq, (size_t)(ntiles + 1) * 8);   // tile_seq[ntiles + 1] then tile_end[ntiles + 1]
     KMG_ALLOC(tile_count, (size_t)ntiles * 4);
     KMG_ALLOC(tile_fwd, (size_t)ntiles * 4);
@@ -314,8 +316,11 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
                 else hipLaunchKernelGGL((extract_part_count_kernel<false, false>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
             }
         } else hipLaunchKernelGGL((extract_kernel<false>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
-        hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_fwd.as<u32>(),
-                           ntiles, ctx->d_state + ST_NWIN);
+        // forward windows of the batch.  (A fused batch without reverse complements holds nothing else: there the
+        // total of the table scan below is both the record count and the window count, and no launch is spent on it.)
+        if (!part || ctx->rc)
+            hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_fwd.as<u32>(),
+                               ntiles, ctx->d_state + ST_NWIN);
     }
     // variable-length build: count the k-mers shorter than k (extract_short.h) -- before the reads are numbered,
     // because a read gets its index at its first k-mer of ANY length
@@ -337,22 +342,13 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
                            ntiles, ctx->d_state + ST_NWIN);
     }
     if (reads) {
-        // ReadIDMapping.geNext over the batch: two scans and three elementwise kernels
-        KMG_ALLOC(tmp_a, nseq * 4);
-        KMG_ALLOC(tmp_b, nseq * 4);
+        // ReadIDMapping.geNext over the batch, one launch (extract.h)
         ProfScope ps(ctx, KP_NUMBER_READS, 0);
-        const dim3 g1(div_up_u64(nseq, 256)), b1(256);
-        hipLaunchKernelGGL(number_emit_kernel, g1, b1, 0, ctx->stream, has_kmer.as<uint8_t>(), tmp_a.as<int32_t>(), nseq);
-        KMG_TRY((device_scan<int32_t, int32_t, OpMax, true>(ctx, tmp_a.as<int32_t>(), tmp_a.as<int32_t>(), nseq, OpMax(),
-                                                            (int32_t)-1, agg.as<int32_t>(), nullptr, false, KP_SCAN)));
-        hipLaunchKernelGGL(number_new_kernel, g1, b1, 0, ctx->stream, has_kmer.as<uint8_t>(), tmp_a.as<int32_t>(),
-                           d_seq_tok, ctx->d_state, tmp_b.as<u32>(), nseq);
-        KMG_TRY((device_scan<u32, u32, OpSum, false>(ctx, tmp_b.as<u32>(), tmp_b.as<u32>(), nseq, OpSum(), 0u,
-                                                     agg.as<u32>(), nullptr, false, KP_SCAN)));
-        hipLaunchKernelGGL(number_final_kernel, g1, b1, 0, ctx->stream, has_kmer.as<uint8_t>(), tmp_b.as<u32>(), ridx,
-                           nseq, ctx->d_state);
-        hipLaunchKernelGGL(number_carry_kernel, dim3(1), dim3(64), 0, ctx->stream, tmp_a.as<int32_t>(),
-                           has_kmer.as<uint8_t>(), tmp_b.as<u32>(), d_seq_tok, nseq, ctx->d_state);
+        const u32 nr_tiles = div_up_u64(nseq, NR_TILE);
+        u32 epoch = 0;
+        KMG_TRY(chained_begin(ctx, nr_tiles, &epoch));
+        hipLaunchKernelGGL(number_reads_kernel, dim3(nr_tiles), dim3(NR_BLOCK), 0, ctx->stream, has_kmer.as<uint8_t>(), d_seq_tok, nseq,
+                           ridx, ctx->d_state, ctx->scan_status, ctx->scan_ctl, epoch, nr_tiles);
     } else {
         hipLaunchKernelGGL(id_bits_kernel, dim3(std::min<u32>(div_up_u64(nseq, 256), 1024)), dim3(256), 0, ctx->stream,
                            d_seq_id, nseq, ctx->d_state);
@@ -360,15 +356,15 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     if (part) {
         // the record count is final once the tiles are counted (the write pass starts at record 0: first batch);
         // with it the build state is complete, and finish() reads this snapshot instead of stopping the stream
-        hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_count.as<u32>(),
-                           ntiles, ctx->d_state + ST_NREC);
+        // (the scan's grand total is the batch's record count: added to the state by the scan's last tile)
+        KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, table.as<u32>(), table.as<u32>(), (u64)RS_DIGITS * pa.ncols, OpSum(),
+                                                    0u, tagg.as<u32>(), nullptr, false, KP_SCAN, ctx->d_state + ST_NREC,
+                                                    ctx->rc ? nullptr : ctx->d_state + ST_NWIN)));
         if (ctx->h_snap) {
             KMG_HIP(hipMemcpyAsync(ctx->h_snap, ctx->d_state, ST_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
             KMG_HIP(hipEventRecord(ctx->ev_snap, ctx->stream));
             ctx->snap_valid = true;
         }
-        KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, table.as<u32>(), table.as<u32>(), (u64)RS_DIGITS * pa.ncols, OpSum(),
-                                                    0u, tagg.as<u32>(), nullptr, false, KP_SCAN)));
         if (exact) {
             u64 nrec = 0;
             KMG_HIP(read_back(ctx, &nrec, ctx->d_state + ST_NREC, 8));

@@ -319,25 +319,34 @@ struct LocalPasses {
     int src[LS_MAX_PASSES];
 };
 
-// seg_off[s] = first record whose top `pbits` key bits are >= s (s = 0 .. 2^pbits); also the largest
-// segment size (atomicMax into *max_seg).  keys must be sorted by that prefix.
-__global__ void ls_segments_kernel(const u64 *__restrict__ keys, u32 n, int pbits, u32 *__restrict__ seg_off,
-                                   u32 nseg, u32 *max_seg) {
-    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s > nseg) return;
+// seg_off[s] = first record whose top `pbits` key bits are >= s (s = 0 .. 2^pbits), and the largest segment size
+// (atomicMax into *max_seg).  keys must be sorted by that prefix.  A block finds 256 boundaries and so the sizes of 255
+// segments: boundaries LSEG_PER * b .. LSEG_PER * b + 255.  `table` (may be null): the scanned digit-major offsets of
+// the last global pass, whose digit was the key's top `top_bits` bits -- table[d * ntiles_tab] is where digit d's
+// records start, so the search for a boundary runs inside its digit's range only.
+#define LSEG_PER 255
+__global__ __launch_bounds__(256) void ls_segments_kernel(const u64 *__restrict__ keys, u32 n, int pbits, u32 *__restrict__ seg_off,
+                                                          u32 nseg, u32 *max_seg, const u32 *__restrict__ table, u32 ntiles_tab,
+                                                          int top_bits) {
+    __shared__ u32 bnd[256];
+    const u32 s = blockIdx.x * LSEG_PER + threadIdx.x;
     u32 lo = 0, hi = n;
-    if (s == nseg) lo = n;
+    if (s >= nseg) lo = n;
     else if (pbits > 0) {
+        if (table) {
+            const u32 d = s >> (pbits - top_bits);
+            lo = table[(u64)d * ntiles_tab];
+            hi = d + 1 < (1u << top_bits) ? table[(u64)(d + 1) * ntiles_tab] : n;
+        }
         while (lo < hi) {
             u32 mid = lo + ((hi - lo) >> 1);
             if ((u32)(keys[mid] >> (64 - pbits)) < s) lo = mid + 1; else hi = mid;
         }
     }
-    seg_off[s] = lo;
-}
-__global__ void ls_maxseg_kernel(const u32 *__restrict__ seg_off, u32 nseg, u32 *max_seg) {
-    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 m = s < nseg ? seg_off[s + 1] - seg_off[s] : 0;
+    bnd[threadIdx.x] = lo;
+    if (s <= nseg && (threadIdx.x < LSEG_PER || s == nseg)) seg_off[s] = lo;
+    __syncthreads();
+    u32 m = (threadIdx.x < LSEG_PER && s < nseg) ? bnd[threadIdx.x + 1] - lo : 0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (u32)__shfl_down(m, d, 64));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(max_seg, m);
@@ -1007,9 +1016,11 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
     KMG_HIP(hipMemsetAsync(max_seg, 0, 4, ctx->stream));
     {
         ProfScope ps(ctx, KP_SORT_SEGMENTS, 0);
-        hipLaunchKernelGGL(ls_segments_kernel, dim3(div_up_u64(nseg + 1, 256)), dim3(256), 0, ctx->stream, ka, n, pbits,
-                           seg, nseg, max_seg);
-        hipLaunchKernelGGL(ls_maxseg_kernel, dim3(div_up_u64(nseg, 256)), dim3(256), 0, ctx->stream, seg, nseg, max_seg);
+        // (the last global pass of this call leaves its scanned table behind: digit = the key's top bits)
+        const bool narrow = !todo.empty();
+        hipLaunchKernelGGL(ls_segments_kernel, dim3(nseg / LSEG_PER + 1), dim3(256), 0, ctx->stream, ka, n, pbits,
+                           seg, nseg, max_seg, narrow ? (const u32 *)table : (const u32 *)nullptr, div_up_u64(n, RS_TILE),
+                           narrow ? todo.back().bits : 0);
     }
     u32 h_max = 0;
     KMG_HIP(read_back(ctx, &h_max, max_seg, 4));
