@@ -382,6 +382,9 @@ def main():
     kernels = {k: {"ms_per_step": round(v["ms"] / prof_steps, 4), "launches_per_step": v["launches"] // prof_steps,
                    "algo_GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) if v["bytes"] else None}
                for k, v in prof.items() if v["launches"]}
+    roofline["stages"] = stage_fractions(lib, ctx, ctx_ref, submit, finish, prof, prof_steps, n_read_win, n_ref_win, u_reads,
+                                         (d_ref_bases, d_ref_off, d_ref_id, len(genomes)), (d_read_bases, d_read_off, d_read_tok, nreads),
+                                         ranges[rank] if headline == "key-range" else None)
     # matched rate = k-mers presented to the join (the DISTINCT read k-mers) / time of stage 3, with HIP
     # events on the library's stream, over prof_steps repetitions
     match_ms = prof["match"]["ms"] / max(prof["match"]["launches"], 1)
@@ -455,6 +458,99 @@ def measured_copy_gbs(torch, dev):
     e1.record()
     torch.cuda.synchronize()
     return 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+ACHIEVABLE_COPY_GBS = 6290.0     # MI355X_MICROARCH.md: what a streaming copy reaches of the 8 TB/s spec peak
+
+# measurement-hook kernel ids per stage of SURVEY 8(d) (read build = the step's critical path; "<id>_ref" = the
+# reference build, which runs underneath it on the second stream).  Every prefix sum -- the fused first digit's table,
+# the global pass's table, the run heads -- counts as sort + dedup: they exist because of the partition.
+STAGE_KERNELS = {
+    "extract": ["extract_tileseq", "extract_count", "extract_write", "number_reads"],
+    "sort_dedup": ["scan", "sort_hist_reads", "sort_hist_ref", "sort_scan", "sort_scatter_reads", "sort_scatter_ref", "sort_segments",
+                   "sort_local_reads", "sort_local_ref", "reduce_flag", "reduce_write", "bucket_offsets"],
+    "match": ["match"],
+}
+# kernel symbols of the rocprofv3 counter runs per stage (both builds: the counters cannot tell them apart by name)
+STAGE_SYMBOLS = {
+    "extract": ["extract_", "seq_maxlen", "number_", "sum_u32", "id_bits"],
+    "sort_dedup": ["rs_", "ls_", "rd_", "scan_", "big_copy", "set_u64"],
+    "match": ["match_"],
+}
+
+
+def stage_fractions(lib, ctx, ctx_ref, submit, finish, prof, prof_steps, n_read_win, n_ref_win, u_reads, ref_in, read_in, key_range):
+    """SURVEY 8(d)'s headline per stage: B_stage / t_stage / 8e12 with its formulas, P as stored on the device
+    (extract: 1 B per base in + (8 + P) B per record out; sort + dedup: 2 (8 + P) B per record + 16 B per distinct k-mer
+    + P' B per value; match: 8 B per search and per reference k-mer in + 8 B per search k-mer out).  t_stage = HIP-event
+    time of the stage's launches on the read build's stream (the step's critical path); the reference build's bytes and
+    times are given beside it.  traffic = the stage's kernels summed over the newest PMC file of these sources."""
+    (rb, ro, ri, rn), (qb, qo, qt, qn) = ref_in, read_in
+    submit(ctx_ref, rb, ro, ri, None, rn, 0, 1, key_range=key_range)
+    submit(ctx, qb, qo, None, qt, qn, 1, 0)
+    ref, _ = finish(ctx_ref)
+    rdb, _ = finish(ctx)
+    u, v = C.c_uint64(), C.c_uint64()
+    lib.kmg_db_info(ref, None, None, None, None, C.byref(u), C.byref(v))
+    u_ref, v_ref = u.value, v.value
+    lib.kmg_db_info(rdb, None, None, None, None, C.byref(u), C.byref(v))
+    v_reads = v.value
+    p_reads = 4 if lib.kmg_db_payload_bits(rdb) == 32 else 8
+    lib.kmg_db_free(rdb)
+    lib.kmg_db_free(ref)
+    n_ref_rec = 2 * n_ref_win                      # both strands (odd k: no palindromes)
+    algo = {
+        "extract": (qb.numel() + (8 + p_reads) * n_read_win, rb.numel() + 12 * n_ref_rec),
+        "sort_dedup": (2 * (8 + p_reads) * n_read_win + 16 * u_reads + p_reads * v_reads, 2 * 12 * n_ref_rec + 16 * u_ref + 8 * v_ref),
+        "match": (8 * (u_reads + u_ref) + 8 * u_reads, 0),
+    }
+    traffic = pmc_stage_traffic()
+    out = {}
+    for st, ids in STAGE_KERNELS.items():
+        # (ids ending in _ref are the reference build's own instantiations; the others' reference-build launches were
+        # renamed <id>_ref when the two contexts' tables were merged)
+        ms = sum(prof[i]["ms"] for i in ids if i in prof and not i.endswith("_ref")) / prof_steps
+        ms_ref = (sum(prof[i]["ms"] for i in ids if i in prof and i.endswith("_ref")) +
+                  sum(prof[i + "_ref"]["ms"] for i in ids if not i.endswith("_ref") and i + "_ref" in prof)) / prof_steps
+        b, b_ref = algo[st]
+        gbs = b / (ms * 1e-3) / 1e9 if ms else 0.0
+        out[st] = {"algo_bytes": int(b), "ms": round(ms, 4), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                   "frac_of_achievable_copy": round(gbs / ACHIEVABLE_COPY_GBS, 4),
+                   "reference_build_underneath": {"algo_bytes": int(b_ref), "ms": round(ms_ref, 4)},
+                   "traffic_both_builds": traffic.get(st), "algo_bytes_both_builds": int(b + b_ref)}
+        if traffic.get(st):
+            out[st]["traffic_over_algo"] = round(traffic[st] / (b + b_ref), 3)
+    out["sort_dedup"]["passes"] = {"global_hbm": prof.get("sort_scatter_reads", {}).get("launches", 0) // prof_steps,
+                                   "fused_into_the_extractor": 1, "local_lds": 1,
+                                   "note": "effective traffic = (global + fused write + local) x 2 x (8 + P) x records"}
+    out["payload_bytes_as_stored"] = p_reads
+    out["timing"] = "HIP events around every launch of the read build's stream, mean of %d steps" % prof_steps
+    return out
+
+
+def pmc_stage_traffic():
+    """HBM bytes per step and stage from the newest committed PMC file, if it was measured on these sources."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
+    if not files:
+        return {}
+    try:
+        data = json.load(open(files[-1]))
+        if data.get("source_hash") != source_hash():
+            return {}
+        ks = data["kernels"]
+        steps = max(v["launches"] for name, v in ks.items() if "extract_part_count_kernel<false, false>" in name)
+        out = {}
+        for st, pats in STAGE_SYMBOLS.items():
+            tot = 0.0
+            for name, v in ks.items():
+                base = name.split("void ")[-1]
+                if any(base.startswith(p_) for p_ in pats):
+                    tot += v["traffic_bytes_per_launch"] * v["launches"] / steps
+            out[st] = int(tot)
+        return out
+    except Exception:
+        return {}
 
 
 # kernel id of the measurement hook -> kernel symbol in the rocprofv3 traces
