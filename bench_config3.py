@@ -85,6 +85,26 @@ def _hash(torch, x):
     return y ^ ((y >> 31) & 0x1FFFFFFFF)
 
 
+def _pmc_traffic(kernel_id):
+    """HBM bytes per launch of the dominant kernel from profiles/*cfg3*_pmc_traffic.json (tools/pmc_traffic.py <tag>
+    --config 3 --no-cpu-baseline), if that file was measured on the sources this library was built from."""
+    import glob
+    from bench import KERNEL_SYMBOL, ROOT, source_hash
+    sym = KERNEL_SYMBOL.get(kernel_id)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*cfg3*_pmc_traffic.json")), key=os.path.getmtime)
+    if not sym or not files:
+        return None, "no measurement"
+    data = json.load(open(files[-1]))
+    if data.get("source_hash") != source_hash():
+        return None, "%s was measured on other kernel sources" % os.path.basename(files[-1])
+    syms = [sym] + (["ls_sortidx_kernel<unsigned int, false>"] if kernel_id == "sort_local_ref" else [])
+    hits = [int(v["traffic_bytes_per_launch"]) for name, v in data["kernels"].items() if any(s_ in name for s_ in syms)]
+    if not hits:
+        return None, "no measurement"
+    # (the reference build's launch is the larger one at this config: 2 G records against 1.2 G per read chunk)
+    return (max(hits) if kernel_id.endswith("_ref") else min(hits)), os.path.basename(files[-1])
+
+
 def run(args, dev):
     import numpy as np
     import torch
@@ -281,6 +301,7 @@ def run(args, dev):
     d = cand[dom]
     avg_ms, bpl = d["ms"] / d["launches"], d["bytes"] / d["launches"]
     achieved = bpl / (avg_ms * 1e-3) / 1e9
+    traffic, traffic_src = _pmc_traffic(dom)
     kernels = {k_: {"ms": round(v["ms"], 3), "launches": v["launches"],
                     "algo_GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) if v["bytes"] else None} for k_, v in prof.items()}
     total_s = t_ref + t_reads
@@ -303,8 +324,8 @@ def run(args, dev):
                    "taxacounts_algo_GBps": round((8 * (U + 1) + 4 * V) / tc / 1e9, 1),
                    "timing": "wall clock around synchronised stages; pool warm (second build / second pass of chunk 0)"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                     "algo_bytes_per_launch": int(bpl), "launches": d["launches"]},
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "avg_launch_ms": round(avg_ms, 4), "algo_bytes_per_launch": int(bpl), "launches": d["launches"]},
         "kernels": kernels,
         "verified": dict(checks, oracle_slice="key buckets [%d, %d) of 4096; first %d reads" % (SLICE[0], SLICE[1], n_first),
                          oracle_seconds=round(oracle_s, 1)),

@@ -16,13 +16,16 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r1"
+# further arguments go to bench.py instead of the default short config-2 run, e.g.  tools/pmc_traffic.py r3_cfg3 --config 3
+# (such a run launches no calibration kernel: the factors are taken from the newest config-2 file under profiles/)
+BENCH_ARGS = sys.argv[2:]
 CALIB_BYTES = (1 << 27) * 8
 
 
 def run_pass(counter):
     out = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (TAG, counter))
-    cmd = ["timeout", "-s", "KILL", "240", "rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--calib"]
+    cmd = ["timeout", "-s", "KILL", "240" if not BENCH_ARGS else "600", "rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+           sys.executable, os.path.join(ROOT, "bench.py")] + (BENCH_ARGS or ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--calib"])
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     per = {}
@@ -46,10 +49,17 @@ def main():
     label = lambda k: k[0] if len(grids[k[0]]) == 1 else "%s [grid %d]" % k
     fetch = {label(k): v for k, v in fetch.items()}
     write = {label(k): v for k, v in write.items()}
-    cal = [k for k in fetch if "calib_copy_kernel" in k][0]
-    # counters are reported in KiB
-    f_fac = CALIB_BYTES / (fetch[cal][0] / fetch[cal][1] * 1024.0)
-    w_fac = CALIB_BYTES / (write[cal][0] / write[cal][1] * 1024.0)
+    cals = [k for k in fetch if "calib_copy_kernel" in k]
+    if cals:
+        cal = cals[0]
+        # counters are reported in KiB
+        f_fac = CALIB_BYTES / (fetch[cal][0] / fetch[cal][1] * 1024.0)
+        w_fac = CALIB_BYTES / (write[cal][0] / write[cal][1] * 1024.0)
+    else:
+        prev = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))
+                      if "calib_copy_kernel" in json.load(open(f))["calibration"]["kernel"])
+        c = json.load(open(max(prev, key=os.path.getmtime)))["calibration"]
+        cal, f_fac, w_fac = "factors of %s" % c["kernel"], c["fetch_factor"], c["write_factor"]
     sys.path.insert(0, ROOT)
     from bench import source_hash
     res = {"source_hash": source_hash(),        # bench.py reports this measurement only for the same kernel sources
