@@ -72,6 +72,12 @@ void *kmg_stream(kmg_ctx *ctx);
  *                     NULL) receives each sequence's index, or -1 if it produced no k-mer, so the
  *                     host can write the read-name map (MakeDatabase.java:165-185).  Position is
  *                     the Java (short)(pos - k) (KmersFromFile.java:165).
+ *                   KMG_PAYLOAD_TAXON with read_index_out given: it receives 0 for every sequence that
+ *                     produced a k-mer and -1 for the others.  The reference turns a header into its
+ *                     taxon only when a sequence hands out its first k-mer (new Kmer(..) is evaluated
+ *                     before mapper.apply, KmersFromFile.java:103,165), so a header that is no int (or
+ *                     not in the -m map) fails there only for the sequences flagged 0: the host passes
+ *                     any taxon for such a header and throws if the flag comes back 0.
  *                   May be called many times; batches are consumed in call order.
  * kmg_build_add_dev: the same with every pointer a DEVICE pointer on this context's GPU (inputs
  *                   already resident in HBM); asynchronous on kmg_stream(); the buffers must stay

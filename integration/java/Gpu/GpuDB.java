@@ -32,6 +32,37 @@ public class GpuDB implements AutoCloseable
         ref = gpu.dbLoad(k, keyLength, true, KmersGpu.PAYLOAD_TAXON, keys, valOff, taxon, count);
     }
 
+    /** The reference database `db` (one or several files: DB.kmers merges them, DB.java:99-109) on the GPU, or null when it
+     *  is not one the GPU path takes (k-mers of several lengths, k > 32): key by key, every entry's k-mer and its
+     *  TreeCountMap in ascending taxon order.  Matcher and TaxaCounts call it once, after `new DB<>(dbfiles, merger)`. */
+    public static GpuDB fromDB(Database.DB<CountMaps.TreeCountMap<Integer>> db) throws Exception
+    {
+        Kmers.KmerStream<CountMaps.TreeCountMap<Integer>> first = db.kmers(0);
+        int minK = first.getMinLength(), maxK = first.getMaxLength();
+        first.close();
+        if (minK != maxK || maxK > 32) return null;
+        int keyLength = Integer.numberOfTrailingZeros(db.getMaxKey()) / 2;                 // maxKey = 4^keyLength
+        java.util.ArrayList<Long> keys = new java.util.ArrayList<>(), off = new java.util.ArrayList<>();
+        java.util.ArrayList<Integer> taxon = new java.util.ArrayList<>(), count = new java.util.ArrayList<>();
+        off.add(0L);
+        for (int key = 0; key < db.getMaxKey(); key++)
+            db.kmers(key).forEach(kwd -> {
+                byte[] cb = kwd.getKmer().compressedBytes();
+                long v = 0;
+                for (int b = 1; b <= 8; b++) v = (v << 8) | (b < cb.length ? (cb[b] & 0xFFL) : 0L);
+                keys.add(v);
+                for (Map.Entry<Integer, Long> e : kwd.getData().entrySet())
+                {
+                    taxon.add(e.getKey());
+                    count.add((int) Math.min(e.getValue(), Integer.MAX_VALUE));
+                }
+                off.add((long) taxon.size());
+            });
+        return new GpuDB(new KmersGpu(0), maxK, keyLength, keys.stream().mapToLong(Long::longValue).toArray(),
+                         off.stream().mapToLong(Long::longValue).toArray(), taxon.stream().mapToInt(Integer::intValue).toArray(),
+                         count.stream().mapToInt(Integer::intValue).toArray());
+    }
+
     /** One batch of search k-mers (ascending, distinct, each with its read positions as CSR) -> for every one that the
      *  database holds, its index there: the caller formats the line with the unchanged ResultsDataType.toString from
      *  (search k-mer, its ReadPos set, KmerDiff "-", counts(hit)). */
@@ -46,6 +77,38 @@ public class GpuDB implements AutoCloseable
         {
             gpu.dbFree(search);
         }
+    }
+
+    /** DB.quickMatchCommonKey (Database/DB.java:129-137) for one key's search k-mers, as DB calls it from its pool
+     *  threads (DB.java:199-201; a context is internally serialised): the k-mers of the list that the database holds,
+     *  each with a ClosestInfoCollector over the database's entry, in the list's (ascending) order -- what
+     *  StreamUtils.matchTwoStreams hands on.  `make` turns (taxa, counts) of an entry into the database's data type
+     *  (TreeCountMap for reference databases). */
+    public <S, D> List<Kmers.KmerWithData<DataTypes.DataPair<S, Database.ClosestInfoCollector<D>>>> quickMatchCommonKey(
+            List<Kmers.KmerWithData<S>> kmers, java.util.function.Function<Map<Integer, Long>, D> make) throws Exception
+    {
+        long[] keys = new long[kmers.size()];
+        for (int i = 0; i < keys.length; i++)
+        {
+            byte[] cb = kmers.get(i).getKmer().compressedBytes();      // [length][2 bits per base, first base in the top bits]
+            long v = 0;
+            for (int b = 1; b <= 8; b++) v = (v << 8) | (b < cb.length ? (cb[b] & 0xFFL) : 0L);
+            keys[i] = v;
+        }
+        long[] valOff = new long[keys.length + 1];                      // the join needs the k-mers only
+        MemorySegment search = gpu.dbLoad(k, keyLength, false, KmersGpu.PAYLOAD_READPOS, keys, valOff, new int[0], new int[0]);
+        long[] hit;
+        try { hit = gpu.match(search, ref, keys.length); }
+        finally { gpu.dbFree(search); }
+        List<Kmers.KmerWithData<DataTypes.DataPair<S, Database.ClosestInfoCollector<D>>>> out = new ArrayList<>();
+        for (int i = 0; i < keys.length; i++)
+            if (hit[i] >= 0)
+            {
+                Kmers.KmerWithData<S> s = kmers.get(i);
+                Kmers.KmerWithData<D> entry = new Kmers.KmerWithData<>(s.getKmer(), make.apply(counts(hit[i])));
+                out.add(new Kmers.KmerWithData<>(s.getKmer(), new DataTypes.DataPair<>(s.getData(), new Database.ClosestInfoCollector<>(entry))));
+            }
+        return out;
     }
 
     /** The TreeCountMap of database k-mer `index` (counts as the file stores them: DB.java:102 adds them as longs). */

@@ -27,6 +27,7 @@ public class GpuFileCreator<I, O> implements AutoCloseable
     private final List<Long> seqOff = new ArrayList<>();
     private final List<Integer> taxa = new ArrayList<>();
     private final List<Long> tokens = new ArrayList<>();
+    private final List<Integer> badHeader = new ArrayList<>();   // sequences of the batch whose header gave no taxon
     private static final int BATCH_BASES = 1 << 28;
 
     /** readIndexSink: called with (header token, read index) for every read that got an index, in order -- what
@@ -51,10 +52,14 @@ public class GpuFileCreator<I, O> implements AutoCloseable
     }
 
     /** One entry into the KMER state = one sequence: its characters > 32 (KmersFromFile.java:154-158) and the header
-     *  current at that time -- the taxon (Integer.parseInt(id) or the -m map) or a token of the header string. */
-    public synchronized void addSequence(byte[] chars, int len, int taxon, long headerToken) throws Exception
+     *  current at that time -- the taxon (Integer.parseInt(id) or the -m map) or a token of the header string.
+     *  headerOk = false: the header gave no taxon (no int / not in the map).  The reference finds that out at the
+     *  sequence's first k-mer and not before (KmersFromFile.java:103,165), so the sequence goes in with any taxon and
+     *  flush() throws if the build reports a k-mer for it (GpuKmersFromFile is the caller). */
+    public synchronized void addSequence(byte[] chars, int len, int taxon, long headerToken, boolean headerOk) throws Exception
     {
         bases.write(chars, 0, len);
+        if (!reads && !headerOk) badHeader.add(seqOff.size() - 1);
         seqOff.add((long) bases.size());
         if (reads) tokens.add(headerToken); else taxa.add(taxon);
         if (bases.size() >= BATCH_BASES) flush();
@@ -66,7 +71,10 @@ public class GpuFileCreator<I, O> implements AutoCloseable
         long[] off = seqOff.stream().mapToLong(Long::longValue).toArray();
         int[] ids = reads ? null : taxa.stream().mapToInt(Integer::intValue).toArray();
         long[] tok = reads ? tokens.stream().mapToLong(Long::longValue).toArray() : null;
-        int[] readIndex = gpu.buildAdd(bases.toByteArray(), off, ids, tok);
+        int[] readIndex = gpu.buildAdd(bases.toByteArray(), off, ids, tok, !badHeader.isEmpty());
+        for (int q : badHeader)      // taxon builds: 0 = the sequence produced a k-mer (kmg_build_add, read_index_out)
+            if (readIndex[q] >= 0) throw new NumberFormatException("header of a sequence with a k-mer is no taxon");
+        badHeader.clear();
         if (reads && readIndexSink != null)
             for (int s = 0; s < readIndex.length; s++)
                 if (readIndex[s] >= 0 && readIndex[s] != lastIndex)

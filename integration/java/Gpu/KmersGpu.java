@@ -85,18 +85,20 @@ public final class KmersGpu implements AutoCloseable
 
     /** One batch of sequences: the characters > 32 of every KMER-state run back to back, their offsets, and per sequence
      *  the taxon (reference) or a header token (reads; equal tokens iff equal header strings).
-     *  @return for reads the read index of every sequence (-1: it handed out no k-mer), else null */
-    public int[] buildAdd(byte[] bases, long[] seqOff, int[] taxa, long[] tokens) throws Exception
+     *  @return for reads the read index of every sequence (-1: it handed out no k-mer); for taxon builds with wantFlags
+     *  0 / -1 per sequence (it produced a k-mer / it did not); else null */
+    public int[] buildAdd(byte[] bases, long[] seqOff, int[] taxa, long[] tokens, boolean wantFlags) throws Exception
     {
         try (Arena a = Arena.ofConfined())
         {
             long nseq = seqOff.length - 1;
+            boolean out = tokens != null || wantFlags;
             MemorySegment b = a.allocateFrom(JAVA_BYTE, bases), o = a.allocateFrom(JAVA_LONG, seqOff);
             MemorySegment id = taxa == null ? MemorySegment.NULL : a.allocateFrom(JAVA_INT, taxa);
             MemorySegment tk = tokens == null ? MemorySegment.NULL : a.allocateFrom(JAVA_LONG, tokens);
-            MemorySegment ri = tokens == null ? MemorySegment.NULL : a.allocate(JAVA_INT, Math.max(nseq, 1));
+            MemorySegment ri = out ? a.allocate(JAVA_INT, Math.max(nseq, 1)) : MemorySegment.NULL;
             check(call(ADD, ctx, b, (long) bases.length, o, id, tk, nseq, ri));
-            return tokens == null ? null : ri.asSlice(0, 4 * nseq).toArray(JAVA_INT);
+            return out ? ri.asSlice(0, 4 * nseq).toArray(JAVA_INT) : null;
         }
     }
 
@@ -108,6 +110,17 @@ public final class KmersGpu implements AutoCloseable
             MemorySegment db = a.allocate(ADDRESS), nwin = a.allocate(JAVA_LONG);
             check(call(FINISH, ctx, db, nwin));
             return db.get(ADDRESS, 0);
+        }
+    }
+
+    /** {distinct k-mers, list entries} of a database (kmg_db_info) */
+    public long[] dbInfo(MemorySegment db) throws Exception
+    {
+        try (Arena a = Arena.ofConfined())
+        {
+            MemorySegment u = a.allocate(JAVA_LONG), v = a.allocate(JAVA_LONG);
+            check(call(DB_INFO, db, MemorySegment.NULL, MemorySegment.NULL, MemorySegment.NULL, MemorySegment.NULL, u, v));
+            return new long[]{u.get(JAVA_LONG, 0), v.get(JAVA_LONG, 0)};
         }
     }
 

@@ -231,9 +231,10 @@ class FileCreator:
         if key_range is not None:
             ctx.check(ctx.lib.kmg_build_set_key_range(ctx.h, int(key_range[0]), int(key_range[1])))
 
-    def add_kmers(self, batch, min_length=None, max_length=None):
+    def add_kmers(self, batch, min_length=None, max_length=None, flags=False):
         """addKmers (FileCreator.java:65-110).  Returns, for read DBs, the read index of every sequence
-        (-1 = no k-mer, so no entry in the read-name map)."""
+        (-1 = no k-mer, so no entry in the read-name map); for reference DBs with flags=True, 0 / -1 per sequence: it
+        produced a k-mer / it did not (the reference maps a header to its taxon at the first k-mer only)."""
         min_length = self.max_k if min_length is None else min_length
         max_length = self.max_k if max_length is None else max_length
         if self.min_k == -1:
@@ -245,7 +246,7 @@ class FileCreator:
             self.ctx.check(self.ctx.lib.kmg_build_set_min_k(self.ctx.h, int(min_length)))
             self._min_set = True
         ridx = None
-        if self.kind == PAYLOAD_READPOS:
+        if self.kind == PAYLOAD_READPOS or flags:
             ridx = np.empty(batch.nseq, np.int32)
         self.ctx.check(self.ctx.lib.kmg_build_add(self.ctx.h, _ptr(batch.bases), len(batch.bases), _ptr(batch.seq_off),
                                                   _ptr(batch.seq_id), _ptr(batch.seq_tok), batch.nseq, _ptr(ridx)))

@@ -484,6 +484,12 @@ __global__ __launch_bounds__(NR_BLOCK) void number_reads_kernel(const uint8_t *_
 }
 
 
+// taxon builds that asked for it (kmg_build_add's read_index_out): 0 = the sequence produced a k-mer, -1 = it did not
+__global__ void has_kmer_flags_kernel(const uint8_t *__restrict__ has_kmer, u64 n, int32_t *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = has_kmer[i] ? 0 : -1;
+}
+
 // MakeDatabase -p input as it lies in the file: Sequence.cBytes (Sequence.java:90-115) of every sequence, 2 bits per
 // base, first base in the top bits of a byte, every sequence starting on a byte boundary.  One thread per packed byte
 // finds its sequence in byte_off (ascending, nseq + 1 entries) and writes up to four base letters.

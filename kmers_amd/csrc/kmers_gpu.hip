@@ -193,10 +193,12 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     if (!ctx->building) return fail(ctx, KMG_ESTATE, "kmg_build_add before kmg_build_begin");
     const bool reads = ctx->kind == KMG_PAYLOAD_READPOS;
     if (nseq == 0 || nbases == 0) {
-        if (reads && d_read_index_out && nseq)
+        if (d_read_index_out && nseq)
             KMG_HIP(hipMemsetAsync(d_read_index_out, 0xFF, nseq * sizeof(int32_t), ctx->stream));
         return KMG_OK;
     }
+    // taxon builds: read_index_out, if given, receives 0 / -1 per sequence: it produced a k-mer / it did not
+    const bool want_flags = !reads && d_read_index_out;
     if (!d_bases || !d_seq_off) return fail(ctx, KMG_EINVAL, "null bases / seq_off");
     if (!reads && !d_seq_id) return fail(ctx, KMG_EINVAL, "seq_id required for taxon payload");
     if (reads && !d_seq_tok) return fail(ctx, KMG_EINVAL, "seq_tok required for read payload");
@@ -245,6 +247,11 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
                            d_seq_off, nseq, tile_seq.as<u32>(), tile_seq.as<u32>() + ntiles + 1, ntiles + 1);
     }
     int32_t *ridx = nullptr;
+    if (want_flags) {
+        KMG_ALLOC(has_kmer, nseq);
+        KMG_HIP(hipMemsetAsync(has_kmer.p, 0, nseq, ctx->stream));
+        a.has_kmer = has_kmer.as<uint8_t>();
+    }
     if (reads) {
         KMG_ALLOC(has_kmer, nseq);
         KMG_HIP(hipMemsetAsync(has_kmer.p, 0, nseq, ctx->stream));
@@ -352,6 +359,9 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     } else {
         hipLaunchKernelGGL(id_bits_kernel, dim3(std::min<u32>(div_up_u64(nseq, 256), 1024)), dim3(256), 0, ctx->stream,
                            d_seq_id, nseq, ctx->d_state);
+        if (want_flags)
+            hipLaunchKernelGGL(has_kmer_flags_kernel, dim3(div_up_u64(nseq, 256)), dim3(256), 0, ctx->stream, has_kmer.as<uint8_t>(),
+                               nseq, d_read_index_out);
     }
     if (part) {
         // the record count is final once the tiles are counted (the write pass starts at record 0: first batch);
@@ -466,7 +476,7 @@ extern "C" int kmg_build_add(kmg_ctx *ctx, const uint8_t *bases, uint64_t nbases
         if (seq_off[i] > seq_off[i + 1]) return fail(ctx, KMG_EINVAL, "seq_off must be non-decreasing");
     KMG_HIP(hipSetDevice(ctx->device));
     if (nbases == 0) {
-        if (reads && read_index_out) for (u64 i = 0; i < nseq; i++) read_index_out[i] = -1;
+        if (read_index_out) for (u64 i = 0; i < nseq; i++) read_index_out[i] = -1;
         return KMG_OK;
     }
     PoolBuf d_bases(ctx), d_off(ctx), d_id(ctx), d_tok(ctx), d_ridx(ctx);
@@ -474,17 +484,17 @@ extern "C" int kmg_build_add(kmg_ctx *ctx, const uint8_t *bases, uint64_t nbases
     KMG_ALLOC(d_off, (nseq + 1) * 8);
     KMG_HIP(hipMemcpyAsync(d_bases.p, bases, nbases, hipMemcpyHostToDevice, ctx->stream));
     KMG_HIP(hipMemcpyAsync(d_off.p, seq_off, (nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (read_index_out) KMG_ALLOC(d_ridx, nseq * 4);
     if (reads) {
         KMG_ALLOC(d_tok, nseq * 8);
         KMG_HIP(hipMemcpyAsync(d_tok.p, seq_tok, nseq * 8, hipMemcpyHostToDevice, ctx->stream));
-        if (read_index_out) KMG_ALLOC(d_ridx, nseq * 4);
     } else {
         KMG_ALLOC(d_id, nseq * 4);
         KMG_HIP(hipMemcpyAsync(d_id.p, seq_id, nseq * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     KMG_TRY(build_add_locked(ctx, d_bases.as<uint8_t>(), nbases, d_off.as<u64>(), d_id.as<int32_t>(),
                              d_tok.as<int64_t>(), nseq, d_ridx.as<int32_t>()));
-    if (reads && read_index_out) {
+    if (read_index_out) {
         KMG_HIP(hipMemcpyAsync(read_index_out, d_ridx.p, nseq * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     // the host buffers may be freed or moved by the caller as soon as we return

@@ -914,16 +914,19 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
                 // that; a FASTQ cut there, or any such file with minK < maxK, is refused rather than built differently.
                 if (pc.last && kmh_eof_in_kmer(b) && (reads || min_k != k))
                     throw Unsupported("input ends inside a sequence line (no final newline): not supported on the GPU path for FASTQ input or with minK < maxK");
-                if (!reads) {
-                    const uint8_t *ok = kmh_id_ok(b);
-                    for (uint64_t q = 0; q < nseq; q++)   // Integer.parseInt throws at the sequence's first k-mer
-                        if (!ok[q] && off[q + 1] - off[q] >= (uint64_t)min_k)
-                            throw std::runtime_error("FASTA header of sequence " + std::to_string(seq_base + q) + " is not an int");
-                }
-                std::vector<int32_t> ridx(reads ? nseq : 0);
+                // Integer.parseInt (or the -m map) throws at a sequence's first k-mer and not before: new Kmer(..) is evaluated
+                // first, KmersFromFile.java:103,165.  A sequence whose header is no int is handed over with whatever taxon
+                // the splitter left there, and the build says which sequences produced a k-mer.
+                const uint8_t *ok = reads ? nullptr : kmh_id_ok(b);
+                bool any_bad = false;
+                for (uint64_t q = 0; ok && q < nseq && !any_bad; q++) any_bad = !ok[q];
+                std::vector<int32_t> ridx(reads || any_bad ? nseq : 0);
                 if (nseq)
                     g.check(kmg_build_add(g.ctx, kmh_bases(b), kmh_nbases(b), off, reads ? nullptr : kmh_seq_id(b),
-                                          reads ? kmh_seq_tok(b) : nullptr, nseq, reads ? ridx.data() : nullptr));
+                                          reads ? kmh_seq_tok(b) : nullptr, nseq, ridx.empty() ? nullptr : ridx.data()));
+                for (uint64_t q = 0; any_bad && q < nseq; q++)
+                    if (!ok[q] && ridx[q] >= 0)
+                        throw std::runtime_error("FASTA header of sequence " + std::to_string(seq_base + q) + (named ? " is not in the id map" : " is not an int"));
                 if (reads) {
                     const uint64_t *noff = kmh_name_off(b);      // (a stream's piece: one name per sequence)
                     const char *names = kmh_names(b);
@@ -976,14 +979,13 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
     if (reads && kmh_empty_header(b)) throw Unsupported("a FASTQ record with an empty header: not supported on the GPU path");
     if (kmh_eof_in_kmer(b) && (reads || min_k != k))
         throw Unsupported("input ends inside a sequence line (no final newline): not supported on the GPU path for FASTQ input or with minK < maxK");
-    if (!reads) {
-        const uint8_t *ok = kmh_id_ok(b);
-        for (uint64_t s = 0; s < nseq; s++)   // Integer.parseInt throws at the sequence's first k-mer
-            if (!ok[s] && off[s + 1] - off[s] >= (uint64_t)min_k)
-                throw std::runtime_error("FASTA header of sequence " + std::to_string(s) + (named ? " is not in the id map" : " is not an int"));
-    }
+    // Integer.parseInt (or the -m map) throws at a sequence's first k-mer and not before (new Kmer(..) is evaluated first,
+    // KmersFromFile.java:103,165): the build says which sequences produced one
+    const uint8_t *id_ok = reads ? nullptr : kmh_id_ok(b);
+    bool any_bad = false;
+    for (uint64_t s = 0; id_ok && s < nseq && !any_bad; s++) any_bad = !id_ok[s];
     clk.lap("split records (host)");
-    std::vector<int32_t> ridx(reads ? nseq : 0);
+    std::vector<int32_t> ridx(reads || any_bad ? nseq : 0);
     kmg_db *db = nullptr;
     const size_t nkeys = (size_t)1 << (2 * key_len);
     // share / shares (-G): this process builds the share-th of `shares` equal key ranges only
@@ -999,7 +1001,10 @@ kmg_db *build_from_text(Gpu &g, const std::string &path, bool reads, int k, int 
         if (min_k != k) g.check(kmg_build_set_min_k(g.ctx, min_k));
         if (ranged) g.check(kmg_build_set_key_range(g.ctx, (uint32_t)lo, (uint32_t)hi));
         g.check(kmg_build_add(g.ctx, kmh_bases(b), kmh_nbases(b), off, reads ? nullptr : kmh_seq_id(b),
-                              reads ? kmh_seq_tok(b) : nullptr, nseq, reads ? ridx.data() : nullptr));
+                              reads ? kmh_seq_tok(b) : nullptr, nseq, ridx.empty() ? nullptr : ridx.data()));
+        for (uint64_t s = 0; any_bad && s < nseq; s++)
+            if (!id_ok[s] && ridx[s] >= 0)
+                throw std::runtime_error("FASTA header of sequence " + std::to_string(s) + (named ? " is not in the id map" : " is not an int"));
         uint64_t w = 0;
         g.check(kmg_build_finish(g.ctx, &db, &w));
         windows += w;

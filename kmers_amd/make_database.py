@@ -31,12 +31,17 @@ def make_reference_db(ctx, fasta, k=32, key_length=6, dust=None, runofsame=None,
     min_k = k if min_k is None else min_k
     pf = fasta if isinstance(fasta, parse.ParsedFile) else parse.parse(fasta, parse.FASTA, k, id_map=id_map)
     _check_eof(pf, parse.FASTA, k, min_k)
-    lens = np.diff(pf.batch.seq_off.astype(np.int64))
-    bad = np.nonzero((pf.id_ok == 0) & (lens >= min_k))[0]
-    if bad.size:   # Integer.parseInt throws NumberFormatException at the sequence's first k-mer (with -m: map.get is null)
-        raise ValueError("FASTA header of sequence %d is not %s" % (int(bad[0]), "in the id map" if pf.named else "an int"))
     fc = FileCreator(ctx, key_length, k, "ref", rc=True, dust=dust, runofsame=runofsame, key_range=key_range)
-    fc.add_kmers(pf.batch, min_length=min_k, max_length=k)
+    any_bad = bool((pf.id_ok == 0).any())
+    has = fc.add_kmers(pf.batch, min_length=min_k, max_length=k, flags=any_bad)
+    if any_bad:
+        # Integer.parseInt throws NumberFormatException (with -m: map.get is null) at the sequence's first k-mer and not
+        # before -- new Kmer(..) is evaluated first, KmersFromFile.java:103,165 -- so a header that is no int only fails
+        # for the sequences the build flags as having produced a k-mer
+        bad = np.nonzero((pf.id_ok == 0) & (has >= 0))[0]
+        if bad.size:
+            fc.create().close()
+            raise ValueError("FASTA header of sequence %d is not %s" % (int(bad[0]), "in the id map" if pf.named else "an int"))
     db = fc.create()
     db.n_windows = fc.n_windows
     return db

@@ -729,3 +729,57 @@ def test_sequence_id_to_taxon_map(tmp_path):
         R.build_ref_db(open(bad_fa, "rb").read(), k, l, min_k=mk, id_map=id_map)
     with pytest.raises(IndexError):
         R.read_id_map(open(bad_map, "rb").read())
+
+
+def test_headers_are_read_at_the_first_kmer(tmp_path):
+    """Integer.parseInt(header) runs when a sequence hands out its first k-mer and not before (new Kmer(..) is evaluated
+    before mapper.apply, KmersFromFile.java:103,165): a record such as `>chr1` whose sequence holds no valid k-mer builds
+    fine in the reference, one with a k-mer throws.  Both drivers decide from the build's has-k-mer flags
+    (kmg_build_add's read_index_out for taxon builds) and are held to the literal restatement."""
+    import subprocess
+    import kmers_amd as km
+    from kmers_amd.__main__ import main as cli
+    from oracle import slow_ref as R
+    kmg = os.path.join(os.path.dirname(km.__file__), "kmg")
+    rng = np.random.Generator(np.random.PCG64(5))
+    seq = lambda n: bytes(rng.choice(list(b"ACGT"), n).tolist())
+    run = lambda *a: subprocess.run([kmg] + list(a), capture_output=True, text=True, timeout=120)
+    for k, mk, l in ((12, 12, 3), (12, 9, 3)):
+        good = b">7\n" + seq(300) + b"\n>8\n" + seq(40) + b"N" + seq(40) + b"\n"
+        # no k-mer under these headers: only N, every window across an N, too short
+        quiet = b">chr1\n" + b"N" * 50 + b"\n>chr2\n" + b"N".join(seq(mk - 1) for _ in range(6)) + b"\n>chr3\n" + seq(mk - 1) + b"\n"
+        if mk < k:
+            # a valid run of minK bases in the middle of a sequence shorter than maxK: neither a full window nor the end
+            quiet += b">chr4\n" + b"N" + seq(mk) + b"N\n"
+        common = ["-K", str(k), "-k", str(mk), "-l", str(l), "-Z"]
+        fa_b = good + quiet
+        want = str(tmp_path / "want.db")
+        R.write_indexed_file(want, R.build_ref_db(fa_b, k, l, min_k=mk), None)
+        assert open(want, "rb").read() == R_bytes(R, good, k, l, mk, tmp_path)      # the quiet records add nothing
+        fa = str(tmp_path / "ref.fa")
+        open(fa, "wb").write(fa_b)
+        for tag, drv in (("kmg", lambda *a: run(*a).returncode), ("py", lambda *a: cli(list(a)))):
+            out = str(tmp_path / ("ref.%s.db" % tag))
+            assert drv("Database.MakeDatabase", "-a", "-i", fa, "-o", out, *common) == 0
+            assert open(out, "rb").read() == open(want, "rb").read()
+            assert drv("Database.MakeDatabase", "-a", "-i", fa, "-o", out + ".p", "-P", "3", *common) == 0
+            assert open(out + ".p", "rb").read() == open(want, "rb").read()
+        # the same headers over sequences that do hand out a k-mer
+        loud = [b">chrA\n" + seq(k) + b"\n", b">chrB\n" + b"N" * 30 + seq(k) + b"\n"]
+        if mk < k:
+            loud.append(b">chrC\n" + seq(mk) + b"\n")                       # a suffix k-mer at the sequence's end
+        for extra in loud:
+            bad = str(tmp_path / "bad.fa")
+            open(bad, "wb").write(fa_b + extra)
+            with pytest.raises(ValueError):
+                R.build_ref_db(fa_b + extra, k, l, min_k=mk)
+            r = run("Database.MakeDatabase", "-a", "-i", bad, "-o", str(tmp_path / "x.db"), *common)
+            assert r.returncode == 1, (extra, r.stderr)
+            with pytest.raises(ValueError):
+                cli(["Database.MakeDatabase", "-a", "-i", bad, "-o", str(tmp_path / "y.db")] + common)
+
+
+def R_bytes(R, fa_b, k, l, mk, tmp_path):
+    p = str(tmp_path / "only_good.db")
+    R.write_indexed_file(p, R.build_ref_db(fa_b, k, l, min_k=mk), None)
+    return open(p, "rb").read()
