@@ -253,7 +253,9 @@ int kmg_match_keys_dev(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run
  *   scratch, the per-tile bounds of the join, lives in a file-scope device array of 1 MiB that every GPU the library
  *   runs on holds until the process ends; hence the limit: at most KMG_MATCH_NOALLOC_MAX_SEARCH distinct search
  *   k-mers per call (KMG_EINVAL beyond).  Both databases must belong to ctx.  Every call on a GPU shares that GPU's
- *   array: calls that overlap on one GPU (two contexts = two streams) race -- serialise them. */
+ *   array; calls from several contexts of one GPU (= several streams) are ordered by the library, each behind the one
+ *   queued before it (an event per context, made with the context), so they give the right results but do not
+ *   overlap. */
 #define KMG_MATCH_NOALLOC_MAX_SEARCH 268433408ull   /* 131071 tiles x 2048 k-mers */
 int kmg_match_dev_noalloc(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *d_hit_index);
 

@@ -191,6 +191,7 @@ struct kmg_ctx {
     uint8_t *sh_len = nullptr;
     u64 sh_n = 0, sh_cap = 0;
     u64 *match_scratch = nullptr; // this device's copy of the file-scope bounds array (kmg_match_dev_noalloc)
+    hipEvent_t ev_scratch = nullptr;   // recorded behind this context's last no-allocation join (orders other contexts' joins)
     // single-pass (chained) scans and their relatives, scan.h: tile status words, two control words, the launch epoch
     u64 *scan_status = nullptr;
     size_t scan_status_cap = 0;

@@ -336,6 +336,17 @@ kmh_batch *kmh_stream_next(kmh_stream *h, const uint8_t *data, uint64_t n, int f
         b = parse_core(data, n, st->mode, k, st, final != 0, &used);
         if (!final) st->carry.assign((const char *)data + used, n - used);
     } else {
+        if (!final && !memchr(data, st->mode == 1 ? '@' : '>', n)) {
+            // No header can start in this piece, so nothing new is complete: the open record only grows.  (Parsing the
+            // carry again from its start for every such piece cost O(record^2 / piece) on a chromosome-sized record --
+            // ADVICE r2.  The open record itself still waits in memory whole: its sequences leave with the record.)
+            st->carry.append((const char *)data, n);
+            b = new Batch();
+            b->seq_off.assign(1, 0);
+            b->name_off.assign(1, 0);
+            b->per_seq_names = true;
+            return (kmh_batch *)b;
+        }
         st->carry.append((const char *)data, n);
         b = parse_core((const uint8_t *)st->carry.data(), st->carry.size(), st->mode, k, st, final != 0, &used);
         if (!final) st->carry.erase(0, used); else st->carry.clear();

@@ -46,6 +46,7 @@ static int fail(kmg_ctx *ctx, int code, const char *msg) {
 
 // ------------------------------------------------------------------------------------------------ context
 static int resolve_match_scratch(kmg_ctx *ctx);
+static void forget_match_scratch_user(kmg_ctx *ctx);
 
 extern "C" int kmg_create(int device, kmg_ctx **out) {
     if (!out) return KMG_EINVAL;
@@ -73,6 +74,7 @@ extern "C" int kmg_create(int device, kmg_ctx **out) {
         delete ctx;
         return KMG_EDEVICE;
     }
+    if (hipEventCreateWithFlags(&ctx->ev_scratch, hipEventDisableTiming) != hipSuccess) ctx->ev_scratch = nullptr;
     if (hipHostMalloc(&ctx->h_pin, PIN_BYTES, hipHostMallocDefault) != hipSuccess) ctx->h_pin = nullptr;   // optional
     if (hipHostMalloc(&ctx->h_snap, PIN_BYTES, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_len, hipEventDisableTiming) != hipSuccess ||
@@ -88,6 +90,8 @@ extern "C" void kmg_destroy(kmg_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    forget_match_scratch_user(ctx);
+    if (ctx->ev_scratch) (void)hipEventDestroy(ctx->ev_scratch);
     prof_drain(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->pool.destroy();
@@ -1727,6 +1731,10 @@ static int match_keys_locked(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_
 static __device__ __align__(256) u64 kmg_match_scratch[KMG_NOALLOC_TILES + 1];
 #define KMG_MAX_DEVICES 64
 static u64 *g_match_scratch[KMG_MAX_DEVICES];          // per device: address of ITS copy of kmg_match_scratch
+// per device: the context whose join used the array last.  Another context's join waits for that context's event
+// (made with the context, recorded behind every no-allocation join) before it writes the array: calls from several
+// contexts of one GPU are ordered one behind the other instead of racing -- still without allocating.
+static kmg_ctx *g_match_scratch_user[KMG_MAX_DEVICES];
 static std::mutex g_match_scratch_mu;
 
 // called by kmg_create with ctx->device current
@@ -1741,6 +1749,13 @@ static int resolve_match_scratch(kmg_ctx *ctx) {
     }
     ctx->match_scratch = g_match_scratch[ctx->device];
     return KMG_OK;
+}
+
+// a context that goes away (its stream has been synchronised: its joins are done) is nobody's predecessor any more
+static void forget_match_scratch_user(kmg_ctx *ctx) {
+    std::lock_guard<std::mutex> g(g_match_scratch_mu);
+    for (int d = 0; d < KMG_MAX_DEVICES; d++)
+        if (g_match_scratch_user[d] == ctx) g_match_scratch_user[d] = nullptr;
 }
 
 extern "C" int kmg_match_dev_noalloc(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *d_hit_index) {
@@ -1759,11 +1774,19 @@ extern "C" int kmg_match_dev_noalloc(kmg_ctx *ctx, const kmg_db *search, const k
     if (search->U == 0) return KMG_OK;
     const u32 ntiles = div_up_u64(search->U, MT_TILE);          // <= KMG_NOALLOC_TILES by the check above
     u64 *bounds = ctx->match_scratch;                            // every word [0, ntiles] is written before it is read
+    std::lock_guard<std::mutex> gs(g_match_scratch_mu);          // (queueing order = the order of the waits below)
+    kmg_ctx *last = g_match_scratch_user[ctx->device];
+    if (last && last != ctx && ctx->ev_scratch && last->ev_scratch)
+        KMG_HIP(hipStreamWaitEvent(ctx->stream, last->ev_scratch, 0));
     hipLaunchKernelGGL(match_bounds_kernel, dim3(div_up_u64(ntiles + 1, 256)), dim3(256), 0, ctx->stream, search->keys, search->U,
                        ref->keys, ref->U, ref->bucket_off, ref->key_len, ntiles, bounds);
     hipLaunchKernelGGL(match_kernel, dim3(ntiles), dim3(MT_BLOCK), 0, ctx->stream, search->keys, search->U, ref->keys,
                        bounds, (long long *)d_hit_index, (u64 *)nullptr);
     KMG_HIP(hipGetLastError());
+    if (ctx->ev_scratch) {
+        KMG_HIP(hipEventRecord(ctx->ev_scratch, ctx->stream));
+        g_match_scratch_user[ctx->device] = ctx;
+    }
     return KMG_OK;
 }
 static_assert((u64)KMG_NOALLOC_TILES * MT_TILE == KMG_MATCH_NOALLOC_MAX_SEARCH, "header limit and scratch size disagree");

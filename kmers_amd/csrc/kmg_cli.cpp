@@ -760,7 +760,9 @@ int make_database_preprocessed(const Args &a, int k, int min_k, int key_len, int
 
 // A sequence file read, inflated and split into records piece by piece on a thread of its own (kmh_stream_*): the
 // consumer takes the pieces' batches in order while the next ones are being made.  Neither the text nor the sequences
-// of the whole input are in memory at any time; the reader runs ahead by at most ~256 MiB of input.
+// of the whole input are in memory at any time; the reader runs ahead by at most ~256 MiB of input -- plus the record it
+// is in the middle of: a record waits whole (as text, appended piece by piece without being parsed again) until the next
+// header start shows, so a chromosome-sized FASTA record is in memory once.
 struct Piece {
     std::unique_ptr<kmh_batch, void (*)(kmh_batch *)> batch{nullptr, kmh_free};
     bool last = false;

@@ -613,8 +613,12 @@ class _Node:                                     # Node.java:3-15
 
 
 def _merge_counts(a, b):                         # CountDataType.getMerger: TreeCountMap.addAll, in place
-    if a is None or b is None:                   # (merge.accept on a cleared node would throw in Java; never reached
-        return                                   #  with k-mers of one length, which is all this restatement is used for)
+    if a is None or b is None:
+        # merge.accept on a cleared node (data == null) is a NullPointerException in Java.  Merges only happen at depths
+        # >= shortest, where data is never null, so this is unreachable as far as the source reads -- raised rather than
+        # skipped, so that a reachable case fails the trie fuzz instead of passing quietly.  (The trie's
+        # parity is pinned by this restatement only: the reference holds no fixture of Matcher's default -k / -K output.)
+        raise TypeError("NullPointerException: merge into / from a node without data (Root.java:48-51,95-102)")
     for t, c in b.items():
         a[t] = a.get(t, 0) + c
 

@@ -168,3 +168,20 @@ def test_pieces_of_a_larger_fastq():
         assert np.concatenate([p.batch.bases for p in parts]).tobytes() == whole.batch.bases.tobytes()
         assert [nm for p in parts for nm in p.names] == [whole.names[t] for t in whole.batch.seq_tok.tolist()]
         assert sum(p.batch.nseq for p in parts) == whole.batch.nseq
+
+
+def test_a_record_that_spans_many_pieces_is_parsed_once():
+    """a piece without a header start used to roll everything back and the next call parsed the whole carry
+    again -- O(record^2 / piece) for a chromosome-sized FASTA record.  Now such pieces are only appended: 6 MB in 2 KiB
+    pieces (3000 pieces inside one record) must cost about what the whole input costs, and give its sequences."""
+    import time
+    rng = np.random.Generator(np.random.PCG64(9))
+    line = bytes(rng.choice(list(b"ACGT"), 6_000_000).tolist())
+    data = b">1\n" + b"ACGTACGTAC" * 5 + b"\n>22\n" + line + b"\n>3\nTTTTGGGGCCCCAAAA\n"
+    t0 = time.perf_counter()
+    whole, parts = _whole_and_pieces(data, parse.FASTA, 11, 2048)
+    dt = time.perf_counter() - t0
+    assert np.concatenate([p.batch.bases for p in parts]).tobytes() == whole.batch.bases.tobytes()
+    assert np.concatenate([p.batch.seq_id for p in parts]).tolist() == whole.batch.seq_id.tolist() == [1, 22, 3]
+    assert sum(p.batch.nseq for p in parts) == 3
+    assert dt < 20, "%.1f s for a 6 MB record in 2 KiB pieces" % dt

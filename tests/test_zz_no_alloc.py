@@ -75,3 +75,43 @@ def test_noalloc_rejects_foreign_and_mismatched():
     finally:
         ctx.close()
         other.close()
+
+
+def test_noalloc_two_contexts_back_to_back():
+    """Two contexts of one GPU share the GPU's scratch array but have a stream each: their joins, queued one
+    right behind the other with nothing waited for in between, must not overwrite each other's tile bounds -- the library
+    orders them with an event per context.  Several rounds, a large join (many tiles) on one context and a different one
+    on the other."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    a, b = km.Context(0), km.Context(0)
+    dev = torch.device("cuda", 0)
+    try:
+        dbs = []
+        for ctx, seed, glen, nreads in ((a, 41, 80000, 6000), (b, 42, 50000, 3000)):
+            taxa, genomes = synth.random_genomes(seed, 3, glen, shared_frac=0.2)
+            reads = synth.random_reads(seed + 100, genomes, nreads, 150, 0.01)
+            ref, rdb = _build(ctx, synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads), 31, 6)
+            want = torch.empty(rdb.n_unique, dtype=torch.int64, device=dev)
+            ctx.check(ctx.lib.kmg_match_dev(ctx.h, rdb.h, ref.h, want.data_ptr()))
+            dbs.append((ctx, ref, rdb, want, torch.empty(rdb.n_unique, dtype=torch.int64, device=dev)))
+        torch.cuda.synchronize(dev)
+        for ctx, *_ in dbs:
+            torch.cuda.ExternalStream(ctx.stream, device=dev).synchronize()
+        for rnd in range(6):
+            for ctx, ref, rdb, want, got in (dbs if rnd % 2 == 0 else dbs[::-1]):
+                got.fill_(-9)
+            torch.cuda.synchronize(dev)
+            for ctx, ref, rdb, want, got in (dbs if rnd % 2 == 0 else dbs[::-1]):
+                ctx.check(ctx.lib.kmg_match_dev_noalloc(ctx.h, rdb.h, ref.h, got.data_ptr()))
+            for ctx, *_ in dbs:
+                torch.cuda.ExternalStream(ctx.stream, device=dev).synchronize()
+            for ctx, ref, rdb, want, got in dbs:
+                assert torch.equal(got, want), "round %d" % rnd
+                assert int((got >= 0).sum()) > 0
+        for ctx, ref, rdb, want, got in dbs:
+            rdb.close()
+            ref.close()
+    finally:
+        a.close()
+        b.close()
