@@ -184,8 +184,9 @@ int kmg_db_restrict_range(kmg_ctx *ctx, const kmg_db *db, int min_length, int ma
  *   they are added (255 = what a database file holds, CountDataType.java:40; 0 for handles loaded from files).
  *   Out: hit_row[n_unique(search)] = row of the answer in *rows, or -1 (no stored k-mer has t as a prefix: no match
  *   line); *rows = a taxon database whose row r (kmg_db_fetch: val_off / val_a / val_b) is answer r, taxa ascending --
- *   its keys are row numbers, not k-mers.  The database searched is ONE file (the reference inserts the files of a set
- *   one after the other, unmerged: not restated -> merge fails with KMG_EUNSUPPORTED for variable-length sets). */
+ *   its keys are row numbers, not k-mers.  The database searched is ONE file or a set laid end to end (kmg_db_merge of
+ *   files that share no key); the reference inserts the files of a set one after the other, unmerged, which for files
+ *   that share a key is not restated: a database merged from such files returns KMG_EUNSUPPORTED here. */
 int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *db, int min_k, int count_cap, kmg_db **rows,
                    int64_t *hit_row, uint64_t *n_hits);
 /* kmg_db_load : upload a decoded database (KmerFile.java:200-250 output) from host CSR arrays. */
@@ -222,8 +223,10 @@ int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint64_t cap, ui
  *   read-position sets unite).  Inputs must agree in datatype, k and key_len (DB.java:36-42,57-64 ->
  *   KMG_EINVAL); they stay valid.  Also the local step after a key-range exchange between GPUs.
  *   Variable-length databases (minK < maxK): a set whose files share no key -- the sets MakeDatabase -S / -G write are
- *   cut at key bounds -- is laid end to end in key order; files that share a key return KMG_EUNSUPPORTED (merge after
- *   kmg_db_restrict, or on the Java path). */
+ *   cut at key bounds -- is laid end to end in key order; files that share keys are merged in Sequence.compareTo order
+ *   (zero-padded value, then length: Kmers/Sequence.java:165-187), length by length.  Such a merged database serves
+ *   TaxaCounts, kmg_db_restrict and the exact join behind it; kmg_match_trie refuses it (KMG_EUNSUPPORTED): the reference's
+ *   trie takes a key's k-mers file by file, unmerged (DB.java:154-158), which is not restated. */
 int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, kmg_db **out);
 
 /* ---- stage 3: match  (replaces DB.getNearestKmers quick branch, DB.java:76-90,129-137) -------

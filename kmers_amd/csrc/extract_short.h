@@ -355,20 +355,25 @@ __global__ __launch_bounds__(ILV_BLOCK) void il_values_kernel(const u64 *__restr
 // ---- KmerUtils.restrictedStream (Kmers/KmerUtils.java:59-74) ---------------------------------------------------------
 // keep[i] = number of values of entry i if its k-mer has at least L bases, else 0
 // (lens == null: every k-mer has len_all bases)
-__global__ void rs_keep_kernel(const uint8_t *__restrict__ lens, int len_all, const u64 *__restrict__ val_off, u64 n, int L,
+// (H: only k-mers of fewer than H bases -- L + 1 picks the k-mers of exactly L bases, 64 all from L on)
+__global__ void rs_keep_kernel(const uint8_t *__restrict__ lens, int len_all, const u64 *__restrict__ val_off, u64 n, int L, int H,
                                u32 *__restrict__ keep) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keep[i] = (lens ? (int)lens[i] : len_all) >= L ? (u32)(val_off[i + 1] - val_off[i]) : 0u;
+    if (i >= n) return;
+    const int len = lens ? (int)lens[i] : len_all;
+    keep[i] = (len >= L && len < H) ? (u32)(val_off[i + 1] - val_off[i]) : 0u;
 }
 // the kept entries' values as (k-mer cut to L bases, payload) records for the merge pipeline (reduce.h, mg_*)
 __global__ void rs_expand_kernel(const u64 *__restrict__ keys, const uint8_t *__restrict__ lens, int len_all,
                                  const u64 *__restrict__ val_off, const int32_t *__restrict__ val_a,
-                                 const int32_t *__restrict__ val_b, u64 n, int L, const u64 *__restrict__ dst, int kind,
+                                 const int32_t *__restrict__ val_b, u64 n, int L, int H, const u64 *__restrict__ dst, u64 base, int kind,
                                  u64 *__restrict__ out_keys, u64 *__restrict__ out_vals) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || (lens ? (int)lens[i] : len_all) < L) return;
+    if (i >= n) return;
+    const int len = lens ? (int)lens[i] : len_all;
+    if (len < L || len >= H) return;
     const u64 key = keys[i] & (L == 32 ? ~0ull : ~(~0ull >> (2 * L)));       // Kmer.limitTo (Kmer.java:277-289)
-    u64 o = dst[i];
+    u64 o = base + dst[i];
     for (u64 v = val_off[i]; v < val_off[i + 1]; v++, o++) {
         out_keys[o] = key;
         out_vals[o] = kind == KMG_PAYLOAD_TAXON ? (((u64)((u32)val_a[v] ^ 0x80000000u) << 32) | (u32)val_b[v])

@@ -1359,8 +1359,91 @@ static int merge_records(kmg_ctx *ctx, kmg_db *db, PoolBuf &k0, PoolBuf &v0, Poo
 }
 
 // ------------------------------------------------------------------------------------------------ merge
+// Variable-length databases whose files SHARE keys: DB.kmers' merge (DB.java:99-109: mergeSortedStreams +
+// groupAndReduceStream(addAll)) in Sequence.compareTo order = (zero-padded value, length).  Length by length: the
+// entries of that length of every file as (k-mer, payload) records, folded by the merge pipeline into a database of one
+// length; the lengths' databases interleaved by rank, shortest first, as a build's length classes are
+// (extract_short.h).  Not a hot path: a handful of launches per length and file.
+static int merge_var_shared(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, kmg_db **out) {
+    const kmg_db *d0 = dbs[0];
+    int rc = 1;
+    for (int i = 0; i < n_dbs; i++) {
+        rc &= dbs[i]->rc;
+        KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(dbs[i])));
+    }
+    std::unique_ptr<kmg_db, void (*)(kmg_db *)> acc(nullptr, db_release);
+    for (int L = d0->min_k; L <= d0->k; L++) {
+        std::vector<std::unique_ptr<PoolBuf>> dsts;
+        std::vector<u64> cnt(n_dbs, 0);
+        u64 total = 0;
+        for (int i = 0; i < n_dbs; i++) {
+            const kmg_db *d = dbs[i];
+            dsts.emplace_back(new PoolBuf(ctx));
+            if (d->U == 0) continue;
+            PoolBuf keep(ctx), agg(ctx);
+            KMG_ALLOC(keep, (d->U + 1) * 4);
+            KMG_ALLOC(agg, (size_t)(div_up_u64(d->U, SCAN_TILE) + 1) * 8);
+            KMG_ALLOC(*dsts[i], (d->U + 2) * 8);
+            hipLaunchKernelGGL(rs_keep_kernel, dim3(div_up_u64(d->U, 256)), dim3(256), 0, ctx->stream, d->lens, d->k, d->val_off, d->U, L, L + 1,
+                               keep.as<u32>());
+            KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, keep.as<u32>(), dsts[i]->as<u64>(), d->U, OpSum(), 0ull, agg.as<u64>(), nullptr,
+                                                        true, KP_SCAN)));
+            KMG_HIP(read_back(ctx, &cnt[i], dsts[i]->as<u64>() + d->U, 8));
+            total += cnt[i];
+        }
+        if (total == 0) continue;
+        if (total >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 values of one k-mer length in the merged database");
+        const u32 n = (u32)total;
+        PoolBuf k0(ctx), v0(ctx), k1(ctx), v1(ctx), totals(ctx);
+        KMG_ALLOC(totals, 64);
+        KMG_HIP(hipMemsetAsync(totals.p, 0, 64, ctx->stream));
+        KMG_ALLOC(k0, ((size_t)n + 1) * 8); KMG_ALLOC(v0, ((size_t)n + 1) * 8);
+        KMG_ALLOC(k1, ((size_t)n + 1) * 8); KMG_ALLOC(v1, ((size_t)n + 1) * 8);
+        u64 base = 0;
+        for (int i = 0; i < n_dbs; i++) {
+            const kmg_db *d = dbs[i];
+            if (!cnt[i]) continue;
+            hipLaunchKernelGGL(rs_expand_kernel, dim3(div_up_u64(d->U, 256)), dim3(256), 0, ctx->stream, d->keys, d->lens, d->k, d->val_off,
+                               d->val_a, d->val_b, d->U, L, L + 1, dsts[i]->as<u64>(), base, d->kind, k0.as<u64>(), v0.as<u64>());
+            base += cnt[i];
+        }
+        KMG_HIP(hipGetLastError());
+        kmg_db *c = new (std::nothrow) kmg_db();
+        if (!c) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+        std::unique_ptr<kmg_db, void (*)(kmg_db *)> cls(c, db_release);
+        c->ctx = ctx; c->k = L; c->min_k = L; c->key_len = d0->key_len; c->rc = rc; c->kind = d0->kind;
+        KMG_TRY(merge_records(ctx, c, k0, v0, k1, v1, n, totals));                 // (ends with a stream synchronisation)
+        if (!acc) acc = std::move(cls);
+        else {
+            kmg_db *m = new (std::nothrow) kmg_db();
+            if (!m) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+            std::unique_ptr<kmg_db, void (*)(kmg_db *)> merged(m, db_release);
+            m->ctx = ctx; m->k = L; m->min_k = acc->min_k; m->key_len = d0->key_len; m->rc = rc; m->kind = d0->kind;
+            KMG_TRY(interleave_dbs(ctx, acc.get(), c, m));
+            KMG_HIP(hipStreamSynchronize(ctx->stream));         // acc and the class go back to the pool behind this
+            acc = std::move(merged);
+        }
+    }
+    if (!acc) return fail(ctx, KMG_ESTATE, "merge of databases that share keys found no k-mer");
+    kmg_db *f = acc.get();
+    if (!f->lens) {                                             // k-mers of one length only
+        void *p;
+        if (ctx->pool.alloc(&p, f->U + 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+        f->lens = (uint8_t *)p;
+        KMG_HIP(hipMemsetAsync(f->lens, f->k, f->U + 1, ctx->stream));
+    }
+    f->k = d0->k; f->min_k = d0->min_k; f->rc = rc;
+    f->shared_key_merge = true;
+    KMG_TRY(ensure_vals(ctx, f));
+    KMG_TRY(db_make_buckets(ctx, f));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    KMG_HIP(hipGetLastError());
+    *out = acc.release();
+    return KMG_OK;
+}
+
 // Variable-length databases: a set whose files share no key (the sets MakeDatabase -S / -G write are cut at key
-// bounds) is laid end to end in key order; files that share a key would need a merge in (value, length) order.
+// bounds) is laid end to end in key order; files that share a key take merge_var_shared.
 static int merge_disjoint_keys(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, kmg_db **out) {
     const kmg_db *d0 = dbs[0];
     const u32 nbuckets = 1u << (2 * d0->key_len);
@@ -1402,8 +1485,10 @@ static int merge_disjoint_keys(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs
     hipLaunchKernelGGL(vm_clash_kernel, bgrid, blk, 0, ctx->stream, holders.as<u32>(), nbuckets, clash.as<u32>());
     u32 h_clash = 0;
     KMG_HIP(read_back(ctx, &h_clash, clash.p, 4));
-    if (h_clash)
-        return fail(ctx, KMG_EUNSUPPORTED, "databases of k-mers of several lengths that share a key: merged on the Java path (or after kmg_db_restrict)");
+    if (h_clash) {
+        db_guard.reset();
+        return merge_var_shared(ctx, dbs, n_dbs, out);
+    }
     for (int i = 0; i < n_dbs; i++) {
         const kmg_db *d = dbs[i];
         if (d->U == 0) continue;
@@ -1565,7 +1650,7 @@ static int restrict_locked(kmg_ctx *ctx, const kmg_db *src, int length, kmg_db *
     KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
     u64 nkept = 0;
     if (U) {
-        hipLaunchKernelGGL(rs_keep_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, src->lens, src->k, src->val_off, U, length,
+        hipLaunchKernelGGL(rs_keep_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, src->lens, src->k, src->val_off, U, length, 64,
                            keep.as<u32>());
         KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, keep.as<u32>(), dst.as<u64>(), U, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
                                                     KP_SCAN)));
@@ -1577,7 +1662,7 @@ static int restrict_locked(kmg_ctx *ctx, const kmg_db *src, int length, kmg_db *
     KMG_ALLOC(k1, ((size_t)n + 1) * 8); KMG_ALLOC(v1, ((size_t)n + 1) * 8);
     if (n)
         hipLaunchKernelGGL(rs_expand_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, src->keys, src->lens, src->k, src->val_off,
-                           src->val_a, src->val_b, U, length, dst.as<u64>(), src->kind, k0.as<u64>(), v0.as<u64>());
+                           src->val_a, src->val_b, U, length, 64, dst.as<u64>(), 0ull, src->kind, k0.as<u64>(), v0.as<u64>());
     KMG_HIP(hipGetLastError());
     (void)reads;
     KMG_TRY(merge_records(ctx, db, k0, v0, k1, v1, n, totals));
@@ -1598,6 +1683,11 @@ extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     // DB.java:78-81 on the search stream's declared lengths [min_k, search->k]
     if (min_k < ref->min_k || search->k > ref->k || min_k > search->min_k || min_k < ref->key_len)
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
+    // The reference puts a key's k-mers into its trie FILE BY FILE, unmerged (DB.java:154-158): with files that share a key
+    // the insertion is no longer in the trie's own preorder, nodes are split by later files' k-mers and a data object can
+    // receive one k-mer more than once -- the closed form below does not hold for that.  Not restated: the Java path.
+    if (ref->shared_key_merge || search->shared_key_merge)
+        return fail(ctx, KMG_EUNSUPPORTED, "the search over several k-mer lengths in a set of files that share a key: not on the GPU path");
     KMG_HIP(hipSetDevice(ctx->device));
     KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(ref)));
     const u64 ns = search->U;

@@ -306,6 +306,7 @@ def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max
             searches = [s_.restrict(min_k, max_k) for s_ in searches]       # KmerFile.allRestrictedKmers (Matcher.java:241)
         # sets (name.1 .. name.N): files that share no key -- what -S / -G write -- are laid end to end (kmg_db_merge);
         # the reference's trie takes one key's k-mers file by file, so files sharing a key stay on the Java path
+        # (kmg_match_trie refuses the merged handle: KMG_EUNSUPPORTED, exit status 3)
         search = searches[0] if len(searches) == 1 else merge_databases(searches)
         if not db.merged.rc:
             raise ValueError("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included")

@@ -1442,11 +1442,82 @@ def test_variable_length_sets_cut_at_key_bounds_merge(ctx, min_k, k, key_len, se
             ot, om, oq = OracleDB(fa, 0, k, key_len, min_k=min_k).taxacounts()
             assert np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
             rows.close()
-            with pytest.raises(km.KmersGpuError):                             # two files holding the same keys
-                km.merge_databases([ref_whole, ref_whole])
+            # two files holding the same keys merge as well (test_variable_length_sets_that_share_keys_merge); what such
+            # a set does not take is the search over several lengths: the reference's trie takes a key's k-mers file by file
+            twice = km.merge_databases([ref_whole, ref_whole])
+            with pytest.raises(km.KmersGpuError):
+                km.match_trie(whole, twice)
+            twice.close()
             whole.close()
             for d in parts:
                 d.close()
+
+
+@pytest.mark.parametrize("min_k,k,key_len,seed", [(3, 6, 2, 91), (24, 32, 4, 92), (20, 31, 3, 93), (5, 5, 2, 94), (2, 9, 1, 95)])
+def test_variable_length_sets_that_share_keys_merge(ctx, min_k, k, key_len, seed):
+    """Files of k-mers of several lengths that SHARE keys -- databases built from different inputs and handed to Matcher /
+    TaxaCounts as several -d files -- are one database as DB.kmers makes it (DB.java:99-109: k-way merge in
+    Sequence.compareTo order = (zero-padded value, length), equal k-mers reduced with addAll): three reference files
+    merged on the GPU equal the database of the three inputs built as one, the literal DB.kmers over the three files,
+    and TaxaCounts / `Matcher -k L -K L` over the set give the whole's rows and hits.  Read databases unite their lists
+    (the reference's sets hold ReadPos objects without equals: both copies stay)."""
+    import kmers_amd as km
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(seed)
+    small = k <= 9
+    alphabet = b"AACCGTN" if small else b"ACGT" * 8 + b"N"
+    fas = [_rand_fasta(rng, 14 if small else 25, 50 if small else 260, alphabet, [3, 4, 5, 77][:2 + i]) for i in range(3)]
+    recs = fas[0].split(b">")[1:]
+    fas[1] += b"".join(b">" + r for r in recs[:len(recs) // 2])          # shared sequences: counts add, taxa sets unite
+    parts = [km.make_reference_db(ctx, fa, k, key_len, min_k=min_k) for fa in fas]
+    merged = km.merge_databases(parts)
+    want = OracleDB(b"".join(fas), 0, k, key_len, min_k=min_k)
+    if min_k < k:
+        _same_var_db(merged, want)
+    else:
+        _same_db(merged, want)
+    # the literal DB.kmers over the three files, key by key
+    files = [R.build_ref_db(fa, k, key_len, min_k=min_k) for fa in fas]
+    lit = R.DB(files)
+    h, lens = merged.fetch(), (merged.lens() if min_k < k else np.full(merged.n_unique, k, np.uint8))
+    u = 0
+    for key in range(4 ** key_len):
+        for kmer, data in lit.kmers(key):
+            text = str(kmer)
+            assert len(text) == int(lens[u])
+            got_text = "".join("ACTG"[(int(h["keys"][u]) >> (62 - 2 * i)) & 3] for i in range(len(text)))
+            assert got_text == text
+            a, b = int(h["val_off"][u]), int(h["val_off"][u + 1])
+            assert dict(zip(h["val_a"][a:b].tolist(), h["val_b"][a:b].tolist())) == data
+            u += 1
+    assert u == merged.n_unique
+    # TaxaCounts over the set, and the exact join after restriction to one length
+    t, m, q = km.taxa_counts(km.DB(parts))
+    ot, om, oq = want.taxacounts()
+    assert np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
+    fq = _rand_fastq(rng, 200, 30 if small else 110, alphabet)
+    rdb = km.make_read_db(ctx, fq, k, key_len, min_k=min_k)[0]
+    o_reads = OracleDB(fq, 1, k, key_len, min_k=min_k)
+    L = (min_k + k) // 2
+    rref, rreads = merged.restrict(L), rdb.restrict(L)
+    cref, creads = want.restrict(L), o_reads.restrict(L)
+    _same_db(rref, cref)
+    hit, nh = km.DB([rref]).get_nearest_kmers(rreads)
+    ohit, onh = creads.match(cref)
+    assert nh == onh and np.array_equal(hit, ohit)
+    if min_k < k:
+        with pytest.raises(km.KmersGpuError):                 # the trie takes a key's k-mers file by file: not restated
+            km.match_trie(rdb, merged)
+        # read databases: the same file twice -- every list doubled, ascending
+        twice = km.merge_databases([rdb, rdb])
+        h1, h2 = rdb.fetch(), twice.fetch()
+        assert np.array_equal(h2["keys"], h1["keys"]) and np.array_equal(twice.lens(), rdb.lens())
+        assert np.array_equal(h2["val_off"], 2 * h1["val_off"])
+        assert np.array_equal(h2["val_a"], np.repeat(h1["val_a"], 2)) and np.array_equal(h2["val_b"], np.repeat(h1["val_b"], 2))
+        twice.close()
+    for d in parts + [merged, rdb, rref, rreads]:
+        d.close()
 
 
 def _trie_case(rng, alphabet, n_seq, seq_len, n_reads, read_len, taxa):

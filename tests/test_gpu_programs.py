@@ -783,3 +783,45 @@ def R_bytes(R, fa_b, k, l, mk, tmp_path):
     p = str(tmp_path / "only_good.db")
     R.write_indexed_file(p, R.build_ref_db(fa_b, k, l, min_k=mk), None)
     return open(p, "rb").read()
+
+
+def test_variable_length_file_sets_that_share_keys(tmp_path):
+    """Databases of k-mers of several lengths built from DIFFERENT inputs and handed over as a set (name.1, name.2:
+    Matcher.java:80-89, TaxaCounts.java:65-92) share keys.  DB.kmers merges them in (k-mer, length) order (DB.java:99-109):
+    TaxaCounts over the set and Matcher -k L -K L (restriction, then the exact join) give what the literal restatement
+    gives over the two files, both drivers.  The search over several lengths (Matcher's default) on such a set stays on
+    the Java path -- the reference's trie takes a key's k-mers file by file (DB.java:154-158) -- and says so: status 3."""
+    import subprocess
+    import kmers_amd as km
+    from kmers_amd import synth
+    from kmers_amd.__main__ import main as cli
+    from oracle import slow_ref as R
+    kmg = os.path.join(os.path.dirname(km.__file__), "kmg")
+    run = lambda *a: subprocess.run([kmg] + list(a), capture_output=True, text=True, timeout=300)
+    p = lambda n: str(tmp_path / n)
+    taxa, genomes = synth.random_genomes(91, 4, 3000, first_taxon=40, shared_frac=0.3)
+    fa1 = synth.fasta_bytes(taxa[:3], genomes[:3])
+    fa2 = synth.fasta_bytes(taxa[1:], genomes[1:])                    # two genomes in both files: counts add
+    fq = synth.fastq_bytes(synth.random_reads(92, genomes, 300, 100, 0.01))
+    k, mk, l, L = 14, 10, 3, 12
+    for name, data in (("a.fa", fa1), ("b.fa", fa2), ("reads.fq", fq)):
+        open(p(name), "wb").write(data)
+    common = ["-K", str(k), "-k", str(mk), "-l", str(l)]
+    assert run("Database.MakeDatabase", "-a", "-i", p("a.fa"), "-o", p("set.db.1"), "-Z", *common).returncode == 0
+    assert run("Database.MakeDatabase", "-a", "-i", p("b.fa"), "-o", p("set.db.2"), *common).returncode == 0
+    assert run("Database.MakeDatabase", "-q", "-i", p("reads.fq"), "-o", p("reads.db"), "-r", p("map.gz"), *common).returncode == 0
+    files = [R.build_ref_db(fa1, k, l, min_k=mk), R.build_ref_db(fa2, k, l, min_k=mk)]
+    lit = R.DB(files)
+    want_counts = R.taxa_counts(lit)
+    o_reads, _ = R.build_read_db(fq, k, l, min_k=mk)
+    want_lines = R.match_lines(o_reads, lit, min_k=L, max_k=L)
+    assert len(want_lines) > 50 and len(want_counts) == 4
+    for tag, drv in (("kmg", lambda *a: run(*a).returncode), ("py", lambda *a: cli(list(a)))):
+        assert drv("Utils.TaxaCounts", "-d", p("set.db"), "-o", p("counts.%s.tsv" % tag)) == 0
+        assert open(p("counts.%s.tsv" % tag)).read().splitlines() == want_counts
+        assert drv("Database.Matcher", "-i", p("reads.db"), "-d", p("set.db"), "-o", p("m.%s.txt" % tag), "-Z", "x", "-k", str(L), "-K", str(L)) == 0
+        assert open(p("m.%s.txt" % tag)).read().splitlines() == want_lines
+    r = run("Database.Matcher", "-i", p("reads.db"), "-d", p("set.db"), "-o", p("m.trie.txt"), "-Z", "x")
+    assert r.returncode == 3, r.stderr
+    with pytest.raises(km.KmersGpuError):
+        cli(["Database.Matcher", "-i", p("reads.db"), "-d", p("set.db"), "-o", p("m.trie.py.txt"), "-Z", "x"])
