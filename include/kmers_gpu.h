@@ -184,9 +184,14 @@ int kmg_db_restrict_range(kmg_ctx *ctx, const kmg_db *db, int min_length, int ma
  *   they are added (255 = what a database file holds, CountDataType.java:40; 0 for handles loaded from files).
  *   Out: hit_row[n_unique(search)] = row of the answer in *rows, or -1 (no stored k-mer has t as a prefix: no match
  *   line); *rows = a taxon database whose row r (kmg_db_fetch: val_off / val_a / val_b) is answer r, taxa ascending --
- *   its keys are row numbers, not k-mers.  The database searched is ONE file or a set laid end to end (kmg_db_merge of
- *   files that share no key); the reference inserts the files of a set one after the other, unmerged, which for files
- *   that share a key is not restated: a database merged from such files returns KMG_EUNSUPPORTED here. */
+ *   its keys are row numbers, not k-mers.  The database searched is one file, a set laid end to end (kmg_db_merge of
+ *   files that share no key), or a set merged from files that SHARE keys: the reference inserts the files of a set one
+ *   after the other, unmerged (DB.java:154-158), so a later file's k-mer can split an edge an earlier file's k-mer made,
+ *   both pieces then hold that k-mer's data object (Root.java:79-80) and a k-mer that walks through both is merged into
+ *   it twice.  For such a database the answer is computed over the files kmg_db_merge kept, in their order, by the
+ *   closed form for several files (match.h; tests/test_trie_closed_form.py holds the derivation to the literal trie).
+ *   A SEARCH side merged from files that share keys returns KMG_EUNSUPPORTED: the reference does not merge its search
+ *   stream (Matcher.java:241). */
 int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *db, int min_k, int count_cap, kmg_db **rows,
                    int64_t *hit_row, uint64_t *n_hits);
 /* kmg_db_load : upload a decoded database (KmerFile.java:200-250 output) from host CSR arrays. */
@@ -225,8 +230,9 @@ int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint64_t cap, ui
  *   Variable-length databases (minK < maxK): a set whose files share no key -- the sets MakeDatabase -S / -G write are
  *   cut at key bounds -- is laid end to end in key order; files that share keys are merged in Sequence.compareTo order
  *   (zero-padded value, then length: Kmers/Sequence.java:165-187), length by length.  Such a merged database serves
- *   TaxaCounts, kmg_db_restrict and the exact join behind it; kmg_match_trie refuses it (KMG_EUNSUPPORTED): the reference's
- *   trie takes a key's k-mers file by file, unmerged (DB.java:154-158), which is not restated. */
+ *   TaxaCounts, kmg_db_restrict and the exact join behind it, and -- because the reference's trie takes a key's k-mers
+ *   file by file, unmerged (DB.java:154-158), so that its answers depend on the files and their order -- it keeps copies
+ *   of its (taxon) files, in the order they were given, for kmg_match_trie. */
 int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, kmg_db **out);
 
 /* ---- stage 3: match  (replaces DB.getNearestKmers quick branch, DB.java:76-90,129-137) -------

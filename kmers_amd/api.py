@@ -352,7 +352,7 @@ def match_trie(search, ref, min_length=None, stored=False):
     the taxon database `rows`, -1 = no line.  min_length = the search stream's declared shortest length (default: the
     search database's); stored = the handles were loaded from files (else counts are cut to the 255 a file holds
     before they add up, as in match_lines)."""
-    ref = ref.merged if isinstance(ref, DB) else ref      # (a set whose files share a key: kmg_match_trie says KMG_EUNSUPPORTED)
+    ref = ref.merged if isinstance(ref, DB) else ref      # (a set whose files share keys keeps them: kmg_match_trie walks the files)
     ctx = search.ctx
     hit = np.empty(max(search.n_unique, 1), np.int64)
     nh = C.c_uint64()

@@ -216,7 +216,10 @@ struct kmg_db {
     int k = 0, key_len = 0, rc = 0, kind = 0;
     int min_k = 0;              // shortest k-mer (== k: every k-mer has k bases and lens is null)
     uint8_t *lens = nullptr;    // U: length of every k-mer of a variable-length database, ascending inside equal keys
-    bool shared_key_merge = false;   // merged from variable-length files that shared keys (kmg_match_trie refuses it)
+    // merged from variable-length files that shared keys: the search over several lengths needs the files as they were
+    // (the reference's trie takes a key's k-mers file by file), so the merged database keeps copies of them, in order
+    bool shared_key_merge = false;
+    std::vector<kmg_db *> parts;
     bool tax_bounds = false;    // taxon databases: every taxon lies in [tax_lo, tax_hi] (known from the build's sequence ids)
     int32_t tax_lo = 0, tax_hi = 0;
     u64 U = 0, V = 0;

@@ -579,7 +579,39 @@ static void db_release(kmg_db *db) {
     ctx->pool.release(db->near_log_s);
     ctx->pool.release(db->near_log_ref);
     ctx->pool.release(db->near_log_dist);
+    for (kmg_db *part : db->parts) db_release(part);
     delete db;
+}
+
+// a copy of the arrays the trie search reads (taxon databases), for a merged set that keeps its files (see kmg_db::parts)
+static int clone_for_trie(kmg_ctx *ctx, const kmg_db *src, kmg_db **out) {
+    kmg_db *db = new (std::nothrow) kmg_db();
+    if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+    std::unique_ptr<kmg_db, void (*)(kmg_db *)> guard(db, db_release);
+    db->ctx = ctx; db->k = src->k; db->min_k = src->min_k; db->key_len = src->key_len; db->rc = src->rc; db->kind = src->kind;
+    db->U = src->U; db->V = src->V;
+    const u32 nbuckets = 1u << (2 * src->key_len);
+    struct { void **dst; const void *from; size_t bytes; } arrays[] = {
+        {(void **)&db->keys, src->keys, (src->U + 1) * 8},       {(void **)&db->lens, src->lens, src->lens ? src->U + 8 : 0},
+        {(void **)&db->val_off, src->val_off, (src->U + 2) * 8}, {(void **)&db->val_a, src->val_a, (src->V + 1) * 4},
+        {(void **)&db->val_b, src->val_b, (src->V + 1) * 4},     {(void **)&db->bucket_off, src->bucket_off, ((size_t)nbuckets + 1) * 8}};
+    for (auto &a : arrays) {
+        if (!a.bytes || !a.from) continue;
+        void *p;
+        if (ctx->pool.alloc(&p, a.bytes) != KMG_OK) return fail(ctx, KMG_ENOMEM, "db allocation failed");
+        *a.dst = p;
+    }
+    // (element counts, not the padded sizes above: the sources hold exactly these)
+    if (src->U) KMG_HIP(hipMemcpyAsync(db->keys, src->keys, src->U * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (src->lens && src->U) KMG_HIP(hipMemcpyAsync(db->lens, src->lens, src->U, hipMemcpyDeviceToDevice, ctx->stream));
+    KMG_HIP(hipMemcpyAsync(db->val_off, src->val_off, (src->U + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (src->V) {
+        KMG_HIP(hipMemcpyAsync(db->val_a, src->val_a, src->V * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        KMG_HIP(hipMemcpyAsync(db->val_b, src->val_b, src->V * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    KMG_HIP(hipMemcpyAsync(db->bucket_off, src->bucket_off, ((size_t)nbuckets + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    *out = guard.release();
+    return KMG_OK;
 }
 
 extern "C" void kmg_db_free(kmg_db *db) {
@@ -1434,6 +1466,20 @@ static int merge_var_shared(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
     }
     f->k = d0->k; f->min_k = d0->min_k; f->rc = rc;
     f->shared_key_merge = true;
+    if (d0->kind == KMG_PAYLOAD_TAXON)
+        for (int i = 0; i < n_dbs; i++) {
+            // the files as they are, in their order: what kmg_match_trie searches (a set merged from sets keeps the files)
+            if (dbs[i]->parts.empty()) {
+                kmg_db *part = nullptr;
+                KMG_TRY(clone_for_trie(ctx, dbs[i], &part));
+                f->parts.push_back(part);
+            } else
+                for (const kmg_db *q : dbs[i]->parts) {
+                    kmg_db *part = nullptr;
+                    KMG_TRY(clone_for_trie(ctx, q, &part));
+                    f->parts.push_back(part);
+                }
+        }
     KMG_TRY(ensure_vals(ctx, f));
     KMG_TRY(db_make_buckets(ctx, f));
     KMG_HIP(hipStreamSynchronize(ctx->stream));
@@ -1686,8 +1732,13 @@ extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     // The reference puts a key's k-mers into its trie FILE BY FILE, unmerged (DB.java:154-158): with files that share a key
     // the insertion is no longer in the trie's own preorder, nodes are split by later files' k-mers and a data object can
     // receive one k-mer more than once -- the closed form below does not hold for that.  Not restated: the Java path.
-    if (ref->shared_key_merge || search->shared_key_merge)
-        return fail(ctx, KMG_EUNSUPPORTED, "the search over several k-mer lengths in a set of files that share a key: not on the GPU path");
+    // -- the database side: match.h's second closed form over the files the merged database kept (trie_files_kernel).
+    // The SEARCH side is a stream the reference does not merge at all (mergeSortedStreams without a reduce,
+    // Matcher.java:241): search files that share k-mers are not restated.
+    if (search->shared_key_merge)
+        return fail(ctx, KMG_EUNSUPPORTED, "search files of several k-mer lengths that share a key: not on the GPU path");
+    const bool by_files = ref->shared_key_merge;
+    if (by_files && ref->parts.empty()) return fail(ctx, KMG_ESTATE, "merged database without its files");
     KMG_HIP(hipSetDevice(ctx->device));
     KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(ref)));
     const u64 ns = search->U;
@@ -1703,7 +1754,26 @@ extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     KMG_ALLOC(row, (ns + 2) * 8); KMG_ALLOC(dst, (ns + 2) * 8); KMG_ALLOC(hit, (ns + 1) * 8);
     KMG_ALLOC(agg, (size_t)(div_up_u64(ns, SCAN_TILE) + 1) * 8);
     u64 nrows = 0, nrec = 0;
-    if (ns) {
+    PoolBuf d_files(ctx), nvals64(ctx);
+    const int nf = (int)ref->parts.size();
+    if (ns && by_files) {
+        std::vector<TrieFile> h_files;
+        for (const kmg_db *q : ref->parts)
+            h_files.push_back(TrieFile{q->keys, q->lens, q->bucket_off, q->val_off, q->val_a, q->val_b, q->k, 0});
+        KMG_ALLOC(d_files, h_files.size() * sizeof(TrieFile));
+        KMG_ALLOC(nvals64, (ns + 1) * 8);
+        KMG_HIP(hipMemcpyAsync(d_files.p, h_files.data(), h_files.size() * sizeof(TrieFile), hipMemcpyHostToDevice, ctx->stream));
+        KMG_HIP(hipStreamSynchronize(ctx->stream));             // (h_files is pageable and on this frame)
+        hipLaunchKernelGGL((trie_files_kernel<false>), dim3(div_up_u64(ns, 256)), dim3(256), 0, ctx->stream, search->keys, search->lens,
+                           search->k, ns, d_files.as<TrieFile>(), nf, ref->key_len, min_k, found.as<u32>(), nvals64.as<u64>(),
+                           (const u64 *)nullptr, (const u64 *)nullptr, count_cap, (u64 *)nullptr, (u64 *)nullptr, (long long *)nullptr);
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, found.as<u32>(), row.as<u64>(), ns, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
+                                                    KP_SCAN)));
+        KMG_TRY((device_scan<u64, u64, OpSum, true>(ctx, nvals64.as<u64>(), dst.as<u64>(), ns, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
+                                                    KP_SCAN)));
+        KMG_HIP(read_back(ctx, &nrows, row.as<u64>() + ns, 8));
+        KMG_HIP(read_back(ctx, &nrec, dst.as<u64>() + ns, 8));
+    } else if (ns) {
         hipLaunchKernelGGL(trie_find_kernel, dim3(div_up_u64(ns, 256)), dim3(256), 0, ctx->stream, search->keys, search->lens, search->k,
                            ns, ref->keys, ref->lens, ref->k, ref->bucket_off, ref->val_off, ref->key_len, min_k,
                            first.as<long long>(), found.as<u32>(), nvals.as<u32>());
@@ -1718,7 +1788,11 @@ extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     const u32 n = (u32)nrec;
     KMG_ALLOC(k0, ((size_t)n + 1) * 8); KMG_ALLOC(v0, ((size_t)n + 1) * 8);
     KMG_ALLOC(k1, ((size_t)n + 1) * 8); KMG_ALLOC(v1, ((size_t)n + 1) * 8);
-    if (ns)
+    if (ns && by_files)
+        hipLaunchKernelGGL((trie_files_kernel<true>), dim3(div_up_u64(ns, 256)), dim3(256), 0, ctx->stream, search->keys, search->lens,
+                           search->k, ns, d_files.as<TrieFile>(), nf, ref->key_len, min_k, (u32 *)nullptr, (u64 *)nullptr,
+                           row.as<u64>(), dst.as<u64>(), count_cap, k0.as<u64>(), v0.as<u64>(), hit.as<long long>());
+    else if (ns)
         hipLaunchKernelGGL(trie_expand_kernel, dim3(div_up_u64(ns, 256)), dim3(256), 0, ctx->stream, first.as<long long>(), nvals.as<u32>(),
                            row.as<u64>(), dst.as<u64>(), ns, ref->val_off, ref->val_a, ref->val_b, count_cap, k0.as<u64>(), v0.as<u64>(),
                            hit.as<long long>());

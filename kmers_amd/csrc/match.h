@@ -257,6 +257,165 @@ __global__ void trie_expand_kernel(const long long *__restrict__ first, const u3
     }
 }
 
+// ---- the same search over a SET of files that share keys ---------------------------------------------------------------
+// The reference puts a key's k-mers into its trie file by file, each file in ascending order (DB.java:154-158).  With
+// several files the insertion is no longer in the trie's preorder: a later file's k-mer can split an edge that an earlier
+// file's k-mer made, after which BOTH pieces hold that k-mer's data object (n1.data = n.data, Root.java:79-80), and a
+// k-mer that then walks through both pieces is merged into the object twice.  In closed form (derived in DESIGN 6b, held
+// against the literal trie on the CPU by tests/test_trie_closed_form.py): the answer for t is the object of x = the
+// earliest inserted stored k-mer that has t as a prefix -- the first file that holds one, its smallest there --, which
+// ends as
+//     D_x + sum over the boundary depths e in [max(L_x + 1, shortest), |x|] of
+//           sum of D_z over the k-mers z inserted at or after the boundary's maker that share x's first e bases,
+// L_x = the longest prefix x shares with anything inserted before it.  The boundary depths are |x| (made by x) and every
+// lcp(x, y) < |x| of a k-mer y inserted after x (made by the first such y).  Per file the k-mers that share x's first e
+// bases are one range of the sorted array, nested for growing e; a maker at depth e is an entry of the range of e that is
+// not in the range of e + 1.  One thread per search k-mer walks files x depths with binary searches: a corner of the
+// search (several -d files built from different inputs), not a hot path.
+struct TrieFile {
+    const u64 *keys;
+    const uint8_t *lens;
+    const u64 *bucket;
+    const u64 *val_off;
+    const int32_t *val_a, *val_b;
+    int len_all, pad;
+};
+
+__device__ __forceinline__ int tf_len(const TrieFile &f, u64 i) { return f.lens ? (int)f.lens[i] : f.len_all; }
+// leading bases two zero-padded k-mers of la / lb bases have in common
+__device__ __forceinline__ int tf_lcp(u64 a, int la, u64 b, int lb) {
+    const u64 x = a ^ b;
+    const int c = x ? (int)(__clzll((long long)x) >> 1) : 32;
+    return min(c, min(la, lb));
+}
+// first entry of [lo, hi) that is >= (v, len) in (value, length) order
+__device__ __forceinline__ u64 tf_lower(const TrieFile &f, u64 lo, u64 hi, u64 v, int len) {
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        const u64 km = f.keys[mid];
+        if (km < v || (km == v && tf_len(f, mid) < len)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// the entries of [lo, hi) that have the first e bases of x: -> [a, b)
+__device__ __forceinline__ void tf_prefix_range(const TrieFile &f, u64 lo, u64 hi, u64 x, int e, u64 &a, u64 &b) {
+    const u64 mask = e >= 32 ? ~0ull : ~(~0ull >> (2 * e));
+    const u64 v = x & mask, top = v | ~mask;
+    a = tf_lower(f, lo, hi, v, e);
+    u64 l = a, h = hi;
+    while (l < h) {
+        const u64 mid = (l + h) >> 1;
+        if (f.keys[mid] <= top) l = mid + 1; else h = mid;
+    }
+    b = l;
+}
+
+template <bool EMIT>
+__device__ __forceinline__ void tf_take(const TrieFile &f, u64 a, u64 b, u64 &count, u64 key, int cap, u64 *__restrict__ out_keys,
+                                        u64 *__restrict__ out_vals, u64 &o) {
+    if (a >= b) return;
+    const u64 v0 = f.val_off[a], v1 = f.val_off[b];
+    count += v1 - v0;
+    if (EMIT) {
+        for (u64 v = v0; v < v1; v++, o++) {
+            int32_t c = f.val_b[v];
+            if (cap > 0 && c > cap) c = cap;
+            out_keys[o] = key;
+            out_vals[o] = ((u64)((u32)f.val_a[v] ^ 0x80000000u) << 32) | (u32)c;
+        }
+    }
+}
+
+// EMIT = false: found[i], nvals[i] (values the answer takes in, with multiplicity).  EMIT = true: the values as (row, taxon,
+// count) records at dst[i], hit[i] = row[i] or -1.
+template <bool EMIT>
+__global__ void trie_files_kernel(const u64 *__restrict__ skeys, const uint8_t *__restrict__ slens, int s_len_all, u64 ns,
+                                  const TrieFile *__restrict__ files, int nf, int key_len, int shortest, u32 *__restrict__ found,
+                                  u64 *__restrict__ nvals, const u64 *__restrict__ row, const u64 *__restrict__ dst, int cap,
+                                  u64 *__restrict__ out_keys, u64 *__restrict__ out_vals, long long *__restrict__ hit) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const u64 t = skeys[i];
+    const int T = slens ? (int)slens[i] : s_len_all;
+    const u64 b = t >> (64 - 2 * key_len);
+    // x: the first file that holds a k-mer with prefix t, its smallest there
+    int f0 = -1;
+    u64 l0 = 0;
+    for (int f = 0; f < nf && f0 < 0; f++) {
+        const TrieFile &F = files[f];
+        const u64 lo = F.bucket[b], hi = F.bucket[b + 1];
+        const u64 l = tf_lower(F, lo, hi, t, T);
+        if (l < hi && tf_len(F, l) >= T && ((F.keys[l] ^ t) >> (64 - 2 * T)) == 0) { f0 = f; l0 = l; }
+    }
+    if (f0 < 0) {
+        if (EMIT) hit[i] = -1;
+        else { found[i] = 0; nvals[i] = 0; }
+        return;
+    }
+    const u64 x = files[f0].keys[l0];
+    const int X = tf_len(files[f0], l0);
+    // L: the longest prefix x shares with anything inserted before it -- its predecessor in its own file, its neighbours in
+    // the files before
+    int L = 0;
+    {
+        const TrieFile &F = files[f0];
+        if (l0 > F.bucket[b]) L = tf_lcp(x, X, F.keys[l0 - 1], tf_len(F, l0 - 1));
+        for (int f = 0; f < f0; f++) {
+            const TrieFile &G = files[f];
+            const u64 lo = G.bucket[b], hi = G.bucket[b + 1];
+            const u64 p = tf_lower(G, lo, hi, x, X);
+            if (p > lo) L = max(L, tf_lcp(x, X, G.keys[p - 1], tf_len(G, p - 1)));
+            if (p < hi) L = max(L, tf_lcp(x, X, G.keys[p], tf_len(G, p)));
+        }
+    }
+    const int m = max(shortest, L + 1);
+    u64 count = 0, o = EMIT ? dst[i] : 0;
+    const u64 key = EMIT ? (row[i] << 32) : 0;
+    // D_x itself
+    tf_take<EMIT>(files[f0], l0, l0 + 1, count, key, cap, out_keys, out_vals, o);
+    u64 made = 1ull << X;                      // bit e: some k-mer at or after x has made a boundary at depth e
+    {
+        // x's own file: the k-mers behind x.  Those that share x's first e bases end at b_e, nested for shrinking e; the
+        // ones between b_(e+1) and b_e make (or find) the boundary at e and count once for it.
+        const TrieFile &F = files[f0];
+        const u64 hi = F.bucket[b + 1];
+        u64 prev = l0 + 1;
+        for (int e = X; e >= m; e--) {
+            u64 a_, b_;
+            tf_prefix_range(F, prev, hi, x, e, a_, b_);          // (everything in [l0 + 1, prev) shares more than e bases)
+            if (b_ > prev) {
+                tf_take<EMIT>(F, prev, b_, count, key, cap, out_keys, out_vals, o);
+                made |= 1ull << e;
+            }
+            prev = max(prev, b_);
+        }
+    }
+    for (int f = f0 + 1; f < nf; f++) {
+        const TrieFile &F = files[f];
+        u64 ra, rb;
+        tf_prefix_range(F, F.bucket[b], F.bucket[b + 1], x, m, ra, rb);
+        for (int e = m; e <= X && ra < rb; e++) {
+            if (e == X) {                                            // x as a prefix (or x again): counts for x's own boundary
+                tf_take<EMIT>(F, ra, rb, count, key, cap, out_keys, out_vals, o);
+                break;
+            }
+            u64 na, nb;
+            tf_prefix_range(F, ra, rb, x, e + 1, na, nb);            // the entries that share more than e bases
+            if (made & (1ull << e)) tf_take<EMIT>(F, ra, rb, count, key, cap, out_keys, out_vals, o);
+            else if (ra < na) {                                      // the range's first entry makes the boundary: all of it counts
+                tf_take<EMIT>(F, ra, rb, count, key, cap, out_keys, out_vals, o);
+                made |= 1ull << e;
+            } else if (nb < rb) {                                    // made behind the deeper entries: only the tail counts
+                tf_take<EMIT>(F, nb, rb, count, key, cap, out_keys, out_vals, o);
+                made |= 1ull << e;
+            }
+            ra = na; rb = nb;
+        }
+    }
+    if (EMIT) hit[i] = (long long)row[i];
+    else { found[i] = 1; nvals[i] = count; }
+}
+
 // ---- TaxaCounts ----------------------------------------------------------------------------------------
 // The distinct taxa of a database come from a presence bitmap over [min taxon, max taxon] (at most 2^32 bits =
 // 512 MB; BASELINE's taxon ids span a few thousand): one pass marks, a popcount scan ranks the words, and the rank

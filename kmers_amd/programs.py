@@ -305,8 +305,8 @@ def matcher(ctx, search_path, db_path, output_path, plain=False, limit=None, max
         if any((s_.min_length, s_.max_length) != (min_k, max_k) for s_ in searches):
             searches = [s_.restrict(min_k, max_k) for s_ in searches]       # KmerFile.allRestrictedKmers (Matcher.java:241)
         # sets (name.1 .. name.N): files that share no key -- what -S / -G write -- are laid end to end (kmg_db_merge);
-        # the reference's trie takes one key's k-mers file by file, so files sharing a key stay on the Java path
-        # (kmg_match_trie refuses the merged handle: KMG_EUNSUPPORTED, exit status 3)
+        # the reference's trie takes one key's k-mers file by file: for files that share keys the merged handle keeps them
+        # and kmg_match_trie answers from the files in their order (search files that share keys: status 3)
         search = searches[0] if len(searches) == 1 else merge_databases(searches)
         if not db.merged.rc:
             raise ValueError("InconsistentDataException: Files contains different kmer parameters (min/max length, key length or reverse complement included")

@@ -1442,11 +1442,15 @@ def test_variable_length_sets_cut_at_key_bounds_merge(ctx, min_k, k, key_len, se
             ot, om, oq = OracleDB(fa, 0, k, key_len, min_k=min_k).taxacounts()
             assert np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
             rows.close()
-            # two files holding the same keys merge as well (test_variable_length_sets_that_share_keys_merge); what such
-            # a set does not take is the search over several lengths: the reference's trie takes a key's k-mers file by file
+            # two files holding the same keys merge as well (test_variable_length_sets_that_share_keys_merge), and the
+            # search over several lengths takes the files one after the other as the reference's trie does: every k-mer of
+            # the second file walks the pieces the first file's k-mers were split into
             twice = km.merge_databases([ref_whole, ref_whole])
-            with pytest.raises(km.KmersGpuError):
-                km.match_trie(whole, twice)
+            rows2, hit2 = km.match_trie(whole, twice)
+            lit = R.build_ref_db(fa, k, key_len, min_k=min_k)
+            assert km.match_lines(whole, rows2, hit2, ref_stored=True) == \
+                R.near_match_lines(R.build_read_db(fq, k, key_len, min_k=min_k)[0], R.DB([lit, lit]), 0, False)
+            rows2.close()
             twice.close()
             whole.close()
             for d in parts:
@@ -1507,10 +1511,21 @@ def test_variable_length_sets_that_share_keys_merge(ctx, min_k, k, key_len, seed
     ohit, onh = creads.match(cref)
     assert nh == onh and np.array_equal(hit, ohit)
     if min_k < k:
-        with pytest.raises(km.KmersGpuError):                 # the trie takes a key's k-mers file by file: not restated
-            km.match_trie(rdb, merged)
+        # the search over several lengths: the reference's trie takes a key's k-mers file by file (DB.java:154-158) --
+        # kmg_match_trie over the files the merged database kept, against the literal trie over the three files, in
+        # both orders of the files (the answers depend on it)
+        reads_lit = R.build_read_db(fq, k, key_len, min_k=min_k)[0]
+        for order in ([0, 1, 2], [2, 0, 1]):
+            mset = km.merge_databases([parts[i] for i in order])
+            rows, hit = km.match_trie(rdb, mset)
+            got = km.match_lines(rdb, rows, hit, ref_stored=True)
+            assert got == R.near_match_lines(reads_lit, R.DB([files[i] for i in order]), 0, False)
+            rows.close()
+            mset.close()
         # read databases: the same file twice -- every list doubled, ascending
         twice = km.merge_databases([rdb, rdb])
+        with pytest.raises(km.KmersGpuError):                 # search files that share k-mers are not merged by the reference
+            km.match_trie(twice, merged)
         h1, h2 = rdb.fetch(), twice.fetch()
         assert np.array_equal(h2["keys"], h1["keys"]) and np.array_equal(twice.lens(), rdb.lens())
         assert np.array_equal(h2["val_off"], 2 * h1["val_off"])
@@ -1518,6 +1533,53 @@ def test_variable_length_sets_that_share_keys_merge(ctx, min_k, k, key_len, seed
         twice.close()
     for d in parts + [merged, rdb, rref, rreads]:
         d.close()
+
+
+def test_trie_search_over_file_sets_matches_literal_trie(ctx):
+    """kmg_match_trie over sets of two to four files that share keys, small alphabets (long shared prefixes: edges split by
+    later files' k-mers, objects that take one k-mer in more than once), the search side sometimes narrower than the
+    database: every line against the literal trie filled file by file (oracle/slow_ref.py Root, DB.java:154-158).  The
+    derivation itself is held on the CPU by tests/test_trie_closed_form.py (1500 seeds in a one-off sweep)."""
+    import random
+    import kmers_amd as km
+    from oracle import slow_ref as R
+    lines = differ = 0
+    for seed in range(int(os.environ.get("KMERS_TRIE_SET_SEEDS", "40"))):
+        rng = random.Random(7000 + seed)
+        alpha = rng.choice(["ACGT", "AC", "AAAC", "ACGTN", "AG"])
+        max_k = rng.randint(3, 12)
+        min_k = rng.randint(1, max_k - 1)
+        key_len = rng.randint(1, min(min_k, 3))
+        pool = ["".join(rng.choice(alpha) for _ in range(rng.randint(0, 70))) for _ in range(rng.randint(2, 8))]
+        fas = []
+        for _ in range(rng.randint(2, 4)):
+            seqs = [rng.choice(pool) if rng.random() < 0.6 else "".join(rng.choice(alpha) for _ in range(rng.randint(0, 70)))
+                    for _ in range(rng.randint(1, 6))]
+            fas.append("".join(">%d\n%s\n" % (rng.randint(1, 5), q) for q in seqs).encode())
+        fq = "".join("@r%d\n%s\n+\n%s\n" % (i, q, "I" * len(q)) for i, q in
+                     enumerate((rng.choice(pool) if rng.random() < 0.5 else "".join(rng.choice(alpha) for _ in range(rng.randint(0, 50))))
+                               for _ in range(rng.randint(1, 10)))).encode()
+        s_min = rng.randint(min_k, max_k)
+        s_max = rng.randint(s_min, max_k)
+        if rng.random() < 0.5:
+            s_min, s_max = min_k, max_k
+        if key_len > s_min or s_min == s_max:
+            continue
+        parts = [km.make_reference_db(ctx, fa, max_k, key_len, min_k=min_k) for fa in fas]
+        if sum(d.n_unique for d in parts) == 0:
+            continue
+        rdb = km.make_read_db(ctx, fq, s_max, key_len, min_k=s_min)[0]
+        mset = km.merge_databases(parts)
+        rows, hit = km.match_trie(rdb, mset)
+        got = km.match_lines(rdb, rows, hit, ref_stored=True)
+        files = [R.build_ref_db(fa, max_k, key_len, min_k=min_k) for fa in fas]
+        want = R.near_match_lines(R.build_read_db(fq, s_max, key_len, min_k=s_min)[0], R.DB(files), 0, False)
+        assert got == want, (seed, alpha, min_k, max_k, s_min, s_max, key_len, len(fas))
+        lines += len(want)
+        differ += want != R.near_match_lines(R.build_read_db(fq, s_max, key_len, min_k=s_min)[0], R.DB(files[::-1]), 0, False)
+        for d in parts + [rdb, mset, rows]:
+            d.close()
+    assert lines > 300 and differ > 3          # (the cases bite: the files' order changes the answers)
 
 
 def _trie_case(rng, alphabet, n_seq, seq_len, n_reads, read_len, taxa):

@@ -789,8 +789,9 @@ def test_variable_length_file_sets_that_share_keys(tmp_path):
     """Databases of k-mers of several lengths built from DIFFERENT inputs and handed over as a set (name.1, name.2:
     Matcher.java:80-89, TaxaCounts.java:65-92) share keys.  DB.kmers merges them in (k-mer, length) order (DB.java:99-109):
     TaxaCounts over the set and Matcher -k L -K L (restriction, then the exact join) give what the literal restatement
-    gives over the two files, both drivers.  The search over several lengths (Matcher's default) on such a set stays on
-    the Java path -- the reference's trie takes a key's k-mers file by file (DB.java:154-158) -- and says so: status 3."""
+    gives over the two files, both drivers.  So does the search over several lengths (Matcher's default, with and without
+    differences): the reference's trie takes a key's k-mers file by file (DB.java:154-158), kmg_match_trie walks the files
+    the merged database kept (match.h: the closed form for several files)."""
     import subprocess
     import kmers_amd as km
     from kmers_amd import synth
@@ -821,7 +822,12 @@ def test_variable_length_file_sets_that_share_keys(tmp_path):
         assert open(p("counts.%s.tsv" % tag)).read().splitlines() == want_counts
         assert drv("Database.Matcher", "-i", p("reads.db"), "-d", p("set.db"), "-o", p("m.%s.txt" % tag), "-Z", "x", "-k", str(L), "-K", str(L)) == 0
         assert open(p("m.%s.txt" % tag)).read().splitlines() == want_lines
-    r = run("Database.Matcher", "-i", p("reads.db"), "-d", p("set.db"), "-o", p("m.trie.txt"), "-Z", "x")
-    assert r.returncode == 3, r.stderr
-    with pytest.raises(km.KmersGpuError):
-        cli(["Database.Matcher", "-i", p("reads.db"), "-d", p("set.db"), "-o", p("m.trie.py.txt"), "-Z", "x"])
+    # Matcher's default on such a set: the search over all lengths, the trie filled file by file (DB.java:154-158)
+    want_trie = R.near_match_lines(o_reads, lit, 0, False)
+    want_near = R.near_match_lines(o_reads, lit, 1, False)
+    assert len(want_trie) > 50 and want_trie != R.near_match_lines(o_reads, R.DB(files[::-1]), 0, False)     # (the order of the files matters)
+    for tag, drv in (("kmg", lambda *a: run(*a).returncode), ("py", lambda *a: cli(list(a)))):
+        assert drv("Database.Matcher", "-i", p("reads.db"), "-d", p("set.db"), "-o", p("t.%s.txt" % tag), "-Z", "x") == 0
+        assert open(p("t.%s.txt" % tag)).read().splitlines() == want_trie
+        assert drv("Database.Matcher", "-i", p("reads.db"), "-d", p("set.db"), "-o", p("n.%s.txt" % tag), "-Z", "x", "-n", "1") == 0
+        assert open(p("n.%s.txt" % tag)).read().splitlines() == want_near
