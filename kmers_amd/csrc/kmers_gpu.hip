@@ -1731,10 +1731,10 @@ extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
     // The reference puts a key's k-mers into its trie FILE BY FILE, unmerged (DB.java:154-158): with files that share a key
     // the insertion is no longer in the trie's own preorder, nodes are split by later files' k-mers and a data object can
-    // receive one k-mer more than once -- the closed form below does not hold for that.  Not restated: the Java path.
-    // -- the database side: match.h's second closed form over the files the merged database kept (trie_files_kernel).
-    // The SEARCH side is a stream the reference does not merge at all (mergeSortedStreams without a reduce,
-    // Matcher.java:241): search files that share k-mers are not restated.
+    // receive one k-mer more than once -- the single-file closed form does not hold for that; the database side then goes
+    // through match.h's second closed form over the files the merged database kept (trie_files_kernel).
+    // The SEARCH side is a stream the reference does not fold at all (mergeSortedStreams without a reduce,
+    // Matcher.java:241: a k-mer two files hold is asked twice), which a merged handle cannot stand for: refused.
     if (search->shared_key_merge)
         return fail(ctx, KMG_EUNSUPPORTED, "search files of several k-mer lengths that share a key: not on the GPU path");
     const bool by_files = ref->shared_key_merge;
