@@ -119,7 +119,7 @@ struct ExtractArgs {
     u32 pos_mask;
 };
 
-// Steps 1 and 2 of a tile (shared by extract_kernel and the short-k-mer kernels of extract_short.h): the tile's bytes
+// Steps 1 and 2 of a tile for the short-k-mer kernels of extract_short.h (the full windows: extract_part.h): the tile's bytes
 // packed into LDS (pk: 2 bits per base, inv: "not ACGTacgt" bits, both with EX_EXT positions past the tile), the
 // "some sequence starts here" bitmap stb, and seqrel[p] = number of sequences beyond the tile's first one that start
 // at or before position p.  -> index of the tile's first sequence.  Ends behind a __syncthreads().
@@ -201,125 +201,6 @@ __device__ __forceinline__ u32 ex_load_tile(const ExtractArgs &a, const u32 tile
     __syncthreads();
 
     return s_lo;
-}
-
-template <bool WRITE>
-__global__ __launch_bounds__(EX_BLOCK) void extract_kernel(ExtractArgs a) {
-    __shared__ u32 pk[EX_TILE / 16 + 4];          // 2-bit packed bases, base 16w at bits 31:30 of word w
-    __shared__ u32 inv[EX_TILE / 32 + 2];         // 1 = base is not one of ACGTacgt (or past the end)
-    __shared__ u32 stb[EX_TILE / 32 + 2];         // 1 = some sequence starts at this position
-    __shared__ u32 seqrel[EX_TILE + EX_EXT];      // #sequences (beyond the tile's first) starting at or before p
-    __shared__ u32 wave_cnt[EX_ROUNDS][EX_BLOCK / 64];
-    __shared__ u32 scan_smem[4];
-    __shared__ u32 blk_total;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 t0 = (u64)blockIdx.x * EX_TILE;
-    const int k = a.k;
-
-    // ---- 1 + 2. load + pack, sequence starts -> per-position sequence index -------------------------
-    const u32 s_lo = ex_load_tile(a, blockIdx.x, pk, inv, stb, seqrel, scan_smem);
-
-    // ---- 3. windows -----------------------------------------------------------------------------------
-    const u64 kmask = k == 32 ? ~0ull : ~(~0ull >> (2 * k));
-    u64 fkey[EX_ROUNDS];
-    u32 vmask = 0, rmask = 0;   // bit j: window of round j is a k-mer / also emits its RC
-#pragma unroll
-    for (int j = 0; j < EX_ROUNDS; j++) {
-        const u32 p = j * EX_BLOCK + tid;
-        const u32 w = p >> 4, r = p & 15;
-        u64 hi = ((u64)pk[w] << 32) | pk[w + 1];
-        u64 win = (hi << (2 * r)) | ((u64)pk[w + 2] >> (32 - 2 * r));
-        u64 key = win & kmask;
-        const u32 w2 = p >> 5, r2 = p & 31;
-        u64 bad = (((u64)inv[w2] << 32) | inv[w2 + 1]) << r2;
-        u64 st = (((u64)stb[w2] << 32) | stb[w2 + 1]) << r2;
-        bool ok = (bad >> (64 - k)) == 0;
-        if (k > 1) ok = ok && (((st << 1) >> (65 - k)) == 0);
-        ok = ok && (t0 + p + (u64)k <= a.nbases);
-        // reads are numbered by the extractor's mapper, i.e. before the -D / -R filters see the k-mer
-        if (!WRITE && ok && a.has_kmer) a.has_kmer[s_lo + seqrel[p]] = 1;
-        if (ok && a.runofsame >= 0) ok = runofsame_keep(key, k, a.runofsame);
-        if (ok && a.dust >= 0) ok = dust_keep(key, k, a.dust);
-        fkey[j] = key;
-        bool emit_rc = false;
-        if (a.rc && ok) {
-            // Kmer.isOwnRC (Kmer.java:210-225) is a palindrome test on even lengths
-            u64 rev = revpairs64(key >> (64 - 2 * k));
-            emit_rc = !(((k & 1) == 0) && rev == key);
-            if (a.ranged && emit_rc) {
-                const u32 rb = (u32)((rev ^ (0xAAAAAAAAAAAAAAAAull & kmask)) >> a.range_shift);
-                emit_rc = rb >= a.range_lo && rb < a.range_hi;
-            }
-        }
-        if (a.ranged && ok) {
-            const u32 fb = (u32)(key >> a.range_shift);
-            ok = fb >= a.range_lo && fb < a.range_hi;
-        }
-        vmask |= (u32)ok << j;
-        rmask |= (u32)emit_rc << j;
-        u64 bal_v = __ballot(ok), bal_r = __ballot(emit_rc);
-        if (lane == 0) wave_cnt[j][wave] = __popcll(bal_v) + __popcll(bal_r);
-    }
-    __syncthreads();
-
-    // ---- 4. counts / offsets --------------------------------------------------------------------------
-    if (tid < 64) {
-        // exclusive scan of the 64 (round, wave) counts in window order
-        u32 v = wave_cnt[tid >> 2][tid & 3];
-        u32 inc = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            u32 o = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += o;
-        }
-        wave_cnt[tid >> 2][tid & 3] = inc - v;
-        if (tid == 63) blk_total = inc;
-    }
-    __syncthreads();
-    if (!WRITE) {
-        // valid forward windows of this tile (summed into ST_NWIN by sum_u32_kernel: one atomic per
-        // 2048 tiles instead of one per wave, which serialised on a single address)
-        u32 nv = __popc(vmask);
-        u32 tot;
-        block_scan_inclusive(nv, OpSum(), scan_smem, &tot);
-        if (tid == 0) {
-            a.tile_count[blockIdx.x] = blk_total;
-            a.tile_fwd[blockIdx.x] = tot;
-        }
-        return;
-    }
-
-    const u64 out_base = a.state[ST_NREC] + a.tile_off[blockIdx.x];
-    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-    for (int j = 0; j < EX_ROUNDS; j++) {
-        const bool ok = (vmask >> j) & 1, erc = (rmask >> j) & 1;
-        u64 bal_v = __ballot(ok), bal_r = __ballot(erc);
-        if (ok || erc) {
-        // (the RC record can be there without the forward one: key-range builds keep each by its own bucket)
-        const u32 p = j * EX_BLOCK + tid;
-        const u32 s = s_lo + seqrel[p];
-        const u64 slot = out_base + wave_cnt[j][wave] + __popcll(bal_v & lt) + __popcll(bal_r & lt);
-        const u64 rslot = slot + (ok ? 1 : 0);
-        const u64 key = fkey[j];
-        if (ok) a.out_keys[slot] = key;
-        if (erc) a.out_keys[rslot] = revpairs64(key >> (64 - 2 * k)) ^ (0xAAAAAAAAAAAAAAAAull & kmask);
-        if (a.kind == KMG_PAYLOAD_TAXON) {
-            u32 v = (u32)a.seq_id[s];
-            u32 *ov = reinterpret_cast<u32 *>(a.out_vals);
-            if (ok) ov[slot] = v;
-            if (erc) ov[rslot] = v;
-        } else {
-            // ReadPos(read, (short)(pos - maxK)): offset of the window start within its sequence
-            u64 pos16 = (u64)((t0 + p - a.seq_off[s]) & 0xFFFFu);
-            u64 v = ((u64)(u32)a.read_index[s] << 16) | pos16;
-            u64 *ov = reinterpret_cast<u64 *>(a.out_vals);
-            if (ok) ov[slot] = v;
-            if (erc) ov[rslot] = v;
-        }
-        }
-    }
 }
 
 // After a write pass: advance the running record count by this batch's total (tile_off[ntiles]).

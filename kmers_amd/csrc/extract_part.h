@@ -9,7 +9,7 @@
 //                staged through LDS in digit order, runs stored contiguously at the scanned offsets.
 // Forward and RC records of a tile form two table columns (2t, 2t+1), so a sub-pass never stages more than
 // EX_TILE records; both are emitted in window order, which keeps the partition stable.
-// Same window logic as extract_kernel (extract.h); a wave owns 64 * windows-per-thread consecutive positions.
+// A wave of the write pass owns 64 * windows-per-thread consecutive positions.
 #pragma once
 #include "common.h"
 #include "extract.h"
@@ -85,10 +85,37 @@ __device__ __forceinline__ u32 ep_seq_rel(const ExtractArgs &a, u32 s_lo, u32 s_
     return (u32)(lo - s_lo);
 }
 
+// Four bases in the bytes of q (first base lowest) -> their 2-bit codes, first base highest (8 bits), and their "not one
+// of ACGTacgt" bits the same way round (4 bits).  A C G T (either case) = 0x41 + {0, 2, 6, 19}: bits 2:1 of the letter
+// are the code (A0 C1 T2 G3), and a byte is a base iff, without its case bit, it IS the letter of its code -- one byte
+// permute looks the four letters up.  Bytes past the end of the input are 0: code 0, not a base.
+__device__ __forceinline__ void ep_pack4(u32 q, u32 &code8, u32 &bad4) {
+    const u32 c = (q >> 1) & 0x03030303u;
+    const u32 diff = __builtin_amdgcn_perm(0u, 0x47544341u, c) ^ (q & 0xDFDFDFDFu);
+    const u32 nz = ((((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) >> 7) & 0x01010101u;   // 1 per byte that differs
+    // gather towards the top byte; the copies left further down collide with nothing that reaches it
+    u32 u = c | (c << 10);
+    u |= u << 20;
+    code8 = u >> 24;
+    u32 b = nz | (nz << 9);
+    b |= b << 18;
+    bad4 = b >> 24;
+}
+
+// bit `bit` of each of the 8 bytes of v -> 8 bits, byte j's at bit j
+__device__ __forceinline__ u32 ep_bit_column(uint2 v, u32 bit) {
+    u32 x = (v.x >> bit) & 0x01010101u, y = (v.y >> bit) & 0x01010101u;
+    x |= x >> 7; x |= x >> 14;
+    y |= y >> 7; y |= y >> 14;
+    return (x & 0xFu) | ((y & 0xFu) << 4);
+}
+
 // ---- count pass: everything up to "which windows are records", the digit histograms, and the tile image -------
 // RC: reverse-complement records asked for.  FILT: -D / -R filters or a key range are on (else none of that code is
 // even compiled in: the common path is branch-free per window).
-template <bool RC, bool FILT>
+// HIST: the partition digit's histograms are wanted (the fused first batch of a build).  Later batches append their
+// records in window order (extract_img_write_kernel): they take everything else -- record bits, tile totals, image.
+template <bool RC, bool FILT, bool HIST = true>
 __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArgs pa) {
     const ExtractArgs &a = pa.e;
     __shared__ u32 pk[EX_TILE / 16 + 4];
@@ -98,6 +125,7 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
     __shared__ u32 hist[2][RS_DIGITS];                 // forward / RC digit histograms
     __shared__ u32 s_tot[2];                           // forward / RC records of the tile
     __shared__ u32 s_dup;                              // some position starts more than one sequence (empty sequences)
+    __shared__ __align__(8) uint8_t tbits[2][EP_BLOCK];   // record bits on their way from the lanes that found them to the image
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order (see rs_scatter_kernel): neighbouring tiles' runs are adjacent in the output
@@ -107,45 +135,44 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
     const u64 t0 = (u64)tile * EX_TILE;
     const int k = a.k;
     const u32 col0 = tile * (a.rc ? 2u : 1u);
-    // Global loads that later phases depend on are issued up front, so that their latency overlaps the packing
+    // ---- 1. load + pack: 8 bases per thread, four at a time inside one 32-bit word (ep_pack4) ---------
+    // One chunk per thread; the EX_EXT bases past the tile are four more chunks, which threads 0-3 take as well.  Every
+    // global load the tile needs is asked for before the first is waited for, the bases first: the whole tile -- not
+    // every thread, not behind a branch (a second trip, or a load under `if`, is a second memory round trip on every
+    // tile's critical path; the threads without a second chunk load their first one again).
+    static_assert((EX_TILE + EX_EXT) / 8 <= EP_BLOCK + 4 && EX_TILE / 8 == EP_BLOCK, "chunks per thread");
+    const bool fast = (((uintptr_t)a.bases) & 7) == 0 && t0 + EX_TILE + EX_EXT <= a.nbases;
+    const int chunk_b = tid < EX_EXT / 8 ? tid + EP_BLOCK : tid;
+    u32 qq[2][2];
+    if (fast) {
+        const uint2 v0 = *reinterpret_cast<const uint2 *>(a.bases + t0 + (u64)tid * 8);
+        const uint2 v1 = *reinterpret_cast<const uint2 *>(a.bases + t0 + (u64)chunk_b * 8);
+        qq[0][0] = v0.x; qq[0][1] = v0.y; qq[1][0] = v1.x; qq[1][1] = v1.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const u64 g = t0 + (u64)(i ? chunk_b : tid) * 8;
+            qq[i][0] = qq[i][1] = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const u64 gi = g + b;
+                qq[i][0] |= (gi < a.nbases ? (u32)a.bases[gi] : 0u) << (8 * b);
+                qq[i][1] |= (gi + 4 < a.nbases ? (u32)a.bases[gi + 4] : 0u) << (8 * b);
+            }
+        }
+    }
     const u32 s_lo = a.tile_seq[tile];
     const u32 s_end = a.tile_end[tile];
     const u64 my_s = (u64)s_lo + 1 + tid;
     const u64 my_start = my_s <= s_end ? a.seq_off[my_s] : 0;
-
-    // ---- 1. load + pack (as extract_kernel) --------------------------------------------------------
-    const bool aligned = (((uintptr_t)a.bases) & 15) == 0;
-    for (int chunk = tid; chunk < (EX_TILE + EX_EXT) / 16; chunk += EP_BLOCK) {
-        u64 g = t0 + (u64)chunk * 16;
-        u32 q[4];
-        if (aligned && g + 16 <= a.nbases) {
-            uint4 v = *reinterpret_cast<const uint4 *>(a.bases + g);
-            q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
-        } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                u32 x = 0;
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    u64 gi = g + i * 4 + b;
-                    u32 c = gi < a.nbases ? a.bases[gi] : 0u;
-                    x |= c << (8 * b);
-                }
-                q[i] = x;
-            }
-        }
-        u32 word = 0, bad = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            u32 c = (q[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            // A C G T (either case) = 0x41 + {0, 2, 6, 19}: one look into a 32-bit set instead of four compares
-            const u32 t = (c & 0xDFu) - 0x41u;
-            const u32 ok = (0x00080045u >> (t < 31u ? t : 31u)) & 1u;
-            word = (word << 2) | ((c >> 1) & 3u);
-            bad = (bad << 1) | (ok ^ 1u);
-        }
-        pk[chunk] = word;
-        reinterpret_cast<uint16_t *>(inv)[chunk ^ 1] = (uint16_t)bad;
+    for (int i = 0; i < 2; i++) {
+        const int chunk = i ? chunk_b : tid;
+        u32 c0, b0, c1, b1;
+        ep_pack4(qq[i][0], c0, b0);
+        ep_pack4(qq[i][1], c1, b1);
+        reinterpret_cast<uint16_t *>(pk)[chunk ^ 1] = (uint16_t)((c0 << 8) | c1);      // base 16w at bits 31:30 of word w
+        reinterpret_cast<uint8_t *>(inv)[chunk ^ 3] = (uint8_t)((b0 << 4) | b1);       // base 32w at bit 31 of word w
     }
     if (tid < RS_DIGITS) {
         hist[0][tid] = 0;
@@ -155,6 +182,9 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
         if (tid == 2) s_dup = 0;
     }
     __syncthreads();
+#ifdef EPC_PROBE
+    if (EPC_PROBE == 1) return;
+#endif
 
     // ---- 2. sequence starts -> bitmap; the sequence of position p = the tile's first + the starts at or before p ---
     // (a start that finds its bit set already shares its position with another one -- an empty sequence: such
@@ -165,6 +195,9 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
         if (atomicOr(&stb[pos >> 5], bit) & bit) s_dup = 1;
     }
     __syncthreads();
+#ifdef EPC_PROBE
+    if (EPC_PROBE == 2) return;
+#endif
     if (wave == EP_WAVES - 1) {
         const u32 c0 = __popc(stb[2 * lane]), c1 = __popc(stb[2 * lane + 1]);
         u32 inc = c0 + c1;
@@ -193,6 +226,9 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
     if (tid < EX_TILE / 32) inv[tid] = vw;
     __syncthreads();
     const bool dup = s_dup != 0;
+#ifdef EPC_PROBE
+    if (EPC_PROBE == 3) return;
+#endif
     // A sequence's first k-mer (of this tile) sits behind a window that is none: a window across its start (k > 1), one
     // with an invalid base, or the tile's edge -- marking there marks every sequence that has a k-mer.  Those windows
     // are one in a read's length: the threads that hold the validity words walk their few set bits, and the window loop
@@ -210,17 +246,42 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
         }
     }
 
-    // ---- 3. windows: a wave owns positions wave*512 .. +511, round j covers 64 consecutive ones ------
+    // ---- 3. windows.  Here a lane owns the EIGHT CONSECUTIVE positions from q on (a count does not care who sees which
+    // window): their bases are 3 packed words read once and shifted so that the stretch starts at q -- window j's k-mer is
+    // the stretch moved on by 2j bits, a constant --, their validity is one byte, and the reverse complements of all eight
+    // are pieces of ONE reversed stretch (window j = its bases 48-j-k .. 48-j-1) instead of a 64-bit reversal each.
+    static_assert(EP_ROUNDS == 8, "a lane's windows are one byte of the validity bitmap");
+#ifdef EPC_PROBE
+    if (EPC_PROBE == 4) return;
+#endif
     const u64 kmask = k == 32 ? ~0ull : ~(~0ull >> (2 * k));
     const u64 rcx = 0xAAAAAAAAAAAAAAAAull & kmask;
-    const u32 pbase = wave * (64 * EP_ROUNDS) + lane;
-    u32 vmask = 0, rmask = 0, nfwd = 0, nrc = 0;
+    const u32 q = (u32)wave * (64 * EP_ROUNDS) + (u32)lane * EP_ROUNDS;
+    u32 y0, y1, y2;
+    {
+        const u32 w = q >> 4, r2 = (q & 15) * 2;
+        const u32 a0 = pk[w], a1 = pk[w + 1], a2 = pk[w + 2];
+        y0 = __funnelshift_l(a1, a0, r2);
+        y1 = __funnelshift_l(a2, a1, r2);
+        y2 = a2 << r2;                                   // (q + 39 bases at most are looked at: 16 + 16 + 8)
+    }
+    const u32 okb = (inv[q >> 5] >> (24 - (q & 24))) & 0xFFu;          // bit 7 = position q
+    u32 r0 = 0, r1 = 0, r2w = 0;                         // the stretch reversed and complemented, 48 bases
+    if (RC) {
+        r0 = __brev(y2); r1 = __brev(y1); r2w = __brev(y0);
+        r0 = (((r0 >> 1) & 0x55555555u) | ((r0 & 0x55555555u) << 1)) ^ 0xAAAAAAAAu;
+        r1 = (((r1 >> 1) & 0x55555555u) | ((r1 & 0x55555555u) << 1)) ^ 0xAAAAAAAAu;
+        r2w = (((r2w >> 1) & 0x55555555u) | ((r2w & 0x55555555u) << 1)) ^ 0xAAAAAAAAu;
+    }
+    u32 vmb = 0, rmb = 0;                                // bit j = window q + j is a forward / reverse-complement record
 #pragma unroll
     for (int j = 0; j < EP_ROUNDS; j++) {
-        const u32 p = pbase + j * 64;
+        const u32 hi = __funnelshift_l(y1, y0, 2 * j);
         // (without reverse complements or filters only the digit is needed here: the upper word)
-        const u64 key = (RC || FILT) ? ep_window(pk, p, kmask) : ((u64)ep_window_hi(pk, p, kmask) << 32);
-        bool ok = (inv[p >> 5] >> (31 - (p & 31))) & 1u;
+        u64 key;
+        if (RC || FILT) key = ((((u64)hi) << 32) | __funnelshift_l(y2, y1, 2 * j)) & kmask;
+        else key = ((u64)(hi & (u32)(kmask >> 32))) << 32;
+        bool ok = (okb >> (7 - j)) & 1u;
         if (FILT) {
             if (ok && a.runofsame >= 0) ok = runofsame_keep(key, k, a.runofsame);
             if (ok && a.dust >= 0) ok = dust_keep(key, k, a.dust);
@@ -228,39 +289,83 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
         bool emit_rc = false;
         u64 rk = 0;
         if (RC) {
-            const u64 rev = revpairs64(key >> (64 - 2 * k));
-            emit_rc = ok && !(((k & 1) == 0) && rev == key);
-            rk = rev ^ rcx;
+            const int o = 48 - j - k;                    // first base of the window's reverse complement in r0:r1:r2w
+            u32 rh, rl;
+            if (o < 16) { rh = __funnelshift_l(r1, r0, 2 * o); rl = __funnelshift_l(r2w, r1, 2 * o); }
+            else if (o < 32) { rh = __funnelshift_l(r2w, r1, 2 * (o - 16)); rl = __funnelshift_l(0u, r2w, 2 * (o - 16)); }
+            else { rh = __funnelshift_l(0u, r2w, 2 * (o - 32)); rl = 0; }
+            rk = ((((u64)rh) << 32) | rl) & kmask;
+            emit_rc = ok && !(((k & 1) == 0) && (rk ^ rcx) == key);
         }
         if (FILT && a.ranged) {
             const u32 fb = (u32)(key >> a.range_shift), rb = (u32)(rk >> a.range_shift);
             emit_rc = emit_rc && rb >= a.range_lo && rb < a.range_hi;
             ok = ok && fb >= a.range_lo && fb < a.range_hi;
         }
-        vmask |= (u32)ok << j;
-        if (RC) rmask |= (u32)emit_rc << j;
+        vmb |= (u32)ok << j;
         // (the partition digit lies in the key's upper word: dshift >= 32 for every plan, see choose_pbits)
-        if (ok) atomicAdd(&hist[0][((u32)(key >> 32) >> (pa.dshift - 32)) & pa.dmask], 1u);
-        nfwd += __popcll(__ballot(ok));          // wave-uniform running totals
+        const u32 fd = ((u32)(key >> 32) >> (pa.dshift - 32)) & pa.dmask;
+        if (HIST) {
+            if (RC || FILT) {
+                if (ok) atomicAdd(&hist[0][fd], 1u);
+            } else atomicAdd(&hist[0][fd], (u32)ok);      // branch-free: nearly every window of a read is a record
+        }
         if (RC) {
-            if (emit_rc) atomicAdd(&hist[1][((u32)(rk >> 32) >> (pa.dshift - 32)) & pa.dmask], 1u);
-            nrc += __popcll(__ballot(emit_rc));
+            rmb |= (u32)emit_rc << j;
+            if (HIST && emit_rc) atomicAdd(&hist[1][((u32)(rk >> 32) >> (pa.dshift - 32)) & pa.dmask], 1u);
         }
     }
-    if (lane == 0) {
-        atomicAdd(&s_tot[0], nfwd);
-        atomicAdd(&s_tot[1], nrc);
+#ifdef EPC_PROBE
+    if (EPC_PROBE == 5) return;
+#endif
+    // the wave's totals, one add per wave (an LDS add of a different value per lane to ONE address is turned by the
+    // compiler into a scalar loop over the 64 lanes -- measured: half of this kernel's time): a lane's count has four
+    // bits, each worth a ballot
+    {
+        const u32 cf = __popc(vmb), cr = __popc(rmb);
+        u32 nf = 0, nr = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            nf += (u32)__popcll(__ballot((cf >> b) & 1u)) << b;
+            if (RC) nr += (u32)__popcll(__ballot((cr >> b) & 1u)) << b;
+        }
+        if (lane == 0) {
+            atomicAdd(&s_tot[0], nf);
+            if (RC) atomicAdd(&s_tot[1], nr);
+        }
     }
+#ifdef EPC_PROBE
+    if (EPC_PROBE == 51) return;
+#endif
+    // The write pass ranks its records round by round over 64 consecutive positions (thread tid: positions
+    // wave*512 + j*64 + lane, bit j of its byte): the bits change hands through LDS, laid out so that a thread's eight
+    // bytes -- one from each lane that holds one of its positions -- are one 8-byte read.
+    tbits[0][wave * 64 + (lane & 7) * 8 + (lane >> 3)] = (uint8_t)vmb;
+    if (RC) tbits[1][wave * 64 + (lane & 7) * 8 + (lane >> 3)] = (uint8_t)rmb;
+#ifdef EPC_PROBE
+    if (EPC_PROBE == 52) return;
+#endif
     // the tile image for the write pass
     u32 *img = pa.img + (u64)tile * EP_IMG_WORDS;
     if (tid < (EX_TILE + EX_EXT) / 16) img[EP_IMG_PK + tid] = pk[tid];
+#ifdef EPC_PROBE
+    if (EPC_PROBE == 53) return;
+#endif
     if (tid < EX_TILE / 32 + 2) img[EP_IMG_STB + tid] = stb[tid];
-    reinterpret_cast<uint8_t *>(img + EP_IMG_VM)[tid] = (uint8_t)vmask;
-    if (RC) reinterpret_cast<uint8_t *>(img + EP_IMG_RM)[tid] = (uint8_t)rmask;
     __syncthreads();
+#ifdef EPC_PROBE
+    if (EPC_PROBE == 6) return;
+#endif
+    {
+        const u32 at = wave * 64 + (lane >> 3) * 8;
+        reinterpret_cast<uint8_t *>(img + EP_IMG_VM)[tid] =
+            (uint8_t)ep_bit_column(*reinterpret_cast<const uint2 *>(&tbits[0][at]), lane & 7);
+        if (RC) reinterpret_cast<uint8_t *>(img + EP_IMG_RM)[tid] =
+            (uint8_t)ep_bit_column(*reinterpret_cast<const uint2 *>(&tbits[1][at]), lane & 7);
+    }
 
     // histogram columns + the tile's record / forward-window totals
-    if (tid < RS_DIGITS) {
+    if (HIST && tid < RS_DIGITS) {
         pa.table[(u64)tid * pa.ncols + col0] = hist[0][tid];
         if (RC) pa.table[(u64)tid * pa.ncols + col0 + 1] = hist[1][tid];
     }
@@ -457,5 +562,90 @@ __global__ __launch_bounds__(EP_BLOCK, 6) void extract_part_write_kernel(PartArg
             for (int w = 0; w < EP_WAVES; w++) wcnt[w][tid] = 0;
         }
         __syncthreads();
+    }
+}
+
+// ---- write pass of a batch that is NOT partitioned (every batch of a build but the first): the records of a tile in
+// window order -- a window's forward record, then its reverse complement -- at tile_off[tile] behind the records the
+// build already holds.  From the count pass's tile image: nothing is loaded, packed or filtered again, and a tile that
+// keeps nothing (key-range builds keep a slice: most windows of most tiles go) costs one load.
+template <typename V>
+__global__ __launch_bounds__(EP_BLOCK) void extract_img_write_kernel(PartArgs pa) {
+    const ExtractArgs &a = pa.e;
+    __shared__ u32 pk[EX_TILE / 16 + 4];
+    __shared__ u32 stb[EX_TILE / 32 + 4];
+    __shared__ u32 wpre[EX_TILE / 32];
+    __shared__ u32 wave_cnt[EP_WAVES * EP_ROUNDS];       // records of (wave, round), then their exclusive prefix
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 tile = blockIdx.x;
+    const u64 t0 = (u64)tile * EX_TILE;
+    const int k = a.k;
+    const u32 *img = pa.img + (u64)tile * EP_IMG_WORDS;
+    const u32 img_w = tid < EP_IMG_VM ? img[tid] : 0u;               // packed bases, then the start bitmap
+    const u32 vmask = reinterpret_cast<const uint8_t *>(img + EP_IMG_VM)[tid];
+    const u32 rmask = a.rc ? reinterpret_cast<const uint8_t *>(img + EP_IMG_RM)[tid] : 0u;
+    const bool dup = img[EP_IMG_FLAG] != 0;
+    const u32 s_lo = a.tile_seq[tile];
+    const u32 s_end = a.tile_end[tile];
+    const u64 out_base = a.state[ST_NREC] + a.tile_off[tile];
+    if (a.tile_count[tile] == 0) return;        // (asked for with the rest: one round trip, not one of its own)
+    if (tid < EP_IMG_STB) pk[tid] = img_w;
+    else if (tid < EP_IMG_VM) stb[tid - EP_IMG_STB] = img_w;
+    // records per (wave, round), in window order: thread tid holds positions wave * 512 + j * 64 + lane
+#pragma unroll
+    for (int j = 0; j < EP_ROUNDS; j++) {
+        const u32 c = (u32)__popcll(__ballot((vmask >> j) & 1u)) + (u32)__popcll(__ballot((rmask >> j) & 1u));
+        if (lane == 0) wave_cnt[wave * EP_ROUNDS + j] = c;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        static_assert(EP_WAVES * EP_ROUNDS == 64, "one wave scans the (wave, round) counts");
+        const u32 v = wave_cnt[lane];
+        u32 inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        wave_cnt[lane] = inc - v;
+    } else if (wave == 1) {
+        const u32 c0 = __popc(stb[2 * lane]), c1 = __popc(stb[2 * lane + 1]);
+        u32 inc = c0 + c1;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const u32 o = __shfl_up(inc, dd, 64);
+            if (lane >= dd) inc += o;
+        }
+        wpre[2 * lane] = inc - c0 - c1;
+        wpre[2 * lane + 1] = inc - c1;
+    }
+    __syncthreads();
+    const u64 kmask = k == 32 ? ~0ull : ~(~0ull >> (2 * k));
+    const u64 rcx = 0xAAAAAAAAAAAAAAAAull & kmask;
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    V *ov = reinterpret_cast<V *>(a.out_vals);
+#pragma unroll
+    for (int j = 0; j < EP_ROUNDS; j++) {
+        const bool ok = (vmask >> j) & 1u, erc = (rmask >> j) & 1u;
+        const u64 bal_v = __ballot(ok), bal_r = __ballot(erc);
+        if ((bal_v | bal_r) == 0) continue;
+        if (ok || erc) {
+            // (the RC record can be there without the forward one: key-range builds keep each by its own bucket)
+            const u32 p = (u32)wave * (64 * EP_ROUNDS) + (u32)j * 64 + (u32)lane;
+            const u64 slot = out_base + wave_cnt[wave * EP_ROUNDS + j] + __popcll(bal_v & lt) + __popcll(bal_r & lt);
+            const u64 rslot = slot + (ok ? 1 : 0);
+            const u64 key = ep_window64(pk, p, kmask);
+            if (ok) a.out_keys[slot] = key;
+            if (erc) a.out_keys[rslot] = revpairs64(key >> (64 - 2 * k)) ^ rcx;
+            u32 rel;
+            if (dup) rel = ep_seq_rel(a, s_lo, s_end, t0 + p);
+            else rel = wpre[p >> 5] + __popc(stb[p >> 5] >> (31 - (p & 31)));
+            const u64 sq = (u64)s_lo + rel;
+            V v;
+            if (a.kind == KMG_PAYLOAD_TAXON) v = (V)(u32)a.seq_id[sq];
+            else v = (V)(((u64)(u32)a.read_index[sq] << 16) | (u64)((t0 + p - a.seq_off[sq]) & 0xFFFFu));   // ReadPos(read, (short)pos)
+            if (ok) ov[slot] = v;
+            if (erc) ov[rslot] = v;
+        }
     }
 }

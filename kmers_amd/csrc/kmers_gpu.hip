@@ -191,6 +191,20 @@ static int ensure_record_capacity(kmg_ctx *ctx, u64 need) {
     return KMG_OK;
 }
 
+// Segment plan of a build's sort (radix.h, SegPlan): the whole key space, or the slice a key-range build keeps
+static SegPlan build_seg_plan(const kmg_ctx *ctx, int pbits) {
+    if (!ctx->ranged || pbits <= 0) return whole_space_plan(pbits);
+    const int s = 64 - 2 * ctx->key_len;
+    const u64 first = (u64)ctx->range_lo << s, last = ((u64)ctx->range_hi << s) - 1;      // (range_hi = 4^key_len wraps to ~0)
+    return key_slice_plan(pbits, first, last);
+}
+// prefix bits for n records of this build: planned for the density inside the slice a key-range build keeps
+static int build_pbits(const kmg_ctx *ctx, u64 n, int kbits) {
+    if (!ctx->ranged) return choose_pbits(n, kbits);
+    const u64 n_dense = n * ((u64)1 << (2 * ctx->key_len)) / std::max<u32>(ctx->range_hi - ctx->range_lo, 1u);
+    return choose_pbits(n_dense, kbits, 30);
+}
+
 // All pointers are device pointers.  Caller holds ctx->mu.
 static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, const u64 *d_seq_off,
                             const int32_t *d_seq_id, const int64_t *d_seq_tok, u64 nseq, int32_t *d_read_index_out) {
@@ -274,7 +288,9 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     // numbered and before the state snapshot below, and written into buffers of their own afterwards)
     const bool var = ctx->min_k < ctx->k;
     const int plan = ctx->n_adds == 0 ? choose_pbits(expect, 2 * ctx->k) : 0;
-    const bool part = plan > 0 && plan <= 32 && nbases < 0xFFFFFFF0ull / 2;   // (<= 32: the partition digit lies in the key's upper word)
+    // (a key-range build whose keys agree on all of the planned prefix bits has no global pass to fuse)
+    const std::vector<SortPass> plan_digits = prefix_digits(plan, build_seg_plan(ctx, plan).shared_top);
+    const bool part = plan > 0 && plan <= 32 && nbases < 0xFFFFFFF0ull / 2 && !plan_digits.empty();   // (<= 32: the partition digit lies in the key's upper word)
     ctx->prepart = part;
     ctx->plan_pbits = plan;
     ctx->n_adds++;
@@ -299,13 +315,15 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         }
         len_pending = true;
     }
+    // the count pass's tile images, read back by the write pass (either kind of batch)
+    KMG_ALLOC(img, (size_t)ntiles * EP_IMG_WORDS * 4);
+    pa.img = img.as<u32>();
+    pa.ntiles = ntiles; pa.ncols = ntiles * (ctx->rc ? 2 : 1);
+    pa.dshift = 32; pa.dmask = 0;
     if (part) {
-        const SortPass d0 = prefix_digits(plan)[0];
+        const SortPass d0 = plan_digits[0];
         pa.dshift = d0.shift; pa.dmask = (1u << d0.bits) - 1u;
-        pa.ntiles = ntiles; pa.ncols = ntiles * (ctx->rc ? 2 : 1);
         KMG_ALLOC(table, (size_t)RS_DIGITS * pa.ncols * 4);
-        KMG_ALLOC(img, (size_t)ntiles * EP_IMG_WORDS * 4);      // the count pass's tile images, read back by the write pass
-        pa.img = img.as<u32>();
         KMG_ALLOC(tagg, (size_t)(div_up_u64((u64)RS_DIGITS * pa.ncols, SCAN_TILE) + 1) * 8);
         pa.table = table.as<u32>();
         // forward and RC records of a tile are written as two runs: (read, pos) order inside a k-mer is
@@ -315,10 +333,10 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     const dim3 pgrid(((ntiles + 7) / 8) * 8);
     {
         ProfScope ps(ctx, KP_EXTRACT_COUNT, nbases);
+        pa.e = a;
+        // (the payload type only matters to the write pass)
+        const bool filt = ctx->dust >= 0 || ctx->runofsame >= 0 || ctx->ranged;
         if (part) {
-            pa.e = a;
-            // (the payload type only matters to the write pass)
-            const bool filt = ctx->dust >= 0 || ctx->runofsame >= 0 || ctx->ranged;
             if (ctx->rc) {
                 if (filt) hipLaunchKernelGGL((extract_part_count_kernel<true, true>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
                 else hipLaunchKernelGGL((extract_part_count_kernel<true, false>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
@@ -326,7 +344,16 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
                 if (filt) hipLaunchKernelGGL((extract_part_count_kernel<false, true>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
                 else hipLaunchKernelGGL((extract_part_count_kernel<false, false>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
             }
-        } else hipLaunchKernelGGL((extract_kernel<false>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
+        } else {
+            // a later batch of the build: the same pass without the partition digit's histograms
+            if (ctx->rc) {
+                if (filt) hipLaunchKernelGGL((extract_part_count_kernel<true, true, false>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+                else hipLaunchKernelGGL((extract_part_count_kernel<true, false, false>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+            } else {
+                if (filt) hipLaunchKernelGGL((extract_part_count_kernel<false, true, false>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+                else hipLaunchKernelGGL((extract_part_count_kernel<false, false, false>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+            }
+        }
         // forward windows of the batch.  (A fused batch without reverse complements holds nothing else: there the
         // total of the table scan below is both the record count and the window count, and no launch is spent on it.)
         if (!part || ctx->rc)
@@ -404,8 +431,10 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases /* + records * rec_b, added at finish when N is known */);
         pa.e = a;
         pa.out_base = 0;
+#ifndef EPC_PROBE          // (timing probes of the count pass leave the table unfinished: nothing may be written from it)
         if (reads && !compact) hipLaunchKernelGGL((extract_part_write_kernel<u64>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
         else hipLaunchKernelGGL((extract_part_write_kernel<u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+#endif
     } else {
         KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, tile_count.as<u32>(), tile_off.as<u64>(), ntiles, OpSum(), 0ull,
                                                     agg.as<u64>(), nullptr, true, KP_SCAN)));
@@ -418,7 +447,9 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
             a.out_keys = ctx->rec_keys; a.out_vals = ctx->rec_vals;
         }
         ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases /* + records * rec_b, added at finish when N is known */);
-        hipLaunchKernelGGL((extract_kernel<true>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, a);
+        pa.e = a;
+        if (reads) hipLaunchKernelGGL((extract_img_write_kernel<u64>), dim3(ntiles), dim3(EP_BLOCK), 0, ctx->stream, pa);
+        else hipLaunchKernelGGL((extract_img_write_kernel<u32>), dim3(ntiles), dim3(EP_BLOCK), 0, ctx->stream, pa);
         hipLaunchKernelGGL(extract_advance_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, tile_off.as<u64>(), ntiles);
     }
     if (var) {
@@ -781,7 +812,7 @@ static int ensure_vals(kmg_ctx *ctx, kmg_db *db) {
 // Sort + dedup the n records (keys, vals) of k-mers of db->k bases into db's CSR arrays (db->k / key_len / kind set by
 // the caller).  When the sorted payloads become a read database's value array, `vals` changes owner and is nulled.
 static int sort_reduce_class(kmg_ctx *ctx, u64 *keys, void *&vals, u32 n, bool compact, int pos_bits,
-                             const std::vector<SortPass> &payload, int pbits, bool prepart, kmg_db *db, bool *heads_done) {
+                             const std::vector<SortPass> &payload, const SegPlan &plan, bool prepart, kmg_db *db, bool *heads_done) {
     const bool reads = db->kind == KMG_PAYLOAD_READPOS;
     const size_t vb = compact ? 4 : val_bytes(db->kind);
     PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx), seg(ctx), ucount(ctx);
@@ -797,19 +828,19 @@ static int sort_reduce_class(kmg_ctx *ctx, u64 *keys, void *&vals, u32 n, bool c
         KMG_ALLOC(v1, (size_t)n * vb);
         KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
         KMG_ALLOC(agg, (size_t)(div_up_u64((u64)RS_DIGITS * ntiles, SCAN_TILE) + 1) * 8);
-        KMG_ALLOC(seg, (((size_t)1 << pbits) + 4) * 4);
+        KMG_ALLOC(seg, ((size_t)plan.nseg + 4) * 4);
         const int low_bit = 64 - 2 * db->k;
         if (reads) {
-            KMG_ALLOC(ucount, (((size_t)1 << pbits) + 1) * 4);
+            KMG_ALLOC(ucount, ((size_t)plan.nseg + 1) * 4);
             heads.ucount = ucount.as<u32>();
             if (compact) {
                 ctx->sort_as_reads = true;
-                r = hybrid_sort_records<u32>(ctx, keys, (u32 *)vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1, &heads);
+                r = hybrid_sort_records<u32>(ctx, keys, (u32 *)vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), plan, prepart, &in1, &heads);
                 ctx->sort_as_reads = false;
             } else
-                r = hybrid_sort_records<u64>(ctx, keys, (u64 *)vals, k1.as<u64>(), v1.as<u64>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1, &heads);
+                r = hybrid_sort_records<u64>(ctx, keys, (u64 *)vals, k1.as<u64>(), v1.as<u64>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), plan, prepart, &in1, &heads);
         }
-        else r = hybrid_sort_records<u32>(ctx, keys, (u32 *)vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, prepart, &in1);
+        else r = hybrid_sort_records<u32>(ctx, keys, (u32 *)vals, k1.as<u64>(), v1.as<u32>(), n, low_bit, payload, table.as<u32>(), agg.as<u32>(), seg.as<u32>(), plan, prepart, &in1);
     }
     if (r == KMG_OK) {
         const u64 *sk = in1 ? k1.as<u64>() : keys;
@@ -955,8 +986,7 @@ static int finish_variable(kmg_ctx *ctx, std::unique_ptr<kmg_db, void (*)(kmg_db
             // (sorted as 32-mers: the length tag in the two lowest bits takes part in the order and in the runs)
             c->ctx = ctx; c->k = 32; c->min_k = 32; c->key_len = ctx->key_len; c->rc = ctx->rc; c->kind = ctx->kind;
             void *vals = cv.detach();
-            const u64 n_dense = ctx->ranged ? (u64)n * (1u << (2 * ctx->key_len)) / std::max<u32>(ctx->range_hi - ctx->range_lo, 1u) : n;
-            int r = sort_reduce_class(ctx, ck.as<u64>(), vals, n, false, 16, payload, choose_pbits(n_dense, 64), false, c, nullptr);
+            int r = sort_reduce_class(ctx, ck.as<u64>(), vals, n, false, 16, payload, build_seg_plan(ctx, build_pbits(ctx, n, 64)), false, c, nullptr);
             ctx->pool.release(vals);
             KMG_TRY(r);
             void *lp;
@@ -1043,12 +1073,12 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     // prefix bits for the global passes: segments of ~1-2 K records on uniform data
     // (a single-batch build keeps the bits its extractor already partitioned the records by)
     const bool prepart = ctx->prepart && ctx->n_adds == 1;
-    // (a key-range build holds its records in a fraction of the prefixes: plan the segments for that density)
-    const u64 n_dense = ctx->ranged ? (u64)n * (1u << (2 * ctx->key_len)) / std::max<u32>(ctx->range_hi - ctx->range_lo, 1u) : n;
-    const int pbits = prepart ? ctx->plan_pbits : choose_pbits(n_dense, 2 * ctx->k);
+    // (a key-range build holds its records in a slice of the prefixes: the segments are planned for the density there,
+    // only the slice's segments exist, and the bits its keys share take no pass -- build_seg_plan)
+    const int pbits = prepart ? ctx->plan_pbits : build_pbits(ctx, n, 2 * ctx->k);
 
     bool heads_done = false;
-    int r = sort_reduce_class(ctx, ctx->rec_keys, ctx->rec_vals, n, compact, pos_bits, payload, pbits, prepart, db, &heads_done);
+    int r = sort_reduce_class(ctx, ctx->rec_keys, ctx->rec_vals, n, compact, pos_bits, payload, build_seg_plan(ctx, pbits), prepart, db, &heads_done);
     // the record buffers go back to the pool: the next build (or the DB arrays of this one) reuses them
     ctx->pool.release(ctx->rec_keys);
     ctx->pool.release(ctx->rec_vals);
@@ -1343,7 +1373,7 @@ static int merge_records(kmg_ctx *ctx, kmg_db *db, PoolBuf &k0, PoolBuf &v0, Poo
         KMG_ALLOC(agg, (size_t)(div_up_u64(std::max<u64>((u64)RS_DIGITS * ntiles, n), SCAN_TILE) + 1) * 8);
         KMG_ALLOC(seg, (((size_t)1 << pbits) + 4) * 4);
         KMG_TRY(hybrid_sort_records<u64>(ctx, k0.as<u64>(), v0.as<u64>(), k1.as<u64>(), v1.as<u64>(), n, 64 - 2 * db->k, payload,
-                                         table.as<u32>(), agg.as<u32>(), seg.as<u32>(), pbits, false, &in1));
+                                         table.as<u32>(), agg.as<u32>(), seg.as<u32>(), whole_space_plan(pbits), false, &in1));
     } else {
         KMG_ALLOC(agg, 64);
     }
@@ -2146,7 +2176,7 @@ extern "C" int kmg_collect_by_read(kmg_ctx *ctx, const kmg_db *search, const kmg
     // index) keep k-mer order -- the sort is stable
     bool in1 = false;
     KMG_TRY(hybrid_sort_records<u32>(ctx, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), (u32)n, shift, {},
-                                     table.as<u32>(), sagg.as<u32>(), seg.as<u32>(), pbits, false, &in1, nullptr,
+                                     table.as<u32>(), sagg.as<u32>(), seg.as<u32>(), whole_space_plan(pbits), false, &in1, nullptr,
                                      /* counting passes only: the low key bits (pos) repeat in long runs */ false));
     const u64 *sk = in1 ? k1.as<u64>() : k0.as<u64>();
     const u32 *sv = in1 ? v1.as<u32>() : v0.as<u32>();

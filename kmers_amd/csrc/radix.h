@@ -57,51 +57,61 @@ __device__ __forceinline__ u32 rs_digit(u64 key, V val, int shift, u32 mask, int
     return (u32)(key >> shift) & mask;
 }
 
-// One block histograms RSH_TILES consecutive tiles, so that each digit's RSH_TILES counters -- adjacent in
+// One block histograms RSH_TILES consecutive tiles at a time, so that each digit's RSH_TILES counters -- adjacent in
 // the digit-major table -- leave as one 64-byte store instead of sixteen stray 4-byte ones (measured with
-// WRITE_SIZE: the one-tile-per-block version wrote 8x the table's size).
+// WRITE_SIZE: the one-tile-per-block version wrote 8x the table's size).  The tiles are dealt out evenly over a grid
+// that is resident all at once (rs_hist_blocks): block b takes tiles [b * ntiles / nblocks, (b+1) * ntiles / nblocks).
+// (Measured, tools/exp/hist_probe.hip: the kernel runs at the speed of its loads alone -- LDS adds on random digits
+// retire ~6.6 per clock and CU, tools/exp/lds_hist_rate.hip, a tenth of the time -- and a grid of 1.8 waves of blocks
+// cost 30 % over one of a single wave.)
 #define RSH_TILES 16
+static inline u32 rs_hist_blocks(u32 ntiles) {
+    const u32 resident = 2048;                       // 256 CUs x 8 blocks of 256 threads
+    return std::max<u32>(1, std::min<u32>(resident, ntiles));
+}
 template <typename V>
 __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const u64 *__restrict__ keys, const V *__restrict__ vals,
                                                             u32 n, int shift, u32 mask, int src,
-                                                            u32 *__restrict__ table, u32 ntiles, int tpb) {
+                                                            u32 *__restrict__ table, u32 ntiles) {
     __shared__ u32 h[RS_DIGITS][RSH_TILES + 1];
-    for (int t = 0; t < tpb; t++) h[threadIdx.x][t] = 0;
-    __syncthreads();
-    const u32 tile0 = blockIdx.x * tpb;
-    for (int t = 0; t < tpb; t++) {
-        const u32 base = (tile0 + t) * RS_TILE;
-        if (base >= n) break;
-        if (n - base >= RS_TILE) {
-            // full tile: all of a thread's loads leave before the first counter is touched (a load under
-            // `if (idx < n)` compiles to a branch with a wait behind it: one memory round trip per record)
-            if (src) {
-                V v[RS_ITEMS];
+    const u32 t_lo = (u32)((u64)blockIdx.x * ntiles / gridDim.x), t_hi = (u32)((u64)(blockIdx.x + 1) * ntiles / gridDim.x);
+    for (u32 tile0 = t_lo; tile0 < t_hi; tile0 += RSH_TILES) {
+        const int tpb = (int)min((u32)RSH_TILES, t_hi - tile0);
+        for (int t = 0; t < tpb; t++) h[threadIdx.x][t] = 0;
+        __syncthreads();
+        for (int t = 0; t < tpb; t++) {
+            const u32 base = (tile0 + t) * RS_TILE;
+            if (n - base >= RS_TILE) {
+                // full tile: all of a thread's loads leave before the first counter is touched (a load under
+                // `if (idx < n)` compiles to a branch with a wait behind it: one memory round trip per record)
+                if (src) {
+                    V v[RS_ITEMS];
 #pragma unroll
-                for (int i = 0; i < RS_ITEMS; i++) v[i] = vals[base + i * RS_BLOCK + threadIdx.x];
+                    for (int i = 0; i < RS_ITEMS; i++) v[i] = vals[base + i * RS_BLOCK + threadIdx.x];
 #pragma unroll
-                for (int i = 0; i < RS_ITEMS; i++) atomicAdd(&h[rs_digit<V>(0, v[i], shift, mask, src)][t], 1u);
-            } else {
-                u64 kk[RS_ITEMS];
+                    for (int i = 0; i < RS_ITEMS; i++) atomicAdd(&h[rs_digit<V>(0, v[i], shift, mask, src)][t], 1u);
+                } else {
+                    u64 kk[RS_ITEMS];
 #pragma unroll
-                for (int i = 0; i < RS_ITEMS; i++) kk[i] = keys[base + i * RS_BLOCK + threadIdx.x];
+                    for (int i = 0; i < RS_ITEMS; i++) kk[i] = keys[base + i * RS_BLOCK + threadIdx.x];
 #pragma unroll
-                for (int i = 0; i < RS_ITEMS; i++) atomicAdd(&h[(u32)(kk[i] >> shift) & mask][t], 1u);
+                    for (int i = 0; i < RS_ITEMS; i++) atomicAdd(&h[(u32)(kk[i] >> shift) & mask][t], 1u);
+                }
+                continue;
             }
-            continue;
-        }
-        for (int i = 0; i < RS_ITEMS; i++) {
-            u32 idx = base + i * RS_BLOCK + threadIdx.x;
-            if (idx < n) {
-                u32 d = src ? rs_digit<V>(0, vals[idx], shift, mask, src) : rs_digit<V>(keys[idx], (V)0, shift, mask, 0);
-                atomicAdd(&h[d][t], 1u);
+            for (int i = 0; i < RS_ITEMS; i++) {
+                u32 idx = base + i * RS_BLOCK + threadIdx.x;
+                if (idx < n) {
+                    u32 d = src ? rs_digit<V>(0, vals[idx], shift, mask, src) : rs_digit<V>(keys[idx], (V)0, shift, mask, 0);
+                    atomicAdd(&h[d][t], 1u);
+                }
             }
         }
+        __syncthreads();
+        u32 *row = table + (u64)threadIdx.x * ntiles + tile0;
+        for (int t = 0; t < tpb; t++) row[t] = h[threadIdx.x][t];
+        __syncthreads();
     }
-    __syncthreads();
-    u32 *row = table + (u64)threadIdx.x * ntiles + tile0;
-    for (int t = 0; t < tpb; t++)
-        if (tile0 + t < ntiles) row[t] = h[threadIdx.x][t];
 }
 
 // Scatter geometry: 512 threads x 8 records.  Eight waves per block and a 32-KB staging buffer that is
@@ -234,22 +244,43 @@ struct SortPass {
 #define LS_MAX (LS_BLOCK * LS_ITEMS)   // 2560 records per segment at most (48 KB of LDS: 3 blocks per CU)
 
 // number of prefix bits sorted by global passes for n records of `kbits` key bits
-static inline int choose_pbits(u64 n, int kbits) {
+static inline int choose_pbits(u64 n, int kbits, int cap = 24) {
     // average segment <= 2300 records: LS_MAX = 2560 is then > 5 sigma away on uniform keys, and segments are as
     // full as the local sort's 512-record rounds allow
     int p = 0;
-    while (p < kbits && p < 24 && (n >> p) > (u64)(LS_BLOCK * LS_ITEMS) * 9 / 10) p++;
+    while (p < kbits && p < cap && (n >> p) > (u64)(LS_BLOCK * LS_ITEMS) * 9 / 10) p++;
     return p;
 }
 
-// the global passes' digits, lowest first
-static inline std::vector<SortPass> prefix_digits(int pbits) {
+// Where the segments of a sort lie.  A build of the whole key space: 2^pbits segments, number = the key's top pbits.
+// A key-range build (kmg_build_set_key_range) holds its records in a slice of the prefixes: the plan counts the
+// prefix bits for the slice's density (up to 30 of them), numbers only the slice's segments -- segment s holds prefix
+// seg_base + s -- and spends no global pass on the `shared_top` leading bits that every key of the range has in common.
+struct SegPlan {
+    int pbits;
+    int shared_top;
+    u32 seg_base;
+    u32 nseg;
+};
+static inline SegPlan whole_space_plan(int pbits) { return {pbits, 0, 0u, 1u << pbits}; }
+// keys of [first_key, last_key] (both inclusive) only
+static inline SegPlan key_slice_plan(int pbits, u64 first_key, u64 last_key) {
+    if (pbits <= 0) return {0, 0, 0u, 1u};
+    const u64 diff = first_key ^ last_key;
+    const int common = diff ? __builtin_clzll(diff) : 64;
+    const u32 lo = (u32)(first_key >> (64 - pbits)), hi = (u32)(last_key >> (64 - pbits));
+    return {pbits, std::min(common, pbits), lo, hi - lo + 1};
+}
+
+// the global passes' digits, lowest first (none for the shared_top leading bits)
+static inline std::vector<SortPass> prefix_digits(int pbits, int shared_top = 0) {
     std::vector<SortPass> prefix;
-    if (pbits > 0) {
-        const int np = (pbits + RS_BITS - 1) / RS_BITS;
+    const int eff = pbits - shared_top;
+    if (eff > 0) {
+        const int np = (eff + RS_BITS - 1) / RS_BITS;
         int shift = 64 - pbits;
         for (int i = 0; i < np; i++) {
-            int bits = pbits / np + (i < pbits % np ? 1 : 0);
+            int bits = eff / np + (i < eff % np ? 1 : 0);
             prefix.push_back({shift, bits, RS_SRC_KEY});
             shift += bits;
         }
@@ -276,11 +307,8 @@ static int radix_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 
         const u32 mask = (1u << p.bits) - 1u;
         {
             ProfScope ps(ctx, sizeof(V) == 8 || ctx->sort_as_reads ? KP_SORT_HIST_V64 : KP_SORT_HIST_V32, (u64)n * (p.src ? sizeof(V) : 8));
-            // tiles per block: as many as keep >= ~2048 blocks in flight (small inputs: one tile per block)
-            int tpb = 1;
-            while (tpb < RSH_TILES && ntiles / (tpb * 2) >= 2048) tpb *= 2;
-            hipLaunchKernelGGL((rs_hist_kernel<V>), dim3(div_up_u64(ntiles, tpb)), dim3(RS_BLOCK), 0, ctx->stream, ki, vi, n, p.shift,
-                               mask, p.src, table, ntiles, tpb);
+            hipLaunchKernelGGL((rs_hist_kernel<V>), dim3(rs_hist_blocks(ntiles)), dim3(RS_BLOCK), 0, ctx->stream, ki, vi, n, p.shift,
+                               mask, p.src, table, ntiles);
         }
         KMG_TRY((device_scan<u32, u32, OpSum, true>(ctx, table, table, (u64)RS_DIGITS * ntiles, OpSum(), 0u, agg,
                                                     nullptr, false, KP_SORT_SCAN)));
@@ -317,9 +345,10 @@ struct LocalPasses {
     int shift[LS_MAX_PASSES];
     int bits[LS_MAX_PASSES];
     int src[LS_MAX_PASSES];
+    u32 seg_base;    // prefix value of segment 0 (key-range builds, SegPlan)
 };
 
-// seg_off[s] = first record whose top `pbits` key bits are >= s (s = 0 .. 2^pbits), and the largest segment size
+// seg_off[s] = first record whose top `pbits` key bits are >= seg_base + s (s = 0 .. nseg), and the largest segment size
 // (atomicMax into *max_seg).  keys must be sorted by that prefix.  A block finds 256 boundaries and so the sizes of 255
 // segments: boundaries LSEG_PER * b .. LSEG_PER * b + 255.  `table` (may be null): the scanned digit-major offsets of
 // the last global pass, whose digit was the key's top `top_bits` bits -- table[d * ntiles_tab] is where digit d's
@@ -327,7 +356,7 @@ struct LocalPasses {
 #define LSEG_PER 255
 __global__ __launch_bounds__(256) void ls_segments_kernel(const u64 *__restrict__ keys, u32 n, int pbits, u32 *__restrict__ seg_off,
                                                           u32 nseg, u32 *max_seg, const u32 *__restrict__ table, u32 ntiles_tab,
-                                                          int top_bits) {
+                                                          int top_bits, u32 seg_base) {
     __shared__ u32 bnd[256];
     const u32 s = blockIdx.x * LSEG_PER + threadIdx.x;
     u32 lo = 0, hi = n;
@@ -340,7 +369,7 @@ __global__ __launch_bounds__(256) void ls_segments_kernel(const u64 *__restrict_
         }
         while (lo < hi) {
             u32 mid = lo + ((hi - lo) >> 1);
-            if ((u32)(keys[mid] >> (64 - pbits)) < s) lo = mid + 1; else hi = mid;
+            if ((u32)(keys[mid] >> (64 - pbits)) < seg_base + s) lo = mid + 1; else hi = mid;
         }
     }
     bnd[threadIdx.x] = lo;
@@ -681,7 +710,7 @@ __device__ __forceinline__ u32 ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *__
         if (valid) svals[li] = vraw[j];
     }
     *reinterpret_cast<uint2 *>(&wcnt[wave][4 * lane]) = make_uint2(0, 0);
-    const u64 seg_prefix = pbits > 0 ? ((u64)blockIdx.x << (64 - pbits)) : 0ull;
+    const u64 seg_prefix = pbits > 0 ? ((u64)(blockIdx.x + lp.seg_base) << (64 - pbits)) : 0ull;
     for (int p = 0; p < lp.n; p++) {
         ls_word_pass<ROUNDS, ROUNDS - 1>(sw, nact, lp.shift[p] + pbits, (1u << lp.bits[p]) - 1u, wcnt, wbase, swords, wave_base, p + 1 < lp.n);
         if (LS_FOLD && HEADS && p + 1 == LS_FOLD_AFTER && lp.n >= LS_FOLD_AFTER + 2) {
@@ -809,7 +838,7 @@ __device__ __forceinline__ void ls_fold_tail(u64 *keys_in, V *vals_in, V *__rest
     uint16_t *gstart = reinterpret_cast<uint16_t *>(swords + LS_GROUPS_MAX);
     uint16_t *delta = reinterpret_cast<uint16_t *>(&wbase[0][0]);    // [G] final place - place now (mod 2^16)
     u32 *recs = reinterpret_cast<u32 *>(swords + LS_MAX / 2);
-    const u64 seg_prefix = pbits > 0 ? ((u64)blockIdx.x << (64 - pbits)) : 0ull;
+    const u64 seg_prefix = pbits > 0 ? ((u64)(blockIdx.x + lp.seg_base) << (64 - pbits)) : 0ull;
     __syncthreads();
     // ---- the remaining passes over one word per group --------------------------------------------------------
     const u32 gwr = (G + 63) >> 6;                                   // 1 .. 16 wave-rounds
@@ -997,13 +1026,14 @@ struct SortHeads {
 template <typename V>
 static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32 n, int low_bit,
                                const std::vector<SortPass> &payload_passes, u32 *table, u32 *agg, u32 *seg,
-                               int pbits, bool skip_first, bool *result_in_1, SortHeads *heads = nullptr,
+                               const SegPlan &plan, bool skip_first, bool *result_in_1, SortHeads *heads = nullptr,
                                bool allow_cmp_finish = true) {
     *result_in_1 = false;
     if (heads) heads->done = false;
     if (n == 0) return KMG_OK;
+    const int pbits = plan.pbits;
     // global LSD passes over the top pbits of the key
-    const std::vector<SortPass> prefix = prefix_digits(pbits);
+    const std::vector<SortPass> prefix = prefix_digits(pbits, plan.shared_top);
     // `skip_first`: the records already arrive partitioned by the first prefix digit (extract_part.h)
     std::vector<SortPass> todo(prefix.begin() + (skip_first && !prefix.empty() ? 1 : 0), prefix.end());
     bool in1 = false;
@@ -1011,16 +1041,17 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
     u64 *ka = in1 ? k1 : k0, *kb = in1 ? k0 : k1;
     V *va = in1 ? v1 : v0, *vb = in1 ? v0 : v1;
 
-    const u32 nseg = 1u << pbits;
+    const u32 nseg = plan.nseg;
     u32 *max_seg = seg + nseg + 1;
     KMG_HIP(hipMemsetAsync(max_seg, 0, 4, ctx->stream));
     {
         ProfScope ps(ctx, KP_SORT_SEGMENTS, 0);
         // (the last global pass of this call leaves its scanned table behind: digit = the key's top bits)
-        const bool narrow = !todo.empty();
+        // (only when that digit is the key's very top: not behind leading bits a key-range build left out of its passes)
+        const bool narrow = !todo.empty() && plan.shared_top == 0 && plan.seg_base == 0;
         hipLaunchKernelGGL(ls_segments_kernel, dim3(nseg / LSEG_PER + 1), dim3(256), 0, ctx->stream, ka, n, pbits,
                            seg, nseg, max_seg, narrow ? (const u32 *)table : (const u32 *)nullptr, div_up_u64(n, RS_TILE),
-                           narrow ? todo.back().bits : 0);
+                           narrow ? todo.back().bits : 0, plan.seg_base);
     }
     u32 h_max = 0;
     KMG_HIP(read_back(ctx, &h_max, max_seg, 4));
@@ -1060,6 +1091,7 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
     }
     if (local_ok) {
         LocalPasses lp;
+        lp.seg_base = plan.seg_base;
         lp.n = (int)rest.size();
         // Reference DBs: counting passes on the top LS_TOP key digits only, the rest is finished by comparison
         // in LDS (measured 0.32 -> 0.14 ms on config 2, and the taxon digits need no pass at all).
