@@ -161,6 +161,7 @@ struct kmg_ctx {
     bool building = false;
     int k = 0, key_len = 0, rc = 0, kind = 0;
     int dust = -1, runofsame = -1;   // MakeDatabase -D / -R, -1 = off
+    bool lds_rank_ok = false;        // returning LDS adds give stable ranks on this device (checked in kmg_create)
     bool ranged = false;             // kmg_build_set_key_range: keep the records of key buckets [range_lo, range_hi)
     u32 range_lo = 0, range_hi = 0;
     u64 *rec_keys = nullptr;     // record keys (left-aligned 2-bit k-mers)

@@ -14,6 +14,7 @@
 #include "common.h"
 #include "extract.h"
 #include "radix.h"
+#include <type_traits>
 
 #define EP_BLOCK 512
 #define EP_WAVES (EP_BLOCK / 64)
@@ -376,17 +377,52 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
     }
 }
 
+// Is the value a returning LDS add hands back a stable rank on this device?  Every wave runs rounds of adds on digits of
+// several distributions (uniform over 256, over 16, over 2, all equal) and holds each returned value against the rank
+// wave_match gives; *bad counts the differences.
+__global__ __launch_bounds__(256) void lds_order_probe_kernel(u32 *bad, int rounds) {
+    __shared__ u32 cnt_a[4][RS_DIGITS];
+    __shared__ u32 cnt_m[4][RS_DIGITS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * RS_DIGITS; i += 256) { (&cnt_a[0][0])[i] = 0; (&cnt_m[0][0])[i] = 0; }
+    __syncthreads();
+    u32 x = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    u32 wrong = 0;
+    for (int r = 0; r < rounds; r++) {
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        const int mode = (blockIdx.x + r) & 3;
+        const u32 d = mode == 0 ? (x >> 8) & 255u : mode == 1 ? (x >> 8) & 15u : mode == 2 ? ((x >> 8) & 1u) * 33u : 77u;
+        const bool valid = ((x >> 20) & 7u) != 0;                 // some lanes sit a round out
+        const u32 got = valid ? atomicAdd(&cnt_a[wave][d], 1u) : 0u;
+        u32 below, total;
+        wave_match(d, valid, below, total);
+        const u32 before = cnt_m[wave][d];
+        if (valid && got != before + below) wrong++;
+        if (valid && below == 0) cnt_m[wave][d] = before + total;
+    }
+    if (wrong) atomicAdd(bad, wrong);
+}
+
 // ---- write pass: from the tile image straight to ranking, staging and the partitioned stores ---------------------
 // Register budget: only the record bits and ranks live per window; the k-mer is re-read from the LDS image where it
 // is needed (broadcast reads), which fits 3 workgroups per CU (<= 80 VGPRs, < 53,760 B of LDS: LDS is handed out in
 // 1280-byte granules on gfx950).
-template <typename V>
+// ATOM: a record's rank among its wave's records of the same digit is what a returning LDS add on the wave's counter
+// of that digit hands back -- same-address adds of one wave instruction are applied in ascending lane order on gfx950
+// and a wave's LDS instructions in program order, so (round, lane) order = window order is kept.  That order is no
+// documented property: lds_order_probe_kernel checks it once per device (kmg_create), and where it fails -- or the
+// library is built with -DEP_RANK_ATOMIC=0 -- the ranks come from wave-level digit matching (wave_match: 8 ballots per
+// round, ~45 VALU instructions where the add is one LDS instruction; measured 0.16 -> 0.0x ms of this pass).
+#ifndef EP_RANK_ATOMIC
+#define EP_RANK_ATOMIC 1
+#endif
+template <typename V, bool ATOM>
 __global__ __launch_bounds__(EP_BLOCK, 6) void extract_part_write_kernel(PartArgs pa) {
     const ExtractArgs &a = pa.e;
     __shared__ u32 pk[EX_TILE / 16 + 4];
     __shared__ u32 stb[EX_TILE / 32 + 4];
     __shared__ u32 wpre[EX_TILE / 32];                 // sequence starts before bitmap word w
-    __shared__ uint16_t wcnt[EP_WAVES][RS_DIGITS];
+    __shared__ typename std::conditional<ATOM, u32, uint16_t>::type wcnt[EP_WAVES][RS_DIGITS];
     __shared__ uint16_t dstart[RS_DIGITS];             // <= EX_TILE
     __shared__ u32 gdelta[RS_DIGITS];
     __shared__ u64 stage[EX_TILE];
@@ -429,6 +465,9 @@ __global__ __launch_bounds__(EP_BLOCK, 6) void extract_part_write_kernel(PartArg
     if (tid < EP_IMG_STB) pk[tid] = img_w;
     else if (tid < EP_IMG_VM) stb[tid - EP_IMG_STB] = img_w;
     __syncthreads();
+#ifdef EPW_PROBE
+    if (EPW_PROBE == 1) return;
+#endif
     if (wave == 0) {
         // starts before each bitmap word: lane owns words 2*lane, 2*lane + 1
         const u32 c0 = __popc(stb[2 * lane]), c1 = __popc(stb[2 * lane + 1]);
@@ -462,14 +501,22 @@ __global__ __launch_bounds__(EP_BLOCK, 6) void extract_part_write_kernel(PartArg
             if (sp) khi = (u32)((revpairs64(ep_window64(pk, pb + j * 64, kmask) >> (64 - 2 * k)) ^ rcx) >> 32);
             else khi = ep_window_hi(pk, pb + j * 64, kmask);
             const u32 d = (khi >> (pa.dshift - 32)) & pa.dmask;                  // dshift >= 32 (choose_pbits <= 24)
-            u32 below, total;
-            wave_match(d, valid, below, total);
-            const u32 before = wcnt[wave][d];
-            lpos[j] = (d << 16) | (before + below);
-            if (valid && below == 0) wcnt[wave][d] = (uint16_t)(before + total);
-            if (j & 1) __builtin_amdgcn_sched_barrier(0);
+            if (ATOM) {
+                const u32 r = valid ? atomicAdd(reinterpret_cast<u32 *>(&wcnt[wave][d]), 1u) : 0u;
+                lpos[j] = (d << 16) | r;
+            } else {
+                u32 below, total;
+                wave_match(d, valid, below, total);
+                const u32 before = wcnt[wave][d];
+                lpos[j] = (d << 16) | (before + below);
+                if (valid && below == 0) wcnt[wave][d] = (uint16_t)(before + total);
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __syncthreads();
+#ifdef EPW_PROBE
+    if (EPW_PROBE == 2) return;
+#endif
         u32 tile_n;
         u32 tdx = tid;                      // opaque copy, as pb: no addresses hoisted out of the loop
         asm volatile("" : "+v"(tdx));
@@ -479,7 +526,7 @@ __global__ __launch_bounds__(EP_BLOCK, 6) void extract_part_write_kernel(PartArg
 #pragma unroll
                 for (int w = 0; w < EP_WAVES; w++) {
                     u32 c = wcnt[w][tdx];
-                    wcnt[w][tdx] = (uint16_t)run;
+                    wcnt[w][tdx] = static_cast<typename std::conditional<ATOM, u32, uint16_t>::type>(run);
                     run += c;
                 }
             }
@@ -491,6 +538,9 @@ __global__ __launch_bounds__(EP_BLOCK, 6) void extract_part_write_kernel(PartArg
             }
         }
         __syncthreads();
+#ifdef EPW_PROBE
+    if (EPW_PROBE == 3) return;
+#endif
 #pragma unroll
         for (int j = 0; j < EP_ROUNDS; j++) {
             if ((imask >> j) & 1) {
@@ -504,12 +554,18 @@ __global__ __launch_bounds__(EP_BLOCK, 6) void extract_part_write_kernel(PartArg
             }
         }
         __syncthreads();
+#ifdef EPW_PROBE
+    if (EPW_PROBE == 4) return;
+#endif
 #pragma unroll 4
         for (int i = 0; i < EP_ROUNDS; i++) {
             const u32 lp = i * EP_BLOCK + tid;
             if (lp < tile_n) a.out_keys[lp + gdelta[sdig[lp]]] = stage[lp];
         }
         __syncthreads();
+#ifdef EPW_PROBE
+    if (EPW_PROBE == 5) return;
+#endif
         // payload of the window: the window's sequence = the tile's first + the sequence starts at or before p.
         // Two copies of the loop behind a block-uniform test: the common one touches LDS only.  (A global load
         // anywhere in the loop, even on a path no lane takes, puts a wait for ALL outstanding vector memory
@@ -551,17 +607,26 @@ __global__ __launch_bounds__(EP_BLOCK, 6) void extract_part_write_kernel(PartArg
             }
         }
         __syncthreads();
+#ifdef EPW_PROBE
+    if (EPW_PROBE == 6) return;
+#endif
 #pragma unroll 4
         for (int i = 0; i < EP_ROUNDS; i++) {
             const u32 lp = i * EP_BLOCK + tid;
             if (lp < tile_n) out_vals[lp + gdelta[sdig[lp]]] = reinterpret_cast<V *>(stage)[lp];
         }
         __syncthreads();
+#ifdef EPW_PROBE
+    if (EPW_PROBE == 7) return;
+#endif
         if (sp == 0 && a.rc && tid < RS_DIGITS) {
 #pragma unroll
             for (int w = 0; w < EP_WAVES; w++) wcnt[w][tid] = 0;
         }
         __syncthreads();
+#ifdef EPW_PROBE
+    if (EPW_PROBE == 8) return;
+#endif
     }
 }
 

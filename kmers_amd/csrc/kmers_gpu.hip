@@ -12,6 +12,7 @@
 #include "collect.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -48,6 +49,31 @@ static int fail(kmg_ctx *ctx, int code, const char *msg) {
 static int resolve_match_scratch(kmg_ctx *ctx);
 static void forget_match_scratch_user(kmg_ctx *ctx);
 
+// Once per device and process: does a returning LDS add hand back a stable rank here (extract_part.h, ATOM)?  A device
+// where the probe cannot run, or finds one difference, takes the wave_match kernels.
+static bool lds_rank_order_holds(kmg_ctx *ctx) {
+    static std::mutex mu;
+    static std::map<int, bool> known;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = known.find(ctx->device);
+    if (it != known.end()) return it->second;
+    bool ok = false;
+    void *d_bad = nullptr;
+    if (ctx->pool.alloc(&d_bad, 64) == KMG_OK) {
+        u32 bad = 1;
+        if (hipMemsetAsync(d_bad, 0, 4, ctx->stream) == hipSuccess) {
+            hipLaunchKernelGGL(lds_order_probe_kernel, dim3(1024), dim3(256), 0, ctx->stream, (u32 *)d_bad, 64);
+            if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                hipStreamSynchronize(ctx->stream) == hipSuccess && hipGetLastError() == hipSuccess)
+                ok = bad == 0;
+        }
+        ctx->pool.release(d_bad);
+    }
+    (void)hipGetLastError();
+    known[ctx->device] = ok;
+    return ok;
+}
+
 extern "C" int kmg_create(int device, kmg_ctx **out) {
     if (!out) return KMG_EINVAL;
     *out = nullptr;
@@ -75,6 +101,9 @@ extern "C" int kmg_create(int device, kmg_ctx **out) {
         return KMG_EDEVICE;
     }
     if (hipEventCreateWithFlags(&ctx->ev_scratch, hipEventDisableTiming) != hipSuccess) ctx->ev_scratch = nullptr;
+    // (KMG_RANK_BY_MATCH in the environment: the wave_match kernels whatever the probe says -- for the test that holds the two
+    // against each other)
+    ctx->lds_rank_ok = EP_RANK_ATOMIC && !getenv("KMG_RANK_BY_MATCH") && lds_rank_order_holds(ctx);
     if (hipHostMalloc(&ctx->h_pin, PIN_BYTES, hipHostMallocDefault) != hipSuccess) ctx->h_pin = nullptr;   // optional
     if (hipHostMalloc(&ctx->h_snap, PIN_BYTES, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_len, hipEventDisableTiming) != hipSuccess ||
@@ -432,8 +461,13 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
         pa.e = a;
         pa.out_base = 0;
 #ifndef EPC_PROBE          // (timing probes of the count pass leave the table unfinished: nothing may be written from it)
-        if (reads && !compact) hipLaunchKernelGGL((extract_part_write_kernel<u64>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
-        else hipLaunchKernelGGL((extract_part_write_kernel<u32>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+        if (ctx->lds_rank_ok) {
+            if (reads && !compact) hipLaunchKernelGGL((extract_part_write_kernel<u64, true>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+            else hipLaunchKernelGGL((extract_part_write_kernel<u32, true>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+        } else {
+            if (reads && !compact) hipLaunchKernelGGL((extract_part_write_kernel<u64, false>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+            else hipLaunchKernelGGL((extract_part_write_kernel<u32, false>), pgrid, dim3(EP_BLOCK), 0, ctx->stream, pa);
+        }
 #endif
     } else {
         KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, tile_count.as<u32>(), tile_off.as<u64>(), ntiles, OpSum(), 0ull,

@@ -112,6 +112,34 @@ def test_read_build_matches_oracle(ctx, k, key_len, seed, alphabet):
     got.close()
 
 
+def test_both_rank_paths_of_the_fused_extractor(monkeypatch):
+    """The fused extractor ranks a tile's records by digit either with returning LDS adds (where the device's probe at
+    kmg_create says their return values are stable ranks) or with wave-level digit matching (KMG_RANK_BY_MATCH forces
+    it): both against the oracle, reads (deep coverage: many equal k-mers whose positions must stay ascending) and a
+    reference with both strands."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(71, 3, 30000, shared_frac=0.3)
+    reads = synth.random_reads(72, genomes, 6000, 150, 0.01, n_rate=0.002)
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    want_ref, want_reads = OracleDB(fa, 0, 31, 6), OracleDB(fq, 1, 31, 6)
+    for by_match in (False, True):
+        if by_match:
+            monkeypatch.setenv("KMG_RANK_BY_MATCH", "1")
+        c = km.Context(0)
+        try:
+            ref = km.make_reference_db(c, fa, 31, 6)
+            rdb, names = km.make_read_db(c, fq, 31, 6)
+            _same_db(ref, want_ref)
+            _same_db(rdb, want_reads)
+            assert names == want_reads.names
+            ref.close()
+            rdb.close()
+        finally:
+            c.close()
+
+
 def test_edge_cases(ctx):
     import kmers_amd as km
     from oracle.c_oracle import OracleDB
