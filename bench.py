@@ -539,7 +539,7 @@ def pmc_stage_traffic():
         if data.get("source_hash") != source_hash():
             return {}
         ks = data["kernels"]
-        steps = max(v["launches"] for name, v in ks.items() if "extract_part_count_kernel<false, false>" in name)
+        steps = max(v["launches"] for name, v in ks.items() if "extract_part_count_kernel<false, false" in name)
         out = {}
         for st, pats in STAGE_SYMBOLS.items():
             tot = 0.0
@@ -561,8 +561,8 @@ KERNEL_SYMBOL = {
     "sort_scatter_reads": "rs_scatter_kernel<unsigned int>", "sort_scatter_ref": "rs_scatter_kernel<unsigned int>",
     "sort_local_reads": "ls_sortidx_kernel<unsigned int, true>", "sort_local_ref": "ls_sort_kernel<unsigned int>",
     "sort_hist_reads": "rs_hist_kernel<unsigned int>", "sort_hist_ref": "rs_hist_kernel<unsigned int>",
-    "extract_write": "extract_part_write_kernel<unsigned int>", "extract_write_ref": "extract_part_write_kernel<unsigned int>",
-    "extract_count": "extract_part_count_kernel<false, false>", "extract_count_ref": "extract_part_count_kernel<true, false>",
+    "extract_write": "extract_part_write_kernel<unsigned int", "extract_write_ref": "extract_part_write_kernel<unsigned int",
+    "extract_count": "extract_part_count_kernel<false, false", "extract_count_ref": "extract_part_count_kernel<true, false",
     "match": "match_kernel",
 }
 

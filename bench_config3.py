@@ -114,7 +114,11 @@ def run(args, dev):
 
     scale = args.scale
     n_taxa = max(20, int(round(10_000 * scale)))
-    n_chunks = 10
+    # KMERS_CFG3_KERNELS_ONLY=1: one reference build and one chunk at full size, nothing checked or timed -- the run
+    # tools/pmc_traffic.py counts HBM bytes over (counter collection serialises every launch: the whole job would take
+    # the better part of an hour under it)
+    kernels_only = os.environ.get("KMERS_CFG3_KERNELS_ONLY") == "1"
+    n_chunks = 1 if kernels_only else 10
     chunk_reads = max(1000, int(round(10_000_000 * scale)))
     log = lambda *a: print("[cfg3 %6.1fs]" % (time.perf_counter() - t_start), *a, flush=True)
     t_start = time.perf_counter()
@@ -140,7 +144,8 @@ def run(args, dev):
 
     # ---- reference build: once to warm the pool (hipMalloc of ~100 GB), then timed, then once more under the hook
     ref_ms = []
-    for rep in range(3):
+    n_rep = 1 if kernels_only else 3
+    for rep in range(n_rep):
         if rep == 2:
             ctx_ref.prof_enable(True)
             ctx_ref.prof_reset()
@@ -150,23 +155,25 @@ def run(args, dev):
         torch.cuda.synchronize()
         ref_ms.append((time.perf_counter() - t0) * 1e3)
         assert nw == n_ref_win, (nw, n_ref_win)
-        if rep < 2:
+        if rep < n_rep - 1:
             lib.kmg_db_free(h)
     prof_ref = {k_: v for k_, v in ctx_ref.prof().items() if v["launches"]}
     ctx_ref.prof_enable(False)
     ref = km.KmerDatabase(ctx_ref, h)
-    t_ref = ref_ms[1] * 1e-3
-    log("reference built: %d distinct k-mers, %d (k-mer, taxon) pairs; %.1f / %.1f / %.1f ms" % (ref.n_unique, ref.n_values, *ref_ms))
+    t_ref = ref_ms[min(1, len(ref_ms) - 1)] * 1e-3
+    log("reference built: %d distinct k-mers, %d (k-mer, taxon) pairs; %s ms" % (ref.n_unique, ref.n_values, " / ".join("%.1f" % m for m in ref_ms)))
 
     # ---- reads: 10 chunks against the resident reference
     d_reads = torch.empty(chunk_reads * RLEN, dtype=torch.uint8, device=dev)
     d_roff = torch.arange(chunk_reads + 1, dtype=torch.int64, device=dev) * RLEN
     n_chunk_win = chunk_reads * (RLEN - K + 1)
     d_hit = torch.empty(n_chunk_win + 16, dtype=torch.int64, device=dev)
+    if os.environ.get("KMERS_CFG3_DEBUG"):
+        d_hit.fill_(-5)
     t_chunks, u_total, hits_total, match_ms = [], 0, 0, []
     first_reads = None
     prof_reads = None
-    for ci in range(n_chunks + 1):                       # chunk 0 is run twice: the first pass warms the pool
+    for ci in range(1 if kernels_only else 0, n_chunks + 1):     # chunk 0 is run twice: the first pass warms the pool
         chunk = max(ci - 1, 0)
         if ci <= 1:
             make_reads(torch, dev, bases, n_taxa, chunk_reads, 4, d_reads)
@@ -189,6 +196,9 @@ def run(args, dev):
         u = C.c_uint64()
         lib.kmg_db_info(rdb, None, None, None, None, C.byref(u), None)
         hits = int((d_hit[:u.value] >= 0).sum().item())
+        if os.environ.get("KMERS_CFG3_DEBUG"):
+            log("debug: min %d max %d, entries >= U_ref %d" % (int(d_hit[:u.value].min().item()), int(d_hit[:u.value].max().item()),
+                                                            int((d_hit[:u.value] >= ref.n_unique).sum().item())))
         lib.kmg_db_free(rdb)
         if ci == n_chunks:
             prof_reads = {k_: v for k_, v in ctx.prof().items() if v["launches"]}
@@ -202,6 +212,8 @@ def run(args, dev):
             (chunk, " (warm-up)" if ci == 0 else "", chunk_reads, u.value, hits, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
     t_reads = sum(t_chunks)
     n_read_win = n_chunk_win * n_chunks
+    if kernels_only:
+        return {"kernels_only": True, "ref_ms": ref_ms, "chunk_ms": [t * 1e3 for t in t_chunks]}
 
     # ---- TaxaCounts
     tc_ms = []

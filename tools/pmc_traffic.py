@@ -24,9 +24,14 @@ CALIB_BYTES = (1 << 27) * 8
 
 def run_pass(counter):
     out = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (TAG, counter))
-    cmd = ["timeout", "-s", "KILL", "240" if not BENCH_ARGS else "600", "rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+    # (counters for the library's kernels only: a config-3 run launches tens of thousands of small torch kernels while it
+    # makes its input, each of which would be serialised and read out)
+    only = ["--kernel-include-regex", "ls_|rs_|extract_|rd_|match_|scan_|number_reads|calib_copy"] if BENCH_ARGS else []
+    cmd = ["timeout", "-s", "KILL", "240" if not BENCH_ARGS else "300", "rocprofv3", "--pmc", counter] + only + ["--output-format", "csv", "-d", out, "--",
            sys.executable, os.path.join(ROOT, "bench.py")] + (BENCH_ARGS or ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--calib"])
     env = dict(os.environ, TMPDIR="/tmp")
+    if "--config" in BENCH_ARGS and BENCH_ARGS[BENCH_ARGS.index("--config") + 1] == "3":
+        env["KMERS_CFG3_KERNELS_ONLY"] = "1"          # one reference build + one chunk: the launches whose bytes are wanted
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     per = {}
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
