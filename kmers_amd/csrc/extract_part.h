@@ -714,3 +714,134 @@ __global__ __launch_bounds__(EP_BLOCK) void extract_img_write_kernel(PartArgs pa
         }
     }
 }
+
+// ---- the same for batches that keep little (key-range builds: a slice of the key space, ~1 window in 64 at 64 of 4096
+// buckets).  A 512-thread workgroup per tile spends its time waiting for a 2.6 KB image to arrive and on 64 wave-rounds
+// with a lane or two at work; here ONE WAVE takes a tile -- eight times the tiles in flight per CU, no workgroup
+// barrier -- and a LANE takes a record: the wave first notes, per (wave, round) of the image's layout, which lanes hold a
+// forward / reverse-complement record (two 64-bit masks) and how many records precede the round; record r of the tile
+// then finds its round by a binary search over those counts and its lane by one over the masks' bit counts, and the
+// stores of 64 consecutive records leave together.  Same order as extract_img_write_kernel: window by window, a
+// window's forward record before its reverse complement.
+#define EPS_WAVES 4                                    // tiles per workgroup (one per wave)
+__device__ __forceinline__ void eps_wave_sync() {     // a wave's LDS traffic is in program order: keep the compiler to it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <typename V>
+__global__ __launch_bounds__(64 * EPS_WAVES) void extract_img_write_sparse_kernel(PartArgs pa) {
+    const ExtractArgs &a = pa.e;
+    __shared__ u32 s_pk[EPS_WAVES][EX_TILE / 16 + 4];
+    __shared__ u32 s_stb[EPS_WAVES][EX_TILE / 32 + 4];
+    __shared__ u32 s_wpre[EPS_WAVES][EX_TILE / 32];
+    __shared__ u64 s_bv[EPS_WAVES][EP_WAVES * EP_ROUNDS];   // lanes with a forward record, per (wave, round) of the image
+    __shared__ u64 s_br[EPS_WAVES][EP_WAVES * EP_ROUNDS];   // ... with a reverse-complement record
+    __shared__ u32 s_before[EPS_WAVES][EP_WAVES * EP_ROUNDS + 1];   // records before the round; [64] = the tile's total
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u32 tile = blockIdx.x * EPS_WAVES + wv;
+    if (tile >= pa.ntiles) return;
+    u32 *pk = s_pk[wv], *stb = s_stb[wv], *wpre = s_wpre[wv], *before = s_before[wv];
+    u64 *bv = s_bv[wv], *br = s_br[wv];
+    const u64 t0 = (u64)tile * EX_TILE;
+    const int k = a.k;
+    const u32 *img = pa.img + (u64)tile * EP_IMG_WORDS;
+    // everything the tile needs, asked for at once: the image's words (6 + 1 per lane), the record bits of the image's
+    // thread w * 64 + lane for w = 0 .. 7
+    u32 iw[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const u32 at = (u32)i * 64 + (u32)lane;
+        iw[i] = at < EP_IMG_VM ? img[at] : 0u;
+    }
+    u32 vmw[EP_WAVES], rmw[EP_WAVES];
+#pragma unroll
+    for (int w = 0; w < EP_WAVES; w++) {
+        vmw[w] = reinterpret_cast<const uint8_t *>(img + EP_IMG_VM)[w * 64 + lane];
+        rmw[w] = a.rc ? reinterpret_cast<const uint8_t *>(img + EP_IMG_RM)[w * 64 + lane] : 0u;
+    }
+    const bool dup = img[EP_IMG_FLAG] != 0;
+    const u32 s_lo = a.tile_seq[tile];
+    const u32 s_end = a.tile_end[tile];
+    const u64 out_base = a.state[ST_NREC] + a.tile_off[tile];
+    const u32 n = a.tile_count[tile];
+    if (n == 0) return;
+    static_assert(EP_IMG_VM <= 7 * 64 && EP_IMG_STB == EX_TILE / 16 + 4, "image words per lane");
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const u32 at = (u32)i * 64 + (u32)lane;
+        if (at < EP_IMG_STB) pk[at] = iw[i];
+        else if (at < EP_IMG_VM) stb[at - EP_IMG_STB] = iw[i];
+    }
+    // the rounds' masks and the records before each round, in the image's (wave, round) order = window order
+    u32 run = 0;
+#pragma unroll
+    for (int w = 0; w < EP_WAVES; w++) {
+#pragma unroll
+        for (int j = 0; j < EP_ROUNDS; j++) {
+            const u64 mv = __ballot((vmw[w] >> j) & 1u), mr = __ballot((rmw[w] >> j) & 1u);
+            if (lane == 0) {
+                bv[w * EP_ROUNDS + j] = mv;
+                br[w * EP_ROUNDS + j] = mr;
+                before[w * EP_ROUNDS + j] = run;
+            }
+            run += (u32)__popcll(mv) + (u32)__popcll(mr);
+        }
+    }
+    if (lane == 0) before[EP_WAVES * EP_ROUNDS] = run;
+    eps_wave_sync();
+    {
+        const u32 c0 = __popc(stb[2 * lane]), c1 = __popc(stb[2 * lane + 1]);
+        u32 inc = c0 + c1;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const u32 o = __shfl_up(inc, dd, 64);
+            if (lane >= dd) inc += o;
+        }
+        wpre[2 * lane] = inc - c0 - c1;
+        wpre[2 * lane + 1] = inc - c1;
+    }
+    eps_wave_sync();
+    const u64 kmask = k == 32 ? ~0ull : ~(~0ull >> (2 * k));
+    const u64 rcx = 0xAAAAAAAAAAAAAAAAull & kmask;
+    V *ov = reinterpret_cast<V *>(a.out_vals);
+    for (u32 r0 = 0; r0 < run; r0 += 64) {
+        const u32 r = r0 + (u32)lane;
+        if (r >= run) continue;
+        // the round: the last one with no more than r records before it (it holds records: the next round has more)
+        u32 lo = 0, hi = EP_WAVES * EP_ROUNDS;             // before[lo] <= r < before[hi]
+#pragma unroll
+        for (int st = 0; st < 6; st++) {
+            const u32 mid = (lo + hi) >> 1;
+            if (before[mid] <= r) lo = mid; else hi = mid;
+        }
+        const u32 q = r - before[lo];
+        const u64 mv = bv[lo], mr = br[lo];
+        // the lane: the first t with more than q records in lanes 0 .. t
+        u32 tl = 0, th = 63;
+#pragma unroll
+        for (int st = 0; st < 6; st++) {
+            const u32 mid = (tl + th) >> 1;
+            const u64 upto = mid == 63 ? ~0ull : ((1ull << (mid + 1)) - 1);
+            const u32 c = (u32)__popcll(mv & upto) + (u32)__popcll(mr & upto);
+            if (c > q) th = mid; else tl = mid + 1;
+        }
+        const u32 t = tl;
+        const u64 below = t == 0 ? 0ull : ((1ull << t) - 1);
+        const u32 cb = (u32)__popcll(mv & below) + (u32)__popcll(mr & below);
+        const bool has_f = (mv >> t) & 1ull;
+        const bool is_rc = !has_f || q != cb;                // the forward record comes first where both are there
+        const u32 p = (lo >> 3) * (64 * EP_ROUNDS) + (lo & 7u) * 64 + t;
+        u64 key = ep_window64(pk, p, kmask);
+        if (is_rc) key = revpairs64(key >> (64 - 2 * k)) ^ rcx;
+        u32 rel;
+        if (dup) rel = ep_seq_rel(a, s_lo, s_end, t0 + p);
+        else rel = wpre[p >> 5] + __popc(stb[p >> 5] >> (31 - (p & 31)));
+        const u64 sq = (u64)s_lo + rel;
+        V v;
+        if (a.kind == KMG_PAYLOAD_TAXON) v = (V)(u32)a.seq_id[sq];
+        else v = (V)(((u64)(u32)a.read_index[sq] << 16) | (u64)((t0 + p - a.seq_off[sq]) & 0xFFFFu));   // ReadPos(read, (short)pos)
+        a.out_keys[out_base + r] = key;
+        ov[out_base + r] = v;
+    }
+}

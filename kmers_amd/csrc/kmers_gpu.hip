@@ -472,17 +472,25 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     } else {
         KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, tile_count.as<u32>(), tile_off.as<u64>(), ntiles, OpSum(), 0ull,
                                                     agg.as<u64>(), nullptr, true, KP_SCAN)));
+        u64 batch_added = 0;
         if (exact) {
             u64 before = 0, added = 0;
             KMG_HIP(read_back(ctx, &before, ctx->d_state + ST_NREC, 8));
             KMG_HIP(read_back(ctx, &added, tile_off.as<u64>() + ntiles, 8));
+            batch_added = added;
             upper = std::max<u64>(before + added, 1);
             KMG_TRY(ensure_record_capacity(ctx, upper));
             a.out_keys = ctx->rec_keys; a.out_vals = ctx->rec_vals;
         }
         ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases /* + records * rec_b, added at finish when N is known */);
         pa.e = a;
-        if (reads) hipLaunchKernelGGL((extract_img_write_kernel<u64>), dim3(ntiles), dim3(EP_BLOCK), 0, ctx->stream, pa);
+        // a batch that keeps little (key-range builds know their count by now): one wave per tile, a lane per record
+        const bool sparse = exact && batch_added < (u64)ntiles * 1024;
+        if (sparse) {
+            const dim3 sgrid(div_up_u64(ntiles, EPS_WAVES)), sblk(64 * EPS_WAVES);
+            if (reads) hipLaunchKernelGGL((extract_img_write_sparse_kernel<u64>), sgrid, sblk, 0, ctx->stream, pa);
+            else hipLaunchKernelGGL((extract_img_write_sparse_kernel<u32>), sgrid, sblk, 0, ctx->stream, pa);
+        } else if (reads) hipLaunchKernelGGL((extract_img_write_kernel<u64>), dim3(ntiles), dim3(EP_BLOCK), 0, ctx->stream, pa);
         else hipLaunchKernelGGL((extract_img_write_kernel<u32>), dim3(ntiles), dim3(EP_BLOCK), 0, ctx->stream, pa);
         hipLaunchKernelGGL(extract_advance_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, tile_off.as<u64>(), ntiles);
     }

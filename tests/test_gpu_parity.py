@@ -248,6 +248,39 @@ def test_many_empty_reads_inside_one_tile(ctx):
         got.close()
 
 
+def test_later_batches_of_key_range_builds_with_empty_reads(ctx):
+    """Later batches of a build are written from the count pass's tile image, by a workgroup per tile or -- where a key
+    range keeps little -- by a wave per tile with a lane per record.  Both against the oracle's slice: three batches, a
+    narrow and a wide key range, tiles in which thousands of empty reads start at one position (sequences looked up by
+    search instead of by counting start bits), reads whose headers repeat across the batch cuts."""
+    import kmers_amd as km
+    from kmers_amd import parse, synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(63, 3, 20000, shared_frac=0.2)
+    reads = synth.random_reads(64, genomes, 900, 120, 0.01, n_rate=0.003)
+    recs = [synth.fastq_bytes(reads[i:i + 1], first_index=i) for i in range(reads.shape[0])]
+    empties = b"".join(b"@e%d\n\n+\n\n" % i for i in range(5000))
+    fq = b"".join(recs[:300]) + empties + b"".join(recs[300:650]) + empties.replace(b"@e", b"@f") + b"".join(recs[650:])
+    k, l = 27, 4
+    want = OracleDB(fq, 1, k, l, threads=4)
+    b = parse.parse(fq, parse.FASTQ, k).batch
+    cuts = [0, 280, 5400, b.nseq]
+    nkeys = 4 ** l
+    for first, end in ((0, nkeys), (7, 9), (9, 200), (200, nkeys)):
+        fc = km.FileCreator(ctx, l, k, "read", rc=False, key_range=(first, end))
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            a0, a1 = int(b.seq_off[lo]), int(b.seq_off[hi])
+            fc.add_kmers(km.SequenceBatch(b.bases[a0:a1], b.seq_off[lo:hi + 1] - b.seq_off[lo], seq_tok=b.seq_tok[lo:hi]))
+        got = fc.create()
+        h = got.fetch()
+        u0, u1 = int(want.bucket_off[first]), int(want.bucket_off[end])
+        v0, v1 = int(want.val_off[u0]), int(want.val_off[u1])
+        assert np.array_equal(h["keys"], want.keys[u0:u1])
+        assert np.array_equal(h["val_off"].astype(np.int64), want.val_off[u0:u1 + 1].astype(np.int64) - v0)
+        assert np.array_equal(h["val_a"], want.val_a[v0:v1]) and np.array_equal(h["val_b"], want.val_b[v0:v1])
+        got.close()
+
+
 def test_large_first_batch_then_more_batches(ctx):
     """The first batch of a build is written already partitioned by the sort's first digit; a second batch
     voids that plan (window-order append) and finish() must run every pass.  Both DB kinds, sizes well above
