@@ -275,37 +275,51 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
         r2w = (((r2w >> 1) & 0x55555555u) | ((r2w & 0x55555555u) << 1)) ^ 0xAAAAAAAAu;
     }
     u32 vmb = 0, rmb = 0;                                // bit j = window q + j is a forward / reverse-complement record
+    // A record's partition digit and its key bucket lie in the k-mer's upper word (dshift >= 32 for every plan, see
+    // choose_pbits; key lengths stop at 12 bases): the lower word is formed only where something reads it -- a -D / -R
+    // filter, or the palindrome test of an even k -- and nothing here shifts 64 bits by a run-time amount (a quarter
+    // of the rate of a 32-bit shift).
+    const u32 km_hi = (u32)(kmask >> 32), km_lo = (u32)kmask;
+    const u32 rcx_hi = (u32)(rcx >> 32), rcx_lo = (u32)rcx;
+    const bool k_even = (k & 1) == 0;
+    const bool filters = FILT && (a.runofsame >= 0 || a.dust >= 0);
+    const int bshift = a.range_shift - 32;
 #pragma unroll
     for (int j = 0; j < EP_ROUNDS; j++) {
-        const u32 hi = __funnelshift_l(y1, y0, 2 * j);
-        // (without reverse complements or filters only the digit is needed here: the upper word)
-        u64 key;
-        if (RC || FILT) key = ((((u64)hi) << 32) | __funnelshift_l(y2, y1, 2 * j)) & kmask;
-        else key = ((u64)(hi & (u32)(kmask >> 32))) << 32;
+        const u32 hi = __funnelshift_l(y1, y0, 2 * j) & km_hi;
+        u32 lo = 0;
+        if ((RC && k_even) || filters) lo = __funnelshift_l(y2, y1, 2 * j) & km_lo;
         bool ok = (okb >> (7 - j)) & 1u;
-        if (FILT) {
+        if (filters) {
+            const u64 key = (((u64)hi) << 32) | lo;
             if (ok && a.runofsame >= 0) ok = runofsame_keep(key, k, a.runofsame);
             if (ok && a.dust >= 0) ok = dust_keep(key, k, a.dust);
         }
         bool emit_rc = false;
-        u64 rk = 0;
+        u32 rh = 0;
         if (RC) {
             const int o = 48 - j - k;                    // first base of the window's reverse complement in r0:r1:r2w
-            u32 rh, rl;
-            if (o < 16) { rh = __funnelshift_l(r1, r0, 2 * o); rl = __funnelshift_l(r2w, r1, 2 * o); }
-            else if (o < 32) { rh = __funnelshift_l(r2w, r1, 2 * (o - 16)); rl = __funnelshift_l(0u, r2w, 2 * (o - 16)); }
-            else { rh = __funnelshift_l(0u, r2w, 2 * (o - 32)); rl = 0; }
-            rk = ((((u64)rh) << 32) | rl) & kmask;
-            emit_rc = ok && !(((k & 1) == 0) && (rk ^ rcx) == key);
+            if (o < 16) rh = __funnelshift_l(r1, r0, 2 * o);
+            else if (o < 32) rh = __funnelshift_l(r2w, r1, 2 * (o - 16));
+            else rh = __funnelshift_l(0u, r2w, 2 * (o - 32));
+            rh &= km_hi;
+            emit_rc = ok;
+            if (k_even) {                                // Kmer.isOwnRC (Kmer.java:210-225) is a palindrome test on even lengths
+                u32 rl;
+                if (o < 16) rl = __funnelshift_l(r2w, r1, 2 * o);
+                else if (o < 32) rl = __funnelshift_l(0u, r2w, 2 * (o - 16));
+                else rl = 0;
+                rl &= km_lo;
+                emit_rc = ok && !((rh ^ rcx_hi) == hi && (rl ^ rcx_lo) == lo);
+            }
         }
         if (FILT && a.ranged) {
-            const u32 fb = (u32)(key >> a.range_shift), rb = (u32)(rk >> a.range_shift);
+            const u32 fb = hi >> bshift, rb = rh >> bshift;
             emit_rc = emit_rc && rb >= a.range_lo && rb < a.range_hi;
             ok = ok && fb >= a.range_lo && fb < a.range_hi;
         }
         vmb |= (u32)ok << j;
-        // (the partition digit lies in the key's upper word: dshift >= 32 for every plan, see choose_pbits)
-        const u32 fd = ((u32)(key >> 32) >> (pa.dshift - 32)) & pa.dmask;
+        const u32 fd = (hi >> (pa.dshift - 32)) & pa.dmask;
         if (HIST) {
             if (RC || FILT) {
                 if (ok) atomicAdd(&hist[0][fd], 1u);
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
         }
         if (RC) {
             rmb |= (u32)emit_rc << j;
-            if (HIST && emit_rc) atomicAdd(&hist[1][((u32)(rk >> 32) >> (pa.dshift - 32)) & pa.dmask], 1u);
+            if (HIST && emit_rc) atomicAdd(&hist[1][(rh >> (pa.dshift - 32)) & pa.dmask], 1u);
         }
     }
 #ifdef EPC_PROBE
