@@ -277,8 +277,9 @@ __global__ __launch_bounds__(EP_BLOCK, 8) void extract_part_count_kernel(PartArg
     u32 vmb = 0, rmb = 0;                                // bit j = window q + j is a forward / reverse-complement record
     // A record's partition digit and its key bucket lie in the k-mer's upper word (dshift >= 32 for every plan, see
     // choose_pbits; key lengths stop at 12 bases): the lower word is formed only where something reads it -- a -D / -R
-    // filter, or the palindrome test of an even k -- and nothing here shifts 64 bits by a run-time amount (a quarter
-    // of the rate of a 32-bit shift).
+    // filter, or the palindrome test of an even k --, and masks, compares and shifts are 32-bit ones (half the
+    // instructions of their 64-bit forms; the shift itself is not the cost: tools/exp/shift64_rate.hip puts a 64-bit
+    // shift by a wave-uniform amount at ~1.2 plain instructions).
     const u32 km_hi = (u32)(kmask >> 32), km_lo = (u32)kmask;
     const u32 rcx_hi = (u32)(rcx >> 32), rcx_lo = (u32)rcx;
     const bool k_even = (k & 1) == 0;
