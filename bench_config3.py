@@ -97,7 +97,7 @@ def _pmc_traffic(kernel_id):
     data = json.load(open(files[-1]))
     if data.get("source_hash") != source_hash():
         return None, "%s was measured on other kernel sources" % os.path.basename(files[-1])
-    syms = [sym] + (["ls_sortidx_kernel<unsigned int, false>"] if kernel_id == "sort_local_ref" else [])
+    syms = [sym] + (["ls_sortidx_kernel<unsigned int, false"] if kernel_id == "sort_local_ref" else [])
     hits = [int(v["traffic_bytes_per_launch"]) for name, v in data["kernels"].items() if any(s_ in name for s_ in syms)]
     if not hits:
         return None, "no measurement"

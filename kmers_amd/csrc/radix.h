@@ -602,7 +602,7 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
 // One stable counting pass of the one-word-per-record local sort: the wave's words (registers) -> dst[] in digit order,
 // and, if `reload`, back into the registers in the new order.  Round j of this wave holds slots iff j < ALWAYS (known
 // at compile time) or j < nact (wave-uniform).  Three barriers; wcnt rows must be zero on entry and are zero on exit.
-template <int R, int ALWAYS>
+template <int R, int ALWAYS, bool ATOM>
 __device__ __forceinline__ void ls_word_pass(u64 (&w)[R], u32 nact, int shift, u32 mask, uint16_t (*wcnt)[RS_DIGITS],
                                              uint16_t (*wbase)[RS_DIGITS], u64 *dst, u32 wave_base, bool reload) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -612,11 +612,19 @@ __device__ __forceinline__ void ls_word_pass(u64 (&w)[R], u32 nact, int shift, u
     for (int j = 0; j < R; j++) {
         if (!LSW_ACT(j)) continue;
         const u32 d = (u32)(w[j] >> shift) & mask;
-        u32 below, total;
-        wave_match(d, true, below, total);
-        const u32 before = wcnt[wave][d];
-        rank[j] = before + below;
-        wcnt[wave][d] = before + total;      // every lane of the digit stores the same sum: no branch around the store
+        if (ATOM) {
+            // the rank = what a returning LDS add on the wave's counter hands back (two 16-bit counters per 32-bit word, a
+            // wave holds at most LS_ITEMS * 64 records: the halves never carry) -- where the device's probe allows it, see
+            // extract_part.h (ATOM).  ~45 VALU instructions of wave_match become one LDS instruction: 0.927 -> 0.905 ms.
+            const u32 old = atomicAdd(reinterpret_cast<u32 *>(&wcnt[wave][d & ~1u]), (d & 1u) ? 0x10000u : 1u);
+            rank[j] = (d & 1u) ? (old >> 16) : (old & 0xFFFFu);
+        } else {
+            u32 below, total;
+            wave_match(d, true, below, total);
+            const u32 before = wcnt[wave][d];
+            rank[j] = before + below;
+            wcnt[wave][d] = before + total;      // every lane of the digit stores the same sum: no branch around the store
+        }
     }
     __syncthreads();
     if (wave == 0) {
@@ -676,7 +684,7 @@ __device__ __forceinline__ void ls_word_pass(u64 (&w)[R], u32 nact, int shift, u
 #define LS_FOLD_AFTER 2          // passes before the groups are looked for
 #define LS_GROUPS_MAX 1024       // two group words per thread; a 12-bit group number
 
-template <typename V, bool HEADS, int ROUNDS>
+template <typename V, bool HEADS, int ROUNDS, bool ATOM>
 __device__ __forceinline__ u32 ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *__restrict__ keys_out, V *__restrict__ vals_out,
                                                 const LocalPasses &lp, int pbits, u32 *__restrict__ ucount, u32 s0, u32 m,
                                                 uint16_t (*wcnt)[RS_DIGITS], uint16_t (*wbase)[RS_DIGITS], u64 *swords, V *svals) {
@@ -714,7 +722,7 @@ __device__ __forceinline__ u32 ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *__
     *reinterpret_cast<uint2 *>(&wcnt[wave][4 * lane]) = make_uint2(0, 0);
     const u64 seg_prefix = pbits > 0 ? ((u64)(blockIdx.x + lp.seg_base) << (64 - pbits)) : 0ull;
     for (int p = 0; p < lp.n; p++) {
-        ls_word_pass<ROUNDS, ROUNDS - 1>(sw, nact, lp.shift[p] + pbits, (1u << lp.bits[p]) - 1u, wcnt, wbase, swords, wave_base, p + 1 < lp.n);
+        ls_word_pass<ROUNDS, ROUNDS - 1, ATOM>(sw, nact, lp.shift[p] + pbits, (1u << lp.bits[p]) - 1u, wcnt, wbase, swords, wave_base, p + 1 < lp.n);
         if (LS_FOLD && HEADS && p + 1 == LS_FOLD_AFTER && lp.n >= LS_FOLD_AFTER + 2) {
             // ---- groups: runs of equal words (the index bits aside) in the order of the two lowest digits -------------
             u32 *wtot = reinterpret_cast<u32 *>(&wbase[0][0]);   // heads per wave-round, in slot order (wbase is free between passes)
@@ -831,7 +839,7 @@ __device__ __forceinline__ u32 ls_sortidx_body(u64 *keys_in, V *vals_in, u64 *__
 // The second half of the fold (see ls_sortidx_body): G group words in swords[0 .. G), the groups' first slots behind
 // them, every record's (group number << 12 | load index) in the upper half of swords.  Compiled once, behind the
 // switch over the round counts: nothing of the body's registers is live here.
-template <typename V>
+template <typename V, bool ATOM>
 __device__ __forceinline__ void ls_fold_tail(u64 *keys_in, V *vals_in, V *__restrict__ vals_out, const LocalPasses &lp, int pbits,
                                              u32 *__restrict__ ucount, u32 s0, u32 m, u32 G, uint16_t (*wcnt)[RS_DIGITS],
                                              uint16_t (*wbase)[RS_DIGITS], u64 *swords, V *svals) {
@@ -859,7 +867,7 @@ __device__ __forceinline__ void ls_fold_tail(u64 *keys_in, V *vals_in, V *__rest
     // pass per digit is needed here: ONE counting pass on the top eight bits leaves buckets of a few words each, and
     // a word's place inside its bucket is the number of smaller words there (a short walk through LDS).  Five barriers
     // instead of twelve for the four passes this replaces: with a few hundred words per segment a pass is all latency.
-    ls_word_pass<2, 0>(gw, gnact, 56, 0xFFu, wcnt, wbase, gbuf, gwave_base, true);
+    ls_word_pass<2, 0, ATOM>(gw, gnact, 56, 0xFFu, wcnt, wbase, gbuf, gwave_base, true);
     u32 npos[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
@@ -968,11 +976,11 @@ __global__ __launch_bounds__(256) void big_copy_kernel(const BigChunk *__restric
     }
 }
 
-template <typename V, bool HEADS>
+template <typename V, bool HEADS, bool ATOM>
 __global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *keys_in, V *vals_in, u64 *__restrict__ keys_out,
                                                                V *__restrict__ vals_out, const u32 *__restrict__ seg_off,
                                                                LocalPasses lp, int pbits, u32 *__restrict__ ucount) {
-    __shared__ uint16_t wcnt[LS_WAVES][RS_DIGITS];
+    __shared__ __align__(8) uint16_t wcnt[LS_WAVES][RS_DIGITS];
     __shared__ uint16_t wbase[LS_WAVES][RS_DIGITS];
     __shared__ u64 swords[LS_MAX];
     __shared__ V svals[LS_MAX];
@@ -985,13 +993,13 @@ __global__ __launch_bounds__(LS_BLOCK, LS_MINWAVES) void ls_sortidx_kernel(u64 *
     }
     u32 G = 0;
     switch ((m + LS_BLOCK - 1) / LS_BLOCK) {
-        case 1: G = ls_sortidx_body<V, HEADS, 1>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
-        case 2: G = ls_sortidx_body<V, HEADS, 2>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
-        case 3: G = ls_sortidx_body<V, HEADS, 3>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
-        case 4: G = ls_sortidx_body<V, HEADS, 4>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
-        default: G = ls_sortidx_body<V, HEADS, 5>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        case 1: G = ls_sortidx_body<V, HEADS, 1, ATOM>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        case 2: G = ls_sortidx_body<V, HEADS, 2, ATOM>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        case 3: G = ls_sortidx_body<V, HEADS, 3, ATOM>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        case 4: G = ls_sortidx_body<V, HEADS, 4, ATOM>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
+        default: G = ls_sortidx_body<V, HEADS, 5, ATOM>(keys_in, vals_in, keys_out, vals_out, lp, pbits, ucount, s0, m, wcnt, wbase, swords, svals); break;
     }
-    if (LS_FOLD && HEADS && G) ls_fold_tail<V>(keys_in, vals_in, vals_out, lp, pbits, ucount, s0, m, G, wcnt, wbase, swords, svals);
+    if (LS_FOLD && HEADS && G) ls_fold_tail<V, ATOM>(keys_in, vals_in, vals_out, lp, pbits, ucount, s0, m, G, wcnt, wbase, swords, svals);
 }
 
 // Gathers what ls_sortidx_kernel<.., true> left per segment into the DB arrays: one block per segment.
@@ -1115,8 +1123,12 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
             // key digits only and room for a 12-bit index under the key: the one-word-per-record kernel
             if (idx_kernel) {
                 if (with_heads) {
-                    hipLaunchKernelGGL((ls_sortidx_kernel<V, true>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg,
-                                       lp, pbits, heads->ucount);
+                    if (ctx->lds_rank_ok)
+                        hipLaunchKernelGGL((ls_sortidx_kernel<V, true, true>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg,
+                                           lp, pbits, heads->ucount);
+                    else
+                        hipLaunchKernelGGL((ls_sortidx_kernel<V, true, false>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg,
+                                           lp, pbits, heads->ucount);
                     heads->done = true;
                     heads->head_keys = ka;
                     heads->head_first = va;
@@ -1124,8 +1136,12 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
                     heads->seg_off = seg;
                     heads->nseg = nseg;
                 } else
-                    hipLaunchKernelGGL((ls_sortidx_kernel<V, false>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg,
-                                       lp, pbits, (u32 *)nullptr);
+                    if (ctx->lds_rank_ok)
+                        hipLaunchKernelGGL((ls_sortidx_kernel<V, false, true>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg,
+                                           lp, pbits, (u32 *)nullptr);
+                    else
+                        hipLaunchKernelGGL((ls_sortidx_kernel<V, false, false>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg,
+                                           lp, pbits, (u32 *)nullptr);
             } else
                 hipLaunchKernelGGL((ls_sort_kernel<V>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp);
             KMG_HIP(hipGetLastError());
