@@ -559,7 +559,7 @@ def pmc_stage_traffic():
 # the larger one)
 KERNEL_SYMBOL = {
     "sort_scatter_reads": "rs_scatter_kernel<unsigned int>", "sort_scatter_ref": "rs_scatter_kernel<unsigned int>",
-    "sort_local_reads": "ls_sortidx_kernel<unsigned int, true", "sort_local_ref": "ls_sort_kernel<unsigned int>",
+    "sort_local_reads": "ls_sortidx_kernel<unsigned int, true", "sort_local_ref": "ls_sort_kernel<unsigned int",
     "sort_hist_reads": "rs_hist_kernel<unsigned int>", "sort_hist_ref": "rs_hist_kernel<unsigned int>",
     "extract_write": "extract_part_write_kernel<unsigned int", "extract_write_ref": "extract_part_write_kernel<unsigned int",
     "extract_count": "extract_part_count_kernel<false, false", "extract_count_ref": "extract_part_count_kernel<true, false",

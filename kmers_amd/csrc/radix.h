@@ -399,7 +399,7 @@ __device__ __forceinline__ bool ls_greater(u64 ka, V va, u64 kb, V vb, int mode)
 // still agree on those digits.  A segment with an over-long run is sorted with the complete digit list
 // (payload digits, then every key digit), which is correct from any arrangement the stable steps produce.
 // (compiled once per number of rounds, as ls_sortidx_body: straight-line loops over a thread's records)
-template <typename V, int ROUNDS>
+template <typename V, int ROUNDS, bool ATOM>
 __device__ __forceinline__ void ls_sort_body(const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
                                              u64 *__restrict__ keys_out, V *__restrict__ vals_out, const LocalPasses &lp, u32 s0, u32 m,
                                              uint16_t (*wcnt)[RS_DIGITS], uint16_t (*wbase)[RS_DIGITS], u64 *skeys, V *svals) {
@@ -448,11 +448,16 @@ __device__ __forceinline__ void ls_sort_body(const u64 *__restrict__ keys_in, co
                 const u32 li = wave_base + j * 64 + lane;
                 const bool valid = li < m;
                 const u32 d = rs_digit<V>(key[j], val[j], shift, mask, src);
-                u32 below, total;
-                wave_match(d, valid, below, total);
-                const u32 before = wcnt[wave][d];
-                rank[j] = before + below;
-                if (valid && below == 0) wcnt[wave][d] = before + total;
+                if (ATOM) {                              // (as ls_word_pass: the rank a returning LDS add hands back)
+                    const u32 old = valid ? atomicAdd(reinterpret_cast<u32 *>(&wcnt[wave][d & ~1u]), (d & 1u) ? 0x10000u : 1u) : 0u;
+                    rank[j] = (d & 1u) ? (old >> 16) : (old & 0xFFFFu);
+                } else {
+                    u32 below, total;
+                    wave_match(d, valid, below, total);
+                    const u32 before = wcnt[wave][d];
+                    rank[j] = before + below;
+                    if (valid && below == 0) wcnt[wave][d] = before + total;
+                }
             }
         }
         __syncthreads();
@@ -564,11 +569,11 @@ __device__ __forceinline__ void ls_sort_body(const u64 *__restrict__ keys_in, co
 }
 #undef LS_ACT
 
-template <typename V>
+template <typename V, bool ATOM>
 __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
                                                             u64 *__restrict__ keys_out, V *__restrict__ vals_out,
                                                             const u32 *__restrict__ seg_off, LocalPasses lp) {
-    __shared__ uint16_t wcnt[LS_WAVES][RS_DIGITS];    // per-wave digit counts of the current pass (<= LS_MAX)
+    __shared__ __align__(8) uint16_t wcnt[LS_WAVES][RS_DIGITS];    // per-wave digit counts of the current pass (<= LS_MAX)
     __shared__ uint16_t wbase[LS_WAVES][RS_DIGITS];   // per-wave first LDS slot of each digit
     __shared__ u64 skeys[LS_MAX];
     __shared__ V svals[LS_MAX];
@@ -577,11 +582,11 @@ __global__ __launch_bounds__(LS_BLOCK, 6) void ls_sort_kernel(const u64 *__restr
     const u32 m = seg_off[blockIdx.x + 1] - s0;
     if (m == 0 || m > LS_MAX) return;   // oversize segments: the host falls back to full LSD passes
     switch ((m + LS_BLOCK - 1) / LS_BLOCK) {
-        case 1: ls_sort_body<V, 1>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
-        case 2: ls_sort_body<V, 2>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
-        case 3: ls_sort_body<V, 3>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
-        case 4: ls_sort_body<V, 4>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
-        default: ls_sort_body<V, 5>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
+        case 1: ls_sort_body<V, 1, ATOM>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
+        case 2: ls_sort_body<V, 2, ATOM>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
+        case 3: ls_sort_body<V, 3, ATOM>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
+        case 4: ls_sort_body<V, 4, ATOM>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
+        default: ls_sort_body<V, 5, ATOM>(keys_in, vals_in, keys_out, vals_out, lp, s0, m, wcnt, wbase, skeys, svals); break;
     }
 }
 
@@ -1143,7 +1148,8 @@ static int hybrid_sort_records(kmg_ctx *ctx, u64 *k0, V *v0, u64 *k1, V *v1, u32
                         hipLaunchKernelGGL((ls_sortidx_kernel<V, false, false>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg,
                                            lp, pbits, (u32 *)nullptr);
             } else
-                hipLaunchKernelGGL((ls_sort_kernel<V>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp);
+                if (ctx->lds_rank_ok) hipLaunchKernelGGL((ls_sort_kernel<V, true>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp);
+                else hipLaunchKernelGGL((ls_sort_kernel<V, false>), dim3(nseg), dim3(LS_BLOCK), 0, ctx->stream, ka, va, kb, vb, seg, lp);
             KMG_HIP(hipGetLastError());
         }
         if (!big.empty()) {
