@@ -528,16 +528,32 @@ def stage_fractions(lib, ctx, ctx_ref, submit, finish, prof, prof_steps, n_read_
     return out
 
 
+def _pmc_file():
+    """The committed PMC measurement of the default workload for these kernel sources: the newest
+    profiles/*_pmc_traffic.json (config 3's own measurements aside) whose source hash is this library's.
+    -> (parsed file, name), or (None, reason)."""
+    import glob
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")) if "cfg3" not in f),
+                   key=os.path.getmtime)
+    if not files:
+        return None, "no measurement"
+    h = source_hash()
+    for f in reversed(files):
+        try:
+            data = json.load(open(f))
+        except Exception:
+            continue
+        if data.get("source_hash") == h:
+            return data, os.path.basename(f)
+    return None, "%s was measured on other kernel sources" % os.path.basename(files[-1])
+
+
 def pmc_stage_traffic():
     """HBM bytes per step and stage from the newest committed PMC file, if it was measured on these sources."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
-    if not files:
+    data, _ = _pmc_file()
+    if data is None:
         return {}
     try:
-        data = json.load(open(files[-1]))
-        if data.get("source_hash") != source_hash():
-            return {}
         ks = data["kernels"]
         steps = max(v["launches"] for name, v in ks.items() if "extract_part_count_kernel<false, false" in name)
         out = {}
@@ -572,18 +588,16 @@ def pmc_traffic(kernel_id):
     (profiles/*_pmc_traffic.json, produced by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE
     passes, calibrated on a copy of known size).  -> (bytes, file name), or (None, reason) when no measurement covers
     the kernel or the measurement was taken on other kernel sources than the ones this library was built from."""
-    import glob
     sym = KERNEL_SYMBOL.get(kernel_id)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
-    if not sym or not files:
+    if not sym:
         return None, "no measurement"
+    data, name = _pmc_file()
+    if data is None:
+        return None, name
     try:
-        data = json.load(open(files[-1]))
-        if data.get("source_hash") != source_hash():
-            return None, "%s was measured on other kernel sources" % os.path.basename(files[-1])
-        hits = [int(v["traffic_bytes_per_launch"]) for name, v in data["kernels"].items() if sym in name]
+        hits = [int(v["traffic_bytes_per_launch"]) for kname, v in data["kernels"].items() if sym in kname]
         if hits:
-            return (min(hits) if kernel_id.endswith("_ref") else max(hits)), os.path.basename(files[-1])
+            return (min(hits) if kernel_id.endswith("_ref") else max(hits)), name
     except Exception:
         pass
     return None, "no measurement"
