@@ -14,13 +14,18 @@
  * copies inputs before returning and retains no host pointer.  A context is bound to one GPU and is
  * internally serialised (safe to call from several threads; calls do not overlap on the device).
  * Supported: 1 <= minK <= maxK = k <= 32, 1 <= key_len <= min(minK, 12); the exact join takes k-mers of one
- * length (restrict variable-length databases first, kmg_db_restrict).  Anything else returns
- * KMG_EUNSUPPORTED so a shim can fall back to the Java path.
+ * length (restrict variable-length databases first, kmg_db_restrict).  k-mers of 33 .. 64 bases ("two-word
+ * k-mers", see below) of one length (minK = maxK): build, fetch, load, encode, the exact join, TaxaCounts and the
+ * per-read tools.  Anything else returns KMG_EUNSUPPORTED so a shim can fall back to the Java path.
  *
  * K-mer representation everywhere: uint64, 2 bits per base, code order A=0 C=1 T=2 G=3
  * (Kmers/Base.java:7-10), first base in the top bits, low 64-2k bits zero -- i.e. the bytes of
  * Sequence.cBytes() (Kmers/Sequence.java:90-115) read big-endian.  Unsigned integer order of this
  * value == Sequence.compareTo order (Kmers/Sequence.java:165-187) for fixed k.
+ * k > 32 (the reference's Sequence is a byte array of any length, Sequence.java:15-35,90-115): a k-mer is TWO such
+ * words -- `keys` holds bases 0 .. 31 as above, `keys_lo` bases 32 .. k-1, first of them in the top bits, the low
+ * 128-2k bits zero; the two words, big-endian one after the other and cut to ceil(k/4) bytes, are cBytes(), and the
+ * order of the (keys, keys_lo) pairs is Sequence.compareTo's.  Kmer.key(key_len) (Kmer.java:47-55) lies in `keys`.
  */
 #ifndef KMERS_GPU_H
 #define KMERS_GPU_H
@@ -35,7 +40,7 @@ extern "C" {
 #define KMG_EINVAL       (-1)   /* bad argument / inconsistent parameters (InconsistentDataException) */
 #define KMG_ENOMEM       (-2)   /* host or device allocation failed */
 #define KMG_EDEVICE      (-3)   /* HIP runtime error */
-#define KMG_EUNSUPPORTED (-4)   /* k > 32, a join over several k-mer lengths, > 2^32-16 records in one build ... */
+#define KMG_EUNSUPPORTED (-4)   /* k > 64, a join over several k-mer lengths, > 2^32-16 records in one build ... */
 #define KMG_ESTATE       (-5)   /* call out of order (add before begin, ...) */
 
 #define KMG_PAYLOAD_TAXON   0   /* reference DB: int32 taxon per sequence  (DataCollector.getCountInstance) */
@@ -149,6 +154,15 @@ int kmg_db_payload_bits(const kmg_db *db);
  *   Kmer.key(key_len) bucket (Kmer.java:47-55) -- the per-key blocks of the DB file. */
 int kmg_db_fetch(const kmg_db *db, uint64_t *keys, uint64_t *val_off, int32_t *val_a, int32_t *val_b,
                  uint64_t *bucket_off);
+/* Two-word k-mers (k > 32; Kmers/Sequence.java:90-115 packs any length, Kmer.java:90-97 writes it).
+ *   kmg_db_fetch_keys_lo: keys_lo[n_unique] = bases 32 .. k-1 of every k-mer (zeros for a database of k <= 32); the
+ *     first 32 bases come with kmg_db_fetch's keys.
+ *   kmg_db_load_wide: kmg_db_load for 32 < k <= 64 -- what KmerFile's decoder (KmerFile.java:200-250) yields for such a
+ *     file; (keys, keys_lo) strictly ascending as pairs, bits behind base k zero. */
+int kmg_db_fetch_keys_lo(const kmg_db *db, uint64_t *keys_lo);
+int kmg_db_load_wide(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *keys,
+                     const uint64_t *keys_lo, uint64_t n_unique, const uint64_t *val_off, const int32_t *val_a,
+                     const int32_t *val_b, kmg_db **out);
 /* Variable-length databases (minK < maxK).  kmg_db_min_k: the shortest k-mer length (== k of kmg_db_info for a
  *   database of one length).  kmg_db_fetch_lens: lens[n_unique] = number of bases of every k-mer (the length byte of
  *   Kmer.compressedBytes, Kmer.java:90-97); keys are zero-padded behind it.  kmg_db_load_var: kmg_db_load with lens
@@ -210,6 +224,7 @@ int kmg_db_load(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, cons
 #define KMG_DB_VAL_A      2
 #define KMG_DB_VAL_B      3
 #define KMG_DB_BUCKET_OFF 4
+#define KMG_DB_KEYS_LO    5   /* u64; databases of k > 32 only */
 int kmg_db_copy_dev(const kmg_db *db, int which, void *d_dst, uint64_t first, uint64_t count);
 int kmg_db_load_dev(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *d_keys,
                     uint64_t n_unique, const uint64_t *d_val_off, const int32_t *d_val_a, const int32_t *d_val_b,

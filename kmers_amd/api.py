@@ -98,14 +98,19 @@ class KmerDatabase:
         self._host = None
 
     @classmethod
-    def load(cls, ctx, k, key_length, rc, kind, keys, val_off, val_a, val_b, lens=None, min_length=None):
-        """lens / min_length: a database of k-mers of several lengths (kmg_db_load_var)."""
+    def load(cls, ctx, k, key_length, rc, kind, keys, val_off, val_a, val_b, lens=None, min_length=None, keys_lo=None):
+        """lens / min_length: a database of k-mers of several lengths (kmg_db_load_var).
+        keys_lo: bases 32 .. k-1 of k-mers of more than 32 bases (kmg_db_load_wide)."""
         keys = np.ascontiguousarray(keys, np.uint64)
         val_off = np.ascontiguousarray(val_off, np.uint64)
         val_a = np.ascontiguousarray(val_a, np.int32)
         val_b = np.ascontiguousarray(val_b, np.int32)
         h = C.c_void_p()
-        if min_length is not None and min_length != k:
+        if k > 32:
+            keys_lo = np.ascontiguousarray(keys_lo, np.uint64)
+            ctx.check(ctx.lib.kmg_db_load_wide(ctx.h, k, key_length, 1 if rc else 0, kind, _ptr(keys), _ptr(keys_lo), len(keys),
+                                               _ptr(val_off), _ptr(val_a), _ptr(val_b), C.byref(h)))
+        elif min_length is not None and min_length != k:
             lens = np.ascontiguousarray(lens, np.uint8)
             ctx.check(ctx.lib.kmg_db_load_var(ctx.h, k, min_length, key_length, 1 if rc else 0, kind, _ptr(keys), _ptr(lens),
                                               len(keys), _ptr(val_off), _ptr(val_a), _ptr(val_b), C.byref(h)))
@@ -191,6 +196,10 @@ class KmerDatabase:
             boff = np.empty(4 ** self.key_length + 1, np.uint64)
             self.ctx.check(self.ctx.lib.kmg_db_fetch(self.h, _ptr(keys), _ptr(val_off), _ptr(val_a), _ptr(val_b), _ptr(boff)))
             self._host = dict(keys=keys, val_off=val_off, val_a=val_a, val_b=val_b, bucket_off=boff)
+            if self.k > 32:
+                lo = np.empty(max(U, 1), np.uint64)
+                self.ctx.check(self.ctx.lib.kmg_db_fetch_keys_lo(self.h, _ptr(lo)))
+                self._host["keys_lo"] = lo[:U]
         return self._host
 
     def encode_blocks(self):
@@ -475,8 +484,11 @@ def read_call_blocks(call, has_hit):
 _BASES = np.frombuffer(b"ACTG", dtype=np.uint8)
 
 
-def kmer_strings(keys, k):
-    """Sequence.toString (Sequence.java:117-134) for an array of left-aligned 2-bit k-mers."""
+def kmer_strings(keys, k, keys_lo=None):
+    """Sequence.toString (Sequence.java:117-134) for an array of left-aligned 2-bit k-mers (keys_lo: bases 32 .. of
+    k-mers of more than 32 bases)."""
+    if k > 32:
+        return [a + b for a, b in zip(kmer_strings(keys, 32), kmer_strings(keys_lo, k - 32))]
     keys = np.asarray(keys, np.uint64)
     shifts = (np.uint64(62) - np.uint64(2) * np.arange(k, dtype=np.uint64))
     codes = ((keys[:, None] >> shifts[None, :]) & np.uint64(3)).astype(np.intp)
@@ -493,7 +505,7 @@ def match_lines(search, ref, hit, stored=False, ref_stored=None):
     cap = (1 << 31) if stored else 255
     rcap = cap if ref_stored is None else ((1 << 31) if ref_stored else 255)     # (match_trie's rows hold sums: ref_stored=True)
     idx = np.nonzero(hit >= 0)[0]
-    names = kmer_strings(s["keys"][idx], search.k)
+    names = kmer_strings(s["keys"][idx], search.k, s["keys_lo"][idx] if search.k > 32 else None)
     if search.min_length != search.k:                    # k-mers of several lengths: zero-padded behind their own
         names = [n[:l] for n, l in zip(names, search.lens()[idx].tolist())]
     lines = []

@@ -228,6 +228,8 @@ static int match_sharded_checks(kmg_ctx *ctx, const kmg_db *search, const kmg_db
                                 const int64_t *d_hit_index, std::vector<u64> &cut) {
     if (search->ctx->device != ctx->device || ref_shard->ctx->device != ctx->device)
         return fail(ctx, KMG_EINVAL, "database belongs to another device");
+    KMG_NO_WIDE(search);
+    KMG_NO_WIDE(ref_shard);
     if (search->k != ref_shard->k || search->key_len != ref_shard->key_len)                          // DB.java:78-81
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
     if (search->min_k != search->k || ref_shard->min_k != ref_shard->k)
@@ -293,6 +295,7 @@ extern "C" int kmg_db_exchange_by_key_range(kmg_comm *c, const kmg_db *local, co
         // the checks and preparation that need no other rank; their verdict travels with the counts (comm_counts)
         const int st = [&]() -> int {
             if (local->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
+            KMG_NO_WIDE(local);
             if (local->min_k != local->k) return fail(ctx, KMG_EUNSUPPORTED, "databases of k-mers of several lengths are not exchanged");
             KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(local)));
             KMG_TRY(comm_cuts(ctx, local, bounds, n, cut));

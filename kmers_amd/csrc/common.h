@@ -164,7 +164,8 @@ struct kmg_ctx {
     bool lds_rank_ok = false;        // returning LDS adds give stable ranks on this device (checked in kmg_create)
     bool ranged = false;             // kmg_build_set_key_range: keep the records of key buckets [range_lo, range_hi)
     u32 range_lo = 0, range_hi = 0;
-    u64 *rec_keys = nullptr;     // record keys (left-aligned 2-bit k-mers)
+    u64 *rec_keys = nullptr;     // record keys (left-aligned 2-bit k-mers; k > 32: bases 0 .. 31)
+    u64 *rec_lo = nullptr;       // k > 32 (wide.h): bases 32 .. k-1 of every record, left-aligned
     void *rec_vals = nullptr;    // u32 taxon | u64 (read << 16 | pos16)
     u64 rec_cap = 0;             // capacity in records
     u64 rec_upper = 0;           // host-known upper bound of records added so far
@@ -225,6 +226,7 @@ struct kmg_db {
     int32_t tax_lo = 0, tax_hi = 0;
     u64 U = 0, V = 0;
     u64 *keys = nullptr;        // U; zero-padded to k bases: (keys, lens) ascending == Sequence.compareTo order
+    u64 *keys_lo = nullptr;     // k > 32 only (wide.h): bases 32 .. k-1, left-aligned; (keys, keys_lo) ascends strictly
     u64 *val_off = nullptr;     // U + 1
     int32_t *val_a = nullptr;   // V
     int32_t *val_b = nullptr;   // V

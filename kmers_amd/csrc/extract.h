@@ -123,13 +123,16 @@ struct ExtractArgs {
 // packed into LDS (pk: 2 bits per base, inv: "not ACGTacgt" bits, both with EX_EXT positions past the tile), the
 // "some sequence starts here" bitmap stb, and seqrel[p] = number of sequences beyond the tile's first one that start
 // at or before position p.  -> index of the tile's first sequence.  Ends behind a __syncthreads().
-__device__ __forceinline__ u32 ex_load_tile(const ExtractArgs &a, const u32 tile, u32 *pk, u32 *inv, u32 *stb, u32 *seqrel,
-                                            u32 *scan_smem) {
+// (EXT = bases past the tile that its windows may cover: EX_EXT for k <= 32, 64 for the two-word k-mers of wide.h; the
+// arrays hold (EX_TILE + EXT) / 16 words of pk, (EX_TILE + EXT) / 32 of inv and stb, EX_TILE + EXT of seqrel)
+template <int EXT>
+__device__ __forceinline__ u32 ex_load_tile_ext(const ExtractArgs &a, const u32 tile, u32 *pk, u32 *inv, u32 *stb, u32 *seqrel,
+                                                u32 *scan_smem) {
     const int tid = threadIdx.x;
     const u64 t0 = (u64)tile * EX_TILE;
     // ---- 1. load + pack ---------------------------------------------------------------------------
     const bool aligned = (((uintptr_t)a.bases) & 15) == 0;
-    for (int chunk = tid; chunk < (EX_TILE + EX_EXT) / 16; chunk += EX_BLOCK) {
+    for (int chunk = tid; chunk < (EX_TILE + EXT) / 16; chunk += EX_BLOCK) {
         u64 g = t0 + (u64)chunk * 16;
         u32 q[4];
         if (aligned && g + 16 <= a.nbases) {
@@ -161,14 +164,14 @@ __device__ __forceinline__ u32 ex_load_tile(const ExtractArgs &a, const u32 tile
         pk[chunk] = word;
         reinterpret_cast<uint16_t *>(inv)[chunk ^ 1] = (uint16_t)bad;
     }
-    for (int i = tid; i < EX_TILE + EX_EXT; i += EX_BLOCK) seqrel[i] = 0;
+    for (int i = tid; i < EX_TILE + EXT; i += EX_BLOCK) seqrel[i] = 0;
     __syncthreads();
 
     // ---- 2. sequence starts -> per-position sequence index ------------------------------------------
     const u32 s_lo = a.tile_seq[tile];
     for (u64 s = (u64)s_lo + 1 + tid; s <= a.nseq; s += EX_BLOCK) {
         u64 o = a.seq_off[s];
-        if (o >= t0 + EX_TILE + EX_EXT) break;
+        if (o >= t0 + EX_TILE + EXT) break;
         atomicAdd(&seqrel[(u32)(o - t0)], 1u);
     }
     __syncthreads();
@@ -183,7 +186,7 @@ __device__ __forceinline__ u32 ex_load_tile(const ExtractArgs &a, const u32 tile
             sum += c[i];
         }
         reinterpret_cast<uint16_t *>(stb)[tid ^ 1] = (uint16_t)bits;
-        if (tid < EX_EXT / 16) {
+        if (tid < EXT / 16) {
             u32 eb = 0;
 #pragma unroll
             for (int i = 0; i < 16; i++) eb = (eb << 1) | (seqrel[EX_TILE + tid * 16 + i] != 0);
@@ -201,6 +204,10 @@ __device__ __forceinline__ u32 ex_load_tile(const ExtractArgs &a, const u32 tile
     __syncthreads();
 
     return s_lo;
+}
+__device__ __forceinline__ u32 ex_load_tile(const ExtractArgs &a, const u32 tile, u32 *pk, u32 *inv, u32 *stb, u32 *seqrel,
+                                            u32 *scan_smem) {
+    return ex_load_tile_ext<EX_EXT>(a, tile, pk, inv, stb, seqrel, scan_smem);
 }
 
 // After a write pass: advance the running record count by this batch's total (tile_off[ntiles]).

@@ -427,6 +427,7 @@ int kmh_empty_header(const kmh_batch *h) { return ((const Batch *)h)->empty_head
 // bases cannot be represented on the GPU path: returns NULL.
 struct Decoded {
     std::vector<uint64_t> keys, val_off;
+    std::vector<uint64_t> keys_lo;      // bases 32 .. of k-mers of more than 32 bases (zero for the others)
     std::vector<int32_t> val_a, val_b;
     std::vector<uint8_t> lens;          // length byte of every k-mer (Kmer.compressedBytes, Kmer.java:90-97)
 };
@@ -434,7 +435,7 @@ struct Decoded {
 kmh_batch *kmh_decode_blocks(const uint8_t *data, uint64_t n, int kind) {
     Decoded *d = new Decoded();
     d->val_off.push_back(0);
-    uint8_t prev[10] = {0}, kb[10];
+    uint8_t prev[18] = {0}, kb[18];
     uint64_t off = 0;
     auto fail = [&]() -> kmh_batch * { delete d; return nullptr; };
     while (off < n) {
@@ -442,7 +443,7 @@ kmh_batch *kmh_decode_blocks(const uint8_t *data, uint64_t n, int kind) {
         int len;
         if (copy == 0) { if (off >= n) return fail(); len = (int8_t)data[off++]; }
         else len = (int8_t)prev[0];
-        if (len < 1 || len > 32 || copy < 0) return fail();
+        if (len < 1 || len > 64 || copy < 0) return fail();
         const int l = (len - 1) / 4 + 1;
         if (copy > l + 1) return fail();
         if (copy > 0) {
@@ -458,9 +459,11 @@ kmh_batch *kmh_decode_blocks(const uint8_t *data, uint64_t n, int kind) {
             off += l;
         }
         memcpy(prev, kb, (size_t)l + 1);
-        uint64_t key = 0;
-        for (int i = 0; i < l; i++) key |= (uint64_t)kb[1 + i] << (56 - 8 * i);
+        uint64_t key = 0, key_lo = 0;
+        for (int i = 0; i < l && i < 8; i++) key |= (uint64_t)kb[1 + i] << (56 - 8 * i);
+        for (int i = 8; i < l; i++) key_lo |= (uint64_t)kb[1 + i] << (56 - 8 * (i - 8));
         d->keys.push_back(key);
+        d->keys_lo.push_back(key_lo);
         d->lens.push_back((uint8_t)len);
         if (kind == 0) {
             if (off + 2 > n) return fail();
@@ -494,6 +497,7 @@ uint64_t kmh_decoded_nkeys(const kmh_batch *h) { return ((const Decoded *)h)->ke
 uint64_t kmh_decoded_nvals(const kmh_batch *h) { return ((const Decoded *)h)->val_a.size(); }
 const uint8_t *kmh_decoded_lens(const kmh_batch *h) { return ((const Decoded *)h)->lens.data(); }
 const uint64_t *kmh_decoded_keys(const kmh_batch *h) { return ((const Decoded *)h)->keys.data(); }
+const uint64_t *kmh_decoded_keys_lo(const kmh_batch *h) { return ((const Decoded *)h)->keys_lo.data(); }
 const uint64_t *kmh_decoded_val_off(const kmh_batch *h) { return ((const Decoded *)h)->val_off.data(); }
 const int32_t *kmh_decoded_val_a(const kmh_batch *h) { return ((const Decoded *)h)->val_a.data(); }
 const int32_t *kmh_decoded_val_b(const kmh_batch *h) { return ((const Decoded *)h)->val_b.data(); }

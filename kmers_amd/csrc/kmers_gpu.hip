@@ -10,6 +10,7 @@
 #include "reduce.h"
 #include "match.h"
 #include "collect.h"
+#include "wide.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -33,7 +34,13 @@ struct PoolBuf {
     int alloc(size_t bytes) { return ctx->pool.alloc(&p, bytes); }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
     void *detach() { void *q = p; p = nullptr; return q; }
+    void free() { ctx->pool.release(p); p = nullptr; }
 };
+
+// entry points that take one-word k-mers only (two-word ones, wide.h: build, fetch, encode, load, exact join, TaxaCounts,
+// the per-read tools)
+#define KMG_NO_WIDE(db) \
+    do { if ((db)->k > 32) return fail(ctx, KMG_EUNSUPPORTED, "not built for k-mers of more than 32 bases"); } while (0)
 
 static int fail(kmg_ctx *ctx, int code, const char *msg) {
     if (ctx) ctx->err = msg;
@@ -142,7 +149,7 @@ extern "C" int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int pay
     if (!ctx) return KMG_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
     if (k < 1 || key_len < 1) return fail(ctx, KMG_EINVAL, "k and key_len must be positive");
-    if (k > 32) return fail(ctx, KMG_EUNSUPPORTED, "k > 32 is not supported on the GPU path");
+    if (k > 64) return fail(ctx, KMG_EUNSUPPORTED, "k > 64 is not supported on the GPU path");
     if (key_len > k || key_len > 12) return fail(ctx, KMG_EUNSUPPORTED, "key_len must be <= min(k, 12)");
     if (payload_kind != KMG_PAYLOAD_TAXON && payload_kind != KMG_PAYLOAD_READPOS)
         return fail(ctx, KMG_EINVAL, "unknown payload kind");
@@ -167,6 +174,8 @@ extern "C" int kmg_build_set_filters(kmg_ctx *ctx, int dust_threshold, int runof
     std::lock_guard<std::mutex> g(ctx->mu);
     if (!ctx->building) return fail(ctx, KMG_ESTATE, "kmg_build_set_filters before kmg_build_begin");
     if (ctx->rec_upper) return fail(ctx, KMG_ESTATE, "filters must be set before the first kmg_build_add");
+    if (ctx->k > 32 && (dust_threshold >= 0 || runofsame_length >= 0))
+        return fail(ctx, KMG_EUNSUPPORTED, "the Dust / RunOfSame filters are built for k <= 32");
     ctx->dust = dust_threshold < 0 ? -1 : dust_threshold;
     ctx->runofsame = runofsame_length < 0 ? -1 : runofsame_length;
     return KMG_OK;
@@ -178,6 +187,7 @@ extern "C" int kmg_build_set_min_k(kmg_ctx *ctx, int min_k) {
     if (!ctx->building) return fail(ctx, KMG_ESTATE, "kmg_build_set_min_k before kmg_build_begin");
     if (ctx->n_adds) return fail(ctx, KMG_ESTATE, "the shortest k-mer length must be set before the first kmg_build_add");
     if (min_k < 1 || min_k > ctx->k) return fail(ctx, KMG_EINVAL, "min_k must lie in 1 .. k");
+    if (ctx->k > 32 && min_k != ctx->k) return fail(ctx, KMG_EUNSUPPORTED, "k-mers of several lengths are built for k <= 32");
     if (min_k < ctx->key_len) return fail(ctx, KMG_EUNSUPPORTED, "key_len must be <= min_k");      // Kmer.key(keyLength) of a shorter k-mer throws
     ctx->min_k = min_k;
     return KMG_OK;
@@ -202,20 +212,25 @@ static int ensure_record_capacity(kmg_ctx *ctx, u64 need) {
     if (need <= ctx->rec_cap && ctx->rec_keys) return KMG_OK;
     u64 ncap = std::max(need, ctx->rec_cap + ctx->rec_cap / 2);
     const size_t vb = val_bytes(ctx->kind);
-    void *nk = nullptr, *nv = nullptr;
+    const bool wide = ctx->k > 32;
+    void *nk = nullptr, *nv = nullptr, *nl = nullptr;
     if (ctx->pool.alloc(&nk, ncap * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "record buffer allocation failed");
-    if (ctx->pool.alloc(&nv, ncap * vb) != KMG_OK) {
+    if (ctx->pool.alloc(&nv, ncap * vb) != KMG_OK || (wide && ctx->pool.alloc(&nl, ncap * 8) != KMG_OK)) {
         ctx->pool.release(nk);
+        ctx->pool.release(nv);
         return fail(ctx, KMG_ENOMEM, "record buffer allocation failed");
     }
     if (ctx->rec_keys && ctx->rec_upper) {
         KMG_HIP(hipMemcpyAsync(nk, ctx->rec_keys, ctx->rec_upper * 8, hipMemcpyDeviceToDevice, ctx->stream));
         KMG_HIP(hipMemcpyAsync(nv, ctx->rec_vals, ctx->rec_upper * vb, hipMemcpyDeviceToDevice, ctx->stream));
+        if (wide) KMG_HIP(hipMemcpyAsync(nl, ctx->rec_lo, ctx->rec_upper * 8, hipMemcpyDeviceToDevice, ctx->stream));
     }
     ctx->pool.release(ctx->rec_keys);
     ctx->pool.release(ctx->rec_vals);
+    ctx->pool.release(ctx->rec_lo);
     ctx->rec_keys = (u64 *)nk;
     ctx->rec_vals = nv;
+    ctx->rec_lo = (u64 *)nl;
     ctx->rec_cap = ncap;
     return KMG_OK;
 }
@@ -232,6 +247,82 @@ static int build_pbits(const kmg_ctx *ctx, u64 n, int kbits) {
     if (!ctx->ranged) return choose_pbits(n, kbits);
     const u64 n_dense = n * ((u64)1 << (2 * ctx->key_len)) / std::max<u32>(ctx->range_hi - ctx->range_lo, 1u);
     return choose_pbits(n_dense, kbits, 30);
+}
+
+// A batch of a build of two-word k-mers (k > 32, wide.h): count pass, numbering, scan, write pass -- the records are
+// appended in window order behind those of the earlier batches.  Arguments checked by build_add_locked.
+static int build_add_wide(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, const u64 *d_seq_off, const int32_t *d_seq_id,
+                          const int64_t *d_seq_tok, u64 nseq, int32_t *d_read_index_out) {
+    const bool reads = ctx->kind == KMG_PAYLOAD_READPOS;
+    const bool want_flags = !reads && d_read_index_out;
+    const u64 upper = ctx->rec_upper + nbases * (ctx->rc ? 2 : 1);
+    KMG_TRY(ensure_record_capacity(ctx, upper));
+    const u32 ntiles = div_up_u64(nbases, EX_TILE);
+    PoolBuf tile_seq(ctx), tile_count(ctx), tile_fwd(ctx), tile_off(ctx), agg(ctx), has_kmer(ctx), read_index(ctx);
+    KMG_ALLOC(tile_seq, (size_t)(ntiles + 1) * 4);
+    KMG_ALLOC(tile_count, (size_t)ntiles * 4);
+    KMG_ALLOC(tile_fwd, (size_t)ntiles * 4);
+    KMG_ALLOC(tile_off, (size_t)(ntiles + 1) * 8);
+    KMG_ALLOC(agg, (size_t)(std::max<u64>(div_up_u64(ntiles, SCAN_TILE), div_up_u64(nseq, SCAN_TILE)) + 1) * 8);
+    WideArgs wa;
+    memset(&wa, 0, sizeof wa);
+    ExtractArgs &a = wa.e;
+    a.bases = d_bases; a.nbases = nbases; a.seq_off = d_seq_off; a.nseq = nseq; a.seq_id = d_seq_id;
+    a.tile_seq = tile_seq.as<u32>(); a.k = ctx->k; a.rc = ctx->rc; a.kind = ctx->kind;
+    a.dust = -1; a.runofsame = -1;
+    a.ranged = ctx->ranged ? 1 : 0; a.range_shift = 64 - 2 * ctx->key_len; a.range_lo = ctx->range_lo; a.range_hi = ctx->range_hi;
+    a.tile_count = tile_count.as<u32>(); a.tile_fwd = tile_fwd.as<u32>(); a.tile_off = tile_off.as<u64>();
+    a.out_keys = ctx->rec_keys; a.out_vals = ctx->rec_vals; a.state = ctx->d_state;
+    a.pos_bits = 16; a.pos_mask = 0xFFFFu;
+    wa.out_lo = ctx->rec_lo;
+    {
+        ProfScope ps(ctx, KP_EXTRACT_TILESEQ, 0);
+        hipLaunchKernelGGL(extract_tileseq_kernel, dim3(div_up_u64(ntiles + 1, 256)), dim3(256), 0, ctx->stream,
+                           d_seq_off, nseq, tile_seq.as<u32>(), (u32 *)nullptr, ntiles + 1);
+    }
+    int32_t *ridx = nullptr;
+    if (want_flags || reads) {
+        KMG_ALLOC(has_kmer, nseq);
+        KMG_HIP(hipMemsetAsync(has_kmer.p, 0, nseq, ctx->stream));
+        a.has_kmer = has_kmer.as<uint8_t>();
+    }
+    if (reads) {
+        if (d_read_index_out) ridx = d_read_index_out;
+        else { KMG_ALLOC(read_index, nseq * 4); ridx = read_index.as<int32_t>(); }
+        a.read_index = ridx;
+    }
+    ctx->prepart = false; ctx->plan_pbits = 0; ctx->snap_valid = false;
+    ctx->n_adds++;
+    {
+        ProfScope ps(ctx, KP_EXTRACT_COUNT, nbases);
+        hipLaunchKernelGGL((wide_extract_kernel<false>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, wa);
+        hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_fwd.as<u32>(),
+                           ntiles, ctx->d_state + ST_NWIN);
+    }
+    if (reads) {
+        ProfScope ps(ctx, KP_NUMBER_READS, 0);
+        const u32 nr_tiles = div_up_u64(nseq, NR_TILE);
+        u32 epoch = 0;
+        KMG_TRY(chained_begin(ctx, nr_tiles, &epoch));
+        hipLaunchKernelGGL(number_reads_kernel, dim3(nr_tiles), dim3(NR_BLOCK), 0, ctx->stream, has_kmer.as<uint8_t>(), d_seq_tok, nseq,
+                           ridx, ctx->d_state, ctx->scan_status, ctx->scan_ctl, epoch, nr_tiles);
+    } else {
+        hipLaunchKernelGGL(id_bits_kernel, dim3(std::min<u32>(div_up_u64(nseq, 256), 1024)), dim3(256), 0, ctx->stream,
+                           d_seq_id, nseq, ctx->d_state);
+        if (want_flags)
+            hipLaunchKernelGGL(has_kmer_flags_kernel, dim3(div_up_u64(nseq, 256)), dim3(256), 0, ctx->stream, has_kmer.as<uint8_t>(),
+                               nseq, d_read_index_out);
+    }
+    KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, tile_count.as<u32>(), tile_off.as<u64>(), ntiles, OpSum(), 0ull,
+                                                agg.as<u64>(), nullptr, true, KP_SCAN)));
+    {
+        ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases);
+        hipLaunchKernelGGL((wide_extract_kernel<true>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, wa);
+        hipLaunchKernelGGL(extract_advance_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, tile_off.as<u64>(), ntiles);
+    }
+    KMG_HIP(hipGetLastError());
+    ctx->rec_upper = upper;
+    return KMG_OK;
 }
 
 // All pointers are device pointers.  Caller holds ctx->mu.
@@ -251,6 +342,8 @@ static int build_add_locked(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, co
     if (reads && !d_seq_tok) return fail(ctx, KMG_EINVAL, "seq_tok required for read payload");
     if (nseq >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "too many sequences in one batch");
     if (nbases >= (u64)0xFFFFFFF0ull * 1024) return fail(ctx, KMG_EUNSUPPORTED, "batch too large");
+
+    if (ctx->k > 32) return build_add_wide(ctx, d_bases, nbases, d_seq_off, d_seq_id, d_seq_tok, nseq, d_read_index_out);
 
     if (ctx->compact_pb) {
         // a second batch: the first one's 32-bit payloads go back to the 64-bit form every other path uses
@@ -641,6 +734,7 @@ static void db_release(kmg_db *db) {
         db->foreign_use.clear();
     }
     ctx->pool.release(db->keys);
+    ctx->pool.release(db->keys_lo);
     ctx->pool.release(db->lens);
     ctx->pool.release(db->val_off);
     ctx->pool.release(db->val_a);
@@ -854,7 +948,8 @@ static int ensure_vals(kmg_ctx *ctx, kmg_db *db) {
 // Sort + dedup the n records (keys, vals) of k-mers of db->k bases into db's CSR arrays (db->k / key_len / kind set by
 // the caller).  When the sorted payloads become a read database's value array, `vals` changes owner and is nulled.
 static int sort_reduce_class(kmg_ctx *ctx, u64 *keys, void *&vals, u32 n, bool compact, int pos_bits,
-                             const std::vector<SortPass> &payload, const SegPlan &plan, bool prepart, kmg_db *db, bool *heads_done) {
+                             const std::vector<SortPass> &payload, const SegPlan &plan, bool prepart, kmg_db *db, bool *heads_done,
+                             int key_bits = 0 /* bits of the keys that count, from the top; 0: 2 * db->k */) {
     const bool reads = db->kind == KMG_PAYLOAD_READPOS;
     const size_t vb = compact ? 4 : val_bytes(db->kind);
     PoolBuf k1(ctx), v1(ctx), table(ctx), agg(ctx), totals(ctx), seg(ctx), ucount(ctx);
@@ -871,7 +966,7 @@ static int sort_reduce_class(kmg_ctx *ctx, u64 *keys, void *&vals, u32 n, bool c
         KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
         KMG_ALLOC(agg, (size_t)(div_up_u64((u64)RS_DIGITS * ntiles, SCAN_TILE) + 1) * 8);
         KMG_ALLOC(seg, ((size_t)plan.nseg + 4) * 4);
-        const int low_bit = 64 - 2 * db->k;
+        const int low_bit = 64 - (key_bits ? key_bits : 2 * db->k);
         if (reads) {
             KMG_ALLOC(ucount, ((size_t)plan.nseg + 1) * 4);
             heads.ucount = ucount.as<u32>();
@@ -1070,6 +1165,66 @@ static int finish_variable(kmg_ctx *ctx, std::unique_ptr<kmg_db, void (*)(kmg_db
     return KMG_OK;
 }
 
+// The records of a build of two-word k-mers (ctx->rec_keys / rec_lo / rec_vals, window order) -> db's CSR.  wide.h, steps 2-5.
+static int finish_wide(kmg_ctx *ctx, u32 n, const std::vector<SortPass> &payload, kmg_db *db) {
+    PoolBuf ka(ctx), kb(ctx), i0(ctx), i1(ctx), table(ctx), agg(ctx), seg(ctx), flag(ctx), before(ctx), rank(ctx), d_hi(ctx), d_lo(ctx);
+    u64 U = 0;
+    int rbits = 1;
+    if (n > 0) {
+        const u32 ntiles = div_up_u64(n, RS_TILE);
+        const int lo_bits = 2 * (ctx->k - 32);
+        const int p_lo = choose_pbits(n, lo_bits), p_hi = choose_pbits(n, 64);
+        KMG_ALLOC(ka, (size_t)n * 8);
+        KMG_ALLOC(kb, (size_t)n * 8);
+        KMG_ALLOC(i0, (size_t)n * 4);
+        KMG_ALLOC(i1, (size_t)n * 4);
+        KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
+        KMG_ALLOC(agg, (size_t)(div_up_u64(std::max<u64>((u64)RS_DIGITS * ntiles, n), SCAN_TILE) + 1) * 8);
+        KMG_ALLOC(seg, (((size_t)1 << std::max(p_lo, p_hi)) + 4) * 4);
+        const dim3 grid(div_up_u64(n, 256)), blk(256);
+        const std::vector<SortPass> none;
+        // by lo (any order among equal words), then -- stable -- by hi: every launch below is a kernel of radix.h
+        KMG_HIP(hipMemcpyAsync(ka.p, ctx->rec_lo, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(wide_iota_kernel, grid, blk, 0, ctx->stream, i0.as<u32>(), n);
+        bool in1 = false;
+        KMG_TRY(hybrid_sort_records<u32>(ctx, ka.as<u64>(), i0.as<u32>(), kb.as<u64>(), i1.as<u32>(), n, 64 - lo_bits, none, table.as<u32>(),
+                                         agg.as<u32>(), seg.as<u32>(), whole_space_plan(p_lo), false, &in1, nullptr, false));
+        u32 *perm = in1 ? i1.as<u32>() : i0.as<u32>(), *perm_other = in1 ? i0.as<u32>() : i1.as<u32>();
+        hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, (const u64 *)ctx->rec_keys, (const u32 *)perm, n, ka.as<u64>());
+        KMG_TRY(hybrid_sort_records<u32>(ctx, ka.as<u64>(), perm, kb.as<u64>(), perm_other, n, 0, none, table.as<u32>(), agg.as<u32>(),
+                                         seg.as<u32>(), whole_space_plan(p_hi), false, &in1, nullptr, false));
+        const u64 *his = in1 ? kb.as<u64>() : ka.as<u64>();
+        u64 *los = in1 ? ka.as<u64>() : kb.as<u64>();
+        const u32 *order = in1 ? perm_other : perm;
+        hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, (const u64 *)ctx->rec_lo, order, n, los);
+        KMG_ALLOC(flag, (size_t)n * 4);
+        KMG_ALLOC(before, ((size_t)n + 1) * 8);
+        hipLaunchKernelGGL(wide_heads_kernel, grid, blk, 0, ctx->stream, his, (const u64 *)los, n, flag.as<u32>());
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, flag.as<u32>(), before.as<u64>(), n, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
+                                                    KP_SCAN)));
+        KMG_HIP(read_back(ctx, &U, before.as<u64>() + n, 8));
+        while (rbits < 32 && ((u64)1 << rbits) < U) rbits++;
+        KMG_ALLOC(rank, (size_t)n * 8);
+        KMG_ALLOC(d_hi, (U + 1) * 8);
+        KMG_ALLOC(d_lo, (U + 1) * 8);
+        hipLaunchKernelGGL(wide_rank_kernel, grid, blk, 0, ctx->stream, his, (const u64 *)los, order, flag.as<u32>(), before.as<u64>(), n, rbits,
+                           rank.as<u64>(), d_hi.as<u64>(), d_lo.as<u64>());
+        KMG_HIP(hipGetLastError());
+        ka.free(); kb.free(); i0.free(); i1.free(); flag.free(); before.free(); table.free(); seg.free();
+    } else {
+        KMG_ALLOC(d_hi, 8);
+        KMG_ALLOC(d_lo, 8);
+    }
+    // (rank, payload) records: the ranks order and compare as the k-mers do
+    KMG_TRY(sort_reduce_class(ctx, rank.as<u64>(), ctx->rec_vals, n, false, 16, payload, whole_space_plan(choose_pbits(n, rbits)), false, db,
+                              nullptr, rbits));
+    if (db->U != U) return fail(ctx, KMG_EDEVICE, "two-word build: the ranks' distinct count differs from the k-mers'");
+    ctx->pool.release(db->keys);
+    db->keys = (u64 *)d_hi.detach();
+    db->keys_lo = (u64 *)d_lo.detach();
+    return db_make_buckets(ctx, db);
+}
+
 extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows) {
     if (!ctx || !out) return KMG_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
@@ -1111,6 +1266,19 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
         int bits = pos_bits;
         while (bits < pos_bits + 32 && (st[ST_READ_BASE] >> (bits - pos_bits)) != 0) bits++;
         for (int shift = 0; shift < bits; shift += RS_BITS) payload.push_back({shift, std::min(RS_BITS, bits - shift), RS_SRC_VAL64});
+    }
+    if (ctx->k > 32) {
+        int r = finish_wide(ctx, n, payload, db);
+        ctx->pool.release(ctx->rec_keys); ctx->pool.release(ctx->rec_vals); ctx->pool.release(ctx->rec_lo);
+        ctx->rec_keys = nullptr; ctx->rec_vals = nullptr; ctx->rec_lo = nullptr; ctx->rec_cap = 0; ctx->rec_upper = 0;
+        if (r != KMG_OK) return r;
+        if (!reads && st[ST_ID_MIN] <= st[ST_ID_MAX]) {
+            db->tax_bounds = true;
+            db->tax_lo = (int32_t)((u32)st[ST_ID_MIN] ^ 0x80000000u);
+            db->tax_hi = (int32_t)((u32)st[ST_ID_MAX] ^ 0x80000000u);
+        }
+        *out = db_guard.release();
+        return KMG_OK;
     }
     // prefix bits for the global passes: segments of ~1-2 K records on uniform data
     // (a single-batch build keeps the bits its extractor already partitioned the records by)
@@ -1204,6 +1372,17 @@ extern "C" int kmg_db_fetch(const kmg_db *db, uint64_t *keys, uint64_t *val_off,
     return KMG_OK;
 }
 
+extern "C" int kmg_db_fetch_keys_lo(const kmg_db *db, uint64_t *keys_lo) {
+    if (!db || !keys_lo) return KMG_EINVAL;
+    kmg_ctx *ctx = db->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    if (!db->keys_lo) { memset(keys_lo, 0, db->U * 8); return KMG_OK; }      // k <= 32: no base behind the 32nd
+    if (db->U) KMG_HIP(hipMemcpyAsync(keys_lo, db->keys_lo, db->U * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    return KMG_OK;
+}
+
 // device check of a key array handed over by the caller: *bad += 1 wherever keys[i - 1] >= keys[i]
 __global__ void keys_ascending_kernel(const u64 *__restrict__ keys, u64 n, u32 *bad) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1;
@@ -1277,6 +1456,34 @@ extern "C" int kmg_db_load(kmg_ctx *ctx, int k, int key_len, int rc, int payload
                           reinterpret_cast<const u64 *>(val_off), val_a, val_b, V, hipMemcpyHostToDevice, out);
 }
 
+extern "C" int kmg_db_load_wide(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *keys,
+                                const uint64_t *keys_lo, uint64_t n_unique, const uint64_t *val_off, const int32_t *val_a,
+                                const int32_t *val_b, kmg_db **out) {
+    if (!ctx || !out) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *out = nullptr;
+    if (k <= 32 || key_len < 1) return fail(ctx, KMG_EINVAL, "k-mers of 33 .. 64 bases (kmg_db_load takes the shorter ones); key_len must be positive");
+    if (k > 64 || key_len > 12) return fail(ctx, KMG_EUNSUPPORTED, "k > 64 or key_len > 12");
+    if (!val_off || (n_unique && (!keys || !keys_lo))) return fail(ctx, KMG_EINVAL, "null keys / val_off");
+    const u64 V = val_off[n_unique];
+    if (V && (!val_a || !val_b)) return fail(ctx, KMG_EINVAL, "null values");
+    for (u64 i = 0; i < n_unique; i++) {
+        if (k < 64 && (keys_lo[i] << (2 * (k - 32))) != 0) return fail(ctx, KMG_EINVAL, "k-mer bits behind its length must be zero");
+        if (i && (keys[i - 1] > keys[i] || (keys[i - 1] == keys[i] && keys_lo[i - 1] >= keys_lo[i])))
+            return fail(ctx, KMG_EINVAL, "k-mers must be strictly ascending");
+    }
+    KMG_TRY(db_load_common(ctx, k, key_len, rc, payload_kind, reinterpret_cast<const u64 *>(keys), n_unique,
+                           reinterpret_cast<const u64 *>(val_off), val_a, val_b, V, hipMemcpyHostToDevice, out));
+    kmg_db *db = *out;
+    void *p;
+    if (ctx->pool.alloc(&p, (n_unique + 1) * 8) != KMG_OK) { db_release(db); *out = nullptr; return fail(ctx, KMG_ENOMEM, "device allocation failed"); }
+    db->keys_lo = (u64 *)p;
+    hipError_t e = n_unique ? hipMemcpyAsync(db->keys_lo, keys_lo, n_unique * 8, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->err = hipGetErrorString(e); db_release(db); *out = nullptr; return KMG_EDEVICE; }
+    return KMG_OK;
+}
+
 extern "C" int kmg_db_load_dev(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *d_keys,
                                uint64_t n_unique, const uint64_t *d_val_off, const int32_t *d_val_a,
                                const int32_t *d_val_b, uint64_t n_values, kmg_db **out) {
@@ -1337,6 +1544,9 @@ extern "C" int kmg_db_copy_dev(const kmg_db *db, int which, void *d_dst, uint64_
     u64 limit = 0;
     switch (which) {
         case KMG_DB_KEYS: src = db->keys; limit = db->U; break;
+        case KMG_DB_KEYS_LO:
+            if (!db->keys_lo) return fail(ctx, KMG_EINVAL, "k-mers of at most 32 bases have no second word");
+            src = db->keys_lo; limit = db->U; break;
         case KMG_DB_VAL_OFF: src = db->val_off; limit = db->U + 1; break;
         case KMG_DB_VAL_A:
         case KMG_DB_VAL_B:
@@ -1366,7 +1576,11 @@ extern "C" int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint6
     KMG_ALLOC(enc_off, (U + 2) * 8);
     KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
     ProfScope ps(ctx, KP_ENCODE, 0);
-    if (U) {
+    const bool wide = db->keys_lo != nullptr;
+    if (U && wide) {
+        hipLaunchKernelGGL((wide_enc_kernel<false>), dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys, db->keys_lo, db->val_off,
+                           db->val_a, db->val_b, U, db->k, db->key_len, db->kind, sizes.as<u32>(), (const u64 *)nullptr, (uint8_t *)nullptr);
+    } else if (U) {
         hipLaunchKernelGGL(enc_size_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys, db->lens, db->val_off, U,
                            db->k, db->key_len, db->kind, sizes.as<u32>());
     }
@@ -1386,6 +1600,11 @@ extern "C" int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint6
         if (cap < total) return fail(ctx, KMG_EINVAL, "encode buffer too small");
         if (total) {
             KMG_ALLOC(d_out, total);
+            if (wide)
+                hipLaunchKernelGGL((wide_enc_kernel<true>), dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys, db->keys_lo,
+                                   db->val_off, db->val_a, db->val_b, U, db->k, db->key_len, db->kind, (u32 *)nullptr, enc_off.as<u64>(),
+                                   d_out.as<uint8_t>());
+            else
             hipLaunchKernelGGL(enc_write_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys, db->lens,
                                db->val_off, db->val_a, db->val_b, U, db->k, db->key_len, db->kind, enc_off.as<u64>(),
                                d_out.as<uint8_t>());
@@ -1628,6 +1847,7 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
     const kmg_db *d0 = dbs[0];
     u64 Vt = 0;
     int rc = 1;
+    for (int i = 0; i < n_dbs; i++) if (dbs[i]) KMG_NO_WIDE(dbs[i]);
     for (int i = 0; i < n_dbs; i++) {
         const kmg_db *d = dbs[i];
         if (!d || d->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
@@ -1676,6 +1896,7 @@ extern "C" int kmg_db_restrict(kmg_ctx *ctx, const kmg_db *src, int length, kmg_
     std::lock_guard<std::mutex> g(ctx->mu);
     *out = nullptr;
     if (src->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
+    KMG_NO_WIDE(src);
     if (length < src->min_k || length > src->k)                                                     // DB.java:78-81
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
     if (length < src->key_len) return fail(ctx, KMG_EINVAL, "length below the key length");
@@ -1691,6 +1912,7 @@ extern "C" int kmg_db_restrict_range(kmg_ctx *ctx, const kmg_db *src, int min_le
     std::lock_guard<std::mutex> g(ctx->mu);
     *out = nullptr;
     if (src->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
+    KMG_NO_WIDE(src);
     if (min_length > max_length || min_length < src->key_len || max_length > 32)
         return fail(ctx, KMG_EINVAL, "key length <= min_length <= max_length <= 32");
     KMG_HIP(hipSetDevice(ctx->device));
@@ -1797,6 +2019,8 @@ extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     if (n_hits) *n_hits = 0;
     if (search->ctx != ctx || ref->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
     if (ref->kind != KMG_PAYLOAD_TAXON) return fail(ctx, KMG_EINVAL, "the database searched holds taxon counts");
+    KMG_NO_WIDE(search);
+    KMG_NO_WIDE(ref);
     if (search->key_len != ref->key_len) return fail(ctx, KMG_EINVAL, "key lengths differ");
     // DB.java:78-81 on the search stream's declared lengths [min_k, search->k]
     if (min_k < ref->min_k || search->k > ref->k || min_k > search->min_k || min_k < ref->key_len)
@@ -1890,6 +2114,16 @@ static int match_locked(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, l
     if (search->min_k != search->k || ref->min_k != ref->k)
         return fail(ctx, KMG_EUNSUPPORTED, "k-mers of several lengths: restrict the databases to one length first");
     if (search->U == 0) return KMG_OK;
+    if (search->k > 32) {
+        // two-word k-mers (wide.h): a lower-bound search per search k-mer inside its key bucket
+        ProfScope ps(ctx, KP_MATCH, 16 * (search->U + ref->U) + 8 * search->U);
+        hipLaunchKernelGGL(wide_match_kernel, dim3(div_up_u64(search->U, 256)), dim3(256), 0, ctx->stream, search->keys, search->keys_lo,
+                           search->U, ref->keys, ref->keys_lo, ref->bucket_off, ref->key_len, d_hit, d_nhits);
+        KMG_HIP(hipGetLastError());
+        KMG_TRY(note_foreign_use(ctx, search));
+        KMG_TRY(note_foreign_use(ctx, ref));
+        return KMG_OK;
+    }
     ProfScope ps(ctx, KP_MATCH, 8 * (search->U + ref->U) + 8 * search->U);
     const u32 ntiles = div_up_u64(search->U, MT_TILE);
     PoolBuf bounds(ctx);
@@ -1925,6 +2159,7 @@ extern "C" int kmg_match_keys_dev(kmg_ctx *ctx, const uint64_t *d_keys, const ui
 static int match_keys_locked(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run_off, int n_runs, int k,
                              const kmg_db *ref, int64_t *d_hit_index) {
     if (ref->ctx->device != ctx->device) return fail(ctx, KMG_EINVAL, "database belongs to another device");
+    KMG_NO_WIDE(ref);
     if (k != ref->k)                                                                             // DB.java:78-81
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
     if (ref->min_k != ref->k) return fail(ctx, KMG_EUNSUPPORTED, "k-mers of several lengths: restrict the database to one length first");
@@ -2001,6 +2236,8 @@ extern "C" int kmg_match_dev_noalloc(kmg_ctx *ctx, const kmg_db *search, const k
     if (!ctx->match_scratch) return fail(ctx, KMG_EDEVICE, "no scratch array on this device");
     // (a foreign database would need an event of its own to order its release: that is an allocation)
     if (search->ctx != ctx || ref->ctx != ctx) return fail(ctx, KMG_EINVAL, "both databases must belong to this context");
+    KMG_NO_WIDE(search);
+    KMG_NO_WIDE(ref);
     if (search->k != ref->k || search->key_len != ref->key_len)                                  // DB.java:78-81
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
     if (search->min_k != search->k || ref->min_k != ref->k)
@@ -2057,6 +2294,8 @@ extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     std::lock_guard<std::mutex> g(ctx->mu);
     KMG_HIP(hipSetDevice(ctx->device));
     *n_pairs = 0;
+    KMG_NO_WIDE(search);
+    KMG_NO_WIDE(ref);
     if (max_diff < 0) return fail(ctx, KMG_EINVAL, "max_diff must not be negative");
     // up to two differences: the neighbours are enumerated (near_kernel); more: the trie walk over the sorted array
     const bool walk = max_diff > 2;

@@ -1051,6 +1051,8 @@ int make_database(int argc, char **argv) {
     g_threads = std::max(1, a.geti('t', g_threads));
     if (min_k > k) throw std::runtime_error("-k (shortest k-mer) above -K (longest)");
     if (min_k != k && a.has('h')) throw Unsupported("human-readable databases (-h) hold k-mers of one length on the GPU path");
+    // (k-mers of 33 .. 64 bases: the library builds and encodes them; this driver's text writer knows one word per k-mer)
+    if (k > 32 && a.has('h')) throw Unsupported("human-readable databases (-h) of k-mers of more than 32 bases: use the Java path");
     if ((int)a.has('a') + (int)a.has('q') + (int)a.has('p') != 1)
         throw std::runtime_error("exactly one of -a (FASTA reference) / -q (FASTQ reads) / -p (preprocessed) is required");
     if (!a.has('i') || !a.has('o')) throw std::runtime_error("-i and -o are required");

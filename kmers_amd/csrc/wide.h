@@ -1,0 +1,267 @@
+// wide.h -- k-mers of 33 .. 64 bases: two 64-bit words per k-mer.
+//
+// The reference's k-mer is a byte array of any length (Kmers/Sequence.java:15-35,90-115; Kmer.java:47-55,90-97,142-225);
+// its order is base by base (Sequence.compareTo, Sequence.java:165-187).  Here a k-mer of k > 32 bases is (hi, lo): hi =
+// bases 0 .. 31, lo = bases 32 .. k-1 left-aligned and zero-padded, 2 bits per base (A0 C1 T2 G3) -- (hi, lo) ascending
+// as a pair of unsigned words is the reference's order, and hi then lo, big-endian, cut to ceil(k / 4) bytes, is
+// Sequence.cBytes.  Kmer.key(keyLength <= 12) lies in hi's top bits, so buckets work as for one-word k-mers.
+//
+// The build reuses the one-word machinery instead of doubling it (BASELINE's configs all have k = 31: this path is
+// about coverage of the reference's interface, every kernel here is HBM-bound byte work like its one-word twin):
+//   1. wide_extract_kernel: windows -> (hi, lo, payload) records, count pass + write pass, window order;
+//   2. two stable index sorts (radix.h, hybrid_sort_records<u32>): by lo, then by hi -> the records' order by k-mer;
+//   3. heads + scan over that order -> every record's RANK among the distinct k-mers, and the distinct k-mers;
+//   4. the ranks, left-aligned, are one-word keys with the k-mers' order and equality: the ordinary sort + dedup
+//      (sort_reduce_class) builds the CSR from (rank, payload) records -- taxa order, read sets and all;
+//   5. the CSR's keys (0 .. U-1) are swapped for the distinct k-mers' (hi, lo).
+// The exact join is a lower-bound search per search k-mer inside its key bucket.
+#pragma once
+#include "extract.h"
+
+#define EXW_EXT 64
+
+struct WideArgs {
+    ExtractArgs e;        // k = 33 .. 64; out_keys = the hi words
+    u64 *out_lo;
+};
+
+struct WideSite {
+    u64 hi, lo, rhi, rlo;
+    bool valid, ef, er;
+    u32 seq;
+    u32 pos;
+};
+
+// the window of W bases at position p of the tile (pk / inv / stb / seqrel: ex_load_tile_ext<EXW_EXT>)
+__device__ __forceinline__ WideSite wide_site(const ExtractArgs &a, const u32 *pk, const u32 *inv, const u32 *stb,
+                                              const u32 *seqrel, u32 s_lo, u64 t0, u32 p) {
+    WideSite x;
+    x.valid = x.ef = x.er = false;
+    x.hi = x.lo = x.rhi = x.rlo = 0; x.seq = 0; x.pos = 0;
+    const int W = a.k;
+    const u64 gp = t0 + p;
+    if (gp + (u64)W > a.nbases) return x;
+    const u32 w2 = p >> 5, r2 = p & 31;
+    const u64 b0 = ((u64)inv[w2] << 32) | inv[w2 + 1], b1 = (u64)inv[w2 + 2] << 32;
+    const u64 s0 = ((u64)stb[w2] << 32) | stb[w2 + 1], s1 = (u64)stb[w2 + 2] << 32;
+    const u64 bad = r2 ? (b0 << r2) | (b1 >> (64 - r2)) : b0;     // bit 63 - i: base p + i is invalid
+    const u64 st = r2 ? (s0 << r2) | (s1 >> (64 - r2)) : s0;      // bit 63 - i: a sequence starts at p + i
+    if ((bad >> (64 - W)) != 0) return x;                         // Sequence.java:15-35 would throw: no k-mer
+    if (((st << 1) >> (65 - W)) != 0) return x;                   // the window crosses into the next sequence
+    x.valid = true;
+    const u32 w = p >> 4, sh = 2 * (p & 15);
+    const u64 a0 = ((u64)pk[w] << 32) | pk[w + 1], a1 = ((u64)pk[w + 2] << 32) | pk[w + 3], a2 = (u64)pk[w + 4] << 32;
+    const int nlo = W - 32;
+    const u64 mask_lo = nlo == 32 ? ~0ull : ~(~0ull >> (2 * nlo));
+    x.hi = sh ? (a0 << sh) | (a1 >> (64 - sh)) : a0;
+    x.lo = (sh ? (a1 << sh) | (a2 >> (64 - sh)) : a1) & mask_lo;
+    x.seq = s_lo + seqrel[p];
+    x.pos = (u32)(gp - a.seq_off[x.seq]);
+    x.ef = true;
+    if (a.ranged) {
+        const u32 fb = (u32)(x.hi >> a.range_shift);
+        x.ef = fb >= a.range_lo && fb < a.range_hi;
+    }
+    if (a.rc) {
+        // the W bases in reverse order, left-aligned (Kmer.inplaceRC, Kmer.java:142-208: reversed, code ^ 2)
+        const u64 rh = revpairs64(x.lo), rl = revpairs64(x.hi);
+        const int s = 2 * (64 - W);
+        const u64 vh = s ? (rh << s) | (rl >> (64 - s)) : rh, vl = rl << s;
+        x.er = !(((W & 1) == 0) && vh == x.hi && vl == x.lo);     // Kmer.isOwnRC (Kmer.java:210-225): a palindrome of even length
+        x.rhi = vh ^ 0xAAAAAAAAAAAAAAAAull;
+        x.rlo = vl ^ (0xAAAAAAAAAAAAAAAAull & mask_lo);
+        if (x.er && a.ranged) {
+            const u32 rb = (u32)(x.rhi >> a.range_shift);
+            x.er = rb >= a.range_lo && rb < a.range_hi;
+        }
+    }
+    return x;
+}
+
+// Count pass (WRITE = false): records and forward windows per tile, has_kmer flags.  Write pass: the records of tile t
+// behind the ST_NREC records of earlier batches, at tile_off[t], in window order, the forward record of a window before its reverse complement's.
+template <bool WRITE>
+__global__ __launch_bounds__(EX_BLOCK) void wide_extract_kernel(WideArgs wa) {
+    __shared__ u32 pk[(EX_TILE + EXW_EXT) / 16 + 2];
+    __shared__ u32 inv[(EX_TILE + EXW_EXT) / 32 + 2];
+    __shared__ u32 stb[(EX_TILE + EXW_EXT) / 32 + 2];
+    __shared__ u32 seqrel[EX_TILE + EXW_EXT];
+    __shared__ u32 wave_cnt[EX_ROUNDS][EX_BLOCK / 64];
+    __shared__ u32 scan_smem[4];
+    __shared__ u32 blk_fwd;
+    const ExtractArgs &a = wa.e;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 t0 = (u64)blockIdx.x * EX_TILE;
+    if (tid == 0) blk_fwd = 0;
+    const u32 s_lo = ex_load_tile_ext<EXW_EXT>(a, blockIdx.x, pk, inv, stb, seqrel, scan_smem);
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    u32 fmask = 0, rmask = 0, wave_fwd = 0;
+    for (int j = 0; j < EX_ROUNDS; j++) {
+        const u32 p = j * EX_BLOCK + tid;
+        const WideSite x = wide_site(a, pk, inv, stb, seqrel, s_lo, t0, p);
+        // reads are numbered by the mapper, which runs when the k-mer is built: whatever a key range keeps of it
+        if (!WRITE && x.valid && a.has_kmer) a.has_kmer[x.seq] = 1;
+        fmask |= (u32)x.ef << j;
+        rmask |= (u32)x.er << j;
+        const u64 bf = __ballot(x.ef), br = __ballot(x.er);
+        if (lane == 0) wave_cnt[j][wave] = (u32)__popcll(bf) + (u32)__popcll(br);
+        wave_fwd += (u32)__popcll(bf);
+    }
+    if (!WRITE && lane == 0 && wave_fwd) atomicAdd(&blk_fwd, wave_fwd);
+    __syncthreads();
+    if (tid < 64) {     // 64 (round, wave) counts in position order: exclusive scan
+        const u32 v = wave_cnt[tid >> 2][tid & 3];
+        u32 inc = v;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const u32 o = __shfl_up(inc, dd, 64);
+            if (lane >= dd) inc += o;
+        }
+        if (WRITE) wave_cnt[tid >> 2][tid & 3] = inc - v;
+        else if (tid == 63) {
+            a.tile_count[blockIdx.x] = inc;
+            a.tile_fwd[blockIdx.x] = blk_fwd;
+        }
+    }
+    if (!WRITE) return;
+    __syncthreads();
+    const u64 tile_base = a.state[ST_NREC] + a.tile_off[blockIdx.x];
+    for (int j = 0; j < EX_ROUNDS; j++) {
+        const bool ef = (fmask >> j) & 1u, er = (rmask >> j) & 1u;
+        const u64 bf = __ballot(ef), br = __ballot(er);
+        if (!(ef || er)) continue;
+        const u32 p = j * EX_BLOCK + tid;
+        const WideSite x = wide_site(a, pk, inv, stb, seqrel, s_lo, t0, p);
+        u64 slot = tile_base + wave_cnt[j][wave] + (u32)__popcll(bf & lt) + (u32)__popcll(br & lt);
+        const u64 val = a.kind == KMG_PAYLOAD_TAXON ? (u64)(u32)a.seq_id[x.seq]
+                                                    : (((u64)(u32)a.read_index[x.seq] << 16) | (u64)(x.pos & 0xFFFFu));
+        for (int half = 0; half < 2; half++) {
+            if (!(half ? er : ef)) continue;
+            a.out_keys[slot] = half ? x.rhi : x.hi;
+            wa.out_lo[slot] = half ? x.rlo : x.lo;
+            if (a.kind == KMG_PAYLOAD_TAXON) reinterpret_cast<u32 *>(a.out_vals)[slot] = (u32)val;
+            else reinterpret_cast<u64 *>(a.out_vals)[slot] = val;
+            slot++;
+        }
+    }
+}
+
+// ---- ranks ----------------------------------------------------------------------------------------------------------
+__global__ void wide_iota_kernel(u32 *__restrict__ idx, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = i;
+}
+__global__ void wide_gather_kernel(const u64 *__restrict__ src, const u32 *__restrict__ idx, u32 n, u64 *__restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+// his / los: the records' words in k-mer order.  flag[j] = record j starts a new k-mer
+__global__ void wide_heads_kernel(const u64 *__restrict__ his, const u64 *__restrict__ los, u32 n, u32 *__restrict__ flag) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) flag[j] = j == 0 || his[j] != his[j - 1] || los[j] != los[j - 1];
+}
+// before[j] = heads before j (exclusive scan of flag).  rank_key of record perm[j] = its k-mer's rank, left-aligned in
+// `rbits` bits; the distinct k-mers in order.
+__global__ void wide_rank_kernel(const u64 *__restrict__ his, const u64 *__restrict__ los, const u32 *__restrict__ perm,
+                                 const u32 *__restrict__ flag, const u64 *__restrict__ before, u32 n, int rbits,
+                                 u64 *__restrict__ rank_key, u64 *__restrict__ d_hi, u64 *__restrict__ d_lo) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const u64 r = before[j] + flag[j] - 1;
+    rank_key[perm[j]] = r << (64 - rbits);
+    if (flag[j]) { d_hi[r] = his[j]; d_lo[r] = los[j]; }
+}
+
+// ---- exact join (DB.quickMatch, Database/DB.java:76-90: equal k-mers of one key bucket) ---------------------------------
+// hit[i] = index of search k-mer i in the reference, or -1
+__global__ __launch_bounds__(256) void wide_match_kernel(const u64 *__restrict__ s_hi, const u64 *__restrict__ s_lo, u64 n,
+                                                          const u64 *__restrict__ r_hi, const u64 *__restrict__ r_lo,
+                                                          const u64 *__restrict__ r_bucket, int key_len,
+                                                          long long *__restrict__ hit, u64 *__restrict__ nhits) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    bool found = false;
+    if (i < n) {
+        const u64 h = s_hi[i], l = s_lo[i];
+        const u64 b = h >> (64 - 2 * key_len);
+        u64 lo = r_bucket[b], hi = r_bucket[b + 1];
+        const u64 end = hi;
+        while (lo < hi) {
+            const u64 mid = (lo + hi) >> 1;
+            const u64 mh = r_hi[mid];
+            if (mh < h || (mh == h && r_lo[mid] < l)) lo = mid + 1; else hi = mid;
+        }
+        found = lo < end && r_hi[lo] == h && r_lo[lo] == l;
+        hit[i] = found ? (long long)lo : -1ll;
+    }
+    if (nhits) {
+        const u64 b = __ballot(found);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd((unsigned long long *)nhits, (unsigned long long)__popcll(b));
+    }
+}
+
+// ---- block encoding (FileCreator.java:312-347) of two-word k-mers ---------------------------------------------------------
+// compressedBytes = [k][cBytes: hi then lo, big-endian, l = ceil(k / 4) bytes]; s = bytes shared with the previous k-mer of
+// the bucket (FileCreator.shared, :244-252)
+__device__ __forceinline__ int wide_enc_shared(u64 ph, u64 pl, u64 ch, u64 cl, int l) {
+    int same;
+    const u64 xh = ph ^ ch;
+    if (xh) same = __clzll((long long)xh) >> 3;
+    else {
+        const u64 xl = pl ^ cl;
+        same = 8 + (xl ? (__clzll((long long)xl) >> 3) : 8);
+    }
+    if (same > l) same = l;
+    return 1 + same;
+}
+__device__ __forceinline__ uint8_t wide_byte(u64 h, u64 l, int i) {
+    return (uint8_t)(i < 8 ? h >> (56 - 8 * i) : l >> (56 - 8 * (i - 8)));
+}
+template <bool WRITE>
+__global__ void wide_enc_kernel(const u64 *__restrict__ k_hi, const u64 *__restrict__ k_lo, const u64 *__restrict__ val_off,
+                                const int32_t *__restrict__ val_a, const int32_t *__restrict__ val_b, u64 U, int k, int key_len,
+                                int kind, u32 *__restrict__ sizes, const u64 *__restrict__ enc_off, uint8_t *__restrict__ out) {
+    const u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const int l = (k - 1) / 4 + 1;
+    const int sh = 64 - 2 * key_len;
+    const u64 ch = k_hi[u], cl = k_lo[u];
+    int s = 0;
+    if (u > 0) {
+        const u64 ph = k_hi[u - 1];
+        if ((ph >> sh) == (ch >> sh)) s = wide_enc_shared(ph, k_lo[u - 1], ch, cl, l);
+    }
+    const u64 a = val_off[u], b = val_off[u + 1];
+    const u64 nv = b - a;
+    if (!WRITE) {
+        sizes[u] = (u32)(1 + (u64)(l + 1 - s) + (kind == KMG_PAYLOAD_TAXON ? 2 + 5 * nv : 4 + 6 * nv));
+        return;
+    }
+    uint8_t *p = out + enc_off[u];
+    *p++ = (uint8_t)s;
+    if (s == 0) *p++ = (uint8_t)k;
+    for (int i = (s == 0 ? 0 : s - 1); i < l; i++) *p++ = wide_byte(ch, cl, i);
+    if (kind == KMG_PAYLOAD_TAXON) {
+        *p++ = (uint8_t)(nv >> 8);
+        *p++ = (uint8_t)nv;
+        for (u64 v = a; v < b; v++) {
+            const u32 t = (u32)val_a[v];
+            const int32_t c = val_b[v];
+            *p++ = (uint8_t)(t >> 24); *p++ = (uint8_t)(t >> 16); *p++ = (uint8_t)(t >> 8); *p++ = (uint8_t)t;
+            *p++ = (uint8_t)(c > 255 ? 255 : c);   // CountDataType.java:40
+        }
+    } else {
+        *p++ = (uint8_t)(nv >> 24); *p++ = (uint8_t)(nv >> 16); *p++ = (uint8_t)(nv >> 8); *p++ = (uint8_t)nv;
+        for (u64 v = a; v < b; v++) {
+            const u32 r = (u32)val_a[v];
+            const u32 q = (u32)val_b[v];
+            *p++ = (uint8_t)(r >> 24); *p++ = (uint8_t)(r >> 16); *p++ = (uint8_t)(r >> 8); *p++ = (uint8_t)r;
+            *p++ = (uint8_t)(q >> 8); *p++ = (uint8_t)q;
+        }
+    }
+}
+
+// a loaded database's k-mers must ascend strictly as (hi, lo) pairs
+__global__ void wide_ascending_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, u64 n, u32 *bad) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (i < n && (hi[i - 1] > hi[i] || (hi[i - 1] == hi[i] && lo[i - 1] >= lo[i]))) atomicAdd(bad, 1u);
+}

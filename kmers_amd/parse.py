@@ -55,7 +55,7 @@ def _load():
         for n in ("nkeys", "nvals"):
             f = getattr(lib, "kmh_decoded_" + n)
             f.restype, f.argtypes = u64, [vp]
-        for n in ("keys", "val_off", "val_a", "val_b", "lens"):
+        for n in ("keys", "keys_lo", "val_off", "val_a", "val_b", "lens"):
             f = getattr(lib, "kmh_decoded_" + n)
             f.restype, f.argtypes = vp, [vp]
         _lib = lib
@@ -152,17 +152,22 @@ def parse_pieces(pieces, mode: int, k: int, id_map: bytes = None):
         lib.kmh_stream_close(st)
 
 
-def decode_blocks(data: bytes, kind: int, with_lens=False):
+def decode_blocks(data: bytes, kind: int, with_lens=False, with_lo=False):
     """KmerFile's prefix-delta decode (KmerFile.java:200-250) of all key blocks back to back
-    -> (keys u64, val_off u64, val_a i32, val_b i32[, lens u8]).  kind 0 = reference (counts), 1 = reads."""
+    -> (keys u64, val_off u64, val_a i32, val_b i32[, lens u8][, keys_lo u64]).  kind 0 = reference (counts), 1 = reads.
+    keys_lo: bases 32 .. of k-mers of more than 32 bases."""
     lib = _load()
     h = lib.kmh_decode_blocks(data, len(data), kind)
     if not h:
-        raise ValueError("malformed k-mer blocks, or k-mers longer than 32 bases (not supported on the GPU path)")
+        raise ValueError("malformed k-mer blocks, or k-mers longer than 64 bases (not supported on the GPU path)")
     try:
         nk, nv = lib.kmh_decoded_nkeys(h), lib.kmh_decoded_nvals(h)
         out = (_arr(lib.kmh_decoded_keys(h), nk, np.uint64), _arr(lib.kmh_decoded_val_off(h), nk + 1, np.uint64),
                _arr(lib.kmh_decoded_val_a(h), nv, np.int32), _arr(lib.kmh_decoded_val_b(h), nv, np.int32))
-        return out + (_arr(lib.kmh_decoded_lens(h), nk, np.uint8),) if with_lens else out
+        if with_lens:
+            out = out + (_arr(lib.kmh_decoded_lens(h), nk, np.uint8),)
+        if with_lo:
+            out = out + (_arr(lib.kmh_decoded_keys_lo(h), nk, np.uint64),)
+        return out
     finally:
         lib.kmh_decoded_free(h)

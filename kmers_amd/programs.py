@@ -58,7 +58,7 @@ def write_database(db: KmerDatabase, path, zip_level=5, hr=False, out=None, key_
     if with_meta:
         out.write_all(("%d\n%d\n%d\n%s\n%s\n" % (db.k, db.k, db.key_length, ids, "1" if db.rc else "0")).encode(), -1)
     h = db.fetch()
-    names = kmer_strings(h["keys"], db.k)
+    names = kmer_strings(h["keys"], db.k, h.get("keys_lo"))
     val_off, va, vb = h["val_off"].tolist(), h["val_a"].tolist(), h["val_b"].tolist()
     boff = h["bucket_off"].tolist()
     for key in range(first, end):
@@ -85,8 +85,8 @@ def _read_hr_database(ctx, f: container.IndexedInputFile, first=0, last=None):
     min_k, max_k, key_len = int(m[0]), int(m[1]), int(m[2])
     ids = [int(x) for x in m[3].split()]
     rc = m[4] == "1"
-    if min_k != max_k or max_k > 32:
-        raise KmersGpuError(KMG_EUNSUPPORTED, "minK != maxK or k > 32: use the Java path")
+    if min_k != max_k or max_k > 64:
+        raise KmersGpuError(KMG_EUNSUPPORTED, "minK != maxK or k > 64: use the Java path")
     if ids == REF_ID:
         kind = PAYLOAD_TAXON
     elif ids == READ_ID:
@@ -94,7 +94,7 @@ def _read_hr_database(ctx, f: container.IndexedInputFile, first=0, last=None):
     else:
         raise ValueError("UnexpectedDataTypeException")
     code = {"A": 0, "C": 1, "T": 2, "G": 3}
-    keys, val_off, va, vb = [], [0], [], []
+    keys, keys_lo, val_off, va, vb = [], [], [0], [], []
     prev = None
     for line in f.read_keys(first, f.max_index() if last is None else last).decode().splitlines():
         part, vals = line.split("\t")
@@ -103,7 +103,9 @@ def _read_hr_database(ctx, f: container.IndexedInputFile, first=0, last=None):
         v = 0
         for ch in cur:
             v = (v << 2) | code[ch.upper()]
-        keys.append(v << (64 - 2 * len(cur)))
+        v <<= 128 - 2 * len(cur)                 # (two words: bases 0 .. 31, bases 32 ..)
+        keys.append(v >> 64)
+        keys_lo.append(v & (2 ** 64 - 1))
         if kind == PAYLOAD_TAXON:
             for item in vals.split("|"):
                 t, c = item.split("x")
@@ -114,7 +116,7 @@ def _read_hr_database(ctx, f: container.IndexedInputFile, first=0, last=None):
                 va.append(int(r)); vb.append(int(p))
         val_off.append(len(va))
     return KmerDatabase.load(ctx, max_k, key_len, rc, kind, np.array(keys, np.uint64), np.array(val_off, np.uint64),
-                             np.array(va, np.int32), np.array(vb, np.int32))
+                             np.array(va, np.int32), np.array(vb, np.int32), keys_lo=np.array(keys_lo, np.uint64))
 
 
 def read_meta(f: container.IndexedInputFile):
@@ -134,16 +136,16 @@ def open_database(ctx, path, key_range=None) -> KmerDatabase:
     if f.hr:
         return _read_hr_database(ctx, f, first, last)
     min_k, max_k, key_len, ids, rc = read_meta(f)
-    if max_k > 32:
-        raise KmersGpuError(KMG_EUNSUPPORTED, "k > 32: use the Java path")
+    if max_k > 64 or (max_k > 32 and min_k != max_k):
+        raise KmersGpuError(KMG_EUNSUPPORTED, "k > 64, or k-mers of several lengths beyond 32 bases: use the Java path")
     if ids == REF_ID:
         kind = PAYLOAD_TAXON
     elif ids == READ_ID:
         kind = PAYLOAD_READPOS
     else:
         raise ValueError("UnexpectedDataTypeException: %s" % path)       # KmerFile.java:30-33
-    keys, val_off, val_a, val_b, lens = parse.decode_blocks(f.read_keys(first, last), kind, with_lens=True)
-    return KmerDatabase.load(ctx, max_k, key_len, rc, kind, keys, val_off, val_a, val_b, lens=lens, min_length=min_k)
+    keys, val_off, val_a, val_b, lens, keys_lo = parse.decode_blocks(f.read_keys(first, last), kind, with_lens=True, with_lo=True)
+    return KmerDatabase.load(ctx, max_k, key_len, rc, kind, keys, val_off, val_a, val_b, lens=lens, min_length=min_k, keys_lo=keys_lo)
 
 
 _UNPACK = np.array([[65, 67, 84, 71][(b >> s) & 3] for b in range(256) for s in (6, 4, 2, 0)], np.uint8).reshape(256, 4)

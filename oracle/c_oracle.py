@@ -7,16 +7,17 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libkmers_oracle.so")
+_SO_WIDE = os.path.join(_HERE, "_build", "libkmers_oracle_wide.so")      # the same source with -DKO_WIDE: k <= 64
 
 
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
-def _load():
-    if not os.path.exists(_SO):
+def _load(so=_SO):
+    if not os.path.exists(so):
         build()
-    lib = C.CDLL(_SO)
+    lib = C.CDLL(so)
     u64, vp = C.c_uint64, C.c_void_p
     lib.ko_build.restype = vp
     lib.ko_build.argtypes = [C.c_char_p, u64, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -33,7 +34,7 @@ def _load():
     for n in ("U", "V", "n_windows", "n_records", "n_reads"):
         f = getattr(lib, "ko_" + n)
         f.restype, f.argtypes = u64, [vp]
-    for n in ("keys", "val_off", "val_a", "val_b", "bucket_off", "name_off", "names"):
+    for n in ("keys", "keys_lo", "val_off", "val_a", "val_b", "bucket_off", "name_off", "names"):
         f = getattr(lib, "ko_" + n)
         f.restype, f.argtypes = vp, [vp]
     lib.ko_encode_blocks.restype = u64
@@ -48,10 +49,16 @@ def _load():
 
 
 _lib = None
+_lib_wide = None
 
 
-def lib():
-    global _lib
+def lib(wide=False):
+    """The restatement for k <= 32, or (wide) its two-word build for k <= 64."""
+    global _lib, _lib_wide
+    if wide:
+        if _lib_wide is None:
+            _lib_wide = _load(_SO_WIDE)
+        return _lib_wide
     if _lib is None:
         _lib = _load()
     return _lib
@@ -68,10 +75,12 @@ class OracleDB:
     """Result of MakeDatabase (-a: mode 0, -q: mode 1) as CSR arrays."""
 
     def __init__(self, data: bytes, mode: int, k: int, key_len: int, threads: int = 1, dust: int = -1,
-                 runofsame: int = -1, key_range=None, min_k=None, _handle=None):
+                 runofsame: int = -1, key_range=None, min_k=None, _handle=None, wide=None):
         """k = maxK (MakeDatabase -K), min_k = minK (-k; default: the same).
-        key_range = (first, end): only the slice of the database in those key buckets (ko_set_key_range)."""
-        L = lib()
+        key_range = (first, end): only the slice of the database in those key buckets (ko_set_key_range).
+        wide: the two-word build of the restatement (default: for k > 32)."""
+        self.wide = (k > 32) if wide is None else bool(wide)
+        L = lib(self.wide)
         if _handle is not None:
             self._h = _handle
         else:
@@ -94,6 +103,7 @@ class OracleDB:
         self.lens = _arr(L.ko_lens(h), self.U, np.uint8)
         self.n_windows, self.n_records = L.ko_n_windows(h), L.ko_n_records(h)
         self.keys = _arr(L.ko_keys(h), self.U, np.uint64)
+        self.keys_lo = _arr(L.ko_keys_lo(h), self.U, np.uint64) if self.wide else np.zeros(self.U, np.uint64)
         self.val_off = _arr(L.ko_val_off(h), self.U + 1, np.uint64)
         self.val_a = _arr(L.ko_val_a(h), self.V, np.int32)
         self.val_b = _arr(L.ko_val_b(h), self.V, np.int32)
@@ -107,7 +117,7 @@ class OracleDB:
 
     def close(self):
         if self._h:
-            lib().ko_free(self._h)
+            lib(self.wide).ko_free(self._h)
             self._h = None
 
     def __del__(self):
@@ -115,14 +125,14 @@ class OracleDB:
 
     def restrict(self, length):
         """KmerUtils.restrictedStream(.., length, length, ..) over the whole database (ko_restrict)."""
-        h = lib().ko_restrict(self._h, int(length))
+        h = lib(self.wide).ko_restrict(self._h, int(length))
         if not h:
             raise ValueError("length outside the database's k-mer lengths")
-        return OracleDB(b"", self.kind, int(length), self.key_len, _handle=h)
+        return OracleDB(b"", self.kind, int(length), self.key_len, _handle=h, wide=self.wide)
 
     def encode_blocks(self):
         """-> (bytes of all 4^l blocks back to back, block_off[4^l+1])."""
-        L = lib()
+        L = lib(self.wide)
         nk = 4 ** self.key_len
         off = np.zeros(nk + 1, dtype=np.uint64)
         need = L.ko_encode_blocks(self._h, None, 0, off.ctypes.data)
@@ -132,11 +142,12 @@ class OracleDB:
 
     def match(self, ref: "OracleDB", threads: int = 1):
         hit = np.empty(self.U, dtype=np.int64)
-        n = lib().ko_match(self._h, ref._h, hit.ctypes.data, threads)
+        assert self.wide == ref.wide
+        n = lib(self.wide).ko_match(self._h, ref._h, hit.ctypes.data, threads)
         return hit, n
 
     def match_lines(self, ref: "OracleDB", hit):
-        L = lib()
+        L = lib(self.wide)
         hit = np.ascontiguousarray(hit, dtype=np.int64)
         need = L.ko_match_lines(self._h, ref._h, hit.ctypes.data, None, 0)
         out = np.zeros(max(need, 1), dtype=np.uint8)
@@ -144,7 +155,7 @@ class OracleDB:
         return out[:need].tobytes()
 
     def taxacounts(self):
-        L = lib()
+        L = lib(self.wide)
         cap = max(self.V, 1)
         t = np.zeros(cap, np.int32)
         m = np.zeros(cap, np.int64)

@@ -24,6 +24,10 @@
  *                                                        KmersFromFile.java:90-133,167-176, Sequence.java:165-187,
  *                                                        KmerUtils.java:59-74
  * Restrictions (documented): k <= 32, input bytes < 128.
+ * Compiled with -DKO_WIDE (a second library, _build/libkmers_oracle_wide.so): k <= 64 -- the reference's Sequence is a
+ * byte array of any length (Sequence.java:15-35,90-115); here a k-mer then takes two words, `kmer` = bases 0 .. 31 and
+ * `lo` = bases 32 .. k-1, both left-aligned, and every step below works on the pair.  For k > 32 that build takes
+ * k-mers of one length and no -D / -R filter (what the GPU path takes); for k <= 32 it gives what the narrow one gives.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -33,8 +37,16 @@
 #include <omp.h>
 #endif
 
+#ifdef KO_WIDE
+#define KO_MAXK 64
+#else
+#define KO_MAXK 32
+#endif
 typedef struct {
     uint64_t kmer;  /* cBytes() zero-padded to 8 bytes, read big-endian == left-aligned 2-bit */
+#ifdef KO_WIDE
+    uint64_t lo;    /* ... and the next 8 bytes */
+#endif
     int32_t a;      /* taxon | read index */
     int32_t b;      /* bits 15..0: (unused) | pos (Java short); bits 23..16: k-mer length */
 } ko_rec;
@@ -48,6 +60,7 @@ typedef struct {
     uint64_t n_records;   /* temp-bucket records (fwd + rc) */
     uint64_t U, V;
     uint64_t *keys;       /* U  */
+    uint64_t *keys_lo;    /* U (KO_WIDE only, else NULL): bases 32 .. k-1 */
     uint64_t *val_off;    /* U+1 */
     int32_t *val_a;       /* V: taxon | read */
     int32_t *val_b;       /* V: count (unsaturated, clamped to int32) | pos */
@@ -81,6 +94,27 @@ static void rv_push(recvec *v, ko_rec r) {
     v->p[v->n++] = r;
 }
 
+#ifdef KO_WIDE
+#define REC_LO(r) ((r).lo)
+static int rec_base(const ko_rec *r, int i) { return (int)(((i < 32 ? r->kmer : r->lo) >> (62 - 2 * (i & 31))) & 3); }
+static void rec_set_base(ko_rec *r, int i, int c) {
+    if (i < 32) r->kmer |= (uint64_t)c << (62 - 2 * i); else r->lo |= (uint64_t)c << (62 - 2 * (i - 32));
+}
+/* Kmer.inplaceRC (Kmer.java:142-208) and Kmer.isOwnRC (:210-225), base by base */
+static ko_rec rec_rc(const ko_rec *x, int k) {
+    ko_rec q = *x; q.kmer = 0; q.lo = 0;
+    for (int i = 0; i < k; i++) rec_set_base(&q, k - 1 - i, rec_base(x, i) ^ 2);
+    return q;
+}
+static int rec_is_palindrome(const ko_rec *x, int k) {
+    if (k & 1) return 0;
+    for (int i = 0; i < k / 2; i++) if (rec_base(x, i) != rec_base(x, k - 1 - i)) return 0;
+    return 1;
+}
+#else
+#define REC_LO(r) 0ull
+#endif
+#ifndef KO_WIDE
 static uint64_t rc_packed(uint64_t x, int k) {
     /* Kmer.inplaceRC: reverse, complement = code ^ 2 */
     uint64_t r = 0;
@@ -96,12 +130,14 @@ static int is_palindrome(uint64_t x, int k) { /* Kmer.isOwnRC */
         if (((x >> (62 - 2 * i)) & 3) != ((x >> (62 - 2 * (k - 1 - i))) & 3)) return 0;
     return 1;
 }
+#endif
 
 static int cmp_rec(const void *pa, const void *pb) {
     const ko_rec *a = (const ko_rec *)pa, *b = (const ko_rec *)pb;
     /* Sequence.compareTo (Sequence.java:165-187): base by base, a proper prefix first == zero-padded value, then
      * length (the pad symbol A = 0 is the smallest base) */
     if (a->kmer != b->kmer) return a->kmer < b->kmer ? -1 : 1;
+    if (REC_LO(*a) != REC_LO(*b)) return REC_LO(*a) < REC_LO(*b) ? -1 : 1;
     if (REC_LEN(*a) != REC_LEN(*b)) return REC_LEN(*a) < REC_LEN(*b) ? -1 : 1;
     if (a->a != b->a) return a->a < b->a ? -1 : 1;               /* TreeCountMap key order / canonical */
     if (REC_POS(*a) != REC_POS(*b)) return REC_POS(*a) < REC_POS(*b) ? -1 : 1;
@@ -110,7 +146,7 @@ static int cmp_rec(const void *pa, const void *pb) {
 
 void ko_free(ko_db *d) {
     if (!d) return;
-    free(d->keys); free(d->val_off); free(d->val_a); free(d->val_b); free(d->bucket_off); free(d->lens);
+    free(d->keys); free(d->keys_lo); free(d->val_off); free(d->val_a); free(d->val_b); free(d->bucket_off); free(d->lens);
     free(d->name_off); free(d->names); free(d);
 }
 
@@ -163,7 +199,8 @@ void ko_set_min_k(int min_k) { g_min_k = min_k; }
 /* mode 0 = FASTA -> reference DB (MakeDatabase -a), 1 = FASTQ -> read DB (MakeDatabase -q).  k = maxK. */
 ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, int threads) {
     const int min_k = g_min_k > 0 ? g_min_k : k;
-    if (k < 1 || k > 32 || min_k < 1 || min_k > k || key_len < 1 || key_len > min_k || key_len > 12) return NULL;
+    if (k > 32 && (min_k != k || g_dust >= 0 || g_runofsame >= 0)) return NULL;
+    if (k < 1 || k > KO_MAXK || min_k < 1 || min_k > k || key_len < 1 || key_len > min_k || key_len > 12) return NULL;
     const int8_t *code = code_table();
     ko_db *d = (ko_db *)calloc(1, sizeof(ko_db));
     d->k = k; d->min_k = min_k; d->key_len = key_len; d->kind = mode; d->rc = (mode == 0);
@@ -183,7 +220,7 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
     /* ---- HOT LOOP 1: tryAdvance + FileCreator.addKmers, single thread like the reference.
      * The outer loop is one tryAdvance call, the inner one its do { } while (kwd == null) (KmersFromFile.java:84-208). */
     recvec recs = {0, 0, 0};
-    uint8_t window[32];
+    uint8_t window[KO_MAXK];
     memset(window, 0, sizeof window);
     int state = ST_OTHER;
     long pos = 0;
@@ -198,7 +235,7 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
         d->name_off = (uint64_t *)malloc(noff_cap * sizeof(uint64_t));
         d->name_off[0] = 0;
     }
-    int have_kwd = 0; ko_rec kwd = {0, 0, 0};     /* the `kwd` FIELD: it survives from one call to the next (quirk C.7) */
+    int have_kwd = 0; ko_rec kwd; memset(&kwd, 0, sizeof kwd);    /* the `kwd` FIELD: it survives from one call to the next (quirk C.7) */
     int ending = 0; long cur_k = 0;
     uint64_t ip = 0;
     for (;;) {                                    /* tryAdvance */
@@ -236,15 +273,20 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
             if (try_len) {
                 /* new Kmer(newbytes) on the last try_len bytes of the window: per-window re-encode,
                  * InvalidBaseException => no k-mer; the mapper runs only after the k-mer was built */
-                uint64_t packed = 0; int ok = 1;
+                uint64_t packed = 0, packed_lo = 0; int ok = 1;
                 for (int i = 0; i < try_len; i++) {
                     uint8_t w = window[k - try_len + i];
                     int v = w < 128 ? code[w] : -1;
                     if (v < 0) { ok = 0; break; }
-                    packed |= (uint64_t)v << (62 - 2 * i);
+                    if (i < 32) packed |= (uint64_t)v << (62 - 2 * i);
+                    else packed_lo |= (uint64_t)v << (62 - 2 * (i - 32));
                 }
+                (void)packed_lo;
                 if (ok) {
                     kwd.kmer = packed;
+#ifdef KO_WIDE
+                    kwd.lo = packed_lo;
+#endif
                     if (mode == 0) {
                         if (tax_of != ms) {       /* Integer.parseInt(id) */
                             char buf[32]; size_t l = ml < 31 ? ml : 31;
@@ -280,10 +322,17 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
         if (g_dust >= 0 && !dust_keep(kwd.kmer, len, g_dust)) continue;
         if (g_runofsame >= 0 && !runofsame_keep(kwd.kmer, len, g_runofsame)) continue;
         if (in_range(kwd.kmer, key_len)) { rv_push(&recs, kwd); d->n_windows++; }
+#ifdef KO_WIDE
+        if (d->rc && !rec_is_palindrome(&kwd, len)) {
+            ko_rec q = rec_rc(&kwd, len);
+            if (in_range(q.kmer, key_len)) rv_push(&recs, q);
+        }
+#else
         if (d->rc && !is_palindrome(kwd.kmer, len)) {
             ko_rec q = kwd; q.kmer = rc_packed(kwd.kmer, len);
             if (in_range(q.kmer, key_len)) rv_push(&recs, q);
         }
+#endif
     }
     d->n_reads = (uint64_t)(cur_read + 1);
     d->n_records = recs.n;
@@ -314,7 +363,7 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
         qsort(p, m, sizeof(ko_rec), cmp_rec);     /* TreeMap<Kmer,..> + TreeCountMap ordering */
         uint64_t u = 0, v = 0;
         for (size_t i = 0; i < m; i++) {
-            int newk = (i == 0) || p[i].kmer != p[i - 1].kmer || REC_LEN(p[i]) != REC_LEN(p[i - 1]);
+            int newk = (i == 0) || p[i].kmer != p[i - 1].kmer || REC_LO(p[i]) != REC_LO(p[i - 1]) || REC_LEN(p[i]) != REC_LEN(p[i - 1]);
             if (newk) u++;
             if (d->kind == 1 || newk || p[i].a != p[i - 1].a) v++;
         }
@@ -327,14 +376,23 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
     d->val_a = (int32_t *)malloc((d->V + 1) * sizeof(int32_t));
     d->val_b = (int32_t *)malloc((d->V + 1) * sizeof(int32_t));
     d->lens = (uint8_t *)malloc(d->U + 1);
+#ifdef KO_WIDE
+    d->keys_lo = (uint64_t *)malloc((d->U + 1) * sizeof(uint64_t));
+#endif
     d->bucket_off = ucount;
 #pragma omp parallel for schedule(dynamic, 16)
     for (int64_t key = 0; key < (int64_t)nkeys; key++) {
         ko_rec *p = sorted + boff[key]; size_t m = boff[key + 1] - boff[key];
         uint64_t u = ucount[key], v = vcount[key];
         for (size_t i = 0; i < m; i++) {
-            int newk = (i == 0) || p[i].kmer != p[i - 1].kmer || REC_LEN(p[i]) != REC_LEN(p[i - 1]);
-            if (newk) { d->keys[u] = p[i].kmer; d->lens[u] = (uint8_t)REC_LEN(p[i]); d->val_off[u] = v; u++; }
+            int newk = (i == 0) || p[i].kmer != p[i - 1].kmer || REC_LO(p[i]) != REC_LO(p[i - 1]) || REC_LEN(p[i]) != REC_LEN(p[i - 1]);
+            if (newk) {
+                d->keys[u] = p[i].kmer; d->lens[u] = (uint8_t)REC_LEN(p[i]); d->val_off[u] = v;
+#ifdef KO_WIDE
+                d->keys_lo[u] = p[i].lo;
+#endif
+                u++;
+            }
             if (d->kind == 1) { d->val_a[v] = p[i].a; d->val_b[v] = REC_POS(p[i]); v++; }
             else if (newk || p[i].a != p[i - 1].a) { d->val_a[v] = p[i].a; d->val_b[v] = 1; v++; }
             else if (d->val_b[v - 1] < INT32_MAX) d->val_b[v - 1]++;   /* TreeCountMap.add */
@@ -354,6 +412,8 @@ uint64_t ko_n_reads(const ko_db *d) { return d->n_reads; }
 int ko_min_k(const ko_db *d) { return d->min_k; }
 const uint8_t *ko_lens(const ko_db *d) { return d->lens; }
 const uint64_t *ko_keys(const ko_db *d) { return d->keys; }
+const uint64_t *ko_keys_lo(const ko_db *d) { return d->keys_lo; }
+int ko_max_k(void) { return KO_MAXK; }
 const uint64_t *ko_val_off(const ko_db *d) { return d->val_off; }
 const int32_t *ko_val_a(const ko_db *d) { return d->val_a; }
 const int32_t *ko_val_b(const ko_db *d) { return d->val_b; }
@@ -369,7 +429,7 @@ static void be16(uint8_t *p, uint16_t v) { p[0] = v >> 8; p[1] = v; }
 uint64_t ko_encode_blocks(const ko_db *d, uint8_t *out, uint64_t cap, uint64_t *block_off) {
     uint32_t nkeys = 1u << (2 * d->key_len);
     uint64_t w = 0;
-    uint8_t kc[9], prev[9];
+    uint8_t kc[17], prev[17];
     for (uint32_t key = 0; key < nkeys; key++) {
         if (block_off) block_off[key] = w;
         memset(prev, 0, sizeof prev);             /* byte[] prev = new byte[1] */
@@ -378,12 +438,13 @@ uint64_t ko_encode_blocks(const ko_db *d, uint8_t *out, uint64_t cap, uint64_t *
             const int l = (d->lens[u] - 1) / 4 + 1;   /* packed bytes of this k-mer */
             kc[0] = d->lens[u];                       /* Kmer.compressedBytes: [length byte][packed] */
             for (int i = 0; i < 8; i++) kc[1 + i] = (uint8_t)(d->keys[u] >> (56 - 8 * i));
+            for (int i = 0; i < 8; i++) kc[9 + i] = d->keys_lo ? (uint8_t)(d->keys_lo[u] >> (56 - 8 * i)) : 0;
             /* shared(): leading bytes in common with the previous record's compressedBytes, within both lengths
              * (FileCreator.java:244-252); prev = new byte[1] at the start of a key, and a record that shares
              * nothing is written whole (:318-330) */
             int s = 0;
             while (s < prev_n && s < l + 1 && prev[s] == kc[s]) s++;
-            memcpy(prev, kc, 9); prev_n = l + 1;
+            memcpy(prev, kc, 17); prev_n = l + 1;
             uint64_t nv = d->val_off[u + 1] - d->val_off[u];
             uint64_t need = 1 + (uint64_t)(l + 1 - s) + (d->kind == 0 ? 2 + 5 * nv : 4 + 6 * nv);
             if (out && w + need <= cap) {
@@ -426,6 +487,7 @@ static int cmp_val(const void *pa, const void *pb) {
 }
 ko_db *ko_restrict(const ko_db *s, int L) {
     if (L < s->min_k || L > s->k) return NULL;     /* DB.java:78-81 */
+    if (s->k > 32) return NULL;                    /* (two-word k-mers come in one length) */
     ko_db *d = (ko_db *)calloc(1, sizeof(ko_db));
     d->k = L; d->min_k = L; d->key_len = s->key_len; d->kind = s->kind; d->rc = s->rc;
     d->n_windows = s->n_windows; d->n_records = s->n_records;
@@ -482,8 +544,9 @@ uint64_t ko_match(const ko_db *s, const ko_db *r, int64_t *hit, int threads) {
         uint64_t b = r->bucket_off[key], be = r->bucket_off[key + 1];
         for (uint64_t i = a; i < ae; i++) hit[i] = -1;
         while (a < ae && b < be) {
-            if (s->keys[a] == r->keys[b]) { hit[a] = (int64_t)b; hits++; a++; b++; }
-            else if (s->keys[a] < r->keys[b]) a++;
+            const uint64_t sl = s->keys_lo ? s->keys_lo[a] : 0, rl = r->keys_lo ? r->keys_lo[b] : 0;
+            if (s->keys[a] == r->keys[b] && sl == rl) { hit[a] = (int64_t)b; hits++; a++; b++; }
+            else if (s->keys[a] < r->keys[b] || (s->keys[a] == r->keys[b] && sl < rl)) a++;
             else b++;
         }
     }
@@ -494,11 +557,11 @@ uint64_t ko_match(const ko_db *s, const ko_db *r, int64_t *hit, int threads) {
 uint64_t ko_match_lines(const ko_db *s, const ko_db *r, const int64_t *hit, char *out, uint64_t cap) {
     static const char B[4] = {'A', 'C', 'T', 'G'};
     uint64_t w = 0;
-    char tmp[64];
+    char tmp[80];
     for (uint64_t i = 0; i < s->U; i++) {
         if (hit[i] < 0) continue;
 #define PUT(str, len) do { if (out && w + (len) <= cap) memcpy(out + w, (str), (len)); w += (len); } while (0)
-        for (int j = 0; j < s->k; j++) tmp[j] = B[(s->keys[i] >> (62 - 2 * j)) & 3];
+        for (int j = 0; j < s->k; j++) tmp[j] = B[((j < 32 ? s->keys[i] : s->keys_lo[i]) >> (62 - 2 * (j & 31))) & 3];
         PUT(tmp, (uint64_t)s->k); PUT("\t", 1);
         for (uint64_t v = s->val_off[i]; v < s->val_off[i + 1]; v++) {
             int n = s->kind == 1 ? snprintf(tmp, sizeof tmp, "%s%d:%d", v > s->val_off[i] ? "|" : "", s->val_a[v], s->val_b[v])

@@ -822,8 +822,8 @@ def test_db_load_roundtrip_and_errors(ctx):
     other = km.make_reference_db(ctx, synth.fasta_bytes(taxa, genomes), 14, 4)
     with pytest.raises(km.InconsistentDataException):       # DB.java:78-81
         km.DB([ref]).get_nearest_kmers(other)
-    with pytest.raises(km.KmersGpuError):                   # k > 32 -> shim falls back to Java
-        km.FileCreator(ctx, 6, 33, "ref", True)
+    with pytest.raises(km.KmersGpuError):                   # k > 64 -> shim falls back to Java
+        km.FileCreator(ctx, 6, 65, "ref", True)
     for d in (ref, again, other):
         d.close()
 

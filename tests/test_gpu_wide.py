@@ -1,0 +1,267 @@
+"""GPU parity for k-mers of 33 .. 64 bases (two words per k-mer; csrc/wide.h), through the C ABI, against the oracle's
+two-word build (oracle/kmers_oracle.c with -DKO_WIDE, itself held byte for byte to the literal restatement
+oracle/slow_ref.py, which keeps a k-mer as a list of bases of any length -- tests/test_oracle_c.py).  Bar: bit-exact.
+Parity with Kmers.jar itself is UNPINNED (no JVM, no reference fixtures).  Reference: Kmers/Sequence.java:15-35,90-115,
+165-187; Kmer.java:47-55,90-97,142-225; FileCreator.java:65-110,271-347; DB.java:76-90."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import kmers_amd as km
+    c = km.Context(0)
+    yield c
+    c.close()
+
+
+def _same_db(got, want):
+    h = got.fetch()
+    assert got.n_unique == want.U and got.n_values == want.V
+    assert np.array_equal(h["keys"], want.keys)
+    assert np.array_equal(h["keys_lo"], want.keys_lo)
+    assert np.array_equal(h["val_off"], want.val_off)
+    assert np.array_equal(h["val_a"], want.val_a)
+    assert np.array_equal(h["val_b"], want.val_b)
+    assert np.array_equal(h["bucket_off"], want.bucket_off)
+    gb, goff = got.encode_blocks()
+    wb, woff = want.encode_blocks()
+    assert gb == wb and np.array_equal(goff, woff)
+
+
+def _rand_fasta(rng, n_seq, max_len, alphabet, taxa=(5, 7, 11, -3, 70000, 2 ** 31 - 1)):
+    parts = []
+    for _ in range(n_seq):
+        L = int(rng.integers(0, max_len))
+        s = bytes(rng.choice(np.frombuffer(alphabet, np.uint8), size=L).tolist())
+        parts.append(b">%d d\n%s\n" % (taxa[int(rng.integers(0, len(taxa)))], s))
+    return b"".join(parts)
+
+
+def _rand_fastq(rng, n_seq, max_len, alphabet):
+    parts = []
+    for i in range(n_seq):
+        L = int(rng.integers(0, max_len))
+        s = bytes(rng.choice(np.frombuffer(alphabet, np.uint8), size=L).tolist())
+        name = b"r%d" % (i - 1 if i % 7 == 3 else i)      # some neighbours share a header
+        parts.append(b"@%s\n%s\n+\n%s\n" % (name, s, b"I" * L))
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("k,key_len,seed,alphabet", [
+    (33, 3, 1, b"ACGTN"), (34, 2, 2, b"ACGTacgtN"), (40, 6, 3, b"ACGT"), (47, 4, 4, b"AC"), (48, 5, 5, b"ACGTN"),
+    (63, 6, 6, b"ACGT"), (64, 6, 7, b"ACGTN"), (64, 1, 8, b"AT"), (36, 2, 9, b"A"), (50, 12, 10, b"ACGT"),
+])
+def test_reference_build_matches_oracle(ctx, k, key_len, seed, alphabet):
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(seed)
+    fa = _rand_fasta(rng, 40, 900, alphabet)
+    got = km.make_reference_db(ctx, fa, k, key_len)
+    want = OracleDB(fa, 0, k, key_len)
+    _same_db(got, want)
+    assert got.n_windows == want.n_windows
+    got.close()
+
+
+@pytest.mark.parametrize("k,key_len,seed,alphabet", [
+    (33, 3, 11, b"ACGTN"), (45, 4, 12, b"ACGT"), (64, 6, 13, b"ACGTN"), (64, 2, 14, b"AT"), (40, 2, 15, b"A"),
+])
+def test_read_build_matches_oracle(ctx, k, key_len, seed, alphabet):
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(seed)
+    fq = _rand_fastq(rng, 300, 400, alphabet)
+    got, names = km.make_read_db(ctx, fq, k, key_len)
+    want = OracleDB(fq, 1, k, key_len)
+    _same_db(got, want)
+    assert names == want.names
+    got.close()
+
+
+def _genome_and_reads(rng, n_genomes, genome_len, n_reads, read_len, err=0.01):
+    genomes = [rng.integers(0, 4, genome_len) for _ in range(n_genomes)]
+    L = np.frombuffer(b"ACGT", np.uint8)
+    fa = b"".join(b">%d g\n%s\n" % (100 + i, L[g].tobytes()) for i, g in enumerate(genomes))
+    parts = []
+    for i in range(n_reads):
+        g = genomes[int(rng.integers(0, n_genomes))]
+        p = int(rng.integers(0, genome_len - read_len))
+        r = g[p:p + read_len].copy()
+        flip = rng.random(read_len) < err
+        r[flip] = (r[flip] + 1 + rng.integers(0, 3, int(flip.sum()))) % 4
+        s = L[r].tobytes()
+        if i % 2:       # the other strand
+            s = s[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+        parts.append(b"@q%d\n%s\n+\n%s\n" % (i, s, b"I" * read_len))
+    return fa, b"".join(parts)
+
+
+@pytest.mark.parametrize("k,key_len,seed", [(33, 4, 21), (48, 6, 22), (64, 6, 23), (55, 3, 24)])
+def test_match_lines_and_taxacounts_match_oracle(ctx, k, key_len, seed):
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(seed)
+    fa, fq = _genome_and_reads(rng, 6, 20000, 1500, 150)
+    ref = km.make_reference_db(ctx, fa, k, key_len)
+    rdb, names = km.make_read_db(ctx, fq, k, key_len)
+    oref, ordb = OracleDB(fa, 0, k, key_len, threads=8), OracleDB(fq, 1, k, key_len, threads=8)
+    _same_db(ref, oref)
+    _same_db(rdb, ordb)
+    hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
+    ohit, onh = ordb.match(oref, threads=8)
+    assert nh == onh and nh > 1000 and np.array_equal(hit, ohit)
+    assert km.match_lines(rdb, ref, hit) == ordb.match_lines(oref, ohit).decode().splitlines()
+    t, m, q = oref.taxacounts()
+    assert km.taxa_count_lines(ref) == ["%d\t%d\t%d" % x for x in zip(t.tolist(), m.tolist(), q.tolist())]
+    ref.close(); rdb.close()
+
+
+def test_batches_equal_one_batch_and_key_ranges_are_slices(ctx):
+    import kmers_amd as km
+    from kmers_amd import parse
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(31)
+    k, l = 41, 3
+    fq = _rand_fastq(rng, 900, 300, b"ACGTN")
+    want = OracleDB(fq, 1, k, l)
+    # the reads in batches (read numbering carries across calls)
+    pf = parse.parse(fq, parse.FASTQ, k)
+    b = pf.batch
+    fc = km.FileCreator(ctx, l, k, "read", False)
+    cuts = [0, 1, 250, 251, 600, b.nseq]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        a0, a1 = int(b.seq_off[lo]), int(b.seq_off[hi])
+        fc.add_kmers(km.SequenceBatch(b.bases[a0:a1], b.seq_off[lo:hi + 1] - b.seq_off[lo], seq_tok=b.seq_tok[lo:hi]))
+    got = fc.create()
+    _same_db(got, want)
+    got.close()
+    # key ranges: every slice equals the oracle's, reference side (reverse complements judged by their own bucket)
+    fa = _rand_fasta(rng, 30, 800, b"ACGT")
+    for lo, hi in ((0, 10), (10, 11), (11, 64), (5, 5)):
+        got = km.make_reference_db(ctx, fa, k, l, key_range=(lo, hi))
+        if lo == hi:
+            assert got.n_unique == 0
+        else:
+            _same_db(got, OracleDB(fa, 0, k, l, key_range=(lo, hi)))
+        got.close()
+
+
+def test_edge_cases(ctx):
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    k, l = 35, 2
+    cases = [
+        b">1\n\n>2\n" + b"A" * 34 + b"\n",                                   # nothing long enough
+        b">1\n" + b"ACGT" * 9 + b"\n",                                      # one window + its reverse complement
+        b">1\n" + b"AT" * 18 + b"\n>2\n" + b"AT" * 18 + b"\n",              # k odd: never its own reverse
+        b">3\n" + b"ACGT" * 8 + b"N" + b"ACGT" * 9 + b"\n",                 # an invalid base mid-way
+        b">4\n" + b"acgtACGT" * 600 + b"\n",                                # periodic: many copies, tile borders
+    ]
+    for fa in cases:
+        got = km.make_reference_db(ctx, fa, k, l)
+        _same_db(got, OracleDB(fa, 0, k, l))
+        got.close()
+    # even k: palindromes (Kmer.isOwnRC is a palindrome test) hand out no reverse complement
+    fa = b">9\n" + b"ACGTTGCA" * 5 + b"\n>9\n" + b"A" * 70 + b"\n"
+    got = km.make_reference_db(ctx, fa, 40, 2)
+    _same_db(got, OracleDB(fa, 0, 40, 2))
+    got.close()
+    # a position past 32767 wraps like a Java short (a random read: the canonical order of one k-mer's positions --
+    # the reference's own is a HashSet's -- is the oracle's signed one only while no k-mer recurs across the wrap)
+    rng = np.random.default_rng(7)
+    long_read = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=34000).tolist())
+    fq = b"@long\n" + long_read + b"\n+\n" + b"I" * 34000 + b"\n"
+    got, _ = km.make_read_db(ctx, fq, 64, 4)
+    _same_db(got, OracleDB(fq, 1, 64, 4))
+    assert got.fetch()["val_b"].min() < 0
+    got.close()
+
+
+def test_files_roundtrip_and_fences(ctx, tmp_path):
+    import kmers_amd as km
+    from kmers_amd import programs
+    from kmers_amd._lib import KMG_EUNSUPPORTED, KmersGpuError
+    rng = np.random.default_rng(41)
+    k, l = 44, 3
+    fa = _rand_fasta(rng, 20, 600, b"ACGT")
+    db = km.make_reference_db(ctx, fa, k, l)
+    for hr in (False, True):
+        path = str(tmp_path / ("db_hr" if hr else "db"))
+        programs.write_database(db, path, hr=hr)
+        back = programs.open_database(ctx, path)
+        a, b = db.fetch(), back.fetch()
+        for f in ("keys", "keys_lo", "val_off", "val_a", "bucket_off"):
+            assert np.array_equal(a[f], b[f]), f
+        assert np.array_equal(np.minimum(a["val_b"], 255), b["val_b"])
+        assert back.encode_blocks()[0] == db.encode_blocks()[0]
+        back.close()
+    # what is not built for two-word k-mers says so
+    for call in (lambda: km.merge_databases([db, db]), lambda: db.restrict(k),
+                 lambda: km.FileCreator(ctx, l, k, "ref", True, dust=2),
+                 lambda: km.FileCreator(ctx, l, 65, "ref", True)):
+        with pytest.raises(KmersGpuError) as e:
+            call()
+        assert e.value.code == KMG_EUNSUPPORTED
+    # (a build that was begun and refused leaves the context usable)
+    db2 = km.make_reference_db(ctx, fa, k, l)
+    assert db2.n_unique == db.n_unique
+    db.close(); db2.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_against_oracle(ctx, seed):
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.integers(33, 65))
+    l = int(rng.integers(1, 7))
+    alphabet = [b"ACGT", b"ACGTN", b"AC", b"ACGTacgtNn", b"AT"][int(rng.integers(0, 5))]
+    fa = _rand_fasta(rng, int(rng.integers(1, 60)), int(rng.integers(2, 3000)), alphabet)
+    fq = _rand_fastq(rng, int(rng.integers(1, 500)), int(rng.integers(2, 500)), alphabet)
+    ref = km.make_reference_db(ctx, fa, k, l)
+    rdb, names = km.make_read_db(ctx, fq, k, l)
+    oref, ordb = OracleDB(fa, 0, k, l), OracleDB(fq, 1, k, l)
+    _same_db(ref, oref)
+    _same_db(rdb, ordb)
+    assert names == ordb.names
+    hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
+    ohit, onh = ordb.match(oref)
+    assert nh == onh and np.array_equal(hit, ohit)
+    ref.close(); rdb.close()
+
+
+@pytest.mark.parametrize("k,l,n_reads,rlen", [(40, 4, 2500, 120), (64, 6, 3000, 150)])
+def test_collect_by_read_and_classifier_match_oracle(ctx, k, l, n_reads, rlen):
+    """kmg_collect_by_read / kmg_classify_reads over two-word k-mers against the restated CollectByRead + ReadClassifier
+    (Utils/CollectByRead.java:105-124,159-184, Utils/ReadClassifier.java:95-220) run on the match lines of the same join."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle import slow_ref as R
+    taxa, genomes = synth.random_genomes(181 + k, 6, 12000, shared_frac=0.4)
+    reads = synth.random_reads(182 + k, genomes, n_reads, rlen, 0.01)
+    fq = synth.fastq_bytes(reads)
+    ref = km.make_reference_db(ctx, synth.fasta_bytes(taxa, genomes), k, l)
+    rdb, names = km.make_read_db(ctx, fq, k, l)
+    hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
+    assert nh > 1000
+    lines = km.match_lines(rdb, ref, hit)
+    want = R.collect_by_read(lines)
+    got = km.collect_by_read_blocks(rdb, ref)
+    assert got.keys() == want.keys()
+    for key in want:
+        assert got[key] == want[key], key
+    call = km.classify_reads(rdb, ref, len(names))
+    out = {}
+    for key, text in want.items():
+        rs = []
+        for line in (text.decode().split("\n") if text else []):
+            r = int(line.split(":", 1)[0])
+            if not rs or rs[-1] != r:
+                rs.append(r)
+        out[key] = "".join("%d\t%d\n" % (r, int(call[r])) for r in rs if call[r] >= 0).encode()
+    assert out == R.read_classifier(want)
+    assert (call >= 0).sum() > 100
+    ref.close(); rdb.close()

@@ -167,3 +167,42 @@ def test_restricted_match_agrees(min_k, k, L, key_len, seed):
     hit, nh = creads.match(cref)
     assert creads.match_lines(cref, hit).decode().splitlines() == want
     assert nh == len(want) and nh > 0
+
+
+# ---- two-word k-mers (k > 32): the restatement built with -DKO_WIDE ---------------------------------------------------
+@pytest.mark.parametrize("k,key_len,seed", [(4, 2, 51), (31, 3, 52), (32, 3, 53)])
+def test_wide_build_of_the_restatement_equals_the_narrow_one_up_to_32(k, key_len, seed):
+    rng = np.random.default_rng(seed)
+    fa = _rand_fasta(rng, 12, 200, alphabet=b"ACGTacgtN" if k > 8 else b"AACCGTN")
+    fq = _rand_fastq(rng, 40, 90, alphabet=b"ACGTN" if k > 8 else b"AACGTN")
+    for data, mode in ((fa, 0), (fq, 1)):
+        a, b = OracleDB(data, mode, k, key_len), OracleDB(data, mode, k, key_len, wide=True)
+        for f in ("keys", "val_off", "val_a", "val_b", "bucket_off"):
+            assert np.array_equal(getattr(a, f), getattr(b, f))
+        assert not b.keys_lo.any()
+        assert a.encode_blocks()[0] == b.encode_blocks()[0] and a.names == b.names
+
+
+@pytest.mark.parametrize("k,key_len,seed,alphabet", [(33, 3, 61, b"ACGTacgtN"), (40, 2, 62, b"ACGT"), (47, 3, 63, b"AC"),
+                                                     (63, 3, 64, b"ACGTN"), (64, 3, 65, b"ACGT"), (64, 2, 66, b"AT"),
+                                                     (36, 2, 67, b"A")])
+def test_wide_builds_agree_with_the_literal_restatement(k, key_len, seed, alphabet):
+    """slow_ref.py keeps a k-mer as a list of bases of any length, as the reference does."""
+    rng = np.random.default_rng(seed)
+    fa = _rand_fasta(rng, 10, 300, alphabet=alphabet)
+    py = R.build_ref_db(fa, k, key_len)
+    c = OracleDB(fa, 0, k, key_len)
+    cb, off = c.encode_blocks()
+    assert cb == _py_blocks_concat(py, key_len)
+    fq = _rand_fastq(rng, 30, 200, alphabet=alphabet)
+    pyr, names = R.build_read_db(fq, k, key_len)
+    cr = OracleDB(fq, 1, k, key_len)
+    assert cr.encode_blocks()[0] == _py_blocks_concat(pyr, key_len)
+    assert cr.names == names
+    # the exact join and its lines, TaxaCounts
+    hit, n = cr.match(c)
+    want = R.match_lines(pyr, R.DB([py]))
+    got = cr.match_lines(c, hit).decode().splitlines()
+    assert got == want and n == len(want)
+    t, m, q = c.taxacounts()
+    assert ["%d\t%d\t%d" % (a, b, cc) for a, b, cc in zip(t, m, q)] == R.taxa_counts(R.DB([py]))
