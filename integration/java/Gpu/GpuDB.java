@@ -23,34 +23,48 @@ public class GpuDB implements AutoCloseable
      *  ascending; valOff / taxon / count: the CSR of its TreeCountMap entries in ascending taxon order. */
     public GpuDB(KmersGpu gpu, int k, int keyLength, long[] keys, long[] valOff, int[] taxon, int[] count) throws Exception
     {
+        this(gpu, k, keyLength, keys, null, valOff, taxon, count);
+    }
+
+    /** keysLo (k > 32 only, else null): bytes 9 .. 16 of every k-mer's compressedBytes, read the same way (bases 32 .. k-1) */
+    public GpuDB(KmersGpu gpu, int k, int keyLength, long[] keys, long[] keysLo, long[] valOff, int[] taxon, int[] count) throws Exception
+    {
         this.gpu = gpu;
         this.k = k;
         this.keyLength = keyLength;
         this.valOff = valOff;
         this.taxon = taxon;
         this.count = count;
-        ref = gpu.dbLoad(k, keyLength, true, KmersGpu.PAYLOAD_TAXON, keys, valOff, taxon, count);
+        ref = k > 32 ? gpu.dbLoadWide(k, keyLength, true, KmersGpu.PAYLOAD_TAXON, keys, keysLo, valOff, taxon, count)
+                     : gpu.dbLoad(k, keyLength, true, KmersGpu.PAYLOAD_TAXON, keys, valOff, taxon, count);
+    }
+
+    /** bytes first .. first + 7 of a k-mer's compressedBytes (cb[0] is the length byte), big-endian, zero-padded */
+    static long word(byte[] cb, int first)
+    {
+        long v = 0;
+        for (int b = first; b < first + 8; b++) v = (v << 8) | (b < cb.length ? (cb[b] & 0xFFL) : 0L);
+        return v;
     }
 
     /** The reference database `db` (one or several files: DB.kmers merges them, DB.java:99-109) on the GPU, or null when it
-     *  is not one the GPU path takes (k-mers of several lengths, k > 32): key by key, every entry's k-mer and its
+     *  is not one the GPU path takes (k-mers of several lengths, k > 64): key by key, every entry's k-mer and its
      *  TreeCountMap in ascending taxon order.  Matcher and TaxaCounts call it once, after `new DB<>(dbfiles, merger)`. */
     public static GpuDB fromDB(Database.DB<CountMaps.TreeCountMap<Integer>> db) throws Exception
     {
         Kmers.KmerStream<CountMaps.TreeCountMap<Integer>> first = db.kmers(0);
         int minK = first.getMinLength(), maxK = first.getMaxLength();
         first.close();
-        if (minK != maxK || maxK > 32) return null;
+        if (minK != maxK || maxK > 64) return null;
         int keyLength = Integer.numberOfTrailingZeros(db.getMaxKey()) / 2;                 // maxKey = 4^keyLength
-        java.util.ArrayList<Long> keys = new java.util.ArrayList<>(), off = new java.util.ArrayList<>();
+        java.util.ArrayList<Long> keys = new java.util.ArrayList<>(), keysLo = new java.util.ArrayList<>(), off = new java.util.ArrayList<>();
         java.util.ArrayList<Integer> taxon = new java.util.ArrayList<>(), count = new java.util.ArrayList<>();
         off.add(0L);
         for (int key = 0; key < db.getMaxKey(); key++)
             db.kmers(key).forEach(kwd -> {
                 byte[] cb = kwd.getKmer().compressedBytes();
-                long v = 0;
-                for (int b = 1; b <= 8; b++) v = (v << 8) | (b < cb.length ? (cb[b] & 0xFFL) : 0L);
-                keys.add(v);
+                keys.add(word(cb, 1));
+                keysLo.add(word(cb, 9));
                 for (Map.Entry<Integer, Long> e : kwd.getData().entrySet())
                 {
                     taxon.add(e.getKey());
@@ -59,6 +73,7 @@ public class GpuDB implements AutoCloseable
                 off.add((long) taxon.size());
             });
         return new GpuDB(new KmersGpu(0), maxK, keyLength, keys.stream().mapToLong(Long::longValue).toArray(),
+                         maxK > 32 ? keysLo.stream().mapToLong(Long::longValue).toArray() : null,
                          off.stream().mapToLong(Long::longValue).toArray(), taxon.stream().mapToInt(Integer::intValue).toArray(),
                          count.stream().mapToInt(Integer::intValue).toArray());
     }
@@ -68,7 +83,13 @@ public class GpuDB implements AutoCloseable
      *  (search k-mer, its ReadPos set, KmerDiff "-", counts(hit)). */
     public long[] getNearestKmers(long[] searchKeys, long[] searchValOff, int[] read, int[] pos) throws Exception
     {
-        MemorySegment search = gpu.dbLoad(k, keyLength, false, KmersGpu.PAYLOAD_READPOS, searchKeys, searchValOff, read, pos);
+        return getNearestKmers(searchKeys, null, searchValOff, read, pos);
+    }
+
+    public long[] getNearestKmers(long[] searchKeys, long[] searchKeysLo, long[] searchValOff, int[] read, int[] pos) throws Exception
+    {
+        MemorySegment search = k > 32 ? gpu.dbLoadWide(k, keyLength, false, KmersGpu.PAYLOAD_READPOS, searchKeys, searchKeysLo, searchValOff, read, pos)
+                                      : gpu.dbLoad(k, keyLength, false, KmersGpu.PAYLOAD_READPOS, searchKeys, searchValOff, read, pos);
         try
         {
             return gpu.match(search, ref, searchKeys.length);
@@ -87,16 +108,16 @@ public class GpuDB implements AutoCloseable
     public <S, D> List<Kmers.KmerWithData<DataTypes.DataPair<S, Database.ClosestInfoCollector<D>>>> quickMatchCommonKey(
             List<Kmers.KmerWithData<S>> kmers, java.util.function.Function<Map<Integer, Long>, D> make) throws Exception
     {
-        long[] keys = new long[kmers.size()];
+        long[] keys = new long[kmers.size()], keysLo = new long[kmers.size()];
         for (int i = 0; i < keys.length; i++)
         {
             byte[] cb = kmers.get(i).getKmer().compressedBytes();      // [length][2 bits per base, first base in the top bits]
-            long v = 0;
-            for (int b = 1; b <= 8; b++) v = (v << 8) | (b < cb.length ? (cb[b] & 0xFFL) : 0L);
-            keys[i] = v;
+            keys[i] = word(cb, 1);
+            keysLo[i] = word(cb, 9);
         }
         long[] valOff = new long[keys.length + 1];                      // the join needs the k-mers only
-        MemorySegment search = gpu.dbLoad(k, keyLength, false, KmersGpu.PAYLOAD_READPOS, keys, valOff, new int[0], new int[0]);
+        MemorySegment search = k > 32 ? gpu.dbLoadWide(k, keyLength, false, KmersGpu.PAYLOAD_READPOS, keys, keysLo, valOff, new int[0], new int[0])
+                                      : gpu.dbLoad(k, keyLength, false, KmersGpu.PAYLOAD_READPOS, keys, valOff, new int[0], new int[0]);
         long[] hit;
         try { hit = gpu.match(search, ref, keys.length); }
         finally { gpu.dbFree(search); }

@@ -24,10 +24,12 @@ import Zip.ZipOrNot;
 
 public final class GpuMakeDatabase
 {
-    /** what the GPU path takes: -a / -q, -K <= 32, no -h, no -U, no temp files (MakeDatabase.java:106-111) */
-    public static boolean usable(CommandLine commands, int maxK, boolean useExistingTemp)
+    /** what the GPU path takes: -a / -q, -K <= 32 (or, k-mers of one length and no -D / -R filter, -K <= 64), no -h,
+     *  no -U, no temp files (MakeDatabase.java:106-111) */
+    public static boolean usable(CommandLine commands, int minK, int maxK, boolean useExistingTemp)
     {
-        return (commands.hasOption('a') || commands.hasOption('q')) && !commands.hasOption('O') && maxK <= 32
+        boolean wide = maxK > 32 && maxK <= 64 && minK == maxK && !commands.hasOption('D') && !commands.hasOption('R');
+        return (commands.hasOption('a') || commands.hasOption('q')) && !commands.hasOption('O') && (maxK <= 32 || wide)
                 && !commands.hasOption('h') && !useExistingTemp;
     }
 

@@ -130,6 +130,50 @@ def main():
         print(name, len(lines), "match lines,", os.path.getsize(path), "bytes")
 
 
+# k-mers of more than 32 bases (the reference's Sequence is a byte array of any length, Sequence.java:15-35,90-115)
+WIDE_CASES = [
+    # name, k, key_len, seed, #genomes, genome length, #reads, read length, fasta alphabet, paired headers
+    ("k40", 40, 3, 301, 3, 400, 40, 110, b"ACGT" * 8 + b"acgtN", True),
+    ("k64_even", 64, 2, 302, 3, 420, 40, 120, b"ACGT", False),
+    ("k33_low_entropy", 33, 2, 303, 3, 300, 30, 90, b"AAT", False),
+]
+
+
+def main_wide():
+    for name, k, l, seed, ng, glen, nr, rlen, alphabet, paired in WIDE_CASES:
+        fa, fq = make_inputs(seed, ng, glen, nr, rlen, alphabet, paired)
+        if k % 2 == 0:                           # a palindrome of even length has no reverse complement record (Kmer.isOwnRC)
+            half = fa.split(b"\n")[1][:k // 2].upper().replace(b"N", b"A")
+            fa += b">9\n%s\n" % (half + half[::-1])
+        ref = R.build_ref_db(fa, k, l)
+        reads, names = R.build_read_db(fq, k, l)
+        db = R.DB([ref])
+        lines = R.match_lines(reads, db)
+        counts = R.taxa_counts(db)
+        collected = R.collect_by_read(lines)
+        calls = R.read_classifier(collected)
+        c_ref, c_reads = OracleDB(fa, 0, k, l), OracleDB(fq, 1, k, l)
+        assert c_ref.encode_blocks()[0] == b"".join(ref[key] for key in range(4 ** l)), name
+        assert c_reads.encode_blocks()[0] == b"".join(reads[key] for key in range(4 ** l)) and c_reads.names == names, name
+        hit, _ = c_reads.match(c_ref)
+        assert c_reads.match_lines(c_ref, hit).decode().splitlines() == lines and len(lines) > 20, name
+        out = {
+            "comment": "outputs of oracle/slow_ref.py (restatement of the reference), not of Kmers.jar; see make_golden.py",
+            "k": k, "key_len": l, "fasta": fa.decode(), "fastq": fq.decode(),
+            "ref_blocks": {str(key): ref[key].hex() for key in sorted(ref)},
+            "read_blocks": {str(key): reads[key].hex() for key in sorted(reads)},
+            "read_names": names, "match_lines": lines, "taxa_counts": counts,
+            "collect_by_read": {str(key): collected[key].decode() for key in sorted(collected)},
+            "read_classifier": {str(key): calls[key].decode() for key in sorted(calls)},
+        }
+        path = os.path.join(ROOT, "tests", "golden", "wide_%s.json" % name)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=0, sort_keys=True)
+            f.write("\n")
+        print(name, len(lines), "match lines,", os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     main()
     main_var()
+    main_wide()

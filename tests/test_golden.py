@@ -176,3 +176,73 @@ def test_gpu_reproduces_variable_length_golden(path):
             assert blob[int(off[key]):int(off[key + 1])] == (g["ref_blocks"][key] if lo <= key < hi else b""), key
         part.close()
     ctx.close()
+
+
+# ---- k-mers of more than 32 bases (two words per k-mer on the GPU; Sequence.java:15-35,90-115) ------------------------
+WIDE_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "wide_*.json")))
+
+
+def _load_wide(path):
+    g = json.load(open(path))
+    g["ref_blocks"] = {int(k): bytes.fromhex(v) for k, v in g["ref_blocks"].items()}
+    g["read_blocks"] = {int(k): bytes.fromhex(v) for k, v in g["read_blocks"].items()}
+    g["collect_by_read"] = {int(k): v.encode() for k, v in g["collect_by_read"].items()}
+    g["read_classifier"] = {int(k): v.encode() for k, v in g["read_classifier"].items()}
+    return g
+
+
+def test_wide_golden_files_exist():
+    assert len(WIDE_CASES) >= 3
+
+
+@pytest.mark.parametrize("path", WIDE_CASES, ids=[os.path.basename(p)[5:-5] for p in WIDE_CASES])
+def test_restatements_reproduce_wide_golden(path):
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    g = _load_wide(path)
+    k, l = g["k"], g["key_len"]
+    fa, fq = g["fasta"].encode(), g["fastq"].encode()
+    ref = R.build_ref_db(fa, k, l)
+    reads, names = R.build_read_db(fq, k, l)
+    assert ref == g["ref_blocks"] and reads == g["read_blocks"] and names == g["read_names"]
+    db = R.DB([ref])
+    lines = R.match_lines(reads, db)
+    assert lines == g["match_lines"] and R.taxa_counts(db) == g["taxa_counts"]
+    collected = R.collect_by_read(lines)
+    assert collected == g["collect_by_read"] and R.read_classifier(collected) == g["read_classifier"]
+    c_ref, c_reads = OracleDB(fa, 0, k, l), OracleDB(fq, 1, k, l)
+    for c, want in ((c_ref, g["ref_blocks"]), (c_reads, g["read_blocks"])):
+        blob, off = c.encode_blocks()
+        for key in range(4 ** l):
+            assert blob[int(off[key]):int(off[key + 1])] == want[key]
+    assert c_reads.names == g["read_names"]
+    hit, _ = c_reads.match(c_ref)
+    assert c_reads.match_lines(c_ref, hit).decode().splitlines() == g["match_lines"]
+    t, m, q = c_ref.taxacounts()
+    assert ["%d\t%d\t%d" % x for x in zip(t, m, q)] == g["taxa_counts"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", WIDE_CASES, ids=[os.path.basename(p)[5:-5] for p in WIDE_CASES])
+def test_gpu_reproduces_wide_golden(path):
+    import kmers_amd as km
+    g = _load_wide(path)
+    k, l = g["k"], g["key_len"]
+    ctx = km.Context(0)
+    ref = km.make_reference_db(ctx, g["fasta"].encode(), k, l)
+    reads, names = km.make_read_db(ctx, g["fastq"].encode(), k, l)
+    for db, want in ((ref, g["ref_blocks"]), (reads, g["read_blocks"])):
+        blob, off = db.encode_blocks()
+        assert db.meta() == want[-1]
+        for key in range(4 ** l):
+            assert blob[int(off[key]):int(off[key + 1])] == want[key], key
+    assert names == g["read_names"]
+    hit, nh = km.DB([ref]).get_nearest_kmers(reads)
+    assert km.match_lines(reads, ref, hit) == g["match_lines"] and nh == len(g["match_lines"])
+    assert km.taxa_count_lines(ref) == g["taxa_counts"]
+    assert km.collect_by_read_blocks(reads, ref) == g["collect_by_read"]
+    call2, seen = km.classify_reads(reads, ref, len(names), with_hits=True)
+    assert km.read_call_blocks(call2, seen) == g["read_classifier"]
+    for d in (ref, reads):
+        d.close()
+    ctx.close()
