@@ -1204,9 +1204,25 @@ static int finish_wide(kmg_ctx *ctx, u32 n, const std::vector<SortPass> &payload
                                                     KP_SCAN)));
         KMG_HIP(read_back(ctx, &U, before.as<u64>() + n, 8));
         while (rbits < 32 && ((u64)1 << rbits) < U) rbits++;
-        KMG_ALLOC(rank, (size_t)n * 8);
         KMG_ALLOC(d_hi, (U + 1) * 8);
         KMG_ALLOC(d_lo, (U + 1) * 8);
+        if (db->kind == KMG_PAYLOAD_READPOS && payload.empty()) {
+            // the records' (read, pos) ascend as they were written and both sorts were stable: the CSR from the heads
+            PoolBuf pay(ctx), voff(ctx);
+            KMG_ALLOC(pay, ((size_t)n + 1) * 8);
+            KMG_ALLOC(voff, (U + 2) * 8);
+            hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, (const u64 *)ctx->rec_vals, order, n, pay.as<u64>());
+            hipLaunchKernelGGL(wide_csr_reads_kernel, grid, blk, 0, ctx->stream, his, (const u64 *)los, flag.as<u32>(), before.as<u64>(), n,
+                               d_hi.as<u64>(), d_lo.as<u64>(), voff.as<u64>());
+            KMG_HIP(hipGetLastError());
+            db->U = U; db->V = n;
+            db->keys = (u64 *)d_hi.detach();
+            db->keys_lo = (u64 *)d_lo.detach();
+            db->val_off = (u64 *)voff.detach();
+            db->vals_packed = (u64 *)pay.detach();
+            return db_make_buckets(ctx, db);      // (and val_off[U] = V)
+        }
+        KMG_ALLOC(rank, (size_t)n * 8);
         hipLaunchKernelGGL(wide_rank_kernel, grid, blk, 0, ctx->stream, his, (const u64 *)los, order, flag.as<u32>(), before.as<u64>(), n, rbits,
                            rank.as<u64>(), d_hi.as<u64>(), d_lo.as<u64>());
         KMG_HIP(hipGetLastError());
@@ -2115,10 +2131,10 @@ static int match_locked(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, l
         return fail(ctx, KMG_EUNSUPPORTED, "k-mers of several lengths: restrict the databases to one length first");
     if (search->U == 0) return KMG_OK;
     if (search->k > 32) {
-        // two-word k-mers (wide.h): a lower-bound search per search k-mer inside its key bucket
+        // two-word k-mers (wide.h): every tile of search k-mers against the piece of the reference it can meet
         ProfScope ps(ctx, KP_MATCH, 16 * (search->U + ref->U) + 8 * search->U);
-        hipLaunchKernelGGL(wide_match_kernel, dim3(div_up_u64(search->U, 256)), dim3(256), 0, ctx->stream, search->keys, search->keys_lo,
-                           search->U, ref->keys, ref->keys_lo, ref->bucket_off, ref->key_len, d_hit, d_nhits);
+        hipLaunchKernelGGL(wide_match_kernel, dim3(div_up_u64(search->U, WM_TILE)), dim3(WM_BLOCK), 0, ctx->stream, search->keys,
+                           search->keys_lo, search->U, ref->keys, ref->keys_lo, ref->U, d_hit, d_nhits);
         KMG_HIP(hipGetLastError());
         KMG_TRY(note_foreign_use(ctx, search));
         KMG_TRY(note_foreign_use(ctx, ref));

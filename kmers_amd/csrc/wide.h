@@ -14,7 +14,7 @@
 //   4. the ranks, left-aligned, are one-word keys with the k-mers' order and equality: the ordinary sort + dedup
 //      (sort_reduce_class) builds the CSR from (rank, payload) records -- taxa order, read sets and all;
 //   5. the CSR's keys (0 .. U-1) are swapped for the distinct k-mers' (hi, lo).
-// The exact join is a lower-bound search per search k-mer inside its key bucket.
+// The exact join looks every search k-mer up in the piece of the reference its tile can meet, staged in LDS.
 #pragma once
 #include "extract.h"
 
@@ -172,30 +172,83 @@ __global__ void wide_rank_kernel(const u64 *__restrict__ his, const u64 *__restr
     if (flag[j]) { d_hi[r] = his[j]; d_lo[r] = los[j]; }
 }
 
-// ---- exact join (DB.quickMatch, Database/DB.java:76-90: equal k-mers of one key bucket) ---------------------------------
-// hit[i] = index of search k-mer i in the reference, or -1
-__global__ __launch_bounds__(256) void wide_match_kernel(const u64 *__restrict__ s_hi, const u64 *__restrict__ s_lo, u64 n,
-                                                          const u64 *__restrict__ r_hi, const u64 *__restrict__ r_lo,
-                                                          const u64 *__restrict__ r_bucket, int key_len,
-                                                          long long *__restrict__ hit, u64 *__restrict__ nhits) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    bool found = false;
-    if (i < n) {
-        const u64 h = s_hi[i], l = s_lo[i];
-        const u64 b = h >> (64 - 2 * key_len);
-        u64 lo = r_bucket[b], hi = r_bucket[b + 1];
-        const u64 end = hi;
+// Read databases whose records arrive with ascending (read, pos) (no two sequences shared a read index): the two index
+// sorts are stable, so inside a k-mer the positions already ascend and the CSR follows from the heads alone --
+// val_off[r] = first record of k-mer r, the values = the payloads gathered in k-mer order.
+__global__ void wide_csr_reads_kernel(const u64 *__restrict__ his, const u64 *__restrict__ los, const u32 *__restrict__ flag,
+                                      const u64 *__restrict__ before, u32 n, u64 *__restrict__ d_hi, u64 *__restrict__ d_lo,
+                                      u64 *__restrict__ val_off) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || !flag[j]) return;
+    const u64 r = before[j];
+    d_hi[r] = his[j]; d_lo[r] = los[j]; val_off[r] = j;
+}
+
+// ---- exact join (DB.quickMatchCommonKey, Database/DB.java:129-137: equal k-mers of one key bucket) -----------------------
+// hit[i] = index of search k-mer i in the reference, or -1.  Both sides ascend as (hi, lo) pairs, so the reference
+// k-mers that a tile of WM_TILE consecutive search k-mers can equal are one contiguous piece: two threads find it (a
+// lower and an upper bound over the whole reference), the workgroup loads it into LDS if it has at most WM_CAP k-mers,
+// and every search k-mer is looked up there; a longer piece (a reference much denser than the search side) is searched
+// in place, inside the piece.
+#define WM_BLOCK 256
+#define WM_ITEMS 4
+#define WM_TILE (WM_BLOCK * WM_ITEMS)
+#define WM_CAP 2048
+__device__ __forceinline__ bool wide_less(u64 ah, u64 al, u64 bh, u64 bl) { return ah < bh || (ah == bh && al < bl); }
+__global__ __launch_bounds__(WM_BLOCK) void wide_match_kernel(const u64 *__restrict__ s_hi, const u64 *__restrict__ s_lo, u64 n,
+                                                               const u64 *__restrict__ r_hi, const u64 *__restrict__ r_lo, u64 R,
+                                                               long long *__restrict__ hit, u64 *__restrict__ nhits) {
+    __shared__ u64 l_hi[WM_CAP], l_lo[WM_CAP];
+    __shared__ u64 piece[2];
+    const int tid = threadIdx.x;
+    const u64 i0 = (u64)blockIdx.x * WM_TILE, i1 = min(n, i0 + (u64)WM_TILE);
+    if (tid == 0 || tid == 64) {
+        const bool upper = tid == 64;
+        const u64 kh = upper ? s_hi[i1 - 1] : s_hi[i0], kl = upper ? s_lo[i1 - 1] : s_lo[i0];
+        u64 lo = 0, hi = R;
         while (lo < hi) {
             const u64 mid = (lo + hi) >> 1;
-            const u64 mh = r_hi[mid];
-            if (mh < h || (mh == h && r_lo[mid] < l)) lo = mid + 1; else hi = mid;
+            const u64 mh = r_hi[mid], ml = r_lo[mid];
+            // lower bound: first reference k-mer >= key; upper bound: first one > key
+            if (upper ? !wide_less(kh, kl, mh, ml) : wide_less(mh, ml, kh, kl)) lo = mid + 1; else hi = mid;
         }
-        found = lo < end && r_hi[lo] == h && r_lo[lo] == l;
-        hit[i] = found ? (long long)lo : -1ll;
+        piece[upper ? 1 : 0] = lo;
+    }
+    __syncthreads();
+    const u64 p0 = piece[0], p1 = piece[1];
+    const bool in_lds = p1 - p0 <= WM_CAP;
+    const u32 span = in_lds ? (u32)(p1 - p0) : 0u;
+    for (u32 j = tid; j < span; j += WM_BLOCK) { l_hi[j] = r_hi[p0 + j]; l_lo[j] = r_lo[p0 + j]; }
+    __syncthreads();
+    u32 found_n = 0;
+#pragma unroll
+    for (int r = 0; r < WM_ITEMS; r++) {
+        const u64 i = i0 + (u64)r * WM_BLOCK + tid;
+        if (i >= i1) break;
+        const u64 h = s_hi[i], l = s_lo[i];
+        long long res = -1;
+        if (in_lds) {
+            u32 a = 0, b = span;
+            while (a < b) {
+                const u32 mid = (a + b) >> 1;
+                if (wide_less(l_hi[mid], l_lo[mid], h, l)) a = mid + 1; else b = mid;
+            }
+            if (a < span && l_hi[a] == h && l_lo[a] == l) res = (long long)(p0 + a);
+        } else {
+            u64 a = p0, b = p1;
+            while (a < b) {
+                const u64 mid = (a + b) >> 1;
+                if (wide_less(r_hi[mid], r_lo[mid], h, l)) a = mid + 1; else b = mid;
+            }
+            if (a < p1 && r_hi[a] == h && r_lo[a] == l) res = (long long)a;
+        }
+        hit[i] = res;
+        found_n += res >= 0;
     }
     if (nhits) {
-        const u64 b = __ballot(found);
-        if ((threadIdx.x & 63) == 0 && b) atomicAdd((unsigned long long *)nhits, (unsigned long long)__popcll(b));
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) found_n += __shfl_down(found_n, d, 64);
+        if ((tid & 63) == 0 && found_n) atomicAdd((unsigned long long *)nhits, (unsigned long long)found_n);
     }
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Two-word k-mers (33 <= k <= 64, csrc/wide.h) at BASELINE config 2's size on one MI355X (run ON the GPU box; not collected
 by pytest -- it lives under tests/ because it calls the oracle, which is a checker):
-    python tests/wide_bench.py [scale] > gpurun_out/wide.json
+    python tests/wide_bench.py [scale [k,k,...]] > gpurun_out/wide.json
 The workload is config 2's (64 genomes, 5 Mbp, 1 M reads x 150 bp at scale 1) with k = 31 (the one-word path, for scale),
 33, 47, 63 and 64.  Per k: reference build, read build, join -- wall clock from host buffers (PCIe included) and the
 kernels' own time from the library's event hook (the two index sorts and the rank kernels of the two-word path are
@@ -50,7 +50,8 @@ def build(kind, batch, k):
 
 out = {"config": {"workload": "BASELINE config 2 x %g at several k: %d genomes, %.1f Mbp, %d reads x %d; key length %d"
                   % (scale, len(taxa), ref_bases.size / 1e6, n, rl, L)}, "k": {}}
-for k in (31, 33, 47, 63, 64):
+ks = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [31, 33, 47, 63, 64]
+for k in ks:
     for rep in range(2):                       # the second repetition is the one reported (pools warm)
         ref, t_ref = timed(lambda: build("ref", ref_batch, k))
         rdb, t_reads = timed(lambda: build("read", read_batch, k))
