@@ -265,3 +265,65 @@ def test_collect_by_read_and_classifier_match_oracle(ctx, k, l, n_reads, rlen):
     assert out == R.read_classifier(want)
     assert (call >= 0).sum() > 100
     ref.close(); rdb.close()
+
+
+def test_programs_on_files_of_two_word_kmers(tmp_path):
+    """MakeDatabase / Matcher / TaxaCounts file to file at -K 40 -k 40: the native MakeDatabase driver and the Python
+    drivers write the oracle's files, the Python Matcher and TaxaCounts read them and give the oracle's lines; the
+    native readers (one word per k-mer) answer with status 3 for the wrapper to run the Java program."""
+    import gzip
+    import os
+    import subprocess
+    import kmers_amd as km
+    from kmers_amd import programs, synth
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    kmg = os.path.join(os.path.dirname(km.__file__), "kmg")
+    taxa, genomes = synth.random_genomes(281, 4, 9000, first_taxon=40, shared_frac=0.2)
+    reads = synth.random_reads(282, genomes, 1200, 110, 0.01, n_rate=0.003)
+    p = lambda n: str(tmp_path / n)
+    fa, fq = p("ref.fa"), p("reads.fq")
+    open(fa, "wb").write(synth.fasta_bytes(taxa, genomes))
+    open(fq, "wb").write(synth.fastq_bytes(reads))
+    k, l = 40, 4
+    o_ref, o_reads = OracleDB(synth.fasta_bytes(taxa, genomes), 0, k, l), OracleDB(synth.fastq_bytes(reads), 1, k, l)
+
+    def blocks(odb):
+        blob, off = odb.encode_blocks()
+        ids = [2048] if odb.kind == 0 else [257, 2052]
+        meta = bytes([odb.k, odb.k, odb.key_len]) + len(ids).to_bytes(4, "big") + b"".join(i.to_bytes(4, "big") for i in ids) + \
+            bytes([1 if odb.kind == 0 else 0])
+        out = {-1: meta}
+        for key in range(4 ** odb.key_len):
+            out[key] = blob[int(off[key]):int(off[key + 1])]
+        return out
+
+    def run(*args, rc=0):
+        r = subprocess.run([kmg] + list(args), capture_output=True, text=True, timeout=110)
+        assert r.returncode == rc, r.stderr
+        return r
+
+    R.write_indexed_file(p("ref.want"), blocks(o_ref), None)
+    R.write_indexed_file(p("reads.want"), blocks(o_reads), 5)
+    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("ref.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-Z")
+    run("Database.MakeDatabase", "-q", "-i", fq, "-o", p("reads.db"), "-r", p("map.gz"), "-K", str(k), "-k", str(k), "-l", str(l))
+    assert open(p("ref.db"), "rb").read() == open(p("ref.want"), "rb").read()
+    assert R.read_indexed_file(p("reads.db")) == R.read_indexed_file(p("reads.want"))
+    assert gzip.open(p("map.gz"), "rt").read().splitlines() == o_reads.names
+    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("x.db"), "-K", str(k), "-l", str(l), rc=3)             # -k 24: several lengths
+    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("x.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-h", rc=3)
+    run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("m.txt"), "-Z", "x", rc=3)
+    run("Utils.TaxaCounts", "-d", p("ref.db"), "-o", p("c.tsv"), rc=3)
+    ctx = km.Context(0)
+    programs.make_database(ctx, fa, p("ref.py.db"), "a", k, k, l, zip_level=None)
+    assert open(p("ref.py.db"), "rb").read() == open(p("ref.want"), "rb").read()
+    programs.make_database(ctx, fq, p("reads.py.db"), "q", k, k, l, read_map_path=p("map.py.gz"), passes=3)
+    assert R.read_indexed_file(p("reads.py.db")) == R.read_indexed_file(p("reads.want"))
+    hit, nh = o_reads.match(o_ref)
+    want = o_reads.match_lines(o_ref, hit).decode().splitlines()
+    assert nh > 1000
+    assert programs.matcher(ctx, p("reads.db"), p("ref.py.db"), p("m.py.txt"), plain=True) == want
+    assert open(p("m.py.txt")).read().splitlines() == want
+    t, m, q = o_ref.taxacounts()
+    assert programs.taxa_counts(ctx, p("ref.db"), p("c.py.tsv")) == ["%d\t%d\t%d" % x for x in zip(t.tolist(), m.tolist(), q.tolist())]
+    ctx.close()
