@@ -15,7 +15,7 @@
  * internally serialised (safe to call from several threads; calls do not overlap on the device).
  * Supported: 1 <= minK <= maxK = k <= 32, 1 <= key_len <= min(minK, 12); the exact join takes k-mers of one
  * length (restrict variable-length databases first, kmg_db_restrict).  k-mers of 33 .. 64 bases ("two-word
- * k-mers", see below) of one length (minK = maxK): build, fetch, load, encode, the exact join, TaxaCounts and the
+ * k-mers", see below) of one length (minK = maxK): build, fetch, load, encode, merge, the exact join, TaxaCounts and the
  * per-read tools.  Anything else returns KMG_EUNSUPPORTED so a shim can fall back to the Java path.
  *
  * K-mer representation everywhere: uint64, 2 bits per base, code order A=0 C=1 T=2 G=3

@@ -37,8 +37,8 @@ struct PoolBuf {
     void free() { ctx->pool.release(p); p = nullptr; }
 };
 
-// entry points that take one-word k-mers only (two-word ones, wide.h: build, fetch, encode, load, exact join, TaxaCounts,
-// the per-read tools)
+// entry points that take one-word k-mers only (two-word ones, wide.h: build, fetch, encode, load, merge, exact join,
+// TaxaCounts, the per-read tools)
 #define KMG_NO_WIDE(db) \
     do { if ((db)->k > 32) return fail(ctx, KMG_EUNSUPPORTED, "not built for k-mers of more than 32 bases"); } while (0)
 
@@ -1166,44 +1166,65 @@ static int finish_variable(kmg_ctx *ctx, std::unique_ptr<kmg_db, void (*)(kmg_db
 }
 
 // The records of a build of two-word k-mers (ctx->rec_keys / rec_lo / rec_vals, window order) -> db's CSR.  wide.h, steps 2-5.
+// n two-word k-mers (hi[i], lo[i]) in any order -> their order as k-mers (wide.h, steps 2-3): `order[j]` = index of the
+// j-th smallest, equal ones in index order (both sorts are stable); his / los = the words in that order; flag[j] = j
+// starts a new k-mer, before[j] = heads before j; U = distinct k-mers, rbits = bits their ranks take.
+struct WideOrder {
+    PoolBuf ka, kb, i0, i1, flag, before;
+    const u64 *his = nullptr;
+    u64 *los = nullptr;
+    const u32 *order = nullptr;
+    u64 U = 0;
+    int rbits = 1;
+    explicit WideOrder(kmg_ctx *c) : ka(c), kb(c), i0(c), i1(c), flag(c), before(c) {}
+};
+static int wide_order(kmg_ctx *ctx, const u64 *hi, const u64 *lo, u32 n, int k, WideOrder &w) {
+    PoolBuf table(ctx), agg(ctx), seg(ctx);
+    const u32 ntiles = div_up_u64(n, RS_TILE);
+    const int lo_bits = 2 * (k - 32);
+    const int p_lo = choose_pbits(n, lo_bits), p_hi = choose_pbits(n, 64);
+    KMG_ALLOC(w.ka, (size_t)n * 8);
+    KMG_ALLOC(w.kb, (size_t)n * 8);
+    KMG_ALLOC(w.i0, (size_t)n * 4);
+    KMG_ALLOC(w.i1, (size_t)n * 4);
+    KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
+    KMG_ALLOC(agg, (size_t)(div_up_u64(std::max<u64>((u64)RS_DIGITS * ntiles, n), SCAN_TILE) + 1) * 8);
+    KMG_ALLOC(seg, (((size_t)1 << std::max(p_lo, p_hi)) + 4) * 4);
+    const dim3 grid(div_up_u64(n, 256)), blk(256);
+    const std::vector<SortPass> none;
+    // by lo (any order among equal words), then -- stable -- by hi: every launch below is a kernel of radix.h
+    KMG_HIP(hipMemcpyAsync(w.ka.p, lo, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(wide_iota_kernel, grid, blk, 0, ctx->stream, w.i0.as<u32>(), n);
+    bool in1 = false;
+    KMG_TRY(hybrid_sort_records<u32>(ctx, w.ka.as<u64>(), w.i0.as<u32>(), w.kb.as<u64>(), w.i1.as<u32>(), n, 64 - lo_bits, none,
+                                     table.as<u32>(), agg.as<u32>(), seg.as<u32>(), whole_space_plan(p_lo), false, &in1, nullptr, false));
+    u32 *perm = in1 ? w.i1.as<u32>() : w.i0.as<u32>(), *perm_other = in1 ? w.i0.as<u32>() : w.i1.as<u32>();
+    hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, hi, (const u32 *)perm, n, w.ka.as<u64>());
+    KMG_TRY(hybrid_sort_records<u32>(ctx, w.ka.as<u64>(), perm, w.kb.as<u64>(), perm_other, n, 0, none, table.as<u32>(), agg.as<u32>(),
+                                     seg.as<u32>(), whole_space_plan(p_hi), false, &in1, nullptr, false));
+    w.his = in1 ? w.kb.as<u64>() : w.ka.as<u64>();
+    w.los = in1 ? w.ka.as<u64>() : w.kb.as<u64>();
+    w.order = in1 ? perm_other : perm;
+    hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, lo, w.order, n, w.los);
+    KMG_ALLOC(w.flag, (size_t)n * 4);
+    KMG_ALLOC(w.before, ((size_t)n + 1) * 8);
+    hipLaunchKernelGGL(wide_heads_kernel, grid, blk, 0, ctx->stream, w.his, (const u64 *)w.los, n, w.flag.as<u32>());
+    KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, w.flag.as<u32>(), w.before.as<u64>(), n, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
+                                                KP_SCAN)));
+    KMG_HIP(read_back(ctx, &w.U, w.before.as<u64>() + n, 8));
+    while (w.rbits < 32 && ((u64)1 << w.rbits) < w.U) w.rbits++;
+    return KMG_OK;
+}
+
 static int finish_wide(kmg_ctx *ctx, u32 n, const std::vector<SortPass> &payload, kmg_db *db) {
-    PoolBuf ka(ctx), kb(ctx), i0(ctx), i1(ctx), table(ctx), agg(ctx), seg(ctx), flag(ctx), before(ctx), rank(ctx), d_hi(ctx), d_lo(ctx);
+    PoolBuf rank(ctx), d_hi(ctx), d_lo(ctx);
     u64 U = 0;
     int rbits = 1;
     if (n > 0) {
-        const u32 ntiles = div_up_u64(n, RS_TILE);
-        const int lo_bits = 2 * (ctx->k - 32);
-        const int p_lo = choose_pbits(n, lo_bits), p_hi = choose_pbits(n, 64);
-        KMG_ALLOC(ka, (size_t)n * 8);
-        KMG_ALLOC(kb, (size_t)n * 8);
-        KMG_ALLOC(i0, (size_t)n * 4);
-        KMG_ALLOC(i1, (size_t)n * 4);
-        KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
-        KMG_ALLOC(agg, (size_t)(div_up_u64(std::max<u64>((u64)RS_DIGITS * ntiles, n), SCAN_TILE) + 1) * 8);
-        KMG_ALLOC(seg, (((size_t)1 << std::max(p_lo, p_hi)) + 4) * 4);
+        WideOrder w(ctx);
+        KMG_TRY(wide_order(ctx, ctx->rec_keys, ctx->rec_lo, n, ctx->k, w));
+        U = w.U; rbits = w.rbits;
         const dim3 grid(div_up_u64(n, 256)), blk(256);
-        const std::vector<SortPass> none;
-        // by lo (any order among equal words), then -- stable -- by hi: every launch below is a kernel of radix.h
-        KMG_HIP(hipMemcpyAsync(ka.p, ctx->rec_lo, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        hipLaunchKernelGGL(wide_iota_kernel, grid, blk, 0, ctx->stream, i0.as<u32>(), n);
-        bool in1 = false;
-        KMG_TRY(hybrid_sort_records<u32>(ctx, ka.as<u64>(), i0.as<u32>(), kb.as<u64>(), i1.as<u32>(), n, 64 - lo_bits, none, table.as<u32>(),
-                                         agg.as<u32>(), seg.as<u32>(), whole_space_plan(p_lo), false, &in1, nullptr, false));
-        u32 *perm = in1 ? i1.as<u32>() : i0.as<u32>(), *perm_other = in1 ? i0.as<u32>() : i1.as<u32>();
-        hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, (const u64 *)ctx->rec_keys, (const u32 *)perm, n, ka.as<u64>());
-        KMG_TRY(hybrid_sort_records<u32>(ctx, ka.as<u64>(), perm, kb.as<u64>(), perm_other, n, 0, none, table.as<u32>(), agg.as<u32>(),
-                                         seg.as<u32>(), whole_space_plan(p_hi), false, &in1, nullptr, false));
-        const u64 *his = in1 ? kb.as<u64>() : ka.as<u64>();
-        u64 *los = in1 ? ka.as<u64>() : kb.as<u64>();
-        const u32 *order = in1 ? perm_other : perm;
-        hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, (const u64 *)ctx->rec_lo, order, n, los);
-        KMG_ALLOC(flag, (size_t)n * 4);
-        KMG_ALLOC(before, ((size_t)n + 1) * 8);
-        hipLaunchKernelGGL(wide_heads_kernel, grid, blk, 0, ctx->stream, his, (const u64 *)los, n, flag.as<u32>());
-        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, flag.as<u32>(), before.as<u64>(), n, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
-                                                    KP_SCAN)));
-        KMG_HIP(read_back(ctx, &U, before.as<u64>() + n, 8));
-        while (rbits < 32 && ((u64)1 << rbits) < U) rbits++;
         KMG_ALLOC(d_hi, (U + 1) * 8);
         KMG_ALLOC(d_lo, (U + 1) * 8);
         if (db->kind == KMG_PAYLOAD_READPOS && payload.empty()) {
@@ -1211,9 +1232,9 @@ static int finish_wide(kmg_ctx *ctx, u32 n, const std::vector<SortPass> &payload
             PoolBuf pay(ctx), voff(ctx);
             KMG_ALLOC(pay, ((size_t)n + 1) * 8);
             KMG_ALLOC(voff, (U + 2) * 8);
-            hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, (const u64 *)ctx->rec_vals, order, n, pay.as<u64>());
-            hipLaunchKernelGGL(wide_csr_reads_kernel, grid, blk, 0, ctx->stream, his, (const u64 *)los, flag.as<u32>(), before.as<u64>(), n,
-                               d_hi.as<u64>(), d_lo.as<u64>(), voff.as<u64>());
+            hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, (const u64 *)ctx->rec_vals, w.order, n, pay.as<u64>());
+            hipLaunchKernelGGL(wide_csr_reads_kernel, grid, blk, 0, ctx->stream, w.his, (const u64 *)w.los, w.flag.as<u32>(),
+                               w.before.as<u64>(), n, d_hi.as<u64>(), d_lo.as<u64>(), voff.as<u64>());
             KMG_HIP(hipGetLastError());
             db->U = U; db->V = n;
             db->keys = (u64 *)d_hi.detach();
@@ -1223,10 +1244,9 @@ static int finish_wide(kmg_ctx *ctx, u32 n, const std::vector<SortPass> &payload
             return db_make_buckets(ctx, db);      // (and val_off[U] = V)
         }
         KMG_ALLOC(rank, (size_t)n * 8);
-        hipLaunchKernelGGL(wide_rank_kernel, grid, blk, 0, ctx->stream, his, (const u64 *)los, order, flag.as<u32>(), before.as<u64>(), n, rbits,
-                           rank.as<u64>(), d_hi.as<u64>(), d_lo.as<u64>());
+        hipLaunchKernelGGL(wide_rank_kernel, grid, blk, 0, ctx->stream, w.his, (const u64 *)w.los, w.order, w.flag.as<u32>(),
+                           w.before.as<u64>(), n, rbits, rank.as<u64>(), d_hi.as<u64>(), d_lo.as<u64>());
         KMG_HIP(hipGetLastError());
-        ka.free(); kb.free(); i0.free(); i1.free(); flag.free(); before.free(); table.free(); seg.free();
     } else {
         KMG_ALLOC(d_hi, 8);
         KMG_ALLOC(d_lo, 8);
@@ -1634,7 +1654,9 @@ extern "C" int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint6
 
 // Second half of kmg_db_merge and kmg_db_restrict: n expanded (k-mer, payload) records in (k0, v0) -> sorted, equal
 // k-mers folded with the data type's reducer (counts add per taxon, read-position sets unite) into db's CSR arrays.
-static int merge_records(kmg_ctx *ctx, kmg_db *db, PoolBuf &k0, PoolBuf &v0, PoolBuf &k1, PoolBuf &v1, u32 n, PoolBuf &totals) {
+static int merge_records(kmg_ctx *ctx, kmg_db *db, PoolBuf &k0, PoolBuf &v0, PoolBuf &k1, PoolBuf &v1, u32 n, PoolBuf &totals,
+                         int key_bits = 0 /* bits of the keys that count, from the top; 0: 2 * db->k */) {
+    if (!key_bits) key_bits = 2 * db->k;
     const bool reads = db->kind == KMG_PAYLOAD_READPOS;
     const u32 nbuckets = 1u << (2 * db->key_len);
     PoolBuf table(ctx), agg(ctx), seg(ctx), fk(ctx), fp(ctx), pk(ctx), pp(ctx);
@@ -1644,12 +1666,12 @@ static int merge_records(kmg_ctx *ctx, kmg_db *db, PoolBuf &k0, PoolBuf &v0, Poo
         std::vector<SortPass> payload;
         if (reads) for (int sh = 0; sh < 48; sh += RS_BITS) payload.push_back({sh, RS_BITS, RS_SRC_VAL64});
         else for (int sh = 32; sh < 64; sh += RS_BITS) payload.push_back({sh, RS_BITS, RS_SRC_VAL64});
-        const int pbits = choose_pbits(n, 2 * db->k);
+        const int pbits = choose_pbits(n, key_bits);
         const u32 ntiles = div_up_u64(n, RS_TILE);
         KMG_ALLOC(table, (size_t)RS_DIGITS * ntiles * 4);
         KMG_ALLOC(agg, (size_t)(div_up_u64(std::max<u64>((u64)RS_DIGITS * ntiles, n), SCAN_TILE) + 1) * 8);
         KMG_ALLOC(seg, (((size_t)1 << pbits) + 4) * 4);
-        KMG_TRY(hybrid_sort_records<u64>(ctx, k0.as<u64>(), v0.as<u64>(), k1.as<u64>(), v1.as<u64>(), n, 64 - 2 * db->k, payload,
+        KMG_TRY(hybrid_sort_records<u64>(ctx, k0.as<u64>(), v0.as<u64>(), k1.as<u64>(), v1.as<u64>(), n, 64 - key_bits, payload,
                                          table.as<u32>(), agg.as<u32>(), seg.as<u32>(), whole_space_plan(pbits), false, &in1));
     } else {
         KMG_ALLOC(agg, 64);
@@ -1863,7 +1885,6 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
     const kmg_db *d0 = dbs[0];
     u64 Vt = 0;
     int rc = 1;
-    for (int i = 0; i < n_dbs; i++) if (dbs[i]) KMG_NO_WIDE(dbs[i]);
     for (int i = 0; i < n_dbs; i++) {
         const kmg_db *d = dbs[i];
         if (!d || d->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
@@ -1890,6 +1911,54 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
     KMG_ALLOC(k0, ((size_t)n + 1) * 8); KMG_ALLOC(v0, ((size_t)n + 1) * 8);
     KMG_ALLOC(k1, ((size_t)n + 1) * 8); KMG_ALLOC(v1, ((size_t)n + 1) * 8);
     u64 base = 0;
+    if (d0->k > 32) {
+        // two-word k-mers (wide.h): the files' k-mers, end to end, are ranked among the distinct ones; the ranks stand in
+        // for the k-mers through the one-word merge, and the merged database gets the distinct k-mers for its keys
+        u64 Ut = 0;
+        for (int i = 0; i < n_dbs; i++) Ut += dbs[i]->U;
+        if (Ut >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 k-mers in the files of the set");
+        PoolBuf ch(ctx), cl(ctx), rank(ctx), d_hi(ctx), d_lo(ctx);
+        KMG_ALLOC(ch, (Ut + 1) * 8); KMG_ALLOC(cl, (Ut + 1) * 8); KMG_ALLOC(rank, (Ut + 1) * 8);
+        u64 at = 0;
+        for (int i = 0; i < n_dbs; i++) {
+            const kmg_db *d = dbs[i];
+            if (!d->U) continue;
+            KMG_HIP(hipMemcpyAsync(ch.as<u64>() + at, d->keys, d->U * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            KMG_HIP(hipMemcpyAsync(cl.as<u64>() + at, d->keys_lo, d->U * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            at += d->U;
+        }
+        int rbits = 1;
+        u64 U = 0;
+        if (Ut) {
+            WideOrder w(ctx);
+            KMG_TRY(wide_order(ctx, ch.as<u64>(), cl.as<u64>(), (u32)Ut, d0->k, w));
+            U = w.U; rbits = w.rbits;
+            KMG_ALLOC(d_hi, (U + 1) * 8); KMG_ALLOC(d_lo, (U + 1) * 8);
+            hipLaunchKernelGGL(wide_rank_kernel, dim3(div_up_u64(Ut, 256)), dim3(256), 0, ctx->stream, w.his, (const u64 *)w.los, w.order,
+                               w.flag.as<u32>(), w.before.as<u64>(), (u32)Ut, rbits, rank.as<u64>(), d_hi.as<u64>(), d_lo.as<u64>());
+            KMG_HIP(hipGetLastError());
+        } else { KMG_ALLOC(d_hi, 8); KMG_ALLOC(d_lo, 8); }
+        at = 0;
+        for (int i = 0; i < n_dbs; i++) {
+            const kmg_db *d = dbs[i];
+            if (d->V) {
+                if (reads && d->vals_packed32) KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(d)));
+                if (reads && !d->vals_packed && !d->val_a) return fail(ctx, KMG_ESTATE, "database has no values");
+                hipLaunchKernelGGL(mg_expand_kernel, dim3(div_up_u64(d->V, 256)), dim3(256), 0, ctx->stream, rank.as<u64>() + at, d->val_off,
+                                   d->U, d->V, d->val_a, d->val_b, reads ? d->vals_packed : nullptr, d->kind, k0.as<u64>(), v0.as<u64>(), base);
+                base += d->V;
+            }
+            at += d->U;
+        }
+        KMG_TRY(merge_records(ctx, db, k0, v0, k1, v1, n, totals, rbits));
+        if (db->U != U) return fail(ctx, KMG_EDEVICE, "two-word merge: the ranks' distinct count differs from the k-mers'");
+        ctx->pool.release(db->keys);
+        db->keys = (u64 *)d_hi.detach();
+        db->keys_lo = (u64 *)d_lo.detach();
+        KMG_TRY(db_make_buckets(ctx, db));
+        *out = db_guard.release();
+        return KMG_OK;
+    }
     for (int i = 0; i < n_dbs; i++) {
         const kmg_db *d = dbs[i];
         if (d->V == 0) continue;

@@ -199,7 +199,7 @@ def test_files_roundtrip_and_fences(ctx, tmp_path):
         assert back.encode_blocks()[0] == db.encode_blocks()[0]
         back.close()
     # what is not built for two-word k-mers says so
-    for call in (lambda: km.merge_databases([db, db]), lambda: db.restrict(k),
+    for call in (lambda: db.restrict(k),
                  lambda: km.FileCreator(ctx, l, k, "ref", True, dust=2),
                  lambda: km.FileCreator(ctx, l, 65, "ref", True)):
         with pytest.raises(KmersGpuError) as e:
@@ -327,3 +327,45 @@ def test_programs_on_files_of_two_word_kmers(tmp_path):
     t, m, q = o_ref.taxacounts()
     assert programs.taxa_counts(ctx, p("ref.db"), p("c.py.tsv")) == ["%d\t%d\t%d" % x for x in zip(t.tolist(), m.tolist(), q.tolist())]
     ctx.close()
+
+
+@pytest.mark.parametrize("k,l", [(33, 3), (64, 6)])
+def test_merge_of_files_equals_one_build(ctx, k, l):
+    """DB.kmers over name.1 .. name.N (DB.java:99-109) for two-word k-mers: the databases of the parts of a FASTA merge
+    into the database of the whole -- counts of equal (k-mer, taxon) pairs add, taxa stay ascending -- and read databases
+    of the halves of a FASTQ unite their position lists; files built in key ranges merge into the whole as well."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(391, 6, 4000, first_taxon=-3, shared_frac=0.4)
+    genomes = list(genomes) + [genomes[0], genomes[1][:1500]]
+    taxa = list(taxa) + [taxa[0], taxa[3]]
+    parts = [(taxa[:3], genomes[:3]), (taxa[3:5], genomes[3:5]), (taxa[5:], genomes[5:])]
+    dbs = [km.make_reference_db(ctx, synth.fasta_bytes(t, g), k, l) for t, g in parts]
+    db = km.DB(dbs)
+    whole_fa = synth.fasta_bytes(taxa, genomes)
+    want = OracleDB(whole_fa, 0, k, l)
+    _same_db(db.merged, want)
+    t, m, q = km.taxa_counts(db)
+    ot, om, oq = want.taxacounts()
+    assert np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
+    reads = synth.random_reads(392, genomes[:6], 400, 120, 0.01)
+    fq = synth.fastq_bytes(reads)
+    rdb, _ = km.make_read_db(ctx, fq, k, l)
+    hit, nh = db.get_nearest_kmers(rdb)
+    o_hit, o_nh = OracleDB(fq, 1, k, l).match(want)
+    assert nh == o_nh and nh > 100 and np.array_equal(hit, o_hit)
+    # key-range files of one input
+    nk = 4 ** l
+    shards = [km.make_reference_db(ctx, whole_fa, k, l, key_range=r) for r in ((0, nk // 3), (nk // 3, nk // 3), (nk // 3, nk))]
+    merged = km.merge_databases(shards)
+    _same_db(merged, want)
+    # read files: the second half's read indices shifted as a multi-process run would
+    a, na = km.make_read_db(ctx, synth.fastq_bytes(reads[:170]), k, l)
+    b, nb = km.make_read_db(ctx, synth.fastq_bytes(reads[170:], first_index=170), k, l)
+    hb = b.fetch()
+    shifted = km.KmerDatabase.load(ctx, k, l, False, 1, hb["keys"], hb["val_off"], hb["val_a"] + len(na), hb["val_b"], keys_lo=hb["keys_lo"])
+    both = km.merge_databases([a, shifted])
+    _same_db(both, OracleDB(fq, 1, k, l))
+    for d in dbs + shards + [db.merged, merged, rdb, a, b, shifted, both]:
+        d.close()
