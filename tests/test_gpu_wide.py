@@ -369,3 +369,39 @@ def test_merge_of_files_equals_one_build(ctx, k, l):
     _same_db(both, OracleDB(fq, 1, k, l))
     for d in dbs + shards + [db.merged, merged, rdb, a, b, shifted, both]:
         d.close()
+
+
+@pytest.mark.parametrize("k,n_reads,read_len", [(33, 3000, 150), (40, 20000, 150), (64, 20000, 200), (47, 60000, 100)])
+def test_skewed_reads_match_oracle(ctx, k, n_reads, read_len):
+    """Homopolymer and dinucleotide tracts: thousands of records share their first word (and many their second), so both
+    index sorts and the rank sort meet oversize segments -- sorted slice by slice, or by the whole-array passes."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(k)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    reads = acgt[rng.integers(0, 4, size=(n_reads, read_len))]
+    for i in range(n_reads):
+        r = rng.random()
+        if r < 0.25:
+            reads[i, :] = ord("A")
+        elif r < 0.40:
+            reads[i, ::2], reads[i, 1::2] = ord("A"), ord("C")
+        elif r < 0.55:
+            s = int(rng.integers(0, read_len // 2))
+            reads[i, s:s + read_len // 2] = ord("T")
+        elif r < 0.65:
+            reads[i, :40] = ord("G")                                  # equal first words, random second words
+    fq = synth.fastq_bytes(reads)
+    got, names = km.make_read_db(ctx, fq, k, 6)
+    want = OracleDB(fq, 1, k, 6, threads=8)
+    _same_db(got, want)
+    assert names == want.names
+    fa = b"".join(b">%d\n%s\n" % (100 + i % 7, reads[i].tobytes()) for i in range(min(n_reads, 4000)))
+    ref = km.make_reference_db(ctx, fa, k, 6)
+    oref = OracleDB(fa, 0, k, 6, threads=8)
+    _same_db(ref, oref)
+    hit, nh = km.DB([ref]).get_nearest_kmers(got)
+    ohit, onh = want.match(oref, threads=8)
+    assert nh == onh and np.array_equal(hit, ohit)
+    got.close(); ref.close()
