@@ -1981,7 +1981,6 @@ extern "C" int kmg_db_restrict(kmg_ctx *ctx, const kmg_db *src, int length, kmg_
     std::lock_guard<std::mutex> g(ctx->mu);
     *out = nullptr;
     if (src->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
-    KMG_NO_WIDE(src);
     if (length < src->min_k || length > src->k)                                                     // DB.java:78-81
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
     if (length < src->key_len) return fail(ctx, KMG_EINVAL, "length below the key length");
@@ -2074,8 +2073,34 @@ static int restrict_locked(kmg_ctx *ctx, const kmg_db *src, int length, kmg_db *
     KMG_ALLOC(dst, (U + 2) * 8);
     KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
     u64 nkept = 0;
+    // two-word k-mers cut to more than 32 bases (wide.h): the cut k-mers are ranked among the distinct ones and the ranks
+    // go through the fold as one-word keys; cut to 32 bases or fewer, the first word is all that is left of them
+    const bool wide_out = length > 32;
+    PoolBuf cut_lo(ctx), rank(ctx), d_hi(ctx), d_lo(ctx);
+    int rbits = 0;
+    u64 Uw = 0;
+    if (wide_out) {
+        KMG_ALLOC(rank, (U + 1) * 8);
+        if (U >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 k-mers in the database");
+        if (U) {
+            KMG_ALLOC(cut_lo, U * 8);
+            hipLaunchKernelGGL(wide_cut_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, (const u64 *)src->keys_lo, U, length,
+                               cut_lo.as<u64>());
+            WideOrder w(ctx);
+            KMG_TRY(wide_order(ctx, src->keys, cut_lo.as<u64>(), (u32)U, length, w));
+            Uw = w.U; rbits = w.rbits;
+            KMG_ALLOC(d_hi, (Uw + 1) * 8); KMG_ALLOC(d_lo, (Uw + 1) * 8);
+            hipLaunchKernelGGL(wide_rank_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, w.his, (const u64 *)w.los, w.order,
+                               w.flag.as<u32>(), w.before.as<u64>(), (u32)U, rbits, rank.as<u64>(), d_hi.as<u64>(), d_lo.as<u64>());
+            KMG_HIP(hipGetLastError());
+        } else { KMG_ALLOC(d_hi, 8); KMG_ALLOC(d_lo, 8); rbits = 1; }
+    }
+    // (what the record kernels see: the ranks are "k-mers of 32 bases" that nothing is cut from)
+    const u64 *rkeys = wide_out ? rank.as<u64>() : src->keys;
+    const uint8_t *rlens = wide_out ? nullptr : src->lens;
+    const int rlen_all = wide_out ? 32 : src->k, rcut = wide_out ? 32 : length;
     if (U) {
-        hipLaunchKernelGGL(rs_keep_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, src->lens, src->k, src->val_off, U, length, 64,
+        hipLaunchKernelGGL(rs_keep_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, rlens, rlen_all, src->val_off, U, rcut, 65,
                            keep.as<u32>());
         KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, keep.as<u32>(), dst.as<u64>(), U, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
                                                     KP_SCAN)));
@@ -2086,11 +2111,18 @@ static int restrict_locked(kmg_ctx *ctx, const kmg_db *src, int length, kmg_db *
     KMG_ALLOC(k0, ((size_t)n + 1) * 8); KMG_ALLOC(v0, ((size_t)n + 1) * 8);
     KMG_ALLOC(k1, ((size_t)n + 1) * 8); KMG_ALLOC(v1, ((size_t)n + 1) * 8);
     if (n)
-        hipLaunchKernelGGL(rs_expand_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, src->keys, src->lens, src->k, src->val_off,
-                           src->val_a, src->val_b, U, length, 64, dst.as<u64>(), 0ull, src->kind, k0.as<u64>(), v0.as<u64>());
+        hipLaunchKernelGGL(rs_expand_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, rkeys, rlens, rlen_all, src->val_off,
+                           src->val_a, src->val_b, U, rcut, 65, dst.as<u64>(), 0ull, src->kind, k0.as<u64>(), v0.as<u64>());
     KMG_HIP(hipGetLastError());
     (void)reads;
-    KMG_TRY(merge_records(ctx, db, k0, v0, k1, v1, n, totals));
+    KMG_TRY(merge_records(ctx, db, k0, v0, k1, v1, n, totals, rbits));
+    if (wide_out) {
+        if (db->U != Uw) return fail(ctx, KMG_EDEVICE, "two-word restriction: the ranks' distinct count differs from the k-mers'");
+        ctx->pool.release(db->keys);
+        db->keys = (u64 *)d_hi.detach();
+        db->keys_lo = (u64 *)d_lo.detach();
+        KMG_TRY(db_make_buckets(ctx, db));
+    }
     *out = db_guard.release();
     return KMG_OK;
 }

@@ -184,6 +184,12 @@ __global__ void wide_csr_reads_kernel(const u64 *__restrict__ his, const u64 *__
     d_hi[r] = his[j]; d_lo[r] = los[j]; val_off[r] = j;
 }
 
+// Kmer.limitTo (Kmer.java:277-289) on the second word: the bases behind the L-th (32 < L <= 64) go
+__global__ void wide_cut_kernel(const u64 *__restrict__ lo, u64 n, int L, u64 *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = L >= 64 ? lo[i] : lo[i] & ~(~0ull >> (2 * (L - 32)));
+}
+
 // ---- exact join (DB.quickMatchCommonKey, Database/DB.java:129-137: equal k-mers of one key bucket) -----------------------
 // hit[i] = index of search k-mer i in the reference, or -1.  Both sides ascend as (hi, lo) pairs, so the reference
 // k-mers that a tile of WM_TILE consecutive search k-mers can equal are one contiguous piece: two threads find it (a

@@ -128,7 +128,10 @@ class OracleDB:
         h = lib(self.wide).ko_restrict(self._h, int(length))
         if not h:
             raise ValueError("length outside the database's k-mer lengths")
-        return OracleDB(b"", self.kind, int(length), self.key_len, _handle=h, wide=self.wide)
+        out = OracleDB(b"", self.kind, int(length), self.key_len, _handle=h, wide=self.wide)
+        if self.wide and int(length) <= 32:
+            out.keys_lo = np.zeros(out.U, np.uint64)
+        return out
 
     def encode_blocks(self):
         """-> (bytes of all 4^l blocks back to back, block_off[4^l+1])."""

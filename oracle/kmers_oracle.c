@@ -487,12 +487,14 @@ static int cmp_val(const void *pa, const void *pb) {
 }
 ko_db *ko_restrict(const ko_db *s, int L) {
     if (L < s->min_k || L > s->k) return NULL;     /* DB.java:78-81 */
-    if (s->k > 32) return NULL;                    /* (two-word k-mers come in one length) */
     ko_db *d = (ko_db *)calloc(1, sizeof(ko_db));
     d->k = L; d->min_k = L; d->key_len = s->key_len; d->kind = s->kind; d->rc = s->rc;
     d->n_windows = s->n_windows; d->n_records = s->n_records;
     const uint32_t nkeys = 1u << (2 * s->key_len);
-    const uint64_t mask = L == 32 ? ~0ull : ~(~0ull >> (2 * L));
+    const uint64_t mask = L >= 32 ? ~0ull : ~(~0ull >> (2 * L));
+    /* (two-word k-mers: the second word keeps bases 32 .. L-1) */
+    const uint64_t mask_lo = L <= 32 ? 0ull : (L >= 64 ? ~0ull : ~(~0ull >> (2 * (L - 32))));
+    if (s->keys_lo && L > 32) d->keys_lo = (uint64_t *)malloc((s->U + 1) * sizeof(uint64_t));
     d->keys = (uint64_t *)malloc((s->U + 1) * sizeof(uint64_t));
     d->val_off = (uint64_t *)malloc((s->U + 1) * sizeof(uint64_t));
     d->val_a = (int32_t *)malloc((s->V + 1) * sizeof(int32_t));
@@ -503,16 +505,17 @@ ko_db *ko_restrict(const ko_db *s, int L) {
     uint64_t U = 0, V = 0;
     for (uint64_t u = 0; u < s->U;) {
         if (s->lens[u] < L) { u++; continue; }
-        const uint64_t key = s->keys[u] & mask;
+        const uint64_t key = s->keys[u] & mask, key_lo = s->keys_lo ? s->keys_lo[u] & mask_lo : 0;
         uint64_t nt = 0;
         /* the run of neighbours with the same cut k-mer (shorter ones in between are filtered out first) */
-        while (u < s->U && (s->lens[u] < L || (s->keys[u] & mask) == key)) {
+        while (u < s->U && (s->lens[u] < L || ((s->keys[u] & mask) == key && (s->keys_lo ? s->keys_lo[u] & mask_lo : 0) == key_lo))) {
             if (s->lens[u] >= L)
                 for (uint64_t v = s->val_off[u]; v < s->val_off[u + 1]; v++) { tmp[nt].a = s->val_a[v]; tmp[nt].b = s->val_b[v]; nt++; }
             u++;
         }
         qsort(tmp, nt, sizeof(ko_val), cmp_val);
         d->keys[U] = key; d->lens[U] = (uint8_t)L; d->val_off[U] = V;
+        if (d->keys_lo) d->keys_lo[U] = key_lo;
         d->bucket_off[(key >> (64 - 2 * s->key_len)) + 1]++;
         U++;
         for (uint64_t i = 0; i < nt; i++) {
