@@ -5,6 +5,7 @@ Parity with Kmers.jar itself is UNPINNED (no JVM, no reference fixtures).  Refer
 165-187; Kmer.java:47-55,90-97,142-225; FileCreator.java:65-110,271-347; DB.java:76-90."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before the HIP library is loaded: torch brings its own runtime, as in test_gpu_parity.py)
 
 pytestmark = pytest.mark.gpu
 
@@ -414,3 +415,56 @@ def test_skewed_reads_match_oracle(ctx, k, n_reads, read_len):
     ohit, onh = want.match(oref, threads=8)
     assert nh == onh and np.array_equal(hit, ohit)
     got.close(); ref.close()
+
+
+def test_packed_and_device_resident_input_and_the_second_word_on_the_device(ctx):
+    """kmg_build_add_packed and kmg_build_add_dev hand two-word builds the same sequences as kmg_build_add;
+    kmg_db_copy_dev hands out the second word (KMG_DB_KEYS_LO); what is not built for two-word k-mers says so."""
+    import ctypes as C
+    import torch
+    import kmers_amd as km
+    from kmers_amd._lib import KMG_EUNSUPPORTED, KmersGpuError
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(57)
+    seqs = ["".join("ACGT"[i] for i in rng.integers(0, 4, size=n)) for n in (4001, 64, 3, 0, 1234, 8192, 777, 47)]
+    ids = [11, 12, 12, 13, 14, 11, 15, 9]
+    k, l = 47, 4
+    fa = b"".join(b">%d\n%s\n" % (t, s.encode()) for t, s in zip(ids, seqs))
+    want = OracleDB(fa, 0, k, l)
+    packed = b"".join(R.sequence_compress(s)[4:] for s in seqs)
+    lens = np.array([len(s) for s in seqs], np.uint64)
+    seq_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    byte_off = np.concatenate([[0], np.cumsum((lens + np.uint64(3)) // np.uint64(4))]).astype(np.uint64)
+    fc = km.FileCreator(ctx, l, k, "ref", rc=True)
+    fc.add_packed(np.frombuffer(packed, np.uint8), seq_off, byte_off, np.array(ids, np.int32))
+    got = fc.create()
+    _same_db(got, want)
+    # device-resident input
+    dev = torch.device("cuda", 0)
+    bases = torch.tensor(np.frombuffer("".join(seqs).encode(), np.uint8).copy(), device=dev)
+    d_off = torch.tensor(seq_off.astype(np.int64), device=dev)
+    d_id = torch.tensor(np.array(ids, np.int32), device=dev)
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.kmg_build_begin(ctx.h, k, l, 1, 0))
+    ctx.check(ctx.lib.kmg_build_add_dev(ctx.h, bases.data_ptr(), bases.numel(), d_off.data_ptr(), d_id.data_ptr(), None, len(seqs), None))
+    h = C.c_void_p()
+    nw = C.c_uint64()
+    ctx.check(ctx.lib.kmg_build_finish(ctx.h, C.byref(h), C.byref(nw)))
+    again = km.KmerDatabase(ctx, h)
+    _same_db(again, want)
+    assert nw.value == want.n_windows
+    lo = torch.empty(got.n_unique, dtype=torch.int64, device=dev)
+    ctx.check(ctx.lib.kmg_db_copy_dev(got.h, 5, lo.data_ptr(), 0, got.n_unique))
+    assert np.array_equal(lo.cpu().numpy().view(np.uint64), want.keys_lo)
+    hit = torch.empty(got.n_unique, dtype=torch.int64, device=dev)
+    ctx.check(ctx.lib.kmg_match_dev(ctx.h, got.h, again.h, hit.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(hit.cpu().numpy(), np.arange(got.n_unique))
+    for call in (lambda: ctx.check(ctx.lib.kmg_match_dev_noalloc(ctx.h, got.h, again.h, hit.data_ptr())),
+                 lambda: km.match_near(got, again, 1), lambda: km.match_trie(got, again),
+                 lambda: got.restrict(k - 2, k)):
+        with pytest.raises(KmersGpuError) as e:
+            call()
+        assert e.value.code == KMG_EUNSUPPORTED
+    got.close(); again.close()
