@@ -14,9 +14,9 @@
  * copies inputs before returning and retains no host pointer.  A context is bound to one GPU and is
  * internally serialised (safe to call from several threads; calls do not overlap on the device).
  * Supported: 1 <= minK <= maxK = k <= 32, 1 <= key_len <= min(minK, 12); the exact join takes k-mers of one
- * length (restrict variable-length databases first, kmg_db_restrict).  k-mers of 33 .. 64 bases ("two-word
- * k-mers", see below) of one length (minK = maxK): build, fetch, load, encode, merge, the exact join, TaxaCounts and the
- * per-read tools.  Anything else returns KMG_EUNSUPPORTED so a shim can fall back to the Java path.
+ * length (restrict variable-length databases first, kmg_db_restrict).  k-mers of up to 64 bases ("two-word
+ * k-mers", see below; 32 < maxK <= 64, any minK): build, fetch, load, encode, restrict, the exact join, TaxaCounts and the
+ * per-read tools; sets of files of one k-mer length merge.  Anything else returns KMG_EUNSUPPORTED so a shim can fall back to the Java path.
  *
  * K-mer representation everywhere: uint64, 2 bits per base, code order A=0 C=1 T=2 G=3
  * (Kmers/Base.java:7-10), first base in the top bits, low 64-2k bits zero -- i.e. the bytes of
@@ -157,12 +157,14 @@ int kmg_db_fetch(const kmg_db *db, uint64_t *keys, uint64_t *val_off, int32_t *v
 /* Two-word k-mers (k > 32; Kmers/Sequence.java:90-115 packs any length, Kmer.java:90-97 writes it).
  *   kmg_db_fetch_keys_lo: keys_lo[n_unique] = bases 32 .. k-1 of every k-mer (zeros for a database of k <= 32); the
  *     first 32 bases come with kmg_db_fetch's keys.
- *   kmg_db_load_wide: kmg_db_load for 32 < k <= 64 -- what KmerFile's decoder (KmerFile.java:200-250) yields for such a
- *     file; (keys, keys_lo) strictly ascending as pairs, bits behind base k zero. */
+ *   kmg_db_load_wide: kmg_db_load / kmg_db_load_var for 32 < k <= 64 -- what KmerFile's decoder (KmerFile.java:200-250)
+ *     yields for such a file; min_k = k and lens NULL for k-mers of one length, else lens[n_unique] as in
+ *     kmg_db_load_var; (keys, keys_lo, lens) strictly ascending (Sequence.compareTo: zero-padded value, then length), bits
+ *     behind a k-mer's last base zero. */
 int kmg_db_fetch_keys_lo(const kmg_db *db, uint64_t *keys_lo);
-int kmg_db_load_wide(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *keys,
-                     const uint64_t *keys_lo, uint64_t n_unique, const uint64_t *val_off, const int32_t *val_a,
-                     const int32_t *val_b, kmg_db **out);
+int kmg_db_load_wide(kmg_ctx *ctx, int k, int min_k, int key_len, int rc, int payload_kind, const uint64_t *keys,
+                     const uint64_t *keys_lo, const uint8_t *lens, uint64_t n_unique, const uint64_t *val_off,
+                     const int32_t *val_a, const int32_t *val_b, kmg_db **out);
 /* Variable-length databases (minK < maxK).  kmg_db_min_k: the shortest k-mer length (== k of kmg_db_info for a
  *   database of one length).  kmg_db_fetch_lens: lens[n_unique] = number of bases of every k-mer (the length byte of
  *   Kmer.compressedBytes, Kmer.java:90-97); keys are zero-padded behind it.  kmg_db_load_var: kmg_db_load with lens

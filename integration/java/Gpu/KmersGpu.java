@@ -41,7 +41,7 @@ public final class KmersGpu implements AutoCloseable
     private static final MethodHandle DB_INFO = fn("kmg_db_info", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
     private static final MethodHandle DB_FREE = fn("kmg_db_free", FunctionDescriptor.ofVoid(ADDRESS));
     private static final MethodHandle DB_LOAD = fn("kmg_db_load", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
-    private static final MethodHandle DB_LOAD_WIDE = fn("kmg_db_load_wide", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
+    private static final MethodHandle DB_LOAD_WIDE = fn("kmg_db_load_wide", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
     private static final MethodHandle ENCODE = fn("kmg_db_encode", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS));
     private static final MethodHandle MATCH = fn("kmg_match", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
     private static final MethodHandle TAXA = fn("kmg_taxacounts", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
@@ -165,8 +165,10 @@ public final class KmersGpu implements AutoCloseable
         try (Arena a = Arena.ofConfined())
         {
             MemorySegment out = a.allocate(ADDRESS);
-            check(call(DB_LOAD_WIDE, ctx, k, keyLength, rc ? 1 : 0, kind, a.allocateFrom(JAVA_LONG, keys), a.allocateFrom(JAVA_LONG, keysLo),
-                       (long) keys.length, a.allocateFrom(JAVA_LONG, valOff), a.allocateFrom(JAVA_INT, valA), a.allocateFrom(JAVA_INT, valB), out));
+            // (k-mers of one length: min_k = k, no length array)
+            check(call(DB_LOAD_WIDE, ctx, k, k, keyLength, rc ? 1 : 0, kind, a.allocateFrom(JAVA_LONG, keys), a.allocateFrom(JAVA_LONG, keysLo),
+                       MemorySegment.NULL, (long) keys.length, a.allocateFrom(JAVA_LONG, valOff), a.allocateFrom(JAVA_INT, valA),
+                       a.allocateFrom(JAVA_INT, valB), out));
             return out.get(ADDRESS, 0);
         }
     }

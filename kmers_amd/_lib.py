@@ -65,7 +65,7 @@ def load():
     lib.kmg_db_fetch_lens.argtypes = [vp, vp]
     lib.kmg_db_load_var.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, u64, vp, vp, vp, P(vp)]
     lib.kmg_db_fetch_keys_lo.argtypes = [vp, vp]
-    lib.kmg_db_load_wide.argtypes = [vp, i32, i32, i32, i32, vp, vp, u64, vp, vp, vp, P(vp)]
+    lib.kmg_db_load_wide.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, u64, vp, vp, vp, P(vp)]
     lib.kmg_db_restrict.argtypes = [vp, vp, i32, P(vp)]
     lib.kmg_db_restrict_range.argtypes = [vp, vp, i32, i32, P(vp)]
     lib.kmg_match_trie.argtypes = [vp, vp, vp, i32, i32, P(vp), vp, P(u64)]

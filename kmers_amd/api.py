@@ -108,8 +108,10 @@ class KmerDatabase:
         h = C.c_void_p()
         if k > 32:
             keys_lo = np.ascontiguousarray(keys_lo, np.uint64)
-            ctx.check(ctx.lib.kmg_db_load_wide(ctx.h, k, key_length, 1 if rc else 0, kind, _ptr(keys), _ptr(keys_lo), len(keys),
-                                               _ptr(val_off), _ptr(val_a), _ptr(val_b), C.byref(h)))
+            var = min_length is not None and min_length != k
+            lens = np.ascontiguousarray(lens, np.uint8) if var else None
+            ctx.check(ctx.lib.kmg_db_load_wide(ctx.h, k, min_length if var else k, key_length, 1 if rc else 0, kind, _ptr(keys),
+                                               _ptr(keys_lo), _ptr(lens), len(keys), _ptr(val_off), _ptr(val_a), _ptr(val_b), C.byref(h)))
         elif min_length is not None and min_length != k:
             lens = np.ascontiguousarray(lens, np.uint8)
             ctx.check(ctx.lib.kmg_db_load_var(ctx.h, k, min_length, key_length, 1 if rc else 0, kind, _ptr(keys), _ptr(lens),

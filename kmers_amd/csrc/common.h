@@ -166,6 +166,7 @@ struct kmg_ctx {
     u32 range_lo = 0, range_hi = 0;
     u64 *rec_keys = nullptr;     // record keys (left-aligned 2-bit k-mers; k > 32: bases 0 .. 31)
     u64 *rec_lo = nullptr;       // k > 32 (wide.h): bases 32 .. k-1 of every record, left-aligned
+    uint8_t *rec_len = nullptr;  // k > 32 and min_k < k: bases of every record (k for the full windows)
     void *rec_vals = nullptr;    // u32 taxon | u64 (read << 16 | pos16)
     u64 rec_cap = 0;             // capacity in records
     u64 rec_upper = 0;           // host-known upper bound of records added so far

@@ -367,12 +367,13 @@ __global__ void rs_keep_kernel(const uint8_t *__restrict__ lens, int len_all, co
 __global__ void rs_expand_kernel(const u64 *__restrict__ keys, const uint8_t *__restrict__ lens, int len_all,
                                  const u64 *__restrict__ val_off, const int32_t *__restrict__ val_a,
                                  const int32_t *__restrict__ val_b, u64 n, int L, int H, const u64 *__restrict__ dst, u64 base, int kind,
-                                 u64 *__restrict__ out_keys, u64 *__restrict__ out_vals) {
+                                 u64 *__restrict__ out_keys, u64 *__restrict__ out_vals, bool cut = true) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int len = lens ? (int)lens[i] : len_all;
     if (len < L || len >= H) return;
-    const u64 key = keys[i] & (L == 32 ? ~0ull : ~(~0ull >> (2 * L)));       // Kmer.limitTo (Kmer.java:277-289)
+    // Kmer.limitTo (Kmer.java:277-289); cut = false: the keys stand in for k-mers that were cut already (wide.h's ranks)
+    const u64 key = !cut || L >= 32 ? keys[i] : keys[i] & ~(~0ull >> (2 * L));
     u64 o = base + dst[i];
     for (u64 v = val_off[i]; v < val_off[i + 1]; v++, o++) {
         out_keys[o] = key;

@@ -187,7 +187,6 @@ extern "C" int kmg_build_set_min_k(kmg_ctx *ctx, int min_k) {
     if (!ctx->building) return fail(ctx, KMG_ESTATE, "kmg_build_set_min_k before kmg_build_begin");
     if (ctx->n_adds) return fail(ctx, KMG_ESTATE, "the shortest k-mer length must be set before the first kmg_build_add");
     if (min_k < 1 || min_k > ctx->k) return fail(ctx, KMG_EINVAL, "min_k must lie in 1 .. k");
-    if (ctx->k > 32 && min_k != ctx->k) return fail(ctx, KMG_EUNSUPPORTED, "k-mers of several lengths are built for k <= 32");
     if (min_k < ctx->key_len) return fail(ctx, KMG_EUNSUPPORTED, "key_len must be <= min_k");      // Kmer.key(keyLength) of a shorter k-mer throws
     ctx->min_k = min_k;
     return KMG_OK;
@@ -212,25 +211,32 @@ static int ensure_record_capacity(kmg_ctx *ctx, u64 need) {
     if (need <= ctx->rec_cap && ctx->rec_keys) return KMG_OK;
     u64 ncap = std::max(need, ctx->rec_cap + ctx->rec_cap / 2);
     const size_t vb = val_bytes(ctx->kind);
-    const bool wide = ctx->k > 32;
-    void *nk = nullptr, *nv = nullptr, *nl = nullptr;
+    const bool wide = ctx->k > 32, lens = wide && ctx->min_k < ctx->k;
+    void *nk = nullptr, *nv = nullptr, *nl = nullptr, *nn = nullptr;
     if (ctx->pool.alloc(&nk, ncap * 8) != KMG_OK) return fail(ctx, KMG_ENOMEM, "record buffer allocation failed");
-    if (ctx->pool.alloc(&nv, ncap * vb) != KMG_OK || (wide && ctx->pool.alloc(&nl, ncap * 8) != KMG_OK)) {
+    if (ctx->pool.alloc(&nv, ncap * vb) != KMG_OK || (wide && ctx->pool.alloc(&nl, ncap * 8) != KMG_OK) ||
+        (lens && ctx->pool.alloc(&nn, ncap + 64) != KMG_OK)) {
         ctx->pool.release(nk);
         ctx->pool.release(nv);
+        ctx->pool.release(nl);
         return fail(ctx, KMG_ENOMEM, "record buffer allocation failed");
     }
+    // (every record has k bases unless the short k-mers' write pass says otherwise)
+    if (lens) KMG_HIP(hipMemsetAsync(nn, ctx->k, ncap + 64, ctx->stream));
     if (ctx->rec_keys && ctx->rec_upper) {
         KMG_HIP(hipMemcpyAsync(nk, ctx->rec_keys, ctx->rec_upper * 8, hipMemcpyDeviceToDevice, ctx->stream));
         KMG_HIP(hipMemcpyAsync(nv, ctx->rec_vals, ctx->rec_upper * vb, hipMemcpyDeviceToDevice, ctx->stream));
         if (wide) KMG_HIP(hipMemcpyAsync(nl, ctx->rec_lo, ctx->rec_upper * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (lens) KMG_HIP(hipMemcpyAsync(nn, ctx->rec_len, ctx->rec_upper, hipMemcpyDeviceToDevice, ctx->stream));
     }
     ctx->pool.release(ctx->rec_keys);
     ctx->pool.release(ctx->rec_vals);
     ctx->pool.release(ctx->rec_lo);
+    ctx->pool.release(ctx->rec_len);
     ctx->rec_keys = (u64 *)nk;
     ctx->rec_vals = nv;
     ctx->rec_lo = (u64 *)nl;
+    ctx->rec_len = (uint8_t *)nn;
     ctx->rec_cap = ncap;
     return KMG_OK;
 }
@@ -299,6 +305,24 @@ static int build_add_wide(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, cons
         hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, tile_fwd.as<u32>(),
                            ntiles, ctx->d_state + ST_NWIN);
     }
+    // a build of several lengths: count the k-mers shorter than k -- before the reads are numbered, because a read gets its
+    // index at its first k-mer of ANY length
+    const bool var = ctx->min_k < ctx->k;
+    PoolBuf sh_count(ctx), sh_fwd(ctx), sh_off(ctx);
+    WideShortArgs sa;
+    memset(&sa, 0, sizeof sa);
+    if (var) {
+        KMG_ALLOC(sh_count, (size_t)ntiles * 4);
+        KMG_ALLOC(sh_fwd, (size_t)ntiles * 4);
+        KMG_ALLOC(sh_off, (size_t)(ntiles + 1) * 8);
+        sa.e = a;
+        sa.min_k = ctx->min_k;
+        sa.e.tile_count = sh_count.as<u32>(); sa.e.tile_fwd = sh_fwd.as<u32>(); sa.e.tile_off = sh_off.as<u64>();
+        ProfScope ps(ctx, KP_EXTRACT_COUNT, nbases);
+        hipLaunchKernelGGL((wide_short_kernel<false>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, sa);
+        hipLaunchKernelGGL(sum_u32_kernel, dim3(div_up_u64(ntiles, 2048)), dim3(256), 0, ctx->stream, sh_fwd.as<u32>(),
+                           ntiles, ctx->d_state + ST_NWIN);
+    }
     if (reads) {
         ProfScope ps(ctx, KP_NUMBER_READS, 0);
         const u32 nr_tiles = div_up_u64(nseq, NR_TILE);
@@ -322,6 +346,23 @@ static int build_add_wide(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, cons
     }
     KMG_HIP(hipGetLastError());
     ctx->rec_upper = upper;
+    if (var) {
+        // the short k-mers go behind the batch's full windows, their lengths beside them
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, sh_count.as<u32>(), sh_off.as<u64>(), ntiles, OpSum(), 0ull,
+                                                    agg.as<u64>(), nullptr, true, KP_SCAN)));
+        u64 added = 0;
+        KMG_HIP(read_back(ctx, &added, sh_off.as<u64>() + ntiles, 8));
+        if (added) {
+            KMG_TRY(ensure_record_capacity(ctx, upper + added));
+            sa.e.read_index = ridx;
+            sa.e.out_keys = ctx->rec_keys; sa.e.out_vals = ctx->rec_vals; sa.out_lo = ctx->rec_lo; sa.out_len = ctx->rec_len;
+            ProfScope ps(ctx, KP_EXTRACT_WRITE, nbases + added * (17 + val_bytes(ctx->kind)));
+            hipLaunchKernelGGL((wide_short_kernel<true>), dim3(ntiles), dim3(EX_BLOCK), 0, ctx->stream, sa);
+            hipLaunchKernelGGL(extract_advance_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, sh_off.as<u64>(), ntiles);
+            KMG_HIP(hipGetLastError());
+            ctx->rec_upper = upper + added;
+        }
+    }
     return KMG_OK;
 }
 
@@ -1170,15 +1211,16 @@ static int finish_variable(kmg_ctx *ctx, std::unique_ptr<kmg_db, void (*)(kmg_db
 // j-th smallest, equal ones in index order (both sorts are stable); his / los = the words in that order; flag[j] = j
 // starts a new k-mer, before[j] = heads before j; U = distinct k-mers, rbits = bits their ranks take.
 struct WideOrder {
-    PoolBuf ka, kb, i0, i1, flag, before;
+    PoolBuf ka, kb, i0, i1, flag, before, lens;      // lens: the lengths in k-mer order (k-mers of several lengths only)
     const u64 *his = nullptr;
     u64 *los = nullptr;
     const u32 *order = nullptr;
     u64 U = 0;
     int rbits = 1;
-    explicit WideOrder(kmg_ctx *c) : ka(c), kb(c), i0(c), i1(c), flag(c), before(c) {}
+    explicit WideOrder(kmg_ctx *c) : ka(c), kb(c), i0(c), i1(c), flag(c), before(c), lens(c) {}
 };
-static int wide_order(kmg_ctx *ctx, const u64 *hi, const u64 *lo, u32 n, int k, WideOrder &w) {
+static int wide_order(kmg_ctx *ctx, const u64 *hi, const u64 *lo, u32 n, int k, WideOrder &w,
+                      const uint8_t *len = nullptr /* k-mers of several lengths: (hi, lo, len) is their order */) {
     PoolBuf table(ctx), agg(ctx), seg(ctx);
     const u32 ntiles = div_up_u64(n, RS_TILE);
     const int lo_bits = 2 * (k - 32);
@@ -1192,13 +1234,21 @@ static int wide_order(kmg_ctx *ctx, const u64 *hi, const u64 *lo, u32 n, int k, 
     KMG_ALLOC(seg, (((size_t)1 << std::max(p_lo, p_hi)) + 4) * 4);
     const dim3 grid(div_up_u64(n, 256)), blk(256);
     const std::vector<SortPass> none;
-    // by lo (any order among equal words), then -- stable -- by hi: every launch below is a kernel of radix.h
-    KMG_HIP(hipMemcpyAsync(w.ka.p, lo, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    // (by length first, where lengths differ,) by lo (any order among equal words), then -- stable -- by hi: every launch
+    // below is a kernel of radix.h
     hipLaunchKernelGGL(wide_iota_kernel, grid, blk, 0, ctx->stream, w.i0.as<u32>(), n);
     bool in1 = false;
-    KMG_TRY(hybrid_sort_records<u32>(ctx, w.ka.as<u64>(), w.i0.as<u32>(), w.kb.as<u64>(), w.i1.as<u32>(), n, 64 - lo_bits, none,
+    u32 *perm = w.i0.as<u32>(), *perm_other = w.i1.as<u32>();
+    if (len) {
+        hipLaunchKernelGGL(wide_lenkey_kernel, grid, blk, 0, ctx->stream, len, n, w.ka.as<u64>());
+        KMG_TRY(hybrid_sort_records<u32>(ctx, w.ka.as<u64>(), perm, w.kb.as<u64>(), perm_other, n, 56, none, table.as<u32>(), agg.as<u32>(),
+                                         seg.as<u32>(), whole_space_plan(choose_pbits(n, 8)), false, &in1, nullptr, false));
+        if (in1) std::swap(perm, perm_other);
+        hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, lo, (const u32 *)perm, n, w.ka.as<u64>());
+    } else KMG_HIP(hipMemcpyAsync(w.ka.p, lo, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    KMG_TRY(hybrid_sort_records<u32>(ctx, w.ka.as<u64>(), perm, w.kb.as<u64>(), perm_other, n, 64 - lo_bits, none,
                                      table.as<u32>(), agg.as<u32>(), seg.as<u32>(), whole_space_plan(p_lo), false, &in1, nullptr, false));
-    u32 *perm = in1 ? w.i1.as<u32>() : w.i0.as<u32>(), *perm_other = in1 ? w.i0.as<u32>() : w.i1.as<u32>();
+    if (in1) std::swap(perm, perm_other);
     hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, hi, (const u32 *)perm, n, w.ka.as<u64>());
     KMG_TRY(hybrid_sort_records<u32>(ctx, w.ka.as<u64>(), perm, w.kb.as<u64>(), perm_other, n, 0, none, table.as<u32>(), agg.as<u32>(),
                                      seg.as<u32>(), whole_space_plan(p_hi), false, &in1, nullptr, false));
@@ -1206,9 +1256,13 @@ static int wide_order(kmg_ctx *ctx, const u64 *hi, const u64 *lo, u32 n, int k, 
     w.los = in1 ? w.ka.as<u64>() : w.kb.as<u64>();
     w.order = in1 ? perm_other : perm;
     hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, lo, w.order, n, w.los);
+    if (len) {
+        KMG_ALLOC(w.lens, (size_t)n + 64);
+        hipLaunchKernelGGL(wide_gather8_kernel, grid, blk, 0, ctx->stream, len, w.order, n, w.lens.as<uint8_t>());
+    }
     KMG_ALLOC(w.flag, (size_t)n * 4);
     KMG_ALLOC(w.before, ((size_t)n + 1) * 8);
-    hipLaunchKernelGGL(wide_heads_kernel, grid, blk, 0, ctx->stream, w.his, (const u64 *)w.los, n, w.flag.as<u32>());
+    hipLaunchKernelGGL(wide_heads_kernel, grid, blk, 0, ctx->stream, w.his, (const u64 *)w.los, (const uint8_t *)w.lens.p, n, w.flag.as<u32>());
     KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, w.flag.as<u32>(), w.before.as<u64>(), n, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
                                                 KP_SCAN)));
     KMG_HIP(read_back(ctx, &w.U, w.before.as<u64>() + n, 8));
@@ -1217,16 +1271,19 @@ static int wide_order(kmg_ctx *ctx, const u64 *hi, const u64 *lo, u32 n, int k, 
 }
 
 static int finish_wide(kmg_ctx *ctx, u32 n, const std::vector<SortPass> &payload, kmg_db *db) {
-    PoolBuf rank(ctx), d_hi(ctx), d_lo(ctx);
+    PoolBuf rank(ctx), d_hi(ctx), d_lo(ctx), d_len(ctx);
     u64 U = 0;
     int rbits = 1;
+    const bool var = ctx->min_k < ctx->k;        // k-mers of several lengths: their lengths travel with them
+    db->min_k = ctx->min_k;
     if (n > 0) {
         WideOrder w(ctx);
-        KMG_TRY(wide_order(ctx, ctx->rec_keys, ctx->rec_lo, n, ctx->k, w));
+        KMG_TRY(wide_order(ctx, ctx->rec_keys, ctx->rec_lo, n, ctx->k, w, var ? ctx->rec_len : nullptr));
         U = w.U; rbits = w.rbits;
         const dim3 grid(div_up_u64(n, 256)), blk(256);
         KMG_ALLOC(d_hi, (U + 1) * 8);
         KMG_ALLOC(d_lo, (U + 1) * 8);
+        if (var) KMG_ALLOC(d_len, U + 64);
         if (db->kind == KMG_PAYLOAD_READPOS && payload.empty()) {
             // the records' (read, pos) ascend as they were written and both sorts were stable: the CSR from the heads
             PoolBuf pay(ctx), voff(ctx);
@@ -1234,22 +1291,26 @@ static int finish_wide(kmg_ctx *ctx, u32 n, const std::vector<SortPass> &payload
             KMG_ALLOC(voff, (U + 2) * 8);
             hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, (const u64 *)ctx->rec_vals, w.order, n, pay.as<u64>());
             hipLaunchKernelGGL(wide_csr_reads_kernel, grid, blk, 0, ctx->stream, w.his, (const u64 *)w.los, w.flag.as<u32>(),
-                               w.before.as<u64>(), n, d_hi.as<u64>(), d_lo.as<u64>(), voff.as<u64>());
+                               w.before.as<u64>(), n, d_hi.as<u64>(), d_lo.as<u64>(), voff.as<u64>(), (const uint8_t *)w.lens.p,
+                               d_len.as<uint8_t>());
             KMG_HIP(hipGetLastError());
             db->U = U; db->V = n;
             db->keys = (u64 *)d_hi.detach();
             db->keys_lo = (u64 *)d_lo.detach();
+            db->lens = (uint8_t *)d_len.detach();
             db->val_off = (u64 *)voff.detach();
             db->vals_packed = (u64 *)pay.detach();
             return db_make_buckets(ctx, db);      // (and val_off[U] = V)
         }
         KMG_ALLOC(rank, (size_t)n * 8);
         hipLaunchKernelGGL(wide_rank_kernel, grid, blk, 0, ctx->stream, w.his, (const u64 *)w.los, w.order, w.flag.as<u32>(),
-                           w.before.as<u64>(), n, rbits, rank.as<u64>(), d_hi.as<u64>(), d_lo.as<u64>());
+                           w.before.as<u64>(), n, rbits, rank.as<u64>(), d_hi.as<u64>(), d_lo.as<u64>(), (const uint8_t *)w.lens.p,
+                           d_len.as<uint8_t>());
         KMG_HIP(hipGetLastError());
     } else {
         KMG_ALLOC(d_hi, 8);
         KMG_ALLOC(d_lo, 8);
+        if (var) KMG_ALLOC(d_len, 64);
     }
     // (rank, payload) records: the ranks order and compare as the k-mers do
     KMG_TRY(sort_reduce_class(ctx, rank.as<u64>(), ctx->rec_vals, n, false, 16, payload, whole_space_plan(choose_pbits(n, rbits)), false, db,
@@ -1258,6 +1319,7 @@ static int finish_wide(kmg_ctx *ctx, u32 n, const std::vector<SortPass> &payload
     ctx->pool.release(db->keys);
     db->keys = (u64 *)d_hi.detach();
     db->keys_lo = (u64 *)d_lo.detach();
+    db->lens = (uint8_t *)d_len.detach();
     return db_make_buckets(ctx, db);
 }
 
@@ -1305,8 +1367,8 @@ extern "C" int kmg_build_finish(kmg_ctx *ctx, kmg_db **out, uint64_t *n_windows)
     }
     if (ctx->k > 32) {
         int r = finish_wide(ctx, n, payload, db);
-        ctx->pool.release(ctx->rec_keys); ctx->pool.release(ctx->rec_vals); ctx->pool.release(ctx->rec_lo);
-        ctx->rec_keys = nullptr; ctx->rec_vals = nullptr; ctx->rec_lo = nullptr; ctx->rec_cap = 0; ctx->rec_upper = 0;
+        ctx->pool.release(ctx->rec_keys); ctx->pool.release(ctx->rec_vals); ctx->pool.release(ctx->rec_lo); ctx->pool.release(ctx->rec_len);
+        ctx->rec_keys = nullptr; ctx->rec_vals = nullptr; ctx->rec_lo = nullptr; ctx->rec_len = nullptr; ctx->rec_cap = 0; ctx->rec_upper = 0;
         if (r != KMG_OK) return r;
         if (!reads && st[ST_ID_MIN] <= st[ST_ID_MAX]) {
             db->tax_bounds = true;
@@ -1492,29 +1554,45 @@ extern "C" int kmg_db_load(kmg_ctx *ctx, int k, int key_len, int rc, int payload
                           reinterpret_cast<const u64 *>(val_off), val_a, val_b, V, hipMemcpyHostToDevice, out);
 }
 
-extern "C" int kmg_db_load_wide(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const uint64_t *keys,
-                                const uint64_t *keys_lo, uint64_t n_unique, const uint64_t *val_off, const int32_t *val_a,
-                                const int32_t *val_b, kmg_db **out) {
+extern "C" int kmg_db_load_wide(kmg_ctx *ctx, int k, int min_k, int key_len, int rc, int payload_kind, const uint64_t *keys,
+                                const uint64_t *keys_lo, const uint8_t *lens, uint64_t n_unique, const uint64_t *val_off,
+                                const int32_t *val_a, const int32_t *val_b, kmg_db **out) {
     if (!ctx || !out) return KMG_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
     *out = nullptr;
-    if (k <= 32 || key_len < 1) return fail(ctx, KMG_EINVAL, "k-mers of 33 .. 64 bases (kmg_db_load takes the shorter ones); key_len must be positive");
-    if (k > 64 || key_len > 12) return fail(ctx, KMG_EUNSUPPORTED, "k > 64 or key_len > 12");
-    if (!val_off || (n_unique && (!keys || !keys_lo))) return fail(ctx, KMG_EINVAL, "null keys / val_off");
+    if (k <= 32 || key_len < 1 || min_k < 1 || min_k > k)
+        return fail(ctx, KMG_EINVAL, "k-mers of 33 .. 64 bases (kmg_db_load / kmg_db_load_var take the shorter ones); key_len and min_k positive, min_k <= k");
+    if (k > 64 || key_len > 12 || key_len > min_k) return fail(ctx, KMG_EUNSUPPORTED, "k > 64 or key_len > min(min_k, 12)");
+    if (!val_off || (n_unique && (!keys || !keys_lo || (min_k < k && !lens)))) return fail(ctx, KMG_EINVAL, "null keys / lens / val_off");
     const u64 V = val_off[n_unique];
     if (V && (!val_a || !val_b)) return fail(ctx, KMG_EINVAL, "null values");
     for (u64 i = 0; i < n_unique; i++) {
-        if (k < 64 && (keys_lo[i] << (2 * (k - 32))) != 0) return fail(ctx, KMG_EINVAL, "k-mer bits behind its length must be zero");
-        if (i && (keys[i - 1] > keys[i] || (keys[i - 1] == keys[i] && keys_lo[i - 1] >= keys_lo[i])))
-            return fail(ctx, KMG_EINVAL, "k-mers must be strictly ascending");
+        const int L = min_k < k ? lens[i] : k;
+        if (L < min_k || L > k) return fail(ctx, KMG_EINVAL, "k-mer length outside min_k .. k");
+        const bool clean = L >= 64 ? true
+                         : L > 32 ? (keys_lo[i] << (2 * (L - 32))) == 0
+                         : L == 32 ? keys_lo[i] == 0 : (keys_lo[i] == 0 && (keys[i] << (2 * L)) == 0);
+        if (!clean) return fail(ctx, KMG_EINVAL, "k-mer bits behind its length must be zero");
+        // Sequence.compareTo order (Sequence.java:165-187): zero-padded value, then length
+        if (i) {
+            const int Lp = min_k < k ? lens[i - 1] : k;
+            const bool less = keys[i - 1] < keys[i] || (keys[i - 1] == keys[i] && (keys_lo[i - 1] < keys_lo[i] || (keys_lo[i - 1] == keys_lo[i] && Lp < L)));
+            if (!less) return fail(ctx, KMG_EINVAL, "k-mers must be strictly ascending");
+        }
     }
     KMG_TRY(db_load_common(ctx, k, key_len, rc, payload_kind, reinterpret_cast<const u64 *>(keys), n_unique,
                            reinterpret_cast<const u64 *>(val_off), val_a, val_b, V, hipMemcpyHostToDevice, out));
     kmg_db *db = *out;
-    void *p;
-    if (ctx->pool.alloc(&p, (n_unique + 1) * 8) != KMG_OK) { db_release(db); *out = nullptr; return fail(ctx, KMG_ENOMEM, "device allocation failed"); }
+    db->min_k = min_k;
+    void *p, *q = nullptr;
+    if (ctx->pool.alloc(&p, (n_unique + 1) * 8) != KMG_OK || (min_k < k && ctx->pool.alloc(&q, n_unique + 64) != KMG_OK)) {
+        db_release(db); *out = nullptr;
+        return fail(ctx, KMG_ENOMEM, "device allocation failed");
+    }
     db->keys_lo = (u64 *)p;
+    db->lens = (uint8_t *)q;
     hipError_t e = n_unique ? hipMemcpyAsync(db->keys_lo, keys_lo, n_unique * 8, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+    if (e == hipSuccess && q && n_unique) e = hipMemcpyAsync(db->lens, lens, n_unique, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx->err = hipGetErrorString(e); db_release(db); *out = nullptr; return KMG_EDEVICE; }
     return KMG_OK;
@@ -1614,7 +1692,7 @@ extern "C" int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint6
     ProfScope ps(ctx, KP_ENCODE, 0);
     const bool wide = db->keys_lo != nullptr;
     if (U && wide) {
-        hipLaunchKernelGGL((wide_enc_kernel<false>), dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys, db->keys_lo, db->val_off,
+        hipLaunchKernelGGL((wide_enc_kernel<false>), dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys, db->keys_lo, db->lens, db->val_off,
                            db->val_a, db->val_b, U, db->k, db->key_len, db->kind, sizes.as<u32>(), (const u64 *)nullptr, (uint8_t *)nullptr);
     } else if (U) {
         hipLaunchKernelGGL(enc_size_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys, db->lens, db->val_off, U,
@@ -1638,7 +1716,7 @@ extern "C" int kmg_db_encode(kmg_ctx *ctx, const kmg_db *db, uint8_t *out, uint6
             KMG_ALLOC(d_out, total);
             if (wide)
                 hipLaunchKernelGGL((wide_enc_kernel<true>), dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys, db->keys_lo,
-                                   db->val_off, db->val_a, db->val_b, U, db->k, db->key_len, db->kind, (u32 *)nullptr, enc_off.as<u64>(),
+                                   db->lens, db->val_off, db->val_a, db->val_b, U, db->k, db->key_len, db->kind, (u32 *)nullptr, enc_off.as<u64>(),
                                    d_out.as<uint8_t>());
             else
             hipLaunchKernelGGL(enc_write_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, db->keys, db->lens,
@@ -1894,7 +1972,10 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
         Vt += d->V;
         rc &= d->rc;
     }
-    if (d0->min_k != d0->k) return merge_disjoint_keys(ctx, dbs, n_dbs, out);
+    if (d0->min_k != d0->k) {
+        KMG_NO_WIDE(d0);            // (sets of two-word databases of several lengths: the Java path)
+        return merge_disjoint_keys(ctx, dbs, n_dbs, out);
+    }
     if (Vt >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 values in the merged database");
     KMG_HIP(hipSetDevice(ctx->device));
     const bool reads = d0->kind == KMG_PAYLOAD_READPOS;
@@ -2082,23 +2163,37 @@ static int restrict_locked(kmg_ctx *ctx, const kmg_db *src, int length, kmg_db *
     if (wide_out) {
         KMG_ALLOC(rank, (U + 1) * 8);
         if (U >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 k-mers in the database");
+        // the entries of at least `length` bases (all of them in a database of one length), cut, side by side
+        PoolBuf kflag(ctx), kcnt(ctx), kpos(ctx), ch(ctx), from(ctx), rank_k(ctx);
+        u64 nk = 0;
         if (U) {
-            KMG_ALLOC(cut_lo, U * 8);
-            hipLaunchKernelGGL(wide_cut_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, (const u64 *)src->keys_lo, U, length,
-                               cut_lo.as<u64>());
+            KMG_ALLOC(kflag, (U + 1) * 4); KMG_ALLOC(kcnt, (U + 1) * 4); KMG_ALLOC(kpos, (U + 2) * 8);
+            hipLaunchKernelGGL(vr_flag_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, src->lens, src->k, src->val_off, U, length, 65,
+                               kflag.as<u32>(), kcnt.as<u32>());
+            KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, kflag.as<u32>(), kpos.as<u64>(), U, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
+                                                        KP_SCAN)));
+            KMG_HIP(read_back(ctx, &nk, kpos.as<u64>() + U, 8));
+        }
+        if (nk) {
+            KMG_ALLOC(ch, nk * 8); KMG_ALLOC(cut_lo, nk * 8); KMG_ALLOC(from, nk * 4); KMG_ALLOC(rank_k, nk * 8);
+            hipLaunchKernelGGL(wide_compact_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, (const u64 *)src->keys,
+                               (const u64 *)src->keys_lo, kflag.as<u32>(), kpos.as<u64>(), U, length, ch.as<u64>(), cut_lo.as<u64>(), from.as<u32>());
             WideOrder w(ctx);
-            KMG_TRY(wide_order(ctx, src->keys, cut_lo.as<u64>(), (u32)U, length, w));
+            KMG_TRY(wide_order(ctx, ch.as<u64>(), cut_lo.as<u64>(), (u32)nk, length, w));
             Uw = w.U; rbits = w.rbits;
             KMG_ALLOC(d_hi, (Uw + 1) * 8); KMG_ALLOC(d_lo, (Uw + 1) * 8);
-            hipLaunchKernelGGL(wide_rank_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, w.his, (const u64 *)w.los, w.order,
-                               w.flag.as<u32>(), w.before.as<u64>(), (u32)U, rbits, rank.as<u64>(), d_hi.as<u64>(), d_lo.as<u64>());
+            hipLaunchKernelGGL(wide_rank_kernel, dim3(div_up_u64(nk, 256)), dim3(256), 0, ctx->stream, w.his, (const u64 *)w.los, w.order,
+                               w.flag.as<u32>(), w.before.as<u64>(), (u32)nk, rbits, rank_k.as<u64>(), d_hi.as<u64>(), d_lo.as<u64>(),
+                               (const uint8_t *)nullptr, (uint8_t *)nullptr);
+            hipLaunchKernelGGL(wide_spread_kernel, dim3(div_up_u64(nk, 256)), dim3(256), 0, ctx->stream, (const u64 *)rank_k.as<u64>(),
+                               (const u32 *)from.as<u32>(), nk, rank.as<u64>());
             KMG_HIP(hipGetLastError());
         } else { KMG_ALLOC(d_hi, 8); KMG_ALLOC(d_lo, 8); rbits = 1; }
     }
     // (what the record kernels see: the ranks are "k-mers of 32 bases" that nothing is cut from)
     const u64 *rkeys = wide_out ? rank.as<u64>() : src->keys;
-    const uint8_t *rlens = wide_out ? nullptr : src->lens;
-    const int rlen_all = wide_out ? 32 : src->k, rcut = wide_out ? 32 : length;
+    const uint8_t *rlens = src->lens;
+    const int rlen_all = src->k, rcut = length;
     if (U) {
         hipLaunchKernelGGL(rs_keep_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, rlens, rlen_all, src->val_off, U, rcut, 65,
                            keep.as<u32>());
@@ -2112,7 +2207,7 @@ static int restrict_locked(kmg_ctx *ctx, const kmg_db *src, int length, kmg_db *
     KMG_ALLOC(k1, ((size_t)n + 1) * 8); KMG_ALLOC(v1, ((size_t)n + 1) * 8);
     if (n)
         hipLaunchKernelGGL(rs_expand_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, rkeys, rlens, rlen_all, src->val_off,
-                           src->val_a, src->val_b, U, rcut, 65, dst.as<u64>(), 0ull, src->kind, k0.as<u64>(), v0.as<u64>());
+                           src->val_a, src->val_b, U, rcut, 65, dst.as<u64>(), 0ull, src->kind, k0.as<u64>(), v0.as<u64>(), !wide_out);
     KMG_HIP(hipGetLastError());
     (void)reads;
     KMG_TRY(merge_records(ctx, db, k0, v0, k1, v1, n, totals, rbits));

@@ -146,6 +146,169 @@ __global__ __launch_bounds__(EX_BLOCK) void wide_extract_kernel(WideArgs wa) {
     }
 }
 
+// ---- the k-mers SHORTER than k of a build of several lengths (kmg_build_set_min_k with k > 32) ---------------------------
+// extract_short.h's rules -- the `ending` branch of KmersFromFileSpliterator.tryAdvance, OtherFiles/KmersFromFile.java:90-133,
+// 167-176: the suffixes of length min(pos, k - 1) .. minK that end at a sequence's last base (C), and those that end at the
+// last base of a full window with an invalid base in it (B), both when the last full window of a sequence is invalid --
+// for windows of up to 64 bases.  A suffix of L <= 32 bases is (hi, 0), a longer one (hi, lo); its length travels
+// beside it.  Sites are rare (one position in a hundred on reads): a thread owns a position and walks its items.
+struct WideShortArgs {
+    ExtractArgs e;        // k = maxK (33 .. 64); out_keys = the hi words; tile_count / tile_fwd / tile_off: the short records'
+    int min_k;
+    u64 *out_lo;
+    uint8_t *out_len;     // length of every record of the build (the write pass of the full windows leaves k there)
+};
+
+// the L bases (1 .. 64) from tile position q, left-aligned and zero-padded
+__device__ __forceinline__ void wide_kmer_at(const u32 *pk, u32 q, int L, u64 &hi, u64 &lo) {
+    const u32 w = q >> 4, sh = 2 * (q & 15);
+    const u64 a0 = ((u64)pk[w] << 32) | pk[w + 1], a1 = ((u64)pk[w + 2] << 32) | pk[w + 3], a2 = (u64)pk[w + 4] << 32;
+    hi = sh ? (a0 << sh) | (a1 >> (64 - sh)) : a0;
+    lo = sh ? (a1 << sh) | (a2 >> (64 - sh)) : a1;
+    if (L <= 32) { lo = 0; hi &= L == 32 ? ~0ull : ~(~0ull >> (2 * L)); }
+    else lo &= L == 64 ? ~0ull : ~(~0ull >> (2 * (L - 32)));
+}
+// reverse complement of a k-mer of L bases (Kmer.inplaceRC), and Kmer.isOwnRC's palindrome test
+__device__ __forceinline__ void wide_rc(u64 hi, u64 lo, int L, u64 &rhi, u64 &rlo, bool &pal) {
+    const u64 rh = revpairs64(lo), rl = revpairs64(hi);      // the 64 base slots reversed: the L bases sit at the bottom
+    const int s = 2 * (64 - L);
+    u64 vh, vl;
+    if (s == 0) { vh = rh; vl = rl; }
+    else if (s < 64) { vh = (rh << s) | (rl >> (64 - s)); vl = rl << s; }
+    else if (s == 64) { vh = rl; vl = 0; }
+    else { vh = rl << (s - 64); vl = 0; }
+    pal = (L & 1) == 0 && vh == hi && vl == lo;
+    const u64 mh = L >= 32 ? ~0ull : ~(~0ull >> (2 * L));
+    const u64 ml = L <= 32 ? 0ull : (L == 64 ? ~0ull : ~(~0ull >> (2 * (L - 32))));
+    rhi = vh ^ (0xAAAAAAAAAAAAAAAAull & mh);
+    rlo = vl ^ (0xAAAAAAAAAAAAAAAAull & ml);
+}
+
+struct WideShortSite {
+    int n;            // bases the suffixes are cut from (k, or the whole of a sequence shorter than k)
+    int d, nB;        // first nB items: lengths d, d - 1, ...
+    int top, nC;      // next nC items: lengths top, top - 1, ...
+    u32 seq;
+    u64 seq_start;
+};
+__device__ __forceinline__ WideShortSite wide_short_site(const ExtractArgs &a, int m, const u32 *inv, const u32 *stb,
+                                                         const u32 *seqrel, u32 s_lo, u64 t0, u32 p) {
+    WideShortSite x;
+    x.n = a.k; x.d = x.nB = x.top = x.nC = 0; x.seq = 0; x.seq_start = 0;
+    const int W = a.k;
+    const u64 gp = t0 + p;
+    if (gp >= a.nbases) return x;
+    const u32 w2 = p >> 5, r2 = p & 31;
+    const u64 b0 = ((u64)inv[w2] << 32) | inv[w2 + 1], b1 = (u64)inv[w2 + 2] << 32;
+    const u64 s0 = ((u64)stb[w2] << 32) | stb[w2 + 1], s1 = (u64)stb[w2 + 2] << 32;
+    const u64 bad = r2 ? (b0 << r2) | (b1 >> (64 - r2)) : b0;     // bit 63 - i: base p + i is invalid
+    const u64 st = r2 ? (s0 << r2) | (s1 >> (64 - r2)) : s0;      // bit 63 - i: a sequence starts at p + i
+    x.seq = s_lo + seqrel[p];
+    x.seq_start = a.seq_off[x.seq];
+    const bool inside = ((st << 1) >> (65 - W)) == 0 && gp + (u64)W <= a.nbases;
+    if (inside) {
+        const u64 badW = bad >> (64 - W);
+        x.d = badW ? __ffsll((long long)badW) - 1 : W;                       // valid bases in a row at the window's end
+        if (badW && x.d >= m) x.nB = x.d - m + 1;                            // (B): lengths d .. m
+        const u32 e = p + (u32)W;                                            // a sequence starts right behind the window?
+        const bool last = gp + (u64)W == a.nbases || ((stb[e >> 5] >> (31 - (e & 31))) & 1u);
+        x.top = x.d < W - 1 ? x.d : W - 1;
+        if (last && x.top >= m) x.nC = x.top - m + 1;                        // (C), sequence of n >= W bases
+    } else if (x.seq_start == gp) {
+        // a sequence of fewer than W bases starts here: its (C), if it has at least m bases
+        const u64 n64 = a.seq_off[x.seq + 1] - gp;
+        if (n64 >= (u64)m && n64 < (u64)W) {
+            x.n = (int)n64;
+            const u64 badn = bad >> (64 - x.n);
+            x.d = badn ? __ffsll((long long)badn) - 1 : x.n;
+            if (x.d >= m) x.nB = x.d - m + 1;
+        }
+    }
+    return x;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(EX_BLOCK) void wide_short_kernel(WideShortArgs sa) {
+    __shared__ u32 pk[(EX_TILE + EXW_EXT) / 16 + 8];
+    __shared__ u32 inv[(EX_TILE + EXW_EXT) / 32 + 2];
+    __shared__ u32 stb[(EX_TILE + EXW_EXT) / 32 + 2];
+    __shared__ u32 seqrel[EX_TILE + EXW_EXT];
+    __shared__ u32 scan_smem[4];
+    __shared__ u32 blk_fwd;
+    const ExtractArgs &a = sa.e;
+    const int tid = threadIdx.x;
+    const u64 t0 = (u64)blockIdx.x * EX_TILE;
+    if (tid == 0) blk_fwd = 0;
+    if (tid < 8) pk[(EX_TILE + EXW_EXT) / 16 + tid] = 0;       // (words behind the image: read, then masked off)
+    const u32 s_lo = ex_load_tile_ext<EXW_EXT>(a, blockIdx.x, pk, inv, stb, seqrel, scan_smem);
+    const u64 tile_base = WRITE ? a.state[ST_NREC] + a.tile_off[blockIdx.x] : 0;
+    u32 running = 0, my_fwd = 0;
+    for (int j = 0; j < EX_ROUNDS; j++) {
+        const u32 p = j * EX_BLOCK + tid;
+        const WideShortSite x = wide_short_site(a, sa.min_k, inv, stb, seqrel, s_lo, t0, p);
+        const int T = x.nB + x.nC;
+        u32 cnt = 0;
+        if (T) {
+            // reads are numbered by the mapper, which runs when the k-mer is built: whatever a key range keeps of it
+            if (!WRITE && a.has_kmer) a.has_kmer[x.seq] = 1;
+            for (int it = 0; it < T; it++) {
+                const int L = it < x.nB ? x.d - it : x.top - (it - x.nB);
+                u64 hi, lo, rhi, rlo;
+                bool pal;
+                wide_kmer_at(pk, p + (u32)(x.n - L), L, hi, lo);
+                bool ef = true, er = false;
+                if (a.ranged) { const u32 fb = (u32)(hi >> a.range_shift); ef = fb >= a.range_lo && fb < a.range_hi; }
+                if (a.rc) {
+                    wide_rc(hi, lo, L, rhi, rlo, pal);
+                    er = !pal;
+                    if (er && a.ranged) { const u32 rb = (u32)(rhi >> a.range_shift); er = rb >= a.range_lo && rb < a.range_hi; }
+                }
+                cnt += (u32)ef + (u32)er;
+                my_fwd += (u32)ef;
+            }
+        }
+        u32 total;
+        const u32 incl = block_scan_inclusive(cnt, OpSum(), scan_smem, &total);
+        if (WRITE && cnt) {
+            u64 slot = tile_base + running + (incl - cnt);
+            for (int it = 0; it < T; it++) {
+                const int L = it < x.nB ? x.d - it : x.top - (it - x.nB);
+                u64 hi, lo, rhi = 0, rlo = 0;
+                bool pal = true;
+                wide_kmer_at(pk, p + (u32)(x.n - L), L, hi, lo);
+                bool ef = true, er = false;
+                if (a.ranged) { const u32 fb = (u32)(hi >> a.range_shift); ef = fb >= a.range_lo && fb < a.range_hi; }
+                if (a.rc) {
+                    wide_rc(hi, lo, L, rhi, rlo, pal);
+                    er = !pal;
+                    if (er && a.ranged) { const u32 rb = (u32)(rhi >> a.range_shift); er = rb >= a.range_lo && rb < a.range_hi; }
+                }
+                const u32 pos = (u32)(t0 + p + (u64)(x.n - L) - x.seq_start);
+                const u64 val = a.kind == KMG_PAYLOAD_TAXON ? (u64)(u32)a.seq_id[x.seq]
+                                                            : (((u64)(u32)a.read_index[x.seq] << 16) | (u64)(pos & 0xFFFFu));
+                for (int half = 0; half < 2; half++) {
+                    if (!(half ? er : ef)) continue;
+                    a.out_keys[slot] = half ? rhi : hi;
+                    sa.out_lo[slot] = half ? rlo : lo;
+                    sa.out_len[slot] = (uint8_t)L;
+                    if (a.kind == KMG_PAYLOAD_TAXON) reinterpret_cast<u32 *>(a.out_vals)[slot] = (u32)val;
+                    else reinterpret_cast<u64 *>(a.out_vals)[slot] = val;
+                    slot++;
+                }
+            }
+        }
+        running += total;
+    }
+    if (!WRITE) {
+        if (my_fwd) atomicAdd(&blk_fwd, my_fwd);
+        __syncthreads();
+        if (tid == 0) {
+            a.tile_count[blockIdx.x] = running;
+            a.tile_fwd[blockIdx.x] = blk_fwd;
+        }
+    }
+}
+
 // ---- ranks ----------------------------------------------------------------------------------------------------------
 __global__ void wide_iota_kernel(u32 *__restrict__ idx, u32 n) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,21 +318,32 @@ __global__ void wide_gather_kernel(const u64 *__restrict__ src, const u32 *__res
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = src[idx[i]];
 }
-// his / los: the records' words in k-mer order.  flag[j] = record j starts a new k-mer
-__global__ void wide_heads_kernel(const u64 *__restrict__ his, const u64 *__restrict__ los, u32 n, u32 *__restrict__ flag) {
+__global__ void wide_gather8_kernel(const uint8_t *__restrict__ src, const u32 *__restrict__ idx, u32 n, uint8_t *__restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+// the length as a sort key of its own (k-mers of several lengths: (value, length) is Sequence.compareTo's order)
+__global__ void wide_lenkey_kernel(const uint8_t *__restrict__ len, u32 n, u64 *__restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (u64)len[i] << 56;
+}
+// his / los (/ lens, may be null: one length): the records' words in k-mer order.  flag[j] = record j starts a new k-mer
+__global__ void wide_heads_kernel(const u64 *__restrict__ his, const u64 *__restrict__ los, const uint8_t *__restrict__ lens, u32 n,
+                                  u32 *__restrict__ flag) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) flag[j] = j == 0 || his[j] != his[j - 1] || los[j] != los[j - 1];
+    if (j < n) flag[j] = j == 0 || his[j] != his[j - 1] || los[j] != los[j - 1] || (lens && lens[j] != lens[j - 1]);
 }
 // before[j] = heads before j (exclusive scan of flag).  rank_key of record perm[j] = its k-mer's rank, left-aligned in
 // `rbits` bits; the distinct k-mers in order.
 __global__ void wide_rank_kernel(const u64 *__restrict__ his, const u64 *__restrict__ los, const u32 *__restrict__ perm,
                                  const u32 *__restrict__ flag, const u64 *__restrict__ before, u32 n, int rbits,
-                                 u64 *__restrict__ rank_key, u64 *__restrict__ d_hi, u64 *__restrict__ d_lo) {
+                                 u64 *__restrict__ rank_key, u64 *__restrict__ d_hi, u64 *__restrict__ d_lo,
+                                 const uint8_t *__restrict__ lens = nullptr, uint8_t *__restrict__ d_len = nullptr) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const u64 r = before[j] + flag[j] - 1;
     rank_key[perm[j]] = r << (64 - rbits);
-    if (flag[j]) { d_hi[r] = his[j]; d_lo[r] = los[j]; }
+    if (flag[j]) { d_hi[r] = his[j]; d_lo[r] = los[j]; if (d_len) d_len[r] = lens[j]; }
 }
 
 // Read databases whose records arrive with ascending (read, pos) (no two sequences shared a read index): the two index
@@ -177,13 +351,31 @@ __global__ void wide_rank_kernel(const u64 *__restrict__ his, const u64 *__restr
 // val_off[r] = first record of k-mer r, the values = the payloads gathered in k-mer order.
 __global__ void wide_csr_reads_kernel(const u64 *__restrict__ his, const u64 *__restrict__ los, const u32 *__restrict__ flag,
                                       const u64 *__restrict__ before, u32 n, u64 *__restrict__ d_hi, u64 *__restrict__ d_lo,
-                                      u64 *__restrict__ val_off) {
+                                      u64 *__restrict__ val_off, const uint8_t *__restrict__ lens = nullptr,
+                                      uint8_t *__restrict__ d_len = nullptr) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n || !flag[j]) return;
     const u64 r = before[j];
     d_hi[r] = his[j]; d_lo[r] = los[j]; val_off[r] = j;
+    if (d_len) d_len[r] = lens[j];
 }
 
+// KmerUtils.restrictedStream on two-word k-mers (KmerUtils.java:59-74): the entries of at least L bases (keep[i] != 0),
+// cut to L bases (wide_cut_kernel's rule), side by side in their order, and where each came from
+__global__ void wide_compact_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, const u32 *__restrict__ keep,
+                                    const u64 *__restrict__ pos, u64 n, int L, u64 *__restrict__ out_hi, u64 *__restrict__ out_lo,
+                                    u32 *__restrict__ from) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const u64 j = pos[i];
+    out_hi[j] = hi[i];
+    out_lo[j] = L >= 64 ? lo[i] : lo[i] & ~(~0ull >> (2 * (L - 32)));
+    from[j] = (u32)i;
+}
+__global__ void wide_spread_kernel(const u64 *__restrict__ vals, const u32 *__restrict__ to, u64 n, u64 *__restrict__ out) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[to[j]] = vals[j];
+}
 // Kmer.limitTo (Kmer.java:277-289) on the second word: the bases behind the L-th (32 < L <= 64) go
 __global__ void wide_cut_kernel(const u64 *__restrict__ lo, u64 n, int L, u64 *__restrict__ out) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -275,19 +467,22 @@ __device__ __forceinline__ int wide_enc_shared(u64 ph, u64 pl, u64 ch, u64 cl, i
 __device__ __forceinline__ uint8_t wide_byte(u64 h, u64 l, int i) {
     return (uint8_t)(i < 8 ? h >> (56 - 8 * i) : l >> (56 - 8 * (i - 8)));
 }
+// (lens, may be null: every k-mer has k bases; k-mers of different lengths share nothing, their length bytes differ)
 template <bool WRITE>
-__global__ void wide_enc_kernel(const u64 *__restrict__ k_hi, const u64 *__restrict__ k_lo, const u64 *__restrict__ val_off,
-                                const int32_t *__restrict__ val_a, const int32_t *__restrict__ val_b, u64 U, int k, int key_len,
+__global__ void wide_enc_kernel(const u64 *__restrict__ k_hi, const u64 *__restrict__ k_lo, const uint8_t *__restrict__ lens,
+                                const u64 *__restrict__ val_off,
+                                const int32_t *__restrict__ val_a, const int32_t *__restrict__ val_b, u64 U, int k_all, int key_len,
                                 int kind, u32 *__restrict__ sizes, const u64 *__restrict__ enc_off, uint8_t *__restrict__ out) {
     const u64 u = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= U) return;
+    const int k = lens ? lens[u] : k_all;
     const int l = (k - 1) / 4 + 1;
     const int sh = 64 - 2 * key_len;
     const u64 ch = k_hi[u], cl = k_lo[u];
     int s = 0;
     if (u > 0) {
         const u64 ph = k_hi[u - 1];
-        if ((ph >> sh) == (ch >> sh)) s = wide_enc_shared(ph, k_lo[u - 1], ch, cl, l);
+        if ((ph >> sh) == (ch >> sh) && (!lens || lens[u - 1] == k)) s = wide_enc_shared(ph, k_lo[u - 1], ch, cl, l);
     }
     const u64 a = val_off[u], b = val_off[u + 1];
     const u64 nv = b - a;

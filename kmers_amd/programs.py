@@ -136,8 +136,8 @@ def open_database(ctx, path, key_range=None) -> KmerDatabase:
     if f.hr:
         return _read_hr_database(ctx, f, first, last)
     min_k, max_k, key_len, ids, rc = read_meta(f)
-    if max_k > 64 or (max_k > 32 and min_k != max_k):
-        raise KmersGpuError(KMG_EUNSUPPORTED, "k > 64, or k-mers of several lengths beyond 32 bases: use the Java path")
+    if max_k > 64:
+        raise KmersGpuError(KMG_EUNSUPPORTED, "k > 64: use the Java path")
     if ids == REF_ID:
         kind = PAYLOAD_TAXON
     elif ids == READ_ID:

@@ -27,7 +27,7 @@
  * Compiled with -DKO_WIDE (a second library, _build/libkmers_oracle_wide.so): k <= 64 -- the reference's Sequence is a
  * byte array of any length (Sequence.java:15-35,90-115); here a k-mer then takes two words, `kmer` = bases 0 .. 31 and
  * `lo` = bases 32 .. k-1, both left-aligned, and every step below works on the pair.  For k > 32 that build takes
- * k-mers of one length and no -D / -R filter (what the GPU path takes); for k <= 32 it gives what the narrow one gives.
+ * no -D / -R filter (what the GPU path takes); for k <= 32 it gives what the narrow one gives.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -199,7 +199,7 @@ void ko_set_min_k(int min_k) { g_min_k = min_k; }
 /* mode 0 = FASTA -> reference DB (MakeDatabase -a), 1 = FASTQ -> read DB (MakeDatabase -q).  k = maxK. */
 ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, int threads) {
     const int min_k = g_min_k > 0 ? g_min_k : k;
-    if (k > 32 && (min_k != k || g_dust >= 0 || g_runofsame >= 0)) return NULL;
+    if (k > 32 && (g_dust >= 0 || g_runofsame >= 0)) return NULL;
     if (k < 1 || k > KO_MAXK || min_k < 1 || min_k > k || key_len < 1 || key_len > min_k || key_len > 12) return NULL;
     const int8_t *code = code_table();
     ko_db *d = (ko_db *)calloc(1, sizeof(ko_db));

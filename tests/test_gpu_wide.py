@@ -301,7 +301,7 @@ def test_programs_on_files_of_two_word_kmers(tmp_path):
     def blocks(odb):
         blob, off = odb.encode_blocks()
         ids = [2048] if odb.kind == 0 else [257, 2052]
-        meta = bytes([odb.k, odb.k, odb.key_len]) + len(ids).to_bytes(4, "big") + b"".join(i.to_bytes(4, "big") for i in ids) + \
+        meta = bytes([odb.min_k, odb.k, odb.key_len]) + len(ids).to_bytes(4, "big") + b"".join(i.to_bytes(4, "big") for i in ids) + \
             bytes([1 if odb.kind == 0 else 0])
         out = {-1: meta}
         for key in range(4 ** odb.key_len):
@@ -320,7 +320,11 @@ def test_programs_on_files_of_two_word_kmers(tmp_path):
     assert open(p("ref.db"), "rb").read() == open(p("ref.want"), "rb").read()
     assert R.read_indexed_file(p("reads.db")) == R.read_indexed_file(p("reads.want"))
     assert gzip.open(p("map.gz"), "rt").read().splitlines() == o_reads.names
-    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("x.db"), "-K", str(k), "-l", str(l), rc=3)             # -k 24: several lengths
+    # -K 40 alone: the default -k 24, k-mers of 24 .. 40 bases (MakeDatabase.java:106-107)
+    run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("var.db"), "-K", str(k), "-l", str(l), "-Z")
+    o_var = OracleDB(synth.fasta_bytes(taxa, genomes), 0, k, l, min_k=24)
+    R.write_indexed_file(p("var.want"), blocks(o_var), None)
+    assert open(p("var.db"), "rb").read() == open(p("var.want"), "rb").read()
     run("Database.MakeDatabase", "-a", "-i", fa, "-o", p("x.db"), "-K", str(k), "-k", str(k), "-l", str(l), "-h", rc=3)
     run("Database.Matcher", "-i", p("reads.db"), "-d", p("ref.db"), "-o", p("m.txt"), "-Z", "x", rc=3)
     run("Utils.TaxaCounts", "-d", p("ref.db"), "-o", p("c.tsv"), rc=3)
@@ -336,6 +340,17 @@ def test_programs_on_files_of_two_word_kmers(tmp_path):
     assert open(p("m.py.txt")).read().splitlines() == want
     t, m, q = o_ref.taxacounts()
     assert programs.taxa_counts(ctx, p("ref.db"), p("c.py.tsv")) == ["%d\t%d\t%d" % x for x in zip(t.tolist(), m.tolist(), q.tolist())]
+    # the database of several lengths: TaxaCounts over all of it, Matcher -k 35 -K 35 through the restriction of both sides
+    t, m, q = o_var.taxacounts()
+    assert programs.taxa_counts(ctx, p("var.db"), p("cv.py.tsv")) == ["%d\t%d\t%d" % x for x in zip(t.tolist(), m.tolist(), q.tolist())]
+    programs.make_database(ctx, fq, p("reads.var.db"), "q", k, 24, l, read_map_path=p("map.var.gz"))
+    o_rvar = OracleDB(synth.fastq_bytes(reads), 1, k, l, min_k=24)
+    for L in (35, 30):
+        a_, b_ = o_rvar.restrict(L), o_var.restrict(L)
+        hit, nh = a_.match(b_)
+        assert nh > 500
+        assert programs.matcher(ctx, p("reads.var.db"), p("var.db"), p("mv.txt"), plain=True, min_k=L, max_k=L) == \
+            a_.match_lines(b_, hit).decode().splitlines()
     ctx.close()
 
 
@@ -468,3 +483,111 @@ def test_packed_and_device_resident_input_and_the_second_word_on_the_device(ctx)
             call()
         assert e.value.code == KMG_EUNSUPPORTED
     got.close(); again.close()
+
+
+# ---- k-mers of several lengths, the longest beyond 32 bases (MakeDatabase -K 40 with the default -k 24) ----------------------
+def _same_var_db(got, want):
+    _same_db(got, want)
+    assert got.min_length == want.min_k and got.max_length == want.k
+    assert np.array_equal(got.lens(), want.lens)
+
+
+@pytest.mark.parametrize("min_k,k,key_len,seed", [(24, 40, 3, 31), (30, 64, 2, 32), (33, 36, 2, 33), (20, 33, 3, 34), (40, 47, 4, 35),
+                                                  (1, 34, 1, 36), (32, 33, 6, 37), (63, 64, 5, 38), (24, 64, 6, 39)])
+def test_variable_length_builds_match_oracle(ctx, min_k, k, key_len, seed):
+    """MakeDatabase -k min_k -K k with k > 32: the suffixes of KmersFromFile.java:90-133,167-176 next to the full windows --
+    those of up to 32 bases one word, the longer ones two --, (k-mer, length) order (Sequence.java:165-187), a length byte
+    per record in the blocks (FileCreator.java:312-347), reads numbered at their first k-mer of any length."""
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(seed)
+    fa = _rand_fasta(rng, 40, 260, b"ACGTacgtACGTACGTACGTACGTN", [5, 9, 1234567, 77])
+    fq = _rand_fastq(rng, 300, 180, b"ACGTACGTACGTACGTACGTACGTN")
+    ref = km.make_reference_db(ctx, fa, k, key_len, min_k=min_k)
+    want = OracleDB(fa, 0, k, key_len, min_k=min_k)
+    _same_var_db(ref, want)
+    assert ref.n_windows == want.n_windows
+    assert len(set(want.lens.tolist())) > 1
+    rdb, names = km.make_read_db(ctx, fq, k, key_len, min_k=min_k)
+    wantr = OracleDB(fq, 1, k, key_len, min_k=min_k)
+    _same_var_db(rdb, wantr)
+    assert names == wantr.names
+    t, m, q = km.taxa_counts(ref)
+    ot, om, oq = want.taxacounts()
+    assert np.array_equal(t, ot) and np.array_equal(m, om) and np.array_equal(q, oq)
+    ref.close(); rdb.close()
+
+
+def test_variable_length_edge_cases(ctx):
+    """Sequences shorter than min_k, of exactly min_k .. k bases, an invalid last window (its suffixes come out twice),
+    low-entropy input (equal k-mers of different lengths), key ranges, several add calls, reads that share headers."""
+    import kmers_amd as km
+    from kmers_amd import parse
+    from kmers_amd.api import FileCreator
+    from oracle.c_oracle import OracleDB
+    u = b"ACGTTGCAAGCTTAGGCATCGATCGGATTACAGGCATTAGC"           # 41 bases
+    seqs = [u[:n] for n in (2, 29, 30, 31, 33, 35, 36, 37, 41)] + [u[:20] + b"N" + u[:36], u + b"N" + u[:3], b"N" * 40,
+                                                                 u + u[::-1] + b"N", u[:36] + b"N", u[:36] + b"NA", b"T" * 90, b"AC" * 50]
+    fa = b"".join(b">%d\n%s\n" % (i + 1, s) for i, s in enumerate(seqs))
+    for min_k, k, kl in ((30, 36, 2), (20, 36, 1), (35, 36, 2), (33, 34, 2), (10, 40, 3)):
+        _same_var_db(km.make_reference_db(ctx, fa, k, kl, min_k=min_k), OracleDB(fa, 0, k, kl, min_k=min_k))
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i // 2, s, b"I" * len(s)) for i, s in enumerate(seqs))
+    rdb, names = km.make_read_db(ctx, fq, 36, 2, min_k=30)
+    want = OracleDB(fq, 1, 36, 2, min_k=30)
+    _same_var_db(rdb, want)
+    assert names == want.names
+    rng = np.random.default_rng(5)
+    fa2 = _rand_fasta(rng, 200, 400, b"AAAAACCGTN", [3, 4])
+    for rng_ in ((0, 20), (20, 64), (64, 64)):
+        got = km.make_reference_db(ctx, fa2, 38, 3, key_range=rng_, min_k=27)
+        if rng_[0] < rng_[1]:
+            _same_var_db(got, OracleDB(fa2, 0, 38, 3, key_range=rng_, min_k=27))
+        else:
+            assert got.n_unique == 0
+    pf = parse.parse(fa2, parse.FASTA, 38)
+    b = pf.batch
+    fc = FileCreator(ctx, 3, 38, "ref", rc=True)
+    cuts = [0, b.nseq // 3, b.nseq // 2, b.nseq]
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        lo, hi = int(b.seq_off[a]), int(b.seq_off[e])
+        fc.add_kmers(km.SequenceBatch(b.bases[lo:hi], b.seq_off[a:e + 1] - b.seq_off[a], seq_id=b.seq_id[a:e]), min_length=27, max_length=38)
+    _same_var_db(fc.create(), OracleDB(fa2, 0, 38, 3, min_k=27))
+
+
+@pytest.mark.parametrize("min_k,k,L,key_len,seed", [(24, 40, 30, 3, 41), (24, 40, 24, 3, 42), (24, 40, 40, 3, 43), (24, 40, 33, 6, 44),
+                                                    (30, 64, 32, 2, 45), (30, 64, 50, 2, 46), (40, 47, 45, 4, 47)])
+def test_restricted_match_matches_oracle(ctx, min_k, k, L, key_len, seed):
+    """Matcher -k L -K L over such databases: both sides through KmerUtils.restrictedStream (KmerUtils.java:59-74;
+    kmg_db_restrict) -- to one word for L <= 32, to two beyond --, then the quick branch's join (DB.java:129-137)."""
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(seed)
+    fa = _rand_fasta(rng, 30, 400, b"ACGT" * 12 + b"N", [11, 12, 13])
+    body = b"".join(ln for ln in fa.split(b"\n") if not ln.startswith(b">"))
+    recs = []
+    for i in range(200):
+        a = int(rng.integers(0, max(len(body) - 120, 1)))
+        sq = body[a:a + int(rng.integers(min_k, 120))]
+        recs.append(b"@q%d\n%s\n+\n%s\n" % (i, sq, b"I" * len(sq)))
+    fq = b"".join(recs)
+    ref = km.make_reference_db(ctx, fa, k, key_len, min_k=min_k)
+    rdb, _ = km.make_read_db(ctx, fq, k, key_len, min_k=min_k)
+    with pytest.raises(km.KmersGpuError):                   # DB.java:83: several lengths never take the quick branch
+        km.DB([ref]).get_nearest_kmers(rdb)
+    cref = OracleDB(fa, 0, k, key_len, min_k=min_k).restrict(L)
+    creads = OracleDB(fq, 1, k, key_len, min_k=min_k).restrict(L)
+    rref, rreads = ref.restrict(L), rdb.restrict(L)
+    for got, want in ((rref, cref), (rreads, creads)):
+        h = got.fetch()
+        assert got.n_unique == want.U and got.n_values == want.V
+        for f in ("keys", "val_off", "val_a", "val_b", "bucket_off"):
+            assert np.array_equal(h[f], getattr(want, f)), f
+        if L > 32:
+            assert np.array_equal(h["keys_lo"], want.keys_lo)
+    assert rref.min_length == rref.max_length == L
+    hit, nh = km.DB([rref]).get_nearest_kmers(rreads)
+    ohit, onh = creads.match(cref)
+    assert nh == onh and nh > 0 and np.array_equal(hit, ohit)
+    assert "\n".join(km.match_lines(rreads, rref, hit)) + "\n" == creads.match_lines(cref, ohit).decode()
+    with pytest.raises(km.InconsistentDataException):       # DB.java:78-81
+        ref.restrict(min_k - 1)
