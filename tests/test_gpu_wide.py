@@ -231,12 +231,21 @@ def test_fuzz_against_oracle(ctx, seed):
     alphabet = [b"ACGT", b"ACGTN", b"AC", b"ACGTacgtNn", b"AT"][int(rng.integers(0, 5))]
     fa = _rand_fasta(rng, int(rng.integers(1, 60)), int(rng.integers(2, 3000)), alphabet)
     fq = _rand_fastq(rng, int(rng.integers(1, 500)), int(rng.integers(2, 500)), alphabet)
-    ref = km.make_reference_db(ctx, fa, k, l)
-    rdb, names = km.make_read_db(ctx, fq, k, l)
-    oref, ordb = OracleDB(fa, 0, k, l), OracleDB(fq, 1, k, l)
+    # every third seed: k-mers of several lengths, joined after both sides are restricted to one of them
+    min_k = int(rng.integers(l, k)) if seed % 3 == 2 else k
+    ref = km.make_reference_db(ctx, fa, k, l, min_k=min_k)
+    rdb, names = km.make_read_db(ctx, fq, k, l, min_k=min_k)
+    oref, ordb = OracleDB(fa, 0, k, l, min_k=min_k), OracleDB(fq, 1, k, l, min_k=min_k)
     _same_db(ref, oref)
     _same_db(rdb, ordb)
     assert names == ordb.names
+    if min_k < k:
+        assert np.array_equal(ref.lens(), oref.lens) and np.array_equal(rdb.lens(), ordb.lens)
+        L = int(rng.integers(min_k, k + 1))
+        ref2, rdb2, oref, ordb = ref.restrict(L), rdb.restrict(L), oref.restrict(L), ordb.restrict(L)
+        ref.close(); rdb.close()
+        ref, rdb = ref2, rdb2
+        assert np.array_equal(ref.fetch()["keys"], oref.keys) and np.array_equal(rdb.fetch()["val_b"], ordb.val_b)
     hit, nh = km.DB([ref]).get_nearest_kmers(rdb)
     ohit, onh = ordb.match(oref)
     assert nh == onh and np.array_equal(hit, ohit)

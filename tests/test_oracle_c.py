@@ -206,3 +206,25 @@ def test_wide_builds_agree_with_the_literal_restatement(k, key_len, seed, alphab
     assert got == want and n == len(want)
     t, m, q = c.taxacounts()
     assert ["%d\t%d\t%d" % (a, b, cc) for a, b, cc in zip(t, m, q)] == R.taxa_counts(R.DB([py]))
+
+
+@pytest.mark.parametrize("min_k,k,key_len,seed,alphabet", [(24, 40, 3, 71, b"ACGTN" * 3 + b"ACGT" * 6), (30, 64, 2, 72, b"ACGT"),
+                                                           (33, 36, 2, 73, b"AC"), (20, 33, 3, 74, b"ACGTacgtN" + b"ACGT" * 5),
+                                                           (40, 47, 4, 75, b"AT")])
+def test_wide_builds_of_several_lengths_agree_with_the_literal_restatement(min_k, k, key_len, seed, alphabet):
+    """MakeDatabase -k min_k -K k with k > 32, and Matcher -k L -K L over the two databases (KmerUtils.restrictedStream)."""
+    rng = np.random.default_rng(seed)
+    fa = _rand_fasta(rng, 12, 300, alphabet=alphabet)
+    fq = _rand_fastq(rng, 40, 200, alphabet=alphabet)
+    py = R.build_ref_db(fa, k, key_len, min_k=min_k)
+    c = OracleDB(fa, 0, k, key_len, min_k=min_k)
+    assert c.encode_blocks()[0] == _py_blocks_concat(py, key_len)
+    pyr, names = R.build_read_db(fq, k, key_len, min_k=min_k)
+    cr = OracleDB(fq, 1, k, key_len, min_k=min_k)
+    assert cr.encode_blocks()[0] == _py_blocks_concat(pyr, key_len) and cr.names == names
+    assert len(set(c.lens.tolist())) > 1
+    for L in (min_k, (min_k + k) // 2, k):
+        want = R.match_lines(pyr, R.DB([py]), min_k=L, max_k=L)
+        s_, d_ = cr.restrict(L), c.restrict(L)
+        hit, _ = s_.match(d_)
+        assert s_.match_lines(d_, hit).decode().splitlines() == want
