@@ -103,7 +103,7 @@ int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind);
  *                   counts < threshold*k*2) and Kmers/RunOfSame.java:12-36 (drop iff a run of equal
  *                   bases reaches length), applied to the forward k-mer before FileCreator.addKmers
  *                   (its RC goes with it); reads are numbered before the filters.  -1 = off.  Call
- *                   between kmg_build_begin and the first kmg_build_add. */
+ *                   between kmg_build_begin and the first kmg_build_add.  k <= 32 (KMG_EUNSUPPORTED beyond). */
 int kmg_build_set_filters(kmg_ctx *ctx, int dust_threshold, int runofsame_length);
 /* kmg_build_set_min_k: MakeDatabase -k <minK> below -K <maxK> = the k of kmg_build_begin (the reference's defaults are
  *   -k 24 -K 32, MakeDatabase.java:106-107).  Replaces the `ending` branch of KmersFromFileSpliterator.tryAdvance
@@ -113,7 +113,8 @@ int kmg_build_set_filters(kmg_ctx *ctx, int dust_threshold, int runofsame_length
  *   last full window of a sequence is invalid both rules fire and those suffixes are recorded twice, as there.  A read
  *   is numbered at its first k-mer of any length.  The database is ordered as Sequence.compareTo orders k-mers
  *   (Kmers/Sequence.java:165-187): zero-padded value first, length second (kmg_db_fetch_lens).  key_len <= min_k
- *   (Kmer.key of a shorter k-mer throws in the reference).  After kmg_build_begin, before the first add. */
+ *   (Kmer.key of a shorter k-mer throws in the reference).  After kmg_build_begin, before the first add.  Any k <= 64:
+ *   beyond 32 the k-mers of up to 32 bases have a zero second word (kmg_db_fetch_keys_lo). */
 int kmg_build_set_min_k(kmg_ctx *ctx, int min_k);
 /* kmg_build_set_key_range: build only the part of the database whose key buckets (Kmer.key(key_len), Kmer.java:47-55)
  *   lie in [first_bucket, end_bucket) -- each record is judged by its own k-mer, so a reverse complement can be kept

@@ -173,7 +173,46 @@ def main_wide():
         print(name, len(lines), "match lines,", os.path.getsize(path), "bytes")
 
 
+# ... and of several lengths (MakeDatabase -K 40 with the default -k 24)
+WIDE_VAR_CASES = [
+    # name, minK, maxK, key_len, restricted length of the match (Matcher -k L -K L), seed, fasta alphabet
+    ("var_k24_40", 24, 40, 3, 35, 401, b"ACGTACGTACGTACGTACGTACGTN"),
+    ("var_k30_64", 30, 64, 2, 31, 402, b"ACGT"),
+]
+
+
+def main_wide_var():
+    for name, mn, mx, l, L, seed, alphabet in WIDE_VAR_CASES:
+        fa, fq = make_inputs(seed, 3, 320, 30, 110, alphabet, True)
+        first = fa.split(b"\n")[1]
+        fa += b">9\n%s\n>9\n%s\n" % (first[:mx - 2], first[5:5 + mn])      # sequences of maxK-2 and of minK bases
+        ref = R.build_ref_db(fa, mx, l, min_k=mn)
+        reads, names = R.build_read_db(fq, mx, l, min_k=mn)
+        db = R.DB([ref])
+        lines = R.match_lines(reads, db, min_k=L, max_k=L)
+        counts = R.taxa_counts(db)
+        c_ref, c_reads = OracleDB(fa, 0, mx, l, min_k=mn), OracleDB(fq, 1, mx, l, min_k=mn)
+        assert c_ref.encode_blocks()[0] == b"".join(ref[key] for key in range(4 ** l)), name
+        assert c_reads.encode_blocks()[0] == b"".join(reads[key] for key in range(4 ** l)) and c_reads.names == names, name
+        cr, cs = c_ref.restrict(L), c_reads.restrict(L)
+        hit, _ = cs.match(cr)
+        assert cs.match_lines(cr, hit).decode().splitlines() == lines and len(lines) > 20, name
+        out = {
+            "comment": "outputs of oracle/slow_ref.py (restatement of the reference), not of Kmers.jar; see make_golden.py",
+            "min_k": mn, "k": mx, "key_len": l, "restrict": L, "fasta": fa.decode(), "fastq": fq.decode(),
+            "ref_blocks": {str(key): ref[key].hex() for key in sorted(ref)},
+            "read_blocks": {str(key): reads[key].hex() for key in sorted(reads)},
+            "read_names": names, "match_lines_restricted": lines, "taxa_counts": counts,
+        }
+        path = os.path.join(ROOT, "tests", "golden", "widevar_%s.json" % name[4:])
+        with open(path, "w") as f:
+            json.dump(out, f, indent=0, sort_keys=True)
+            f.write("\n")
+        print(name, len(lines), "match lines,", os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     main()
     main_var()
     main_wide()
+    main_wide_var()

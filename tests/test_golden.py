@@ -246,3 +246,57 @@ def test_gpu_reproduces_wide_golden(path):
     for d in (ref, reads):
         d.close()
     ctx.close()
+
+
+# ---- ... and of several lengths (MakeDatabase -K 40 with the default -k 24; Matcher -k L -K L) ------------------------------
+WIDE_VAR_CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "widevar_*.json")))
+
+
+def test_wide_var_golden_files_exist():
+    assert len(WIDE_VAR_CASES) >= 2
+
+
+@pytest.mark.parametrize("path", WIDE_VAR_CASES, ids=[os.path.basename(p)[8:-5] for p in WIDE_VAR_CASES])
+def test_restatements_reproduce_wide_variable_length_golden(path):
+    from oracle import slow_ref as R
+    from oracle.c_oracle import OracleDB
+    g = _load_var(path)
+    mn, k, l, L = g["min_k"], g["k"], g["key_len"], g["restrict"]
+    fa, fq = g["fasta"].encode(), g["fastq"].encode()
+    ref = R.build_ref_db(fa, k, l, min_k=mn)
+    reads, names = R.build_read_db(fq, k, l, min_k=mn)
+    assert ref == g["ref_blocks"] and reads == g["read_blocks"] and names == g["read_names"]
+    db = R.DB([ref])
+    assert R.match_lines(reads, db, min_k=L, max_k=L) == g["match_lines_restricted"] and R.taxa_counts(db) == g["taxa_counts"]
+    c_ref, c_reads = OracleDB(fa, 0, k, l, min_k=mn), OracleDB(fq, 1, k, l, min_k=mn)
+    for c, want in ((c_ref, g["ref_blocks"]), (c_reads, g["read_blocks"])):
+        blob, off = c.encode_blocks()
+        for key in range(4 ** l):
+            assert blob[int(off[key]):int(off[key + 1])] == want[key]
+    cr, cs = c_ref.restrict(L), c_reads.restrict(L)
+    hit, _ = cs.match(cr)
+    assert cs.match_lines(cr, hit).decode().splitlines() == g["match_lines_restricted"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", WIDE_VAR_CASES, ids=[os.path.basename(p)[8:-5] for p in WIDE_VAR_CASES])
+def test_gpu_reproduces_wide_variable_length_golden(path):
+    import kmers_amd as km
+    g = _load_var(path)
+    mn, k, l, L = g["min_k"], g["k"], g["key_len"], g["restrict"]
+    ctx = km.Context(0)
+    ref = km.make_reference_db(ctx, g["fasta"].encode(), k, l, min_k=mn)
+    reads, names = km.make_read_db(ctx, g["fastq"].encode(), k, l, min_k=mn)
+    for db, want in ((ref, g["ref_blocks"]), (reads, g["read_blocks"])):
+        blob, off = db.encode_blocks()
+        assert db.meta() == want[-1]
+        for key in range(4 ** l):
+            assert blob[int(off[key]):int(off[key + 1])] == want[key], key
+    assert names == g["read_names"]
+    assert km.taxa_count_lines(ref) == g["taxa_counts"]
+    rref, rreads = ref.restrict(L), reads.restrict(L)
+    hit, nh = km.DB([rref]).get_nearest_kmers(rreads)
+    assert km.match_lines(rreads, rref, hit) == g["match_lines_restricted"] and nh == len(g["match_lines_restricted"])
+    for d in (ref, reads, rref, rreads):
+        d.close()
+    ctx.close()
