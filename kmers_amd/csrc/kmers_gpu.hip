@@ -1972,10 +1972,7 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
         Vt += d->V;
         rc &= d->rc;
     }
-    if (d0->min_k != d0->k) {
-        KMG_NO_WIDE(d0);            // (sets of two-word databases of several lengths: the Java path)
-        return merge_disjoint_keys(ctx, dbs, n_dbs, out);
-    }
+    if (d0->min_k != d0->k && d0->k <= 32) return merge_disjoint_keys(ctx, dbs, n_dbs, out);
     if (Vt >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 values in the merged database");
     KMG_HIP(hipSetDevice(ctx->device));
     const bool reads = d0->kind == KMG_PAYLOAD_READPOS;
@@ -1998,27 +1995,38 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
         u64 Ut = 0;
         for (int i = 0; i < n_dbs; i++) Ut += dbs[i]->U;
         if (Ut >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 k-mers in the files of the set");
-        PoolBuf ch(ctx), cl(ctx), rank(ctx), d_hi(ctx), d_lo(ctx);
+        // (files of several lengths: the lengths are part of the k-mers' order and identity, DB.java:99-109 merges in
+        // Sequence.compareTo order; the search over several lengths is not built for two-word k-mers, so no file is kept)
+        const bool var = d0->min_k != d0->k;
+        db->min_k = d0->min_k;
+        PoolBuf ch(ctx), cl(ctx), cn(ctx), rank(ctx), d_hi(ctx), d_lo(ctx), d_len(ctx);
         KMG_ALLOC(ch, (Ut + 1) * 8); KMG_ALLOC(cl, (Ut + 1) * 8); KMG_ALLOC(rank, (Ut + 1) * 8);
+        if (var) KMG_ALLOC(cn, Ut + 64);
         u64 at = 0;
         for (int i = 0; i < n_dbs; i++) {
             const kmg_db *d = dbs[i];
             if (!d->U) continue;
             KMG_HIP(hipMemcpyAsync(ch.as<u64>() + at, d->keys, d->U * 8, hipMemcpyDeviceToDevice, ctx->stream));
             KMG_HIP(hipMemcpyAsync(cl.as<u64>() + at, d->keys_lo, d->U * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            if (var) {
+                if (d->lens) KMG_HIP(hipMemcpyAsync(cn.as<uint8_t>() + at, d->lens, d->U, hipMemcpyDeviceToDevice, ctx->stream));
+                else KMG_HIP(hipMemsetAsync(cn.as<uint8_t>() + at, d->k, d->U, ctx->stream));
+            }
             at += d->U;
         }
         int rbits = 1;
         u64 U = 0;
         if (Ut) {
             WideOrder w(ctx);
-            KMG_TRY(wide_order(ctx, ch.as<u64>(), cl.as<u64>(), (u32)Ut, d0->k, w));
+            KMG_TRY(wide_order(ctx, ch.as<u64>(), cl.as<u64>(), (u32)Ut, d0->k, w, var ? cn.as<uint8_t>() : nullptr));
             U = w.U; rbits = w.rbits;
             KMG_ALLOC(d_hi, (U + 1) * 8); KMG_ALLOC(d_lo, (U + 1) * 8);
+            if (var) KMG_ALLOC(d_len, U + 64);
             hipLaunchKernelGGL(wide_rank_kernel, dim3(div_up_u64(Ut, 256)), dim3(256), 0, ctx->stream, w.his, (const u64 *)w.los, w.order,
-                               w.flag.as<u32>(), w.before.as<u64>(), (u32)Ut, rbits, rank.as<u64>(), d_hi.as<u64>(), d_lo.as<u64>());
+                               w.flag.as<u32>(), w.before.as<u64>(), (u32)Ut, rbits, rank.as<u64>(), d_hi.as<u64>(), d_lo.as<u64>(),
+                               (const uint8_t *)w.lens.p, d_len.as<uint8_t>());
             KMG_HIP(hipGetLastError());
-        } else { KMG_ALLOC(d_hi, 8); KMG_ALLOC(d_lo, 8); }
+        } else { KMG_ALLOC(d_hi, 8); KMG_ALLOC(d_lo, 8); if (var) KMG_ALLOC(d_len, 64); }
         at = 0;
         for (int i = 0; i < n_dbs; i++) {
             const kmg_db *d = dbs[i];
@@ -2036,6 +2044,7 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
         ctx->pool.release(db->keys);
         db->keys = (u64 *)d_hi.detach();
         db->keys_lo = (u64 *)d_lo.detach();
+        db->lens = (uint8_t *)d_len.detach();
         KMG_TRY(db_make_buckets(ctx, db));
         *out = db_guard.release();
         return KMG_OK;

@@ -600,3 +600,27 @@ def test_restricted_match_matches_oracle(ctx, min_k, k, L, key_len, seed):
     assert "\n".join(km.match_lines(rreads, rref, hit)) + "\n" == creads.match_lines(cref, ohit).decode()
     with pytest.raises(km.InconsistentDataException):       # DB.java:78-81
         ref.restrict(min_k - 1)
+
+
+def test_merge_of_files_of_several_lengths(ctx):
+    """DB.kmers over a set of files of k-mers of several lengths (DB.java:99-109: merged in Sequence.compareTo order,
+    equal k-mers -- value AND length -- reduced): parts of a FASTA, and key-range files of the whole."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    from oracle.c_oracle import OracleDB
+    mn, k, l = 24, 40, 3
+    taxa, genomes = synth.random_genomes(491, 6, 3000, first_taxon=-3, shared_frac=0.4)
+    genomes = list(genomes) + [genomes[0], genomes[1][:1500], genomes[2][:30], genomes[2][:30]]
+    taxa = list(taxa) + [taxa[0], taxa[3], 5, 6]
+    parts = [(taxa[:3], genomes[:3]), (taxa[3:5], genomes[3:5]), (taxa[5:], genomes[5:])]
+    dbs = [km.make_reference_db(ctx, synth.fasta_bytes(t, g), k, l, min_k=mn) for t, g in parts]
+    whole_fa = synth.fasta_bytes(taxa, genomes)
+    want = OracleDB(whole_fa, 0, k, l, min_k=mn)
+    merged = km.merge_databases(dbs)
+    _same_var_db(merged, want)
+    nk = 4 ** l
+    shards = [km.make_reference_db(ctx, whole_fa, k, l, min_k=mn, key_range=r) for r in ((0, nk // 3), (nk // 3, nk))]
+    both = km.merge_databases(shards)
+    _same_var_db(both, want)
+    for d in dbs + shards + [merged, both]:
+        d.close()
