@@ -103,7 +103,7 @@ int kmg_build_begin(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind);
  *                   counts < threshold*k*2) and Kmers/RunOfSame.java:12-36 (drop iff a run of equal
  *                   bases reaches length), applied to the forward k-mer before FileCreator.addKmers
  *                   (its RC goes with it); reads are numbered before the filters.  -1 = off.  Call
- *                   between kmg_build_begin and the first kmg_build_add.  k <= 32 (KMG_EUNSUPPORTED beyond). */
+ *                   between kmg_build_begin and the first kmg_build_add. */
 int kmg_build_set_filters(kmg_ctx *ctx, int dust_threshold, int runofsame_length);
 /* kmg_build_set_min_k: MakeDatabase -k <minK> below -K <maxK> = the k of kmg_build_begin (the reference's defaults are
  *   -k 24 -K 32, MakeDatabase.java:106-107).  Replaces the `ending` branch of KmersFromFileSpliterator.tryAdvance

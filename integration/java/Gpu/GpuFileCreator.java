@@ -1,6 +1,6 @@
 // Gpu/GpuFileCreator.java -- FileCreator's public face (KmerFiles/FileCreator.java:33,65,117,219) over the C ABI.
 // SOURCE ONLY (no JDK in this image: never compiled).  MakeDatabase constructs it instead of FileCreator when
-// -K <= 64 (MakeDatabase.java:130,167; beyond 32 without -D / -R), and feeds it SEQUENCES instead of a KmerStream: the record splitting
+// -K <= 64 (MakeDatabase.java:130,167), and feeds it SEQUENCES instead of a KmerStream: the record splitting
 // (KmersFromFile's ID / KMER / OTHER state machine) stays in Java, windows, reverse complements, read numbering, sort,
 // dedup and block encoding run on the GPU.
 package Gpu;

@@ -24,12 +24,10 @@ import Zip.ZipOrNot;
 
 public final class GpuMakeDatabase
 {
-    /** what the GPU path takes: -a / -q, -K <= 32 (or, without a -D / -R filter, -K <= 64), no -h, no -U, no temp files
-     *  (MakeDatabase.java:106-111) */
+    /** what the GPU path takes: -a / -q, -K <= 64, no -h, no -U, no temp files (MakeDatabase.java:106-111) */
     public static boolean usable(CommandLine commands, int minK, int maxK, boolean useExistingTemp)
     {
-        boolean wide = maxK > 32 && maxK <= 64 && !commands.hasOption('D') && !commands.hasOption('R');
-        return (commands.hasOption('a') || commands.hasOption('q')) && !commands.hasOption('O') && (maxK <= 32 || wide)
+        return (commands.hasOption('a') || commands.hasOption('q')) && !commands.hasOption('O') && maxK <= 64
                 && !commands.hasOption('h') && !useExistingTemp;
     }
 

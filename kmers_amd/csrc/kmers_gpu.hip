@@ -174,8 +174,6 @@ extern "C" int kmg_build_set_filters(kmg_ctx *ctx, int dust_threshold, int runof
     std::lock_guard<std::mutex> g(ctx->mu);
     if (!ctx->building) return fail(ctx, KMG_ESTATE, "kmg_build_set_filters before kmg_build_begin");
     if (ctx->rec_upper) return fail(ctx, KMG_ESTATE, "filters must be set before the first kmg_build_add");
-    if (ctx->k > 32 && (dust_threshold >= 0 || runofsame_length >= 0))
-        return fail(ctx, KMG_EUNSUPPORTED, "the Dust / RunOfSame filters are built for k <= 32");
     ctx->dust = dust_threshold < 0 ? -1 : dust_threshold;
     ctx->runofsame = runofsame_length < 0 ? -1 : runofsame_length;
     return KMG_OK;
@@ -275,7 +273,7 @@ static int build_add_wide(kmg_ctx *ctx, const uint8_t *d_bases, u64 nbases, cons
     ExtractArgs &a = wa.e;
     a.bases = d_bases; a.nbases = nbases; a.seq_off = d_seq_off; a.nseq = nseq; a.seq_id = d_seq_id;
     a.tile_seq = tile_seq.as<u32>(); a.k = ctx->k; a.rc = ctx->rc; a.kind = ctx->kind;
-    a.dust = -1; a.runofsame = -1;
+    a.dust = ctx->dust; a.runofsame = ctx->runofsame;
     a.ranged = ctx->ranged ? 1 : 0; a.range_shift = 64 - 2 * ctx->key_len; a.range_lo = ctx->range_lo; a.range_hi = ctx->range_hi;
     a.tile_count = tile_count.as<u32>(); a.tile_fwd = tile_fwd.as<u32>(); a.tile_off = tile_off.as<u64>();
     a.out_keys = ctx->rec_keys; a.out_vals = ctx->rec_vals; a.state = ctx->d_state;

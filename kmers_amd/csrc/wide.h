@@ -25,6 +25,60 @@ struct WideArgs {
     u64 *out_lo;
 };
 
+// ---- MakeDatabase -D / -R on a k-mer of L bases in two words (extract.h's dust_keep / runofsame_keep on 128 bits) -------------
+__device__ __forceinline__ void wide_shl(u64 hi, u64 lo, int s, u64 &oh, u64 &ol) {      // (hi:lo) << s, 0 <= s < 128
+    if (s == 0) { oh = hi; ol = lo; }
+    else if (s < 64) { oh = (hi << s) | (lo >> (64 - s)); ol = lo << s; }
+    else if (s == 64) { oh = lo; ol = 0; }
+    else { oh = lo << (s - 64); ol = 0; }
+}
+// the first `groups` two-bit groups of a 128-bit string
+__device__ __forceinline__ void wide_top_groups(int groups, u64 &mh, u64 &ml) {
+    mh = groups >= 32 ? ~0ull : (groups <= 0 ? 0ull : ~(~0ull >> (2 * groups)));
+    ml = groups <= 32 ? 0ull : (groups >= 64 ? ~0ull : ~(~0ull >> (2 * (groups - 32))));
+}
+// Kmers/RunOfSame.java:12-36: drop the k-mer iff some run of equal bases reaches `length`
+__device__ __forceinline__ bool wide_runofsame_keep(u64 hi, u64 lo, int L, int length) {
+    const int R = length - 1;                          // consecutive equal neighbour pairs needed
+    if (R < 1 || R > L - 1) return true;
+    const u64 lowbits = 0x5555555555555555ull;
+    u64 sh, sl, mh, ml;
+    wide_shl(hi, lo, 2, sh, sl);
+    const u64 xh = hi ^ sh, xl = lo ^ sl;              // group i: base_i ^ base_{i+1}
+    u64 eh = ~(xh | (xh >> 1)) & lowbits, el = ~(xl | (xl >> 1)) & lowbits;
+    wide_top_groups(L - 1, mh, ml);                    // pairs 0 .. L-2 only
+    eh &= mh; el &= ml;
+    u64 th = eh, tl = el;
+    int s = 1;
+    while (s * 2 <= R) { wide_shl(th, tl, 2 * s, sh, sl); th &= sh; tl &= sl; s *= 2; }      // t[i] = e[i .. i+s-1] all set
+    if (R > s) { wide_shl(th, tl, 2 * (R - s), sh, sl); th &= sh; tl &= sl; }
+    return (th | tl) == 0;
+}
+// Kmers/Dust.java:12-30: score = sum c(c-1) over the triplet counts = twice the pairs of equal triplets; keep iff
+// pairs < threshold * L
+__device__ __forceinline__ bool wide_dust_keep(u64 hi, u64 lo, int L, int threshold) {
+    const int nt = L - 2;
+    int pairs = 0;
+    const u64 lowbits = 0x5555555555555555ull;
+    for (int d = 1; d < nt; d++) {
+        u64 sh, sl, mh, ml;
+        wide_shl(hi, lo, 2 * d, sh, sl);
+        const u64 yh = hi ^ sh, yl = lo ^ sl;          // group i: base_i ^ base_{i+d}
+        const u64 eh = ~(yh | (yh >> 1)) & lowbits, el = ~(yl | (yl >> 1)) & lowbits;
+        u64 ah, al, bh, bl;
+        wide_shl(eh, el, 2, ah, al);
+        wide_shl(eh, el, 4, bh, bl);
+        wide_top_groups(nt - d, mh, ml);               // i = 0 .. nt-1-d
+        pairs += __popcll(eh & ah & bh & mh) + __popcll(el & al & bl & ml);
+    }
+    return pairs < threshold * L;
+}
+__device__ __forceinline__ bool wide_filters_keep(const ExtractArgs &a, u64 hi, u64 lo, int L) {
+    if (a.runofsame >= 0 && !wide_runofsame_keep(hi, lo, L, a.runofsame)) return false;
+    if (a.dust >= 0 && !wide_dust_keep(hi, lo, L, a.dust)) return false;
+    return true;
+}
+
 struct WideSite {
     u64 hi, lo, rhi, rlo;
     bool valid, ef, er;
@@ -57,6 +111,8 @@ __device__ __forceinline__ WideSite wide_site(const ExtractArgs &a, const u32 *p
     x.lo = (sh ? (a1 << sh) | (a2 >> (64 - sh)) : a1) & mask_lo;
     x.seq = s_lo + seqrel[p];
     x.pos = (u32)(gp - a.seq_off[x.seq]);
+    // (the filters judge the forward k-mer, its reverse complement goes with it; reads are numbered before them)
+    if ((a.dust >= 0 || a.runofsame >= 0) && !wide_filters_keep(a, x.hi, x.lo, W)) return x;
     x.ef = true;
     if (a.ranged) {
         const u32 fb = (u32)(x.hi >> a.range_shift);
@@ -256,9 +312,10 @@ __global__ __launch_bounds__(EX_BLOCK) void wide_short_kernel(WideShortArgs sa) 
                 u64 hi, lo, rhi, rlo;
                 bool pal;
                 wide_kmer_at(pk, p + (u32)(x.n - L), L, hi, lo);
-                bool ef = true, er = false;
-                if (a.ranged) { const u32 fb = (u32)(hi >> a.range_shift); ef = fb >= a.range_lo && fb < a.range_hi; }
-                if (a.rc) {
+                const bool keep = !(a.dust >= 0 || a.runofsame >= 0) || wide_filters_keep(a, hi, lo, L);
+                bool ef = keep, er = false;
+                if (ef && a.ranged) { const u32 fb = (u32)(hi >> a.range_shift); ef = fb >= a.range_lo && fb < a.range_hi; }
+                if (keep && a.rc) {
                     wide_rc(hi, lo, L, rhi, rlo, pal);
                     er = !pal;
                     if (er && a.ranged) { const u32 rb = (u32)(rhi >> a.range_shift); er = rb >= a.range_lo && rb < a.range_hi; }
@@ -276,9 +333,10 @@ __global__ __launch_bounds__(EX_BLOCK) void wide_short_kernel(WideShortArgs sa) 
                 u64 hi, lo, rhi = 0, rlo = 0;
                 bool pal = true;
                 wide_kmer_at(pk, p + (u32)(x.n - L), L, hi, lo);
-                bool ef = true, er = false;
-                if (a.ranged) { const u32 fb = (u32)(hi >> a.range_shift); ef = fb >= a.range_lo && fb < a.range_hi; }
-                if (a.rc) {
+                const bool keep = !(a.dust >= 0 || a.runofsame >= 0) || wide_filters_keep(a, hi, lo, L);
+                bool ef = keep, er = false;
+                if (ef && a.ranged) { const u32 fb = (u32)(hi >> a.range_shift); ef = fb >= a.range_lo && fb < a.range_hi; }
+                if (keep && a.rc) {
                     wide_rc(hi, lo, L, rhi, rlo, pal);
                     er = !pal;
                     if (er && a.ranged) { const u32 rb = (u32)(rhi >> a.range_shift); er = rb >= a.range_lo && rb < a.range_hi; }

@@ -27,7 +27,7 @@
  * Compiled with -DKO_WIDE (a second library, _build/libkmers_oracle_wide.so): k <= 64 -- the reference's Sequence is a
  * byte array of any length (Sequence.java:15-35,90-115); here a k-mer then takes two words, `kmer` = bases 0 .. 31 and
  * `lo` = bases 32 .. k-1, both left-aligned, and every step below works on the pair.  For k > 32 that build takes
- * no -D / -R filter (what the GPU path takes); for k <= 32 it gives what the narrow one gives.
+ * the same options; for k <= 32 it gives what the narrow one gives.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -150,6 +150,7 @@ void ko_free(ko_db *d) {
     free(d->name_off); free(d->names); free(d);
 }
 
+#ifndef KO_WIDE
 /* Kmers/Dust.java:12-30: keep iff sum c(c-1) over the 64 triplet counts < threshold * k * 2 */
 static int dust_keep(uint64_t packed, int k, int threshold) {
     int counts[64];
@@ -173,6 +174,28 @@ static int runofsame_keep(uint64_t packed, int k, int length) {
     }
     return 1;
 }
+#endif
+
+#ifdef KO_WIDE
+/* the same two predicates on a k-mer of up to 64 bases, base by base */
+static int rec_dust_keep(const ko_rec *r, int k, int threshold) {
+    int counts[64];
+    memset(counts, 0, sizeof counts);
+    for (int i = 0; i < k - 2; i++) counts[rec_base(r, i) * 16 + rec_base(r, i + 1) * 4 + rec_base(r, i + 2)]++;
+    int score = 0;
+    for (int i = 0; i < 64; i++) score += counts[i] * (counts[i] - 1);
+    return score < threshold * k * 2;
+}
+static int rec_runofsame_keep(const ko_rec *r, int k, int length) {
+    int c = rec_base(r, 0), l = 1;
+    for (int i = 1; i < k; i++) {
+        int b = rec_base(r, i);
+        if (b == c) { l++; if (l == length) return 0; }
+        else { c = b; l = 1; }
+    }
+    return 1;
+}
+#endif
 
 static int g_dust = -1, g_runofsame = -1;
 /* MakeDatabase -D / -R (MakeDatabase.java:279-291): filters applied to the forward k-mer stream of the
@@ -199,7 +222,6 @@ void ko_set_min_k(int min_k) { g_min_k = min_k; }
 /* mode 0 = FASTA -> reference DB (MakeDatabase -a), 1 = FASTQ -> read DB (MakeDatabase -q).  k = maxK. */
 ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, int threads) {
     const int min_k = g_min_k > 0 ? g_min_k : k;
-    if (k > 32 && (g_dust >= 0 || g_runofsame >= 0)) return NULL;
     if (k < 1 || k > KO_MAXK || min_k < 1 || min_k > k || key_len < 1 || key_len > min_k || key_len > 12) return NULL;
     const int8_t *code = code_table();
     ko_db *d = (ko_db *)calloc(1, sizeof(ko_db));
@@ -319,8 +341,13 @@ ko_db *ko_build(const uint8_t *file, uint64_t n, int mode, int k, int key_len, i
         if (!have_kwd) break;                     /* return false */
         /* consumer.accept(kwd): kstream.filter(Dust).filter(RunOfSame), then FileCreator.addKmers (:77-95) */
         const int len = REC_LEN(kwd);
+#ifdef KO_WIDE
+        if (g_dust >= 0 && !rec_dust_keep(&kwd, len, g_dust)) continue;
+        if (g_runofsame >= 0 && !rec_runofsame_keep(&kwd, len, g_runofsame)) continue;
+#else
         if (g_dust >= 0 && !dust_keep(kwd.kmer, len, g_dust)) continue;
         if (g_runofsame >= 0 && !runofsame_keep(kwd.kmer, len, g_runofsame)) continue;
+#endif
         if (in_range(kwd.kmer, key_len)) { rv_push(&recs, kwd); d->n_windows++; }
 #ifdef KO_WIDE
         if (d->rc && !rec_is_palindrome(&kwd, len)) {

@@ -208,8 +208,7 @@ def test_files_roundtrip_and_fences(ctx, tmp_path):
     same.close()
     with pytest.raises(km.InconsistentDataException):
         db.restrict(k - 1)
-    for call in (lambda: db.restrict(k, k + 1) if False else km.FileCreator(ctx, l, k, "ref", True, runofsame=3),
-                 lambda: km.FileCreator(ctx, l, k, "ref", True, dust=2),
+    for call in (lambda: db.restrict(k - 2, k),
                  lambda: km.FileCreator(ctx, l, 65, "ref", True)):
         with pytest.raises(KmersGpuError) as e:
             call()
@@ -624,3 +623,27 @@ def test_merge_of_files_of_several_lengths(ctx):
     _same_var_db(both, want)
     for d in dbs + shards + [merged, both]:
         d.close()
+
+
+@pytest.mark.parametrize("min_k,k,dust,run", [(40, 40, 2, None), (40, 40, None, 6), (30, 50, 3, 5), (64, 64, 1, 4), (33, 33, 14, 5),
+                                              (24, 64, None, 2), (36, 36, 0, 1), (63, 64, 2, 33)])
+def test_dust_and_runofsame_filters_match_oracle(ctx, min_k, k, dust, run):
+    """MakeDatabase -D / -R (Kmers/Dust.java:12-30, Kmers/RunOfSame.java:12-36; MakeDatabase.java:279-291) on k-mers of up
+    to 64 bases, of one length or several: the forward k-mer is judged, its reverse complement goes with it, reads are
+    numbered before the filters."""
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(k * 7 + (dust or 0))
+    fa = _rand_fasta(rng, 60, 500, b"AAAACCGT" * 6 + b"N", [3, 4, 5])
+    fq = _rand_fastq(rng, 300, 300, b"AAACCGT")
+    od, orr = (-1 if dust is None else dust), (-1 if run is None else run)
+    got = km.make_reference_db(ctx, fa, k, 3, dust=dust, runofsame=run, min_k=min_k)
+    want = OracleDB(fa, 0, k, 3, dust=od, runofsame=orr, min_k=min_k)
+    _same_var_db(got, want)
+    assert got.n_windows == want.n_windows
+    rdb, names = km.make_read_db(ctx, fq, k, 3, dust=dust, runofsame=run, min_k=min_k)
+    wantr = OracleDB(fq, 1, k, 3, dust=od, runofsame=orr, min_k=min_k)
+    _same_var_db(rdb, wantr)
+    assert names == wantr.names
+    assert want.U <= OracleDB(fa, 0, k, 3, min_k=min_k).U
+    got.close(); rdb.close()

@@ -228,3 +228,14 @@ def test_wide_builds_of_several_lengths_agree_with_the_literal_restatement(min_k
         s_, d_ = cr.restrict(L), c.restrict(L)
         hit, _ = s_.match(d_)
         assert s_.match_lines(d_, hit).decode().splitlines() == want
+
+
+@pytest.mark.parametrize("min_k,k,dust,run,alphabet", [(40, 40, 2, None, b"AAAACCGT"), (40, 40, None, 6, b"AAAACGT"), (30, 50, 3, 5, b"AAACCGT"),
+                                                       (64, 64, 1, 4, b"AACGT"), (12, 12, 1, 3, b"AAACGT")])
+def test_wide_filters_agree_with_the_literal_restatement(min_k, k, dust, run, alphabet):
+    rng = np.random.default_rng(k + (dust or 0))
+    fa = _rand_fasta(rng, 12, 300, alphabet=alphabet)
+    py = R.build_ref_db(fa, k, 2, min_k=min_k, dust=dust, runofsame=run)
+    c = OracleDB(fa, 0, k, 2, min_k=min_k, dust=-1 if dust is None else dust, runofsame=-1 if run is None else run, wide=True)
+    assert c.encode_blocks()[0] == _py_blocks_concat(py, 2)
+    assert c.U <= OracleDB(fa, 0, k, 2, min_k=min_k, wide=True).U
