@@ -15,8 +15,8 @@
  * internally serialised (safe to call from several threads; calls do not overlap on the device).
  * Supported: 1 <= minK <= maxK = k <= 32, 1 <= key_len <= min(minK, 12); the exact join takes k-mers of one
  * length (restrict variable-length databases first, kmg_db_restrict).  k-mers of up to 64 bases ("two-word
- * k-mers", see below; 32 < maxK <= 64, any minK): build, fetch, load, encode, restrict, the exact join, TaxaCounts and the
- * per-read tools, the merge of file sets.  Anything else returns KMG_EUNSUPPORTED so a shim can fall back to the Java path.
+ * k-mers", see below; 32 < maxK <= 64, any minK): build, fetch, load, encode, restrict, the exact join, the search over several
+ * lengths, TaxaCounts and the per-read tools, the merge of file sets.  Anything else returns KMG_EUNSUPPORTED so a shim can fall back to the Java path.
  *
  * K-mer representation everywhere: uint64, 2 bits per base, code order A=0 C=1 T=2 G=3
  * (Kmers/Base.java:7-10), first base in the top bits, low 64-2k bits zero -- i.e. the bytes of

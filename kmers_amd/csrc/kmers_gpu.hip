@@ -2039,6 +2039,24 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
         }
         KMG_TRY(merge_records(ctx, db, k0, v0, k1, v1, n, totals, rbits));
         if (db->U != U) return fail(ctx, KMG_EDEVICE, "two-word merge: the ranks' distinct count differs from the k-mers'");
+        if (var && n_dbs > 1) {
+            // the search over several lengths takes a key's k-mers file by file (DB.java:154-158): a set whose files share a
+            // key is marked, and kmg_match_trie leaves it to the Java path
+            const u32 nbk = 1u << (2 * d0->key_len);
+            PoolBuf sb(ctx), sv(ctx), holders(ctx), clash(ctx);
+            KMG_ALLOC(sb, ((size_t)nbk + 1) * 8); KMG_ALLOC(sv, ((size_t)nbk + 1) * 8); KMG_ALLOC(holders, ((size_t)nbk + 1) * 4); KMG_ALLOC(clash, 64);
+            KMG_HIP(hipMemsetAsync(sb.p, 0, ((size_t)nbk + 1) * 8, ctx->stream));
+            KMG_HIP(hipMemsetAsync(sv.p, 0, ((size_t)nbk + 1) * 8, ctx->stream));
+            KMG_HIP(hipMemsetAsync(holders.p, 0, ((size_t)nbk + 1) * 4, ctx->stream));
+            KMG_HIP(hipMemsetAsync(clash.p, 0, 4, ctx->stream));
+            for (int i = 0; i < n_dbs; i++)
+                hipLaunchKernelGGL(vm_sum_kernel, dim3(div_up_u64(nbk + 1, 256)), dim3(256), 0, ctx->stream, dbs[i]->bucket_off, dbs[i]->val_off, nbk,
+                                   sb.as<u64>(), sv.as<u64>(), holders.as<u32>());
+            hipLaunchKernelGGL(vm_clash_kernel, dim3(div_up_u64(nbk, 256)), dim3(256), 0, ctx->stream, holders.as<u32>(), nbk, clash.as<u32>());
+            u32 h_clash = 0;
+            KMG_HIP(read_back(ctx, &h_clash, clash.p, 4));
+            db->shared_key_merge = h_clash != 0;
+        }
         ctx->pool.release(db->keys);
         db->keys = (u64 *)d_hi.detach();
         db->keys_lo = (u64 *)d_lo.detach();
@@ -2238,8 +2256,11 @@ extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     if (n_hits) *n_hits = 0;
     if (search->ctx != ctx || ref->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
     if (ref->kind != KMG_PAYLOAD_TAXON) return fail(ctx, KMG_EINVAL, "the database searched holds taxon counts");
-    KMG_NO_WIDE(search);
-    KMG_NO_WIDE(ref);
+    // (two-word k-mers, wide.h: one file, or a set whose files share no key; the search side one word or two as the database)
+    const bool wide = ref->k > 32;
+    if (wide != (search->k > 32) && search->U) return fail(ctx, KMG_EUNSUPPORTED, "one side of the search holds two-word k-mers, the other does not");
+    if (wide && ref->shared_key_merge)
+        return fail(ctx, KMG_EUNSUPPORTED, "files of two-word k-mers of several lengths that share a key: not on the GPU path");
     if (search->key_len != ref->key_len) return fail(ctx, KMG_EINVAL, "key lengths differ");
     // DB.java:78-81 on the search stream's declared lengths [min_k, search->k]
     if (min_k < ref->min_k || search->k > ref->k || min_k > search->min_k || min_k < ref->key_len)
@@ -2289,6 +2310,11 @@ extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
         KMG_HIP(read_back(ctx, &nrows, row.as<u64>() + ns, 8));
         KMG_HIP(read_back(ctx, &nrec, dst.as<u64>() + ns, 8));
     } else if (ns) {
+        if (wide)
+            hipLaunchKernelGGL(trie_find_wide_kernel, dim3(div_up_u64(ns, 256)), dim3(256), 0, ctx->stream, search->keys, search->keys_lo,
+                               search->lens, search->k, ns, ref->keys, ref->keys_lo, ref->lens, ref->k, ref->bucket_off, ref->val_off,
+                               ref->key_len, min_k, first.as<long long>(), found.as<u32>(), nvals.as<u32>());
+        else
         hipLaunchKernelGGL(trie_find_kernel, dim3(div_up_u64(ns, 256)), dim3(256), 0, ctx->stream, search->keys, search->lens, search->k,
                            ns, ref->keys, ref->lens, ref->k, ref->bucket_off, ref->val_off, ref->key_len, min_k,
                            first.as<long long>(), found.as<u32>(), nvals.as<u32>());

@@ -508,6 +508,58 @@ __global__ __launch_bounds__(WM_BLOCK) void wide_match_kernel(const u64 *__restr
     }
 }
 
+// ---- search over k-mers of several lengths, no differences: match.h's trie_find_kernel -- the closed form of what the
+// reference's radix trie hands back (DB.java:83,139-184 over Root.java:29-170; derivation in DESIGN 6b) -- on two words.
+// x0 = the first stored k-mer that has the search k-mer t (T bases) as a prefix; the answer's data object has absorbed
+// the stored k-mers [x0, first entry whose first m bases are larger), m = max(shortest, L + 1), L = the bases x0 shares
+// with its predecessor in the key.  One file, or a set whose files share no key.
+__global__ void trie_find_wide_kernel(const u64 *__restrict__ s_hi, const u64 *__restrict__ s_lo, const uint8_t *__restrict__ slens,
+                                      int s_len_all, u64 ns, const u64 *__restrict__ r_hi, const u64 *__restrict__ r_lo,
+                                      const uint8_t *__restrict__ rlens, int r_len_all, const u64 *__restrict__ rbucket,
+                                      const u64 *__restrict__ rval_off, int key_len, int shortest, long long *__restrict__ first,
+                                      u32 *__restrict__ found, u32 *__restrict__ nvals) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const u64 th = s_hi[i], tl = s_lo[i];
+    const int T = slens ? (int)slens[i] : s_len_all;
+    const u64 b = th >> (64 - 2 * key_len);
+    const u64 lo = rbucket[b], hi = rbucket[b + 1];
+    u64 l = lo, h = hi;
+    while (l < h) {                                // first entry >= (t, T) in (value, length) order
+        const u64 mid = (l + h) >> 1;
+        const u64 kh = r_hi[mid], kl = r_lo[mid];
+        const int lm = rlens ? (int)rlens[mid] : r_len_all;
+        if (wide_less(kh, kl, th, tl) || (kh == th && kl == tl && lm < T)) l = mid + 1; else h = mid;
+    }
+    first[i] = -1; found[i] = 0; nvals[i] = 0;
+    if (l == hi) return;
+    const u64 xh = r_hi[l], xl = r_lo[l];
+    const int len0 = rlens ? (int)rlens[l] : r_len_all;
+    // t a prefix of x0?  (if not: of no stored k-mer)
+    const bool pre = T <= 32 ? ((xh ^ th) >> (64 - 2 * T)) == 0 : (xh == th && (T >= 64 ? xl == tl : ((xl ^ tl) >> (64 - 2 * (T - 32))) == 0));
+    if (len0 < T || !pre) return;
+    int L = 0;
+    if (l > lo) {
+        const u64 dh = xh ^ r_hi[l - 1], dl = xl ^ r_lo[l - 1];
+        const int lp = rlens ? (int)rlens[l - 1] : r_len_all;
+        const int c = dh ? (int)(__clzll((long long)dh) >> 1) : 32 + (dl ? (int)(__clzll((long long)dl) >> 1) : 32);
+        L = min(c, min(len0, lp));
+    }
+    const int m = max(shortest, L + 1);
+    // the largest value with x0's first m bases
+    const u64 toph = m >= 32 ? xh : (xh | (~0ull >> (2 * m)));
+    const u64 topl = m >= 64 ? xl : (m > 32 ? (xl | (~0ull >> (2 * (m - 32)))) : ~0ull);
+    u64 a = l + 1, e = hi;
+    while (a < e) {
+        const u64 mid = (a + e) >> 1;
+        if (!wide_less(toph, topl, r_hi[mid], r_lo[mid])) a = mid + 1; else e = mid;
+    }
+    first[i] = (long long)l;
+    found[i] = 1;
+    const u64 nv = rval_off[a] - rval_off[l];
+    nvals[i] = nv > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)nv;
+}
+
 // ---- block encoding (FileCreator.java:312-347) of two-word k-mers ---------------------------------------------------------
 // compressedBytes = [k][cBytes: hi then lo, big-endian, l = ceil(k / 4) bytes]; s = bytes shared with the previous k-mer of
 // the bucket (FileCreator.shared, :244-252)

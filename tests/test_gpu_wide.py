@@ -353,6 +353,13 @@ def test_programs_on_files_of_two_word_kmers(tmp_path):
     assert programs.taxa_counts(ctx, p("var.db"), p("cv.py.tsv")) == ["%d\t%d\t%d" % x for x in zip(t.tolist(), m.tolist(), q.tolist())]
     programs.make_database(ctx, fq, p("reads.var.db"), "q", k, 24, l, read_map_path=p("map.var.gz"))
     o_rvar = OracleDB(synth.fastq_bytes(reads), 1, k, l, min_k=24)
+    # Matcher with its defaults on these files: the search over several lengths (the trie, in closed form) -- a smaller
+    # read set, the literal trie of the restatement is slow
+    open(p("few.fq"), "wb").write(synth.fastq_bytes(reads[:150]))
+    programs.make_database(ctx, p("few.fq"), p("few.var.db"), "q", k, 24, l, read_map_path=p("map.few.gz"))
+    want_trie = R.near_match_lines(R.read_indexed_file(p("few.var.db")), R.DB([R.read_indexed_file(p("var.want"))]), 0, False)
+    assert len(want_trie) > 500
+    assert programs.matcher(ctx, p("few.var.db"), p("var.db"), p("mt.txt"), plain=True) == want_trie
     for L in (35, 30):
         a_, b_ = o_rvar.restrict(L), o_var.restrict(L)
         hit, nh = a_.match(b_)
@@ -485,8 +492,7 @@ def test_packed_and_device_resident_input_and_the_second_word_on_the_device(ctx)
     torch.cuda.synchronize()
     assert np.array_equal(hit.cpu().numpy(), np.arange(got.n_unique))
     for call in (lambda: ctx.check(ctx.lib.kmg_match_dev_noalloc(ctx.h, got.h, again.h, hit.data_ptr())),
-                 lambda: km.match_near(got, again, 1), lambda: km.match_trie(got, again),
-                 lambda: got.restrict(k - 2, k)):
+                 lambda: km.match_near(got, again, 1), lambda: got.restrict(k - 2, k)):
         with pytest.raises(KmersGpuError) as e:
             call()
         assert e.value.code == KMG_EUNSUPPORTED
@@ -647,3 +653,43 @@ def test_dust_and_runofsame_filters_match_oracle(ctx, min_k, k, dust, run):
     assert names == wantr.names
     assert want.U <= OracleDB(fa, 0, k, 3, min_k=min_k).U
     got.close(); rdb.close()
+
+
+@pytest.mark.parametrize("min_k,k,key_len,alphabet,seed", [
+    (24, 40, 3, b"ACGT" * 12 + b"N", 61), (30, 64, 2, b"ACGT", 62), (33, 36, 2, b"AC", 63), (20, 33, 3, b"AG", 64),
+    (10, 34, 1, b"AAAC", 65), (40, 47, 6, b"ACGT", 66), (63, 64, 4, b"ACGT", 67), (24, 64, 6, b"ACGT" * 12 + b"N", 68)])
+def test_trie_search_matches_literal_trie(ctx, min_k, k, key_len, alphabet, seed):
+    """Matcher with its default -k / -K on files of several lengths beyond 32 bases: DB.getNearestKmers' non-quick branch at
+    maxDiff = 0 (DB.java:83,139-184) -- the closed form on two words (trie_find_wide_kernel) against the literal
+    restatement of Root.addKmer / closestKmers (oracle/slow_ref.py Root; shared data objects included), line by line.
+    Small alphabets force long shared prefixes; the search side also narrower than the database."""
+    import kmers_amd as km
+    from oracle import slow_ref as R
+    rng = np.random.default_rng(seed)
+    fa = _rand_fasta(rng, 30, 400, alphabet, [11, 12, 13])
+    body = b"".join(ln for ln in fa.split(b"\n") if not ln.startswith(b">"))
+    recs = []
+    for i in range(200):
+        a = int(rng.integers(0, max(len(body) - 100, 1)))
+        sq = bytearray(body[a:a + int(rng.integers(1, 101))])
+        if len(sq) and rng.random() < 0.3:                   # a changed base: suffixes / prefixes still match
+            sq[int(rng.integers(0, len(sq)))] = alphabet[int(rng.integers(0, len(alphabet)))]
+        recs.append(b"@q%d\n%s\n+\n%s\n" % (i, bytes(sq), b"I" * len(sq)))
+    fq = b"".join(recs)
+    ref = km.make_reference_db(ctx, fa, k, key_len, min_k=min_k)
+    o_ref = R.build_ref_db(fa, k, key_len, min_k=min_k)
+    total = 0
+    for s_min, s_max in {(min_k, k), (min(min_k + 1, k), k), (min_k, max(k - 1, min_k, 33)), (max(min_k, k - 2), k)}:
+        if key_len > s_min or s_max <= 32:
+            continue
+        rdb, _ = km.make_read_db(ctx, fq, s_max, key_len, min_k=s_min)
+        o_reads, _ = R.build_read_db(fq, s_max, key_len, min_k=s_min)
+        want = R.near_match_lines(o_reads, R.DB([o_ref]), 0, False)
+        rows, hit = km.match_trie(rdb, ref, s_min)
+        got = km.match_lines(rdb, rows, hit, ref_stored=True)
+        assert got == want, (s_min, s_max, len(got), len(want))
+        assert int((hit >= 0).sum()) == len(want) == rows.n_unique
+        total += len(want)
+        rows.close(); rdb.close()
+    assert total > 0
+    ref.close()
