@@ -2093,6 +2093,77 @@ extern "C" int kmg_db_restrict(kmg_ctx *ctx, const kmg_db *src, int length, kmg_
     return restrict_locked(ctx, src, length, out);
 }
 
+// The same for a database of two-word k-mers (wide.h): the entries of at least min_length bases, those beyond max_length
+// cut to it, with their lengths min(length, max_length), are ranked in (value, length) order among the distinct ones;
+// their values go through the fold under their ranks; the result holds the distinct (k-mer, length) pairs -- one word
+// each if max_length <= 32.  Caller holds ctx->mu.
+static int restrict_range_wide(kmg_ctx *ctx, const kmg_db *src, int min_length, int max_length, kmg_db **out) {
+    if (min_length > max_length || min_length < src->key_len || max_length > 64)
+        return fail(ctx, KMG_EINVAL, "key length <= min_length <= max_length <= 64");
+    KMG_HIP(hipSetDevice(ctx->device));
+    KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(src)));
+    const u64 U = src->U;
+    if (U >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 k-mers in the database");
+    kmg_db *db = new (std::nothrow) kmg_db();
+    if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
+    std::unique_ptr<kmg_db, void (*)(kmg_db *)> db_guard(db, db_release);
+    db->ctx = ctx; db->k = max_length; db->min_k = min_length; db->key_len = src->key_len; db->rc = src->rc; db->kind = src->kind;
+    PoolBuf kflag(ctx), kcnt(ctx), kpos(ctx), dst(ctx), agg(ctx), ch(ctx), cl(ctx), cn(ctx), from(ctx), rank_k(ctx), rank(ctx), d_hi(ctx), d_lo(ctx),
+        d_len(ctx), k0(ctx), v0(ctx), k1(ctx), v1(ctx), totals(ctx);
+    KMG_ALLOC(totals, 64);
+    KMG_HIP(hipMemsetAsync(totals.p, 0, 64, ctx->stream));
+    KMG_ALLOC(kflag, (U + 1) * 4); KMG_ALLOC(kcnt, (U + 1) * 4); KMG_ALLOC(kpos, (U + 2) * 8); KMG_ALLOC(dst, (U + 2) * 8);
+    KMG_ALLOC(agg, (size_t)(div_up_u64(U, SCAN_TILE) + 1) * 8);
+    KMG_ALLOC(rank, (U + 1) * 8);
+    u64 nk = 0, nvals = 0, Uw = 0;
+    int rbits = 1;
+    if (U) {
+        // kflag = the entry stays, kcnt = its values
+        hipLaunchKernelGGL(vr_flag_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, src->lens, src->k, src->val_off, U, min_length, 65,
+                           kflag.as<u32>(), kcnt.as<u32>());
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, kflag.as<u32>(), kpos.as<u64>(), U, OpSum(), 0ull, agg.as<u64>(), nullptr, true, KP_SCAN)));
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, kcnt.as<u32>(), dst.as<u64>(), U, OpSum(), 0ull, agg.as<u64>(), nullptr, true, KP_SCAN)));
+        KMG_HIP(read_back(ctx, &nk, kpos.as<u64>() + U, 8));
+        KMG_HIP(read_back(ctx, &nvals, dst.as<u64>() + U, 8));
+    }
+    if (nvals >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 values in the restricted database");
+    const u32 n = (u32)nvals;
+    if (nk) {
+        KMG_ALLOC(ch, nk * 8); KMG_ALLOC(cl, nk * 8); KMG_ALLOC(cn, nk + 64); KMG_ALLOC(from, nk * 4); KMG_ALLOC(rank_k, nk * 8);
+        hipLaunchKernelGGL(wide_compact_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, (const u64 *)src->keys, (const u64 *)src->keys_lo,
+                           kflag.as<u32>(), kpos.as<u64>(), U, max_length, ch.as<u64>(), cl.as<u64>(), from.as<u32>(), (const uint8_t *)src->lens,
+                           src->k, cn.as<uint8_t>());
+        WideOrder w(ctx);
+        // (the order's second word has 2 * (k - 32) bits: 33 stands for "none beyond the first word")
+        KMG_TRY(wide_order(ctx, ch.as<u64>(), cl.as<u64>(), (u32)nk, std::max(max_length, 33), w, cn.as<uint8_t>()));
+        Uw = w.U; rbits = w.rbits;
+        KMG_ALLOC(d_hi, (Uw + 1) * 8); KMG_ALLOC(d_lo, (Uw + 1) * 8); KMG_ALLOC(d_len, Uw + 64);
+        hipLaunchKernelGGL(wide_rank_kernel, dim3(div_up_u64(nk, 256)), dim3(256), 0, ctx->stream, w.his, (const u64 *)w.los, w.order,
+                           w.flag.as<u32>(), w.before.as<u64>(), (u32)nk, rbits, rank_k.as<u64>(), d_hi.as<u64>(), d_lo.as<u64>(),
+                           (const uint8_t *)w.lens.p, d_len.as<uint8_t>());
+        hipLaunchKernelGGL(wide_spread_kernel, dim3(div_up_u64(nk, 256)), dim3(256), 0, ctx->stream, (const u64 *)rank_k.as<u64>(),
+                           (const u32 *)from.as<u32>(), nk, rank.as<u64>());
+        KMG_HIP(hipGetLastError());
+    } else { KMG_ALLOC(d_hi, 8); KMG_ALLOC(d_lo, 8); KMG_ALLOC(d_len, 64); }
+    KMG_ALLOC(k0, ((size_t)n + 1) * 8); KMG_ALLOC(v0, ((size_t)n + 1) * 8);
+    KMG_ALLOC(k1, ((size_t)n + 1) * 8); KMG_ALLOC(v1, ((size_t)n + 1) * 8);
+    if (n)
+        hipLaunchKernelGGL(rs_expand_kernel, dim3(div_up_u64(U, 256)), dim3(256), 0, ctx->stream, (const u64 *)rank.as<u64>(), (const uint8_t *)src->lens,
+                           src->k, src->val_off, src->val_a, src->val_b, U, min_length, 65, dst.as<u64>(), 0ull, src->kind, k0.as<u64>(),
+                           v0.as<u64>(), false);
+    KMG_HIP(hipGetLastError());
+    KMG_TRY(merge_records(ctx, db, k0, v0, k1, v1, n, totals, rbits));
+    if (db->U != Uw) return fail(ctx, KMG_EDEVICE, "two-word restriction: the ranks' distinct count differs from the k-mers'");
+    ctx->pool.release(db->keys);
+    db->keys = (u64 *)d_hi.detach();
+    if (max_length > 32) db->keys_lo = (u64 *)d_lo.detach();
+    db->lens = (uint8_t *)d_len.detach();
+    KMG_TRY(db_make_buckets(ctx, db));
+    KMG_HIP(hipStreamSynchronize(ctx->stream));
+    *out = db_guard.release();
+    return KMG_OK;
+}
+
 // KmerUtils.restrictedStream(stream, minLength, maxLength, dataType) with minLength < maxLength (KmerUtils.java:59-74):
 // the k-mers of at least maxLength bases, cut and folded, are a database of one length (restrict_locked); those of
 // minLength .. maxLength - 1 bases stay as they are; the two interleave by rank as the length classes of a build do.
@@ -2102,7 +2173,7 @@ extern "C" int kmg_db_restrict_range(kmg_ctx *ctx, const kmg_db *src, int min_le
     std::lock_guard<std::mutex> g(ctx->mu);
     *out = nullptr;
     if (src->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
-    KMG_NO_WIDE(src);
+    if (src->k > 32) return restrict_range_wide(ctx, src, min_length, max_length, out);
     if (min_length > max_length || min_length < src->key_len || max_length > 32)
         return fail(ctx, KMG_EINVAL, "key length <= min_length <= max_length <= 32");
     KMG_HIP(hipSetDevice(ctx->device));
@@ -2258,7 +2329,6 @@ extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     if (ref->kind != KMG_PAYLOAD_TAXON) return fail(ctx, KMG_EINVAL, "the database searched holds taxon counts");
     // (two-word k-mers, wide.h: one file, or a set whose files share no key; the search side one word or two as the database)
     const bool wide = ref->k > 32;
-    if (wide != (search->k > 32) && search->U) return fail(ctx, KMG_EUNSUPPORTED, "one side of the search holds two-word k-mers, the other does not");
     if (wide && ref->shared_key_merge)
         return fail(ctx, KMG_EUNSUPPORTED, "files of two-word k-mers of several lengths that share a key: not on the GPU path");
     if (search->key_len != ref->key_len) return fail(ctx, KMG_EINVAL, "key lengths differ");
@@ -2311,7 +2381,7 @@ extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
         KMG_HIP(read_back(ctx, &nrec, dst.as<u64>() + ns, 8));
     } else if (ns) {
         if (wide)
-            hipLaunchKernelGGL(trie_find_wide_kernel, dim3(div_up_u64(ns, 256)), dim3(256), 0, ctx->stream, search->keys, search->keys_lo,
+            hipLaunchKernelGGL(trie_find_wide_kernel, dim3(div_up_u64(ns, 256)), dim3(256), 0, ctx->stream, search->keys, (const u64 *)search->keys_lo,
                                search->lens, search->k, ns, ref->keys, ref->keys_lo, ref->lens, ref->k, ref->bucket_off, ref->val_off,
                                ref->key_len, min_k, first.as<long long>(), found.as<u32>(), nvals.as<u32>());
         else

@@ -420,15 +420,19 @@ __global__ void wide_csr_reads_kernel(const u64 *__restrict__ his, const u64 *__
 
 // KmerUtils.restrictedStream on two-word k-mers (KmerUtils.java:59-74): the entries of at least L bases (keep[i] != 0),
 // cut to L bases (wide_cut_kernel's rule), side by side in their order, and where each came from
+// (lens / out_len, may be null: with them the cut k-mers keep min(length, L) -- KmerUtils.restrictedStream with two lengths
+// leaves the shorter ones as they are; L <= 32 then cuts into the first word)
 __global__ void wide_compact_kernel(const u64 *__restrict__ hi, const u64 *__restrict__ lo, const u32 *__restrict__ keep,
                                     const u64 *__restrict__ pos, u64 n, int L, u64 *__restrict__ out_hi, u64 *__restrict__ out_lo,
-                                    u32 *__restrict__ from) {
+                                    u32 *__restrict__ from, const uint8_t *__restrict__ lens = nullptr, int len_all = 0,
+                                    uint8_t *__restrict__ out_len = nullptr) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !keep[i]) return;
     const u64 j = pos[i];
-    out_hi[j] = hi[i];
-    out_lo[j] = L >= 64 ? lo[i] : lo[i] & ~(~0ull >> (2 * (L - 32)));
+    out_hi[j] = L >= 32 ? hi[i] : hi[i] & ~(~0ull >> (2 * L));
+    out_lo[j] = L >= 64 ? lo[i] : (L <= 32 ? 0ull : lo[i] & ~(~0ull >> (2 * (L - 32))));
     from[j] = (u32)i;
+    if (out_len) { const int len = lens ? (int)lens[i] : len_all; out_len[j] = (uint8_t)(len < L ? len : L); }
 }
 __global__ void wide_spread_kernel(const u64 *__restrict__ vals, const u32 *__restrict__ to, u64 n, u64 *__restrict__ out) {
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -520,7 +524,7 @@ __global__ void trie_find_wide_kernel(const u64 *__restrict__ s_hi, const u64 *_
                                       u32 *__restrict__ found, u32 *__restrict__ nvals) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ns) return;
-    const u64 th = s_hi[i], tl = s_lo[i];
+    const u64 th = s_hi[i], tl = s_lo ? s_lo[i] : 0ull;      // (a search side of at most 32 bases has no second word)
     const int T = slens ? (int)slens[i] : s_len_all;
     const u64 b = th >> (64 - 2 * key_len);
     const u64 lo = rbucket[b], hi = rbucket[b + 1];

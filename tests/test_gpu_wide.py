@@ -208,7 +208,7 @@ def test_files_roundtrip_and_fences(ctx, tmp_path):
     same.close()
     with pytest.raises(km.InconsistentDataException):
         db.restrict(k - 1)
-    for call in (lambda: db.restrict(k - 2, k),
+    for call in (lambda: km.match_near(db, db, 1),
                  lambda: km.FileCreator(ctx, l, 65, "ref", True)):
         with pytest.raises(KmersGpuError) as e:
             call()
@@ -492,7 +492,7 @@ def test_packed_and_device_resident_input_and_the_second_word_on_the_device(ctx)
     torch.cuda.synchronize()
     assert np.array_equal(hit.cpu().numpy(), np.arange(got.n_unique))
     for call in (lambda: ctx.check(ctx.lib.kmg_match_dev_noalloc(ctx.h, got.h, again.h, hit.data_ptr())),
-                 lambda: km.match_near(got, again, 1), lambda: got.restrict(k - 2, k)):
+                 lambda: km.match_near(got, again, 1)):
         with pytest.raises(KmersGpuError) as e:
             call()
         assert e.value.code == KMG_EUNSUPPORTED
@@ -693,3 +693,54 @@ def test_trie_search_matches_literal_trie(ctx, min_k, k, key_len, alphabet, seed
         rows.close(); rdb.close()
     assert total > 0
     ref.close()
+
+
+@pytest.mark.parametrize("min_k,k,key_len,alphabet,seed", [(24, 40, 3, b"ACGT" * 12 + b"N", 91), (30, 36, 1, b"AC", 92), (28, 64, 4, b"ACGT", 93)])
+def test_length_windows_other_than_the_files_own(ctx, min_k, k, key_len, alphabet, seed):
+    """Matcher -k a -K b with a < b on files of k-mers of up to 64 bases: the search side goes through
+    KmerUtils.restrictedStream(a, b) (KmerUtils.java:59-74; kmg_db_restrict_range: shorter dropped, longer cut and folded,
+    the rest untouched -- one word per k-mer if b <= 32), the trie is built with (a, b) over the whole database.  The
+    restricted database entry by entry against the restated stream function, then the lines against the literal trie."""
+    import kmers_amd as km
+    from oracle import slow_ref as R
+    rng = np.random.default_rng(seed)
+    fa = _rand_fasta(rng, 30, 400, alphabet, [6, 7])
+    body = b"".join(ln for ln in fa.split(b"\n") if not ln.startswith(b">"))
+    recs = []
+    for i in range(150):
+        a_ = int(rng.integers(0, max(len(body) - 100, 1)))
+        sq = bytearray(body[a_:a_ + int(rng.integers(1, 101))])
+        if len(sq) and rng.random() < 0.3:
+            sq[int(rng.integers(0, len(sq)))] = alphabet[int(rng.integers(0, len(alphabet)))]
+        recs.append(b"@q%d\n%s\n+\n%s\n" % (i, bytes(sq), b"I" * len(sq)))
+    fq = b"".join(recs)
+    ref = km.make_reference_db(ctx, fa, k, key_len, min_k=min_k)
+    rdb, _ = km.make_read_db(ctx, fq, k, key_len, min_k=min_k)
+    o_ref, (o_reads, _) = R.build_ref_db(fa, k, key_len, min_k=min_k), R.build_read_db(fq, k, key_len, min_k=min_k)
+    windows = {(min_k, k - 1), (min_k + 1, k), (min_k + 1, k - 1), (min_k, min_k + 1), (min_k, 32), (min_k + 2, 33), (31, 34)}
+    done = 0
+    for a, b in sorted(w for w in windows if key_len <= w[0] < w[1] <= k and w[0] >= min_k):
+        for db, blocks, kind in ((ref, o_ref, "ref"), (rdb, o_reads, "read")):
+            cut = db.restrict(a, b)
+            assert (cut.min_length, cut.max_length) == (a, b)
+            want = []
+            for key in range(4 ** key_len):
+                want.extend(R.restricted_stream(R.decode_block(blocks.get(key, b""), kind), min_k, k, a, b, kind))
+            got, lens = cut.fetch(), cut.lens()
+            assert cut.n_unique == len(want)
+            names = km.kmer_strings(got["keys"], 64, got["keys_lo"]) if b > 32 else km.kmer_strings(got["keys"], 32)
+            assert [n[:ln] for n, ln in zip(names, lens.tolist())] == [str(kk) for kk, _ in want]
+            for i in rng.integers(0, max(len(want), 1), size=min(len(want), 200)).tolist():
+                c0, c1 = int(got["val_off"][i]), int(got["val_off"][i + 1])
+                vals = list(zip(got["val_a"][c0:c1].tolist(), got["val_b"][c0:c1].tolist()))
+                assert vals == (sorted(want[i][1].items()) if kind == "ref" else sorted(want[i][1])), (a, b, kind, i)
+            if kind == "read":
+                lines = R.near_match_lines(o_reads, R.DB([o_ref]), 0, False, a, b)
+                rows, hit = km.match_trie(cut, ref, a)
+                assert km.match_lines(cut, rows, hit, ref_stored=True) == lines
+                done += len(lines)
+                rows.close()
+            cut.close()
+    assert done > 20
+    ref.close()
+    rdb.close()
