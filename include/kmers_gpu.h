@@ -16,7 +16,7 @@
  * Supported: 1 <= minK <= maxK = k <= 32, 1 <= key_len <= min(minK, 12); the exact join takes k-mers of one
  * length (restrict variable-length databases first, kmg_db_restrict).  k-mers of up to 64 bases ("two-word
  * k-mers", see below; 32 < maxK <= 64, any minK): build, fetch, load, encode, restrict, the exact join, the search over several
- * lengths, TaxaCounts and the per-read tools, the merge of file sets.  Anything else returns KMG_EUNSUPPORTED so a shim can fall back to the Java path.
+ * lengths, the inexact search, TaxaCounts and the per-read tools, the merge of file sets.  Anything else returns KMG_EUNSUPPORTED so a shim can fall back to the Java path.
  *
  * K-mer representation everywhere: uint64, 2 bits per base, code order A=0 C=1 T=2 G=3
  * (Kmers/Base.java:7-10), first base in the top bits, low 64-2k bits zero -- i.e. the bytes of
@@ -290,7 +290,8 @@ int kmg_match_dev_noalloc(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref,
  *   processNearestCommonKey, DB.java:139-184, over Root.addKmers / closestKmers, Root.java:22-170, and
  *   KmerUtils.getCloseKeys, KmerUtils.java:18-47; Matcher -n 1 | 2): for every search k-mer ALL reference k-mers
  *   within Hamming distance max_diff (any; up to 2 the neighbours are enumerated, beyond that the trie walk of
- *   Root.closestKmers, Root.java:115-170, runs over the sorted array: cost grows as in the reference), as pairs (ref_index, dist) in ascending
+ *   Root.closestKmers, Root.java:115-170, runs over the sorted array: cost grows as in the reference; two-word k-mers take the walk for every
+ *   max_diff), as pairs (ref_index, dist) in ascending
  *   reference order -- the order the reference's trie hands them to ClosestInfoCollector.add -- with
  *   pair_off[i] .. pair_off[i + 1] the pairs of search k-mer i.  `-j` (only the best distance), the reverse-complement
  *   rule of ClosestInfoCollector.add (:30-50) and the KmerDiff text (KmerDiff.java:54-67) are cheap per-k-mer steps

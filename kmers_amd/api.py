@@ -524,13 +524,13 @@ def match_lines(search, ref, hit, stored=False, ref_stored=None):
     return lines
 
 
-def _revcomp_key(key, k):
-    """Kmer.getRC on a left-aligned 2-bit k-mer: bases reversed, each complemented (code ^ 2)."""
-    v, out = int(key) >> (64 - 2 * k), 0
+def _revcomp_key(key, k, width=64):
+    """Kmer.getRC on a left-aligned 2-bit k-mer (in `width` bits): bases reversed, each complemented (code ^ 2)."""
+    v, out = int(key) >> (width - 2 * k), 0
     for _ in range(k):
         out = (out << 2) | ((v & 3) ^ 2)
         v >>= 2
-    return out << (64 - 2 * k)
+    return out << (width - 2 * k)
 
 
 def near_match_lines(search, ref, max_diff, just=False, stored=False):
@@ -566,7 +566,8 @@ def near_match_lines_var(search, ref, max_diff, just=False, min_length=None, sto
         voff[1:] = np.cumsum(cnt)
         take = np.concatenate([np.arange(int(a), int(b)) for a, b in zip(s["val_off"][sel], s["val_off"][sel + 1])]) if len(sel) else np.zeros(0, np.int64)
         sub = KmerDatabase.load(ctx, T, search.key_length, search.rc, search.kind, s["keys"][sel], voff,
-                                np.ascontiguousarray(s["val_a"][take]), np.ascontiguousarray(s["val_b"][take]))
+                                np.ascontiguousarray(s["val_a"][take]), np.ascontiguousarray(s["val_b"][take]),
+                                keys_lo=s["keys_lo"][sel] if T > 32 else None)
         prefixes = one.restrict(T) if (one.min_length != one.k or one.k != T) else one
         rows, row_of = match_trie(prefixes, one, shortest, stored=stored)
         idx, lines = _near_match_rows(sub, prefixes, max_diff, just, stored, data_rows=rows, row_of=row_of)
@@ -595,8 +596,11 @@ def _near_match_rows(search, ref, max_diff, just=False, stored=False, data_rows=
     s, r = search.fetch(), ref.fetch()
     vals, rcap = (r, cap) if data_rows is None else (data_rows.fetch(), 1 << 31)
     k = search.k
+    wide = k > 32                                 # two words a k-mer: one 128-bit integer here
+    width = 128 if wide else 64
+    whole = (lambda f, j: (int(f["keys"][j]) << 64) | int(f["keys_lo"][j])) if wide else (lambda f, j: int(f["keys"][j]))
     rows = np.nonzero(off[1:] > off[:-1])[0]
-    names = kmer_strings(s["keys"][rows], k)
+    names = kmer_strings(s["keys"][rows], k, s["keys_lo"][rows] if wide else None)
     letters = "ACTG"
     lines = []
     for name, i in zip(names, rows.tolist()):
@@ -607,19 +611,19 @@ def _near_match_rows(search, ref, max_diff, just=False, stored=False, data_rows=
             cand = [c for c in cand if c[1] == best]
         kept = {}                                           # reference k-mer (key) -> (hit, dist), in meeting order
         for h, d in cand:
-            key = int(r["keys"][h])
-            rc = _revcomp_key(key, k)
+            key = whole(r, h)
+            rc = _revcomp_key(key, k, width)
             if rc in kept:
                 if d < kept[rc][1]:
                     del kept[rc]
                     kept[key] = (h, d)
             else:
                 kept[key] = (h, d)
-        skey = int(s["keys"][i])
+        skey = whole(s, i)
         entries = []
         for key, (h, d) in kept.items():
-            x = (skey ^ key) >> (64 - 2 * k)
-            diffs = [(p, (key >> (62 - 2 * p)) & 3) for p in range(k) if (x >> (2 * (k - 1 - p))) & 3]
+            x = (skey ^ key) >> (width - 2 * k)
+            diffs = [(p, (key >> (width - 2 - 2 * p)) & 3) for p in range(k) if (x >> (2 * (k - 1 - p))) & 3]
             entries.append(((len(diffs), diffs), h))
         entries.sort(key=lambda e: e[0])
         a0, a1 = int(s["val_off"][i]), int(s["val_off"][i + 1])

@@ -2609,11 +2609,11 @@ extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     std::lock_guard<std::mutex> g(ctx->mu);
     KMG_HIP(hipSetDevice(ctx->device));
     *n_pairs = 0;
-    KMG_NO_WIDE(search);
-    KMG_NO_WIDE(ref);
     if (max_diff < 0) return fail(ctx, KMG_EINVAL, "max_diff must not be negative");
-    // up to two differences: the neighbours are enumerated (near_kernel); more: the trie walk over the sorted array
-    const bool walk = max_diff > 2;
+    // up to two differences: the neighbours are enumerated (near_kernel); more, and every two-word search: the trie walk
+    // over the sorted array
+    const bool wide = search->keys_lo != nullptr;      // (k-mers of the same length below: the other side is as wide)
+    const bool walk = max_diff > 2 || wide;
     if (search->ctx->device != ctx->device || ref->ctx->device != ctx->device)
         return fail(ctx, KMG_EINVAL, "database belongs to another device");
     if (search->k != ref->k || search->key_len != ref->key_len)      // DB.java:78-81
@@ -2655,7 +2655,12 @@ extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
                 log = {sdb->near_log_s, sdb->near_log_ref, sdb->near_log_dist, cap, reinterpret_cast<unsigned long long *>(tot.as<u64>() + 1)};
             } else { ctx->pool.release(a); ctx->pool.release(b); ctx->pool.release(c); }
         }
-        if (walk)
+        if (wide)
+            hipLaunchKernelGGL((wide_near_walk_kernel<false>), dim3(div_up_u64(U, 128)), dim3(128), 0, ctx->stream, search->keys,
+                               search->keys_lo, U, search->k, std::min(max_diff, search->k), ref->keys, ref->keys_lo, ref->U,
+                               ref->bucket_off, ref->key_len, cnt.as<u32>(), (const u64 *)nullptr, (long long *)nullptr,
+                               (uint8_t *)nullptr);
+        else if (walk)
             hipLaunchKernelGGL((near_walk_kernel<false>), dim3(div_up_u64(U, 128)), dim3(128), 0, ctx->stream, search->keys, U, search->k,
                                std::min(max_diff, search->k), ref->keys, ref->U, ref->bucket_off, ref->key_len, cnt.as<u32>(),
                                (const u64 *)nullptr, (long long *)nullptr, (uint8_t *)nullptr);
@@ -2678,7 +2683,11 @@ extern "C" int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
         KMG_ALLOC(d_ref, n * 8);
         KMG_ALLOC(d_dist, n);
         KMG_HIP(hipMemsetAsync(cnt.p, 0, U * 4, ctx->stream));
-        if (walk) {
+        if (wide) {
+            hipLaunchKernelGGL((wide_near_walk_kernel<true>), dim3(div_up_u64(U, 128)), dim3(128), 0, ctx->stream, search->keys,
+                               search->keys_lo, U, search->k, std::min(max_diff, search->k), ref->keys, ref->keys_lo, ref->U,
+                               ref->bucket_off, ref->key_len, cnt.as<u32>(), off_p, d_ref.as<long long>(), d_dist.as<uint8_t>());
+        } else if (walk) {
             hipLaunchKernelGGL((near_walk_kernel<true>), dim3(div_up_u64(U, 128)), dim3(128), 0, ctx->stream, search->keys, U, search->k,
                                std::min(max_diff, search->k), ref->keys, ref->U, ref->bucket_off, ref->key_len, cnt.as<u32>(), off_p,
                                d_ref.as<long long>(), d_dist.as<uint8_t>());

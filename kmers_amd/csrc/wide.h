@@ -633,3 +633,95 @@ __global__ void wide_ascending_kernel(const u64 *__restrict__ hi, const u64 *__r
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (i < n && (hi[i - 1] > hi[i] || (hi[i - 1] == hi[i] && lo[i - 1] >= lo[i]))) atomicAdd(bad, 1u);
 }
+
+// ---- inexact search (Matcher -n) on two words: the trie walk of Root.closestKmers (Root.java:115-170) over the sorted
+// (hi, lo) pairs, as near_walk_kernel (match.h) does on one word -- a node = (range of stored k-mers sharing a prefix,
+// depth, differences so far), children by the next base in base order, so the matches come out ascending.  Every number
+// of differences takes this walk (the enumeration of neighbours that serves one or two differences on one word is not
+// built for two).
+#define WNW_MAXK 64
+__device__ __forceinline__ void wide_prefix_mask(int d, u64 &mh, u64 &ml) {             // the first d bases, 0 <= d <= 64
+    mh = d >= 32 ? ~0ull : (d == 0 ? 0ull : ~(~0ull >> (2 * d)));
+    ml = d <= 32 ? 0ull : (d >= 64 ? ~0ull : ~(~0ull >> (2 * (d - 32))));
+}
+__device__ __forceinline__ u64 wide_lower(const u64 *__restrict__ rh, const u64 *__restrict__ rl, u64 lo, u64 hi, u64 wh, u64 wl) {
+    while (lo < hi) {                                  // first pair in [lo, hi) that is not below (wh, wl)
+        const u64 mid = lo + ((hi - lo) >> 1);
+        if (wide_less(rh[mid], rl[mid], wh, wl)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+template <bool FILL>
+__global__ __launch_bounds__(128) void wide_near_walk_kernel(const u64 *__restrict__ s_hi, const u64 *__restrict__ s_lo, u64 ns, int k,
+                                                             int max_diff, const u64 *__restrict__ r_hi, const u64 *__restrict__ r_lo,
+                                                             u64 nr, const u64 *__restrict__ rbucket, int key_len,
+                                                             u32 *__restrict__ cnt, const u64 *__restrict__ off,
+                                                             long long *__restrict__ out_ref, uint8_t *__restrict__ out_dist) {
+    const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns || nr == 0) return;
+    const u64 kh = s_hi[s], kl = s_lo[s];
+    u64 found = 0;
+    const u64 base_out = FILL ? off[s] : 0;
+    auto emit = [&](u64 r, int d) {
+        if (FILL) { out_ref[base_out + found] = (long long)r; out_dist[base_out + found] = (uint8_t)d; }
+        found++;
+    };
+    auto differing = [&](u64 r) {
+        const u64 x = r_hi[r] ^ kh, y = r_lo[r] ^ kl;
+        return __popcll((x | (x >> 1)) & 0x5555555555555555ull) + __popcll((y | (y >> 1)) & 0x5555555555555555ull);
+    };
+    u64 f_lo[WNW_MAXK + 1], f_hi[WNW_MAXK + 1], f_cur[WNW_MAXK + 1];
+    uint8_t f_next[WNW_MAXK + 1], f_diff[WNW_MAXK + 1];
+    int d = 0;
+    f_lo[0] = 0; f_hi[0] = nr; f_cur[0] = 0; f_next[0] = 0; f_diff[0] = 0;
+    while (d >= 0) {
+        const u64 lo = f_lo[d], hi = f_hi[d];
+        const int used = f_diff[d];
+        if (f_next[d] == 0) {
+            if (hi - lo == 1) {
+                const int dist = differing(lo);
+                if (dist <= max_diff) emit(lo, dist);
+                d--;
+                continue;
+            }
+            if (used == max_diff) {                    // the rest must be the search k-mer's own
+                u64 mh, ml;
+                wide_prefix_mask(d, mh, ml);
+                const u64 wh = (r_hi[lo] & mh) | (kh & ~mh), wl = (r_lo[lo] & ml) | (kl & ~ml);
+                const u64 at = wide_lower(r_hi, r_lo, lo, hi, wh, wl);
+                if (at < hi && r_hi[at] == wh && r_lo[at] == wl) emit(at, used);
+                d--;
+                continue;
+            }
+            f_cur[d] = lo;
+        }
+        if (f_next[d] == 4) { d--; continue; }
+        const int c = f_next[d]++;
+        const u64 c_lo = f_cur[d];
+        u64 c_hi;
+        if (c == 3) c_hi = hi;
+        else if (d < key_len) {                        // (the key lies in the first word)
+            const u64 pre = (r_hi[lo] >> (64 - 2 * (d + 1)) & ~3ull) | (u64)c;
+            c_hi = rbucket[(pre + 1) << (2 * (key_len - d - 1))];
+            c_hi = c_hi < c_lo ? c_lo : (c_hi > hi ? hi : c_hi);
+        } else {
+            u64 mh, ml, nh, nl;
+            wide_prefix_mask(d, mh, ml);
+            wide_prefix_mask(d + 1, nh, nl);
+            u64 ph = r_hi[lo] & mh, pl = r_lo[lo] & ml;
+            if (d < 32) ph |= (u64)c << (62 - 2 * d); else pl |= (u64)c << (62 - 2 * (d - 32));
+            const u64 lh = ph | ~nh, ll = pl | ~nl;    // the largest pair with that prefix
+            c_hi = wide_lower(r_hi, r_lo, c_lo, hi, lh, ll);
+            if (c_hi < hi && r_hi[c_hi] == lh && r_lo[c_hi] == ll) c_hi++;
+        }
+        f_cur[d] = c_hi;
+        if (c_hi == c_lo) continue;
+        const int sb = d < 32 ? (int)((kh >> (62 - 2 * d)) & 3) : (int)((kl >> (62 - 2 * (d - 32))) & 3);
+        const int cost = sb != c;
+        if (used + cost > max_diff) continue;
+        if (d + 1 == k) { emit(c_lo, used + cost); continue; }
+        d++;
+        f_lo[d] = c_lo; f_hi[d] = c_hi; f_next[d] = 0; f_diff[d] = (uint8_t)(used + cost);
+    }
+    if (!FILL) cnt[s] = (u32)(found > 0xFFFFFFFFull ? 0xFFFFFFFFull : found);
+}

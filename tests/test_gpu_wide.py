@@ -208,11 +208,9 @@ def test_files_roundtrip_and_fences(ctx, tmp_path):
     same.close()
     with pytest.raises(km.InconsistentDataException):
         db.restrict(k - 1)
-    for call in (lambda: km.match_near(db, db, 1),
-                 lambda: km.FileCreator(ctx, l, 65, "ref", True)):
-        with pytest.raises(KmersGpuError) as e:
-            call()
-        assert e.value.code == KMG_EUNSUPPORTED
+    with pytest.raises(KmersGpuError) as e:
+        km.FileCreator(ctx, l, 65, "ref", True)
+    assert e.value.code == KMG_EUNSUPPORTED
     # (a build that was begun and refused leaves the context usable)
     db2 = km.make_reference_db(ctx, fa, k, l)
     assert db2.n_unique == db.n_unique
@@ -346,6 +344,12 @@ def test_programs_on_files_of_two_word_kmers(tmp_path):
     assert nh > 1000
     assert programs.matcher(ctx, p("reads.db"), p("ref.py.db"), p("m.py.txt"), plain=True) == want
     assert open(p("m.py.txt")).read().splitlines() == want
+    # Matcher -n 1 -j on the same files (a smaller read set: the literal trie of the restatement is slow)
+    open(p("some.fq"), "wb").write(synth.fastq_bytes(reads[:60]))
+    programs.make_database(ctx, p("some.fq"), p("some.db"), "q", k, k, l, read_map_path=p("map.some.gz"))
+    want_near = R.near_match_lines(R.read_indexed_file(p("some.db")), R.DB([R.read_indexed_file(p("ref.want"))]), 1, True)
+    assert len(want_near) > 500
+    assert programs.matcher(ctx, p("some.db"), p("ref.db"), p("mn.txt"), plain=True, max_diff=1, just=True) == want_near
     t, m, q = o_ref.taxacounts()
     assert programs.taxa_counts(ctx, p("ref.db"), p("c.py.tsv")) == ["%d\t%d\t%d" % x for x in zip(t.tolist(), m.tolist(), q.tolist())]
     # the database of several lengths: TaxaCounts over all of it, Matcher -k 35 -K 35 through the restriction of both sides
@@ -491,11 +495,9 @@ def test_packed_and_device_resident_input_and_the_second_word_on_the_device(ctx)
     ctx.check(ctx.lib.kmg_match_dev(ctx.h, got.h, again.h, hit.data_ptr()))
     torch.cuda.synchronize()
     assert np.array_equal(hit.cpu().numpy(), np.arange(got.n_unique))
-    for call in (lambda: ctx.check(ctx.lib.kmg_match_dev_noalloc(ctx.h, got.h, again.h, hit.data_ptr())),
-                 lambda: km.match_near(got, again, 1)):
-        with pytest.raises(KmersGpuError) as e:
-            call()
-        assert e.value.code == KMG_EUNSUPPORTED
+    with pytest.raises(KmersGpuError) as e:
+        ctx.check(ctx.lib.kmg_match_dev_noalloc(ctx.h, got.h, again.h, hit.data_ptr()))
+    assert e.value.code == KMG_EUNSUPPORTED
     got.close(); again.close()
 
 
@@ -690,7 +692,15 @@ def test_trie_search_matches_literal_trie(ctx, min_k, k, key_len, alphabet, seed
         assert got == want, (s_min, s_max, len(got), len(want))
         assert int((hit >= 0).sum()) == len(want) == rows.n_unique
         total += len(want)
-        rows.close(); rdb.close()
+        rows.close()
+        # ... and with differences allowed (-n 1 | 2 [-j]): every T-base prefix of a stored k-mer within reach, one or
+        # two words wide as T goes, each with what the trie holds at depth T on its path
+        if seed in (61, 63, 66):
+            for max_diff, just in ((1, False), (2, True)):
+                near = R.near_match_lines(o_reads, R.DB([o_ref]), max_diff, just)
+                assert km.near_match_lines_var(rdb, ref, max_diff, just, min_length=s_min) == near, (s_min, s_max, max_diff, just)
+                assert len(near) >= len(want)
+        rdb.close()
     assert total > 0
     ref.close()
 
@@ -744,3 +754,75 @@ def test_length_windows_other_than_the_files_own(ctx, min_k, k, key_len, alphabe
     assert done > 20
     ref.close()
     rdb.close()
+
+
+def _hamming_two_words(s, r):
+    """differing bases of every (search, reference) pair of two-word k-mers"""
+    ham = np.zeros((len(s["keys"]), len(r["keys"])), np.int32)
+    for f in ("keys", "keys_lo"):
+        x = s[f][:, None] ^ r[f][None, :]
+        nz = (x | (x >> np.uint64(1))) & np.uint64(0x5555555555555555)
+        for sh in range(0, 64, 2):
+            ham += ((nz >> np.uint64(sh)) & np.uint64(1)).astype(np.int32)
+    return ham
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_inexact_search_pairs_against_all_pairs_distances(ctx, seed):
+    """kmg_match_near on two-word k-mers (wide_near_walk_kernel): every (search k-mer, reference k-mer) pair within
+    max_diff differences, ascending per search k-mer, with its distance -- against Hamming distances computed for ALL
+    pairs (numpy, on both words): random k in 33 .. 64 and key length, related genomes, low-complexity stretches, reads
+    with errors."""
+    import kmers_amd as km
+    from kmers_amd import synth
+    rng = np.random.default_rng(7100 + seed)
+    k = (33, 64, 40)[seed] if seed < 3 else int(rng.integers(33, 65))
+    l = int(rng.integers(1, 7))
+    taxa, genomes = synth.random_genomes(500 + seed, 3, int(rng.integers(300, 2500)), shared_frac=0.5)
+    if seed % 3 == 0:
+        genomes[0][:200] = ord("A")
+        genomes[1][100:300] = np.frombuffer(b"AC" * 100, np.uint8)
+    reads = synth.random_reads(600 + seed, genomes, int(rng.integers(20, 120)), k + 25, 0.03)
+    ref = km.make_reference_db(ctx, synth.fasta_bytes(taxa, genomes), k, l)
+    rdb, _ = km.make_read_db(ctx, synth.fastq_bytes(reads), k, l)
+    ham = _hamming_two_words(rdb.fetch(), ref.fetch())
+    for max_diff in (0, 1, 2, 3, 4, 7, k):
+        off, idx, dist = km.match_near(rdb, ref, max_diff)
+        rows, cols = np.nonzero(ham <= max_diff)
+        assert np.array_equal(np.diff(off.astype(np.int64)), np.bincount(rows, minlength=ham.shape[0])), max_diff
+        assert np.array_equal(idx, cols) and np.array_equal(dist, ham[rows, cols]), max_diff
+    ref.close()
+    rdb.close()
+
+
+@pytest.mark.parametrize("k,l,seed", [(33, 2, 5), (40, 3, 6), (64, 6, 8)])
+def test_inexact_search_matches_trie_restatement(ctx, k, l, seed):
+    """Matcher -n 1 | 2 | 3 [-j] for two-word k-mers of one length: kmg_match_near + the per-k-mer steps of
+    api.near_match_lines against the reference's radix trie restated in oracle/slow_ref.py (Root, ClosestInfoCollector,
+    processNearestCommonKey; a k-mer there is a list of bases of any length).  Taxa a few bases apart, reads with errors,
+    one database file and a set of two."""
+    import kmers_amd as km
+    from oracle import slow_ref as R
+    from test_oracle_kat import _near_inputs
+    fa1, fa2, _ = _near_inputs(seed, 12)
+    g = fa1.split(b"\n")[1]
+    fq = b"".join(b"@q%d\n%s\n+\n%s\n" % (i, g[o:o + k + 28], b"I" * len(g[o:o + k + 28])) for i, o in enumerate(range(0, 200, 7)))
+    fq = fq.replace(b"ACG", b"ACT", 3)
+    o_reads, _ = R.build_read_db(fq, k, l)
+    o_files = [R.build_ref_db(fa1, k, l), R.build_ref_db(fa2, k, l)]
+    reads, _ = km.make_read_db(ctx, fq, k, l)
+    refs = [km.make_reference_db(ctx, fa1, k, l), km.make_reference_db(ctx, fa2, k, l)]
+    for nfiles in (1, 2):
+        db = km.DB(refs[:nfiles])
+        for max_diff in (1, 2, 3):
+            for just in (False, True):
+                want = R.near_match_lines(o_reads, R.DB(o_files[:nfiles]), max_diff, just)
+                assert km.near_match_lines(reads, db, max_diff, just) == want, (nfiles, max_diff, just)
+                assert len(want) > 5
+        off, idx, dist = km.match_near(reads, db, 0)                  # no difference allowed = the exact join
+        hit, nh = db.get_nearest_kmers(reads)
+        assert len(idx) == nh and np.array_equal(idx, hit[hit >= 0]) and not dist.any()
+        if nfiles == 2:
+            db.merged.close()
+    for d in refs + [reads]:
+        d.close()
