@@ -16,7 +16,7 @@
  * Supported: 1 <= minK <= maxK = k <= 32, 1 <= key_len <= min(minK, 12); the exact join takes k-mers of one
  * length (restrict variable-length databases first, kmg_db_restrict).  k-mers of up to 64 bases ("two-word
  * k-mers", see below; 32 < maxK <= 64, any minK): build, fetch, load, encode, restrict, the exact join, the search over several
- * lengths, the inexact search, TaxaCounts and the per-read tools, the merge of file sets.  Anything else returns KMG_EUNSUPPORTED so a shim can fall back to the Java path.
+ * lengths, the inexact search, TaxaCounts and the per-read tools, the merge of file sets, the RCCL steps.  Anything else returns KMG_EUNSUPPORTED so a shim can fall back to the Java path.
  *
  * K-mer representation everywhere: uint64, 2 bits per base, code order A=0 C=1 T=2 G=3
  * (Kmers/Base.java:7-10), first base in the top bits, low 64-2k bits zero -- i.e. the bytes of
@@ -317,7 +317,8 @@ int kmg_match_near(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int ma
  *                      kmg_stream() after two small host round trips (cut points, counts).
  * kmg_db_exchange_by_key_range: for inputs that are sharded too -- every rank holds the database of ITS part of the
  *                      input; each range's slice travels to its owner (four all-to-all-v: k-mers, values per k-mer, two
- *                      value arrays) and the owner merges what arrived as kmg_db_merge does.  *out = this rank's shard. */
+ *                      value arrays) and the owner merges what arrived as kmg_db_merge does.  *out = this rank's shard.
+ *                      Two-word k-mers: both calls move the second words beside the first (one more all-to-all-v). */
 typedef struct kmg_comm kmg_comm;
 #define KMG_COMM_ID_BYTES 128
 int  kmg_comm_unique_id(uint8_t *id /* KMG_COMM_ID_BYTES */);

@@ -228,8 +228,6 @@ static int match_sharded_checks(kmg_ctx *ctx, const kmg_db *search, const kmg_db
                                 const int64_t *d_hit_index, std::vector<u64> &cut) {
     if (search->ctx->device != ctx->device || ref_shard->ctx->device != ctx->device)
         return fail(ctx, KMG_EINVAL, "database belongs to another device");
-    KMG_NO_WIDE(search);
-    KMG_NO_WIDE(ref_shard);
     if (search->k != ref_shard->k || search->key_len != ref_shard->key_len)                          // DB.java:78-81
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
     if (search->min_k != search->k || ref_shard->min_k != ref_shard->k)
@@ -255,14 +253,20 @@ extern "C" int kmg_match_sharded(kmg_comm *c, const kmg_db *search, const kmg_db
     const u64 nrecv = roff[n];
     // (from here on a local failure -- out of device memory -- leaves the peers waiting in the grouped exchange: the
     // receive buffers can only be sized once the counts are known)
-    PoolBuf rkeys(ctx), rhits(ctx);
+    PoolBuf rkeys(ctx), rlo(ctx), rhits(ctx);
+    const bool wide = search->keys_lo != nullptr;          // two-word k-mers (wide.h): the second words travel as well
     KMG_ALLOC(rkeys, (nrecv + 1) * 8);
     KMG_ALLOC(rhits, (nrecv + 1) * 8);
+    if (wide) KMG_ALLOC(rlo, (nrecv + 1) * 8);
     // k-mers outside every range have no owner: no match
     if (search->U) KMG_HIP(hipMemsetAsync(d_hit_index, 0xFF, search->U * 8, ctx->stream));
     KMG_TRY(comm_alltoallv(c, search->keys, cut, rkeys.p, roff, 8, KMG_NCCL_UINT64));
+    if (wide) KMG_TRY(comm_alltoallv(c, search->keys_lo, cut, rlo.p, roff, 8, KMG_NCCL_UINT64));
     // what this owner received: one ascending run per source GPU, all inside its range -> one launch
-    if (nrecv) {
+    if (nrecv && wide)
+        KMG_TRY(match_keys_wide_locked(ctx, rkeys.as<u64>(), rlo.as<u64>(), (const uint64_t *)roff.data(), n, search->k, ref_shard,
+                                       rhits.as<int64_t>()));
+    else if (nrecv) {
         if (n <= MT_MAX_RUNS) KMG_TRY(match_keys_locked(ctx, rkeys.as<uint64_t>(), (const uint64_t *)roff.data(), n, search->k, ref_shard, rhits.as<int64_t>()));
         else
             for (int s = 0; s < n; s += MT_MAX_RUNS) {
@@ -295,7 +299,6 @@ extern "C" int kmg_db_exchange_by_key_range(kmg_comm *c, const kmg_db *local, co
         // the checks and preparation that need no other rank; their verdict travels with the counts (comm_counts)
         const int st = [&]() -> int {
             if (local->ctx != ctx) return fail(ctx, KMG_EINVAL, "database belongs to another context");
-            KMG_NO_WIDE(local);
             if (local->min_k != local->k) return fail(ctx, KMG_EUNSUPPORTED, "databases of k-mers of several lengths are not exchanged");
             KMG_TRY(ensure_vals(ctx, const_cast<kmg_db *>(local)));
             KMG_TRY(comm_cuts(ctx, local, bounds, n, cut));
@@ -311,9 +314,11 @@ extern "C" int kmg_db_exchange_by_key_range(kmg_comm *c, const kmg_db *local, co
             voff[s + 1] = voff[s] + all[((size_t)s * n + c->rank) * 2 + 1];
         }
         const u64 nk = koff[n], nv = voff[n], sk = cut[n] - cut[0];
-        PoolBuf scnt(ctx), rkeys(ctx), rcnt(ctx), ra(ctx), rb(ctx), off(ctx), agg(ctx);
+        PoolBuf scnt(ctx), rkeys(ctx), rlo(ctx), rcnt(ctx), ra(ctx), rb(ctx), off(ctx), agg(ctx);
+        const bool wide = local->keys_lo != nullptr;       // two-word k-mers (wide.h): a fifth all-to-all-v, the second words
         KMG_ALLOC(scnt, (sk + 1) * 4);
         KMG_ALLOC(rkeys, (nk + 1) * 8);
+        if (wide) KMG_ALLOC(rlo, (nk + 1) * 8);
         KMG_ALLOC(rcnt, (nk + 1) * 4);
         KMG_ALLOC(ra, (nv + 1) * 4);
         KMG_ALLOC(rb, (nv + 1) * 4);
@@ -324,6 +329,7 @@ extern "C" int kmg_db_exchange_by_key_range(kmg_comm *c, const kmg_db *local, co
         std::vector<u64> crel(n + 1), vrel(n + 1);
         for (int r = 0; r <= n; r++) { crel[r] = cut[r] - cut[0]; vrel[r] = vcut[r] - vcut[0]; }
         KMG_TRY(comm_alltoallv(c, local->keys + cut[0], crel, rkeys.p, koff, 8, KMG_NCCL_UINT64));
+        if (wide) KMG_TRY(comm_alltoallv(c, local->keys_lo + cut[0], crel, rlo.p, koff, 8, KMG_NCCL_UINT64));
         KMG_TRY(comm_alltoallv(c, scnt.p, crel, rcnt.p, koff, 4, KMG_NCCL_UINT32));
         KMG_TRY(comm_alltoallv(c, local->val_a + vcut[0], vrel, ra.p, voff, 4, KMG_NCCL_INT32));
         KMG_TRY(comm_alltoallv(c, local->val_b + vcut[0], vrel, rb.p, voff, 4, KMG_NCCL_INT32));
@@ -336,7 +342,8 @@ extern "C" int kmg_db_exchange_by_key_range(kmg_comm *c, const kmg_db *local, co
             kmg_db *part = nullptr;
             if (r == KMG_OK)
                 r = db_load_common(ctx, local->k, local->key_len, local->rc, local->kind, rkeys.as<u64>() + koff[s], pk, off.as<u64>(),
-                                   ra.as<int32_t>() + voff[s], rb.as<int32_t>() + voff[s], pv, hipMemcpyDeviceToDevice, &part);
+                                   ra.as<int32_t>() + voff[s], rb.as<int32_t>() + voff[s], pv, hipMemcpyDeviceToDevice, &part,
+                                   wide ? rlo.as<u64>() + koff[s] : nullptr);
             if (r != KMG_OK) { drop_parts(); return r; }
             parts.push_back(part);
         }
@@ -345,7 +352,7 @@ extern "C" int kmg_db_exchange_by_key_range(kmg_comm *c, const kmg_db *local, co
             const u64 zero = 0;
             kmg_db *part = nullptr;
             const int r = db_load_common(ctx, local->k, local->key_len, local->rc, local->kind, nullptr, 0, &zero, nullptr, nullptr, 0,
-                                         hipMemcpyHostToDevice, &part);
+                                         hipMemcpyHostToDevice, &part, wide ? &zero : nullptr);
             if (r != KMG_OK) return r;
             *out = part;
             return KMG_OK;

@@ -37,8 +37,8 @@ struct PoolBuf {
     void free() { ctx->pool.release(p); p = nullptr; }
 };
 
-// entry points that take one-word k-mers only (two-word ones, wide.h: build, fetch, encode, load, merge, exact join,
-// TaxaCounts, the per-read tools)
+// entry points that take one-word k-mers only: the join from bare device keys, the no-allocation join (two-word k-mers,
+// wide.h, have everything else)
 #define KMG_NO_WIDE(db) \
     do { if ((db)->k > 32) return fail(ctx, KMG_EUNSUPPORTED, "not built for k-mers of more than 32 bases"); } while (0)
 
@@ -1489,7 +1489,7 @@ __global__ void keys_ascending_kernel(const u64 *__restrict__ keys, u64 n, u32 *
 // validated the arguments it can see
 static int db_load_common(kmg_ctx *ctx, int k, int key_len, int rc, int payload_kind, const u64 *keys, u64 n_unique,
                           const u64 *val_off, const int32_t *val_a, const int32_t *val_b, u64 V, hipMemcpyKind how,
-                          kmg_db **out) {
+                          kmg_db **out, const u64 *keys_lo = nullptr /* two-word k-mers: the second words, where keys are */) {
     KMG_HIP(hipSetDevice(ctx->device));
     kmg_db *db = new (std::nothrow) kmg_db();
     if (!db) return fail(ctx, KMG_ENOMEM, "host allocation failed");
@@ -1503,11 +1503,13 @@ static int db_load_common(kmg_ctx *ctx, int k, int key_len, int rc, int payload_
     if (r == KMG_OK && ctx->pool.alloc(&p, (V + 1) * 4) == KMG_OK) db->val_a = (int32_t *)p; else r = KMG_ENOMEM;
     if (r == KMG_OK && ctx->pool.alloc(&p, (V + 1) * 4) == KMG_OK) db->val_b = (int32_t *)p; else r = KMG_ENOMEM;
     if (r == KMG_OK && ctx->pool.alloc(&p, ((size_t)nbuckets + 1) * 8) == KMG_OK) db->bucket_off = (u64 *)p; else r = KMG_ENOMEM;
+    if (keys_lo) { if (r == KMG_OK && ctx->pool.alloc(&p, (n_unique + 1) * 8) == KMG_OK) db->keys_lo = (u64 *)p; else r = KMG_ENOMEM; }
     PoolBuf totals(ctx);
     if (r == KMG_OK && totals.alloc(64) != KMG_OK) r = KMG_ENOMEM;
     if (r != KMG_OK) { db_release(db); return fail(ctx, KMG_ENOMEM, "device allocation failed"); }
     hipError_t e = hipSuccess;
     if (n_unique) e = hipMemcpyAsync(db->keys, keys, n_unique * 8, how, ctx->stream);
+    if (e == hipSuccess && n_unique && keys_lo) e = hipMemcpyAsync(db->keys_lo, keys_lo, n_unique * 8, how, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(db->val_off, val_off, (n_unique + 1) * 8, how, ctx->stream);
     if (e == hipSuccess && V) e = hipMemcpyAsync(db->val_a, val_a, V * 4, how, ctx->stream);
     if (e == hipSuccess && V) e = hipMemcpyAsync(db->val_b, val_b, V * 4, how, ctx->stream);
@@ -1516,7 +1518,10 @@ static int db_load_common(kmg_ctx *ctx, int k, int key_len, int rc, int payload_
     u64 check[3] = {0, V, 0};   // val_off[0], val_off[n_unique], #descents in keys
     if (e == hipSuccess) {
         if (how == hipMemcpyDeviceToDevice) {
-            if (n_unique > 1)
+            if (n_unique > 1 && keys_lo)
+                hipLaunchKernelGGL(wide_ascending_kernel, dim3(div_up_u64(n_unique, 256)), dim3(256), 0, ctx->stream, (const u64 *)db->keys,
+                                   (const u64 *)db->keys_lo, n_unique, reinterpret_cast<u32 *>(totals.as<u64>() + 2));
+            else if (n_unique > 1)
                 hipLaunchKernelGGL(keys_ascending_kernel, dim3(div_up_u64(n_unique, 256)), dim3(256), 0, ctx->stream, db->keys,
                                    n_unique, reinterpret_cast<u32 *>(totals.as<u64>() + 2));
             e = hipMemcpyAsync(&check[0], db->val_off, 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -2462,6 +2467,26 @@ extern "C" int kmg_match_dev(kmg_ctx *ctx, const kmg_db *search, const kmg_db *r
 
 static int match_keys_locked(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run_off, int n_runs, int k,
                              const kmg_db *ref, int64_t *d_hit_index);
+
+// the same for two-word k-mers (wide.h): every ascending run is a search side of its own for wide_match_kernel
+static int match_keys_wide_locked(kmg_ctx *ctx, const u64 *d_hi, const u64 *d_lo, const uint64_t *run_off, int n_runs, int k,
+                                  const kmg_db *ref, int64_t *d_hit_index) {
+    if (ref->ctx->device != ctx->device) return fail(ctx, KMG_EINVAL, "database belongs to another device");
+    if (k != ref->k || !ref->keys_lo)                                                            // DB.java:78-81
+        return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
+    if (ref->min_k != ref->k) return fail(ctx, KMG_EUNSUPPORTED, "k-mers of several lengths: restrict the database to one length first");
+    for (int r = 0; r < n_runs; r++) {
+        if (run_off[r] > run_off[r + 1]) return fail(ctx, KMG_EINVAL, "run_off must be non-decreasing");
+        const u64 a = run_off[r], m = run_off[r + 1] - a;
+        if (m == 0) continue;
+        if (div_up_u64(m, WM_TILE) >= 0x7FFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "too many search k-mers for one call");
+        hipLaunchKernelGGL(wide_match_kernel, dim3(div_up_u64(m, WM_TILE)), dim3(WM_BLOCK), 0, ctx->stream, d_hi + a, d_lo + a, m,
+                           (const u64 *)ref->keys, (const u64 *)ref->keys_lo, ref->U, (long long *)d_hit_index + a, (u64 *)nullptr);
+    }
+    KMG_HIP(hipGetLastError());
+    KMG_TRY(note_foreign_use(ctx, ref));
+    return KMG_OK;
+}
 
 extern "C" int kmg_match_keys_dev(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run_off, int n_runs, int k,
                                   const kmg_db *ref, int64_t *d_hit_index) {

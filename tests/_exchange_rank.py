@@ -48,13 +48,14 @@ def main():
     nr, rk = C.c_int(), C.c_int()
     assert lib.kmg_comm_info(comm, C.byref(nr), C.byref(rk)) == 0 and (nr.value, rk.value) == (nranks, rank)
 
-    k, l = 21, 4
+    k, l = (int(sys.argv[4]) if len(sys.argv) > 4 else 21), 4          # (k > 32: two words a k-mer, the second travels too)
+    wide = k > 32
     nb = 4 ** l
     taxa, genomes = synth.random_genomes(301, 5, 30000, shared_frac=0.3)
     fa_whole = synth.fasta_bytes(taxa, genomes)
     o_ref = OracleDB(fa_whole, 0, k, l)
     # every rank searches its own reads
-    reads = synth.random_reads(302 + rank, genomes, 3000, 100, 0.01, n_rate=0.002)
+    reads = synth.random_reads(302 + rank, genomes, 3000, 100, 0.01 if not wide else 0.004, n_rate=0.002)
     fq = synth.fastq_bytes(reads)
     rdb, _ = km.make_read_db(ctx, fq, k, l)
     o_reads = OracleDB(fq, 1, k, l)
@@ -138,6 +139,7 @@ def main():
         s0, s1 = int(o_all.bucket_off[lo]), int(o_all.bucket_off[hi])
         v0, v1 = int(o_all.val_off[s0]), int(o_all.val_off[s1])
         assert np.array_equal(h["keys"], o_all.keys[s0:s1]), ("exchange keys", b)
+        assert not wide or np.array_equal(h["keys_lo"], o_all.keys_lo[s0:s1]), ("exchange second words", b)
         assert np.array_equal(h["val_off"], o_all.val_off[s0:s1 + 1] - o_all.val_off[s0])
         assert np.array_equal(h["val_a"], o_all.val_a[v0:v1]) and np.array_equal(h["val_b"], o_all.val_b[v0:v1])
         if hi > lo and s1 > s0:
@@ -153,13 +155,14 @@ def main():
     pairs = {}
     lo, hi = layouts[0][rank], layouts[0][rank + 1]
     for r in range(nranks):
-        o_r = OracleDB(synth.fastq_bytes(synth.random_reads(302 + r, genomes, 3000, 100, 0.01, n_rate=0.002)), 1, k, l)
+        o_r = OracleDB(synth.fastq_bytes(synth.random_reads(302 + r, genomes, 3000, 100, 0.01 if not wide else 0.004, n_rate=0.002)), 1, k, l)
         s0, s1 = int(o_r.bucket_off[lo]), int(o_r.bucket_off[hi])
         for i in range(s0, s1):
-            pairs.setdefault(int(o_r.keys[i]), []).extend(
+            pairs.setdefault((int(o_r.keys[i]), int(o_r.keys_lo[i]) if wide else 0), []).extend(
                 zip(o_r.val_a[int(o_r.val_off[i]):int(o_r.val_off[i + 1])].tolist(), o_r.val_b[int(o_r.val_off[i]):int(o_r.val_off[i + 1])].tolist()))
-    want_keys = np.array(sorted(pairs), np.uint64)
+    want_keys = np.array([p[0] for p in sorted(pairs)], np.uint64)
     assert np.array_equal(h["keys"], want_keys)
+    assert not wide or np.array_equal(h["keys_lo"], np.array([p[1] for p in sorted(pairs)], np.uint64))
     want_vals = [p for key in sorted(pairs) for p in sorted(pairs[key])]
     assert h["val_a"].tolist() == [p[0] for p in want_vals] and h["val_b"].tolist() == [p[1] for p in want_vals]
     cases += 1

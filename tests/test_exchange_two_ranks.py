@@ -18,9 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOUBLE_DIR = os.path.join(ROOT, "tests", "transport_double")
 
 
-def _run_ranks(nranks, tmp_path, real=False):
+def _run_ranks(nranks, tmp_path, real=False, k=21):
     env = dict(os.environ, KMG_TEST_REAL_RCCL="1" if real else "0")
-    procs = [subprocess.Popen([sys.executable, "-u", os.path.join(ROOT, "tests", "_exchange_rank.py"), str(r), str(nranks), str(tmp_path)],
+    procs = [subprocess.Popen([sys.executable, "-u", os.path.join(ROOT, "tests", "_exchange_rank.py"), str(r), str(nranks), str(tmp_path), str(k)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT, env=env) for r in range(nranks)]
     outs = []
     for p in procs:
@@ -39,10 +39,10 @@ def _run_ranks(nranks, tmp_path, real=False):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nranks", [2, 3])
-def test_exchange_with_several_ranks_on_one_gpu(nranks, tmp_path):
+@pytest.mark.parametrize("nranks,k", [(2, 21), (3, 21), (2, 40), (3, 64)])
+def test_exchange_with_several_ranks_on_one_gpu(nranks, k, tmp_path):
     assert os.path.exists(os.path.join(DOUBLE_DIR, "librccl.so.1")), "run __graft_entry__.build() (make -C tests/transport_double)"
-    res = _run_ranks(nranks, tmp_path)
+    res = _run_ranks(nranks, tmp_path, k=k)          # (k > 32: two words a k-mer)
     for r in res:
         assert r["ok"] and r["cases"] == 9
         # the grouped exchange and the count all-gather really went through the double, with peers on the other side

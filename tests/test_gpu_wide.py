@@ -826,3 +826,48 @@ def test_inexact_search_matches_trie_restatement(ctx, k, l, seed):
             db.merged.close()
     for d in refs + [reads]:
         d.close()
+
+
+@pytest.mark.parametrize("k", [33, 64])
+def test_exchange_entry_points_with_one_rank(ctx, k):
+    """kmg_match_sharded / kmg_db_exchange_by_key_range on two-word k-mers with one rank (RCCL's sends to self; the second
+    words travel beside the first, the received runs are joined run by run, received parts are rebuilt and merged as
+    two-word databases) against the oracle; several ranks: tests/test_exchange_two_ranks.py at k = 40 and 64."""
+    import kmers_amd as km
+    from kmers_amd import dist as kd, synth
+    from oracle.c_oracle import OracleDB
+    l = 4
+    taxa, genomes = synth.random_genomes(311, 4, 30000, shared_frac=0.3)
+    reads = synth.random_reads(312, genomes, 4000, 120, 0.004, n_rate=0.002)
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    ref = km.make_reference_db(ctx, fa, k, l)
+    rdb, _ = km.make_read_db(ctx, fq, k, l)
+    o_ref, o_reads = OracleDB(fa, 0, k, l), OracleDB(fq, 1, k, l)
+    o_hit, _ = o_reads.match(o_ref)
+    try:
+        comm = kd.Comm(ctx, rank=0, world=1)
+    except km.KmersGpuError as e:
+        pytest.skip("no RCCL on this machine: %s" % e)
+    hit = comm.match_sharded(rdb, ref, [(0, 4 ** l)])
+    assert np.array_equal(hit.cpu().numpy(), o_hit) and (o_hit >= 0).sum() > 1000
+    lo, hi = 37, 4 ** l - 11
+    sub = comm.match_sharded(rdb, ref, [(lo, hi)])
+    boff = o_reads.bucket_off
+    want = o_hit.copy()
+    want[:int(boff[lo])] = -1
+    want[int(boff[hi]):] = -1
+    assert np.array_equal(sub.cpu().numpy(), want)
+    shard = comm.exchange_by_key_range(ref, [(lo, hi)])
+    h = shard.fetch()
+    a, b = int(o_ref.bucket_off[lo]), int(o_ref.bucket_off[hi])
+    va, vb = int(o_ref.val_off[a]), int(o_ref.val_off[b])
+    assert np.array_equal(h["keys"], o_ref.keys[a:b]) and np.array_equal(h["keys_lo"], o_ref.keys_lo[a:b])
+    assert np.array_equal(h["val_off"], o_ref.val_off[a:b + 1] - o_ref.val_off[a])
+    assert np.array_equal(h["val_a"], o_ref.val_a[va:vb]) and np.array_equal(h["val_b"], o_ref.val_b[va:vb])
+    whole = comm.exchange_by_key_range(rdb, [(0, 4 ** l)])
+    _same_db(whole, o_reads)
+    empty = comm.exchange_by_key_range(ref, [(5, 5)])
+    assert empty.n_unique == 0 and empty.n_values == 0 and empty.k == k
+    for d in (shard, whole, empty, ref, rdb):
+        d.close()
+    comm.close()
