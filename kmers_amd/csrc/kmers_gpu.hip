@@ -799,6 +799,7 @@ static int clone_for_trie(kmg_ctx *ctx, const kmg_db *src, kmg_db **out) {
     const u32 nbuckets = 1u << (2 * src->key_len);
     struct { void **dst; const void *from; size_t bytes; } arrays[] = {
         {(void **)&db->keys, src->keys, (src->U + 1) * 8},       {(void **)&db->lens, src->lens, src->lens ? src->U + 8 : 0},
+        {(void **)&db->keys_lo, src->keys_lo, src->keys_lo ? (src->U + 1) * 8 : 0},
         {(void **)&db->val_off, src->val_off, (src->U + 2) * 8}, {(void **)&db->val_a, src->val_a, (src->V + 1) * 4},
         {(void **)&db->val_b, src->val_b, (src->V + 1) * 4},     {(void **)&db->bucket_off, src->bucket_off, ((size_t)nbuckets + 1) * 8}};
     for (auto &a : arrays) {
@@ -810,6 +811,7 @@ static int clone_for_trie(kmg_ctx *ctx, const kmg_db *src, kmg_db **out) {
     // (element counts, not the padded sizes above: the sources hold exactly these)
     if (src->U) KMG_HIP(hipMemcpyAsync(db->keys, src->keys, src->U * 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (src->lens && src->U) KMG_HIP(hipMemcpyAsync(db->lens, src->lens, src->U, hipMemcpyDeviceToDevice, ctx->stream));
+    if (src->keys_lo && src->U) KMG_HIP(hipMemcpyAsync(db->keys_lo, src->keys_lo, src->U * 8, hipMemcpyDeviceToDevice, ctx->stream));
     KMG_HIP(hipMemcpyAsync(db->val_off, src->val_off, (src->U + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (src->V) {
         KMG_HIP(hipMemcpyAsync(db->val_a, src->val_a, src->V * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1999,7 +2001,7 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
         for (int i = 0; i < n_dbs; i++) Ut += dbs[i]->U;
         if (Ut >= 0xFFFFFFF0ull) return fail(ctx, KMG_EUNSUPPORTED, "more than 2^32-16 k-mers in the files of the set");
         // (files of several lengths: the lengths are part of the k-mers' order and identity, DB.java:99-109 merges in
-        // Sequence.compareTo order; the search over several lengths is not built for two-word k-mers, so no file is kept)
+        // Sequence.compareTo order; a set whose files share a key keeps its files for the search over several lengths)
         const bool var = d0->min_k != d0->k;
         db->min_k = d0->min_k;
         PoolBuf ch(ctx), cl(ctx), cn(ctx), rank(ctx), d_hi(ctx), d_lo(ctx), d_len(ctx);
@@ -2046,7 +2048,7 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
         if (db->U != U) return fail(ctx, KMG_EDEVICE, "two-word merge: the ranks' distinct count differs from the k-mers'");
         if (var && n_dbs > 1) {
             // the search over several lengths takes a key's k-mers file by file (DB.java:154-158): a set whose files share a
-            // key is marked, and kmg_match_trie leaves it to the Java path
+            // key is marked and keeps its files
             const u32 nbk = 1u << (2 * d0->key_len);
             PoolBuf sb(ctx), sv(ctx), holders(ctx), clash(ctx);
             KMG_ALLOC(sb, ((size_t)nbk + 1) * 8); KMG_ALLOC(sv, ((size_t)nbk + 1) * 8); KMG_ALLOC(holders, ((size_t)nbk + 1) * 4); KMG_ALLOC(clash, 64);
@@ -2061,6 +2063,20 @@ extern "C" int kmg_db_merge(kmg_ctx *ctx, const kmg_db *const *dbs, int n_dbs, k
             u32 h_clash = 0;
             KMG_HIP(read_back(ctx, &h_clash, clash.p, 4));
             db->shared_key_merge = h_clash != 0;
+            if (db->shared_key_merge && d0->kind == KMG_PAYLOAD_TAXON)
+                for (int i = 0; i < n_dbs; i++) {
+                    // the files as they are, in their order: what kmg_match_trie searches (trie_files_wide_kernel)
+                    if (dbs[i]->parts.empty()) {
+                        kmg_db *part = nullptr;
+                        KMG_TRY(clone_for_trie(ctx, dbs[i], &part));
+                        db->parts.push_back(part);
+                    } else
+                        for (const kmg_db *q : dbs[i]->parts) {
+                            kmg_db *part = nullptr;
+                            KMG_TRY(clone_for_trie(ctx, q, &part));
+                            db->parts.push_back(part);
+                        }
+                }
         }
         ctx->pool.release(db->keys);
         db->keys = (u64 *)d_hi.detach();
@@ -2334,8 +2350,6 @@ extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     if (ref->kind != KMG_PAYLOAD_TAXON) return fail(ctx, KMG_EINVAL, "the database searched holds taxon counts");
     // (two-word k-mers, wide.h: one file, or a set whose files share no key; the search side one word or two as the database)
     const bool wide = ref->k > 32;
-    if (wide && ref->shared_key_merge)
-        return fail(ctx, KMG_EUNSUPPORTED, "files of two-word k-mers of several lengths that share a key: not on the GPU path");
     if (search->key_len != ref->key_len) return fail(ctx, KMG_EINVAL, "key lengths differ");
     // DB.java:78-81 on the search stream's declared lengths [min_k, search->k]
     if (min_k < ref->min_k || search->k > ref->k || min_k > search->min_k || min_k < ref->key_len)
@@ -2367,7 +2381,27 @@ extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     u64 nrows = 0, nrec = 0;
     PoolBuf d_files(ctx), nvals64(ctx);
     const int nf = (int)ref->parts.size();
-    if (ns && by_files) {
+    if (ns && by_files && wide) {
+        std::vector<WideTrieFile> h_files;
+        for (const kmg_db *q : ref->parts) {
+            if (!q->keys_lo) return fail(ctx, KMG_ESTATE, "a file of the set holds one-word k-mers");
+            h_files.push_back(WideTrieFile{TrieFile{q->keys, q->lens, q->bucket_off, q->val_off, q->val_a, q->val_b, q->k, 0}, q->keys_lo});
+        }
+        KMG_ALLOC(d_files, h_files.size() * sizeof(WideTrieFile));
+        KMG_ALLOC(nvals64, (ns + 1) * 8);
+        KMG_HIP(hipMemcpyAsync(d_files.p, h_files.data(), h_files.size() * sizeof(WideTrieFile), hipMemcpyHostToDevice, ctx->stream));
+        KMG_HIP(hipStreamSynchronize(ctx->stream));             // (h_files is pageable and on this frame)
+        hipLaunchKernelGGL((trie_files_wide_kernel<false>), dim3(div_up_u64(ns, 256)), dim3(256), 0, ctx->stream, (const u64 *)search->keys,
+                           (const u64 *)search->keys_lo, (const uint8_t *)search->lens, search->k, ns, d_files.as<WideTrieFile>(), nf, ref->key_len,
+                           min_k, found.as<u32>(), nvals64.as<u64>(), (const u64 *)nullptr, (const u64 *)nullptr, count_cap, (u64 *)nullptr,
+                           (u64 *)nullptr, (long long *)nullptr);
+        KMG_TRY((device_scan<u32, u64, OpSum, true>(ctx, found.as<u32>(), row.as<u64>(), ns, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
+                                                    KP_SCAN)));
+        KMG_TRY((device_scan<u64, u64, OpSum, true>(ctx, nvals64.as<u64>(), dst.as<u64>(), ns, OpSum(), 0ull, agg.as<u64>(), nullptr, true,
+                                                    KP_SCAN)));
+        KMG_HIP(read_back(ctx, &nrows, row.as<u64>() + ns, 8));
+        KMG_HIP(read_back(ctx, &nrec, dst.as<u64>() + ns, 8));
+    } else if (ns && by_files) {
         std::vector<TrieFile> h_files;
         for (const kmg_db *q : ref->parts)
             h_files.push_back(TrieFile{q->keys, q->lens, q->bucket_off, q->val_off, q->val_a, q->val_b, q->k, 0});
@@ -2404,7 +2438,12 @@ extern "C" int kmg_match_trie(kmg_ctx *ctx, const kmg_db *search, const kmg_db *
     const u32 n = (u32)nrec;
     KMG_ALLOC(k0, ((size_t)n + 1) * 8); KMG_ALLOC(v0, ((size_t)n + 1) * 8);
     KMG_ALLOC(k1, ((size_t)n + 1) * 8); KMG_ALLOC(v1, ((size_t)n + 1) * 8);
-    if (ns && by_files)
+    if (ns && by_files && wide)
+        hipLaunchKernelGGL((trie_files_wide_kernel<true>), dim3(div_up_u64(ns, 256)), dim3(256), 0, ctx->stream, (const u64 *)search->keys,
+                           (const u64 *)search->keys_lo, (const uint8_t *)search->lens, search->k, ns, d_files.as<WideTrieFile>(), nf, ref->key_len,
+                           min_k, (u32 *)nullptr, (u64 *)nullptr, row.as<u64>(), dst.as<u64>(), count_cap, k0.as<u64>(), v0.as<u64>(),
+                           hit.as<long long>());
+    else if (ns && by_files)
         hipLaunchKernelGGL((trie_files_kernel<true>), dim3(div_up_u64(ns, 256)), dim3(256), 0, ctx->stream, search->keys, search->lens,
                            search->k, ns, d_files.as<TrieFile>(), nf, ref->key_len, min_k, (u32 *)nullptr, (u64 *)nullptr,
                            row.as<u64>(), dst.as<u64>(), count_cap, k0.as<u64>(), v0.as<u64>(), hit.as<long long>());

@@ -725,3 +725,128 @@ __global__ __launch_bounds__(128) void wide_near_walk_kernel(const u64 *__restri
     }
     if (!FILL) cnt[s] = (u32)(found > 0xFFFFFFFFull ? 0xFFFFFFFFull : found);
 }
+
+// ---- the search over several lengths across a SET of files that share keys, on two words: match.h's trie_files_kernel
+// (the second closed form, derived in DESIGN 6b/6c: the answer's object belongs to the earliest inserted stored k-mer x that
+// has the search k-mer as a prefix, and has absorbed, per boundary depth on x's path, the k-mers inserted at or after the
+// boundary's maker that share that many bases with x) with (hi, lo) compares, prefixes and common-prefix lengths.
+struct WideTrieFile {
+    TrieFile t;               // keys = the first words
+    const u64 *keys_lo;
+};
+__device__ __forceinline__ int tfw_lcp(u64 ah, u64 al, int la, u64 bh, u64 bl, int lb) {
+    const u64 x = ah ^ bh, y = al ^ bl;
+    const int c = x ? (int)(__clzll((long long)x) >> 1) : (y ? 32 + (int)(__clzll((long long)y) >> 1) : 64);
+    return min(c, min(la, lb));
+}
+// first entry of [lo, hi) that is >= (v, len) in (value, length) order
+__device__ __forceinline__ u64 tfw_lower(const WideTrieFile &f, u64 lo, u64 hi, u64 vh, u64 vl, int len) {
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        const u64 kh = f.t.keys[mid], kl = f.keys_lo[mid];
+        if (wide_less(kh, kl, vh, vl) || (kh == vh && kl == vl && tf_len(f.t, mid) < len)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// the entries of [lo, hi) that have the first e bases of x: -> [a, b)
+__device__ __forceinline__ void tfw_prefix_range(const WideTrieFile &f, u64 lo, u64 hi, u64 xh, u64 xl, int e, u64 &a, u64 &b) {
+    u64 mh, ml;
+    wide_prefix_mask(e, mh, ml);
+    const u64 vh = xh & mh, vl = xl & ml, th = vh | ~mh, tl = vl | ~ml;
+    a = tfw_lower(f, lo, hi, vh, vl, e);
+    u64 l = a, h = hi;
+    while (l < h) {
+        const u64 mid = (l + h) >> 1;
+        if (!wide_less(th, tl, f.t.keys[mid], f.keys_lo[mid])) l = mid + 1; else h = mid;
+    }
+    b = l;
+}
+
+template <bool EMIT>
+__global__ void trie_files_wide_kernel(const u64 *__restrict__ s_hi, const u64 *__restrict__ s_lo /* null: one word */,
+                                       const uint8_t *__restrict__ slens, int s_len_all, u64 ns,
+                                       const WideTrieFile *__restrict__ files, int nf, int key_len, int shortest,
+                                       u32 *__restrict__ found, u64 *__restrict__ nvals, const u64 *__restrict__ row,
+                                       const u64 *__restrict__ dst, int cap, u64 *__restrict__ out_keys, u64 *__restrict__ out_vals,
+                                       long long *__restrict__ hit) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const u64 th = s_hi[i], tl = s_lo ? s_lo[i] : 0ull;
+    const int T = slens ? (int)slens[i] : s_len_all;
+    const u64 b = th >> (64 - 2 * key_len);
+    u64 tmh, tml;
+    wide_prefix_mask(T, tmh, tml);
+    // x: the first file that holds a k-mer with prefix t, its smallest there
+    int f0 = -1;
+    u64 l0 = 0;
+    for (int f = 0; f < nf && f0 < 0; f++) {
+        const WideTrieFile &F = files[f];
+        const u64 lo = F.t.bucket[b], hi = F.t.bucket[b + 1];
+        const u64 l = tfw_lower(F, lo, hi, th, tl, T);
+        if (l < hi && tf_len(F.t, l) >= T && ((F.t.keys[l] ^ th) & tmh) == 0 && ((F.keys_lo[l] ^ tl) & tml) == 0) { f0 = f; l0 = l; }
+    }
+    if (f0 < 0) {
+        if (EMIT) hit[i] = -1;
+        else { found[i] = 0; nvals[i] = 0; }
+        return;
+    }
+    const u64 xh = files[f0].t.keys[l0], xl = files[f0].keys_lo[l0];
+    const int X = tf_len(files[f0].t, l0);
+    // L: the longest prefix x shares with anything inserted before it
+    int L = 0;
+    {
+        const WideTrieFile &F = files[f0];
+        if (l0 > F.t.bucket[b]) L = tfw_lcp(xh, xl, X, F.t.keys[l0 - 1], F.keys_lo[l0 - 1], tf_len(F.t, l0 - 1));
+        for (int f = 0; f < f0; f++) {
+            const WideTrieFile &G = files[f];
+            const u64 lo = G.t.bucket[b], hi = G.t.bucket[b + 1];
+            const u64 p = tfw_lower(G, lo, hi, xh, xl, X);
+            if (p > lo) L = max(L, tfw_lcp(xh, xl, X, G.t.keys[p - 1], G.keys_lo[p - 1], tf_len(G.t, p - 1)));
+            if (p < hi) L = max(L, tfw_lcp(xh, xl, X, G.t.keys[p], G.keys_lo[p], tf_len(G.t, p)));
+        }
+    }
+    const int m = max(shortest, L + 1);
+    u64 count = 0, o = EMIT ? dst[i] : 0;
+    const u64 key = EMIT ? (row[i] << 32) : 0;
+    tf_take<EMIT>(files[f0].t, l0, l0 + 1, count, key, cap, out_keys, out_vals, o);          // D_x itself
+    u64 made[2] = {0, 0};                      // bit e (0 .. 64): some k-mer at or after x has made a boundary at depth e
+    made[X >> 6] |= 1ull << (X & 63);
+    {
+        const WideTrieFile &F = files[f0];
+        const u64 hi = F.t.bucket[b + 1];
+        u64 prev = l0 + 1;
+        for (int e = X; e >= m; e--) {
+            u64 a_, b_;
+            tfw_prefix_range(F, prev, hi, xh, xl, e, a_, b_);
+            if (b_ > prev) {
+                tf_take<EMIT>(F.t, prev, b_, count, key, cap, out_keys, out_vals, o);
+                made[e >> 6] |= 1ull << (e & 63);
+            }
+            prev = max(prev, b_);
+        }
+    }
+    for (int f = f0 + 1; f < nf; f++) {
+        const WideTrieFile &F = files[f];
+        u64 ra, rb;
+        tfw_prefix_range(F, F.t.bucket[b], F.t.bucket[b + 1], xh, xl, m, ra, rb);
+        for (int e = m; e <= X && ra < rb; e++) {
+            if (e == X) {
+                tf_take<EMIT>(F.t, ra, rb, count, key, cap, out_keys, out_vals, o);
+                break;
+            }
+            u64 na, nb;
+            tfw_prefix_range(F, ra, rb, xh, xl, e + 1, na, nb);
+            if (made[e >> 6] & (1ull << (e & 63))) tf_take<EMIT>(F.t, ra, rb, count, key, cap, out_keys, out_vals, o);
+            else if (ra < na) {
+                tf_take<EMIT>(F.t, ra, rb, count, key, cap, out_keys, out_vals, o);
+                made[e >> 6] |= 1ull << (e & 63);
+            } else if (nb < rb) {
+                tf_take<EMIT>(F.t, nb, rb, count, key, cap, out_keys, out_vals, o);
+                made[e >> 6] |= 1ull << (e & 63);
+            }
+            ra = na; rb = nb;
+        }
+    }
+    if (EMIT) hit[i] = (long long)row[i];
+    else { found[i] = 1; nvals[i] = count; }
+}

@@ -871,3 +871,58 @@ def test_exchange_entry_points_with_one_rank(ctx, k):
     for d in (shard, whole, empty, ref, rdb):
         d.close()
     comm.close()
+
+
+def test_trie_search_over_file_sets_matches_literal_trie(ctx):
+    """kmg_match_trie over sets of two to four files of two-word k-mers that share keys (trie_files_wide_kernel), small
+    alphabets (long shared prefixes: edges split by later files' k-mers, objects that take one k-mer in more than once),
+    the search side sometimes narrower than the database or one word wide: every line against the literal trie filled
+    file by file (oracle/slow_ref.py Root, DB.java:154-158)."""
+    import os
+    import random
+    import kmers_amd as km
+    from oracle import slow_ref as R
+    lines = differ = 0
+    for seed in range(int(os.environ.get("KMERS_TRIE_SET_SEEDS", "60"))):
+        rng = random.Random(7500 + seed)
+        alpha = rng.choice(["ACGT", "AC", "AAAC", "ACGTN", "AG"])
+        max_k = rng.choice([33, 34, 36, 40, 48, 64])
+        min_k = rng.randint(max(1, max_k - 12), max_k - 1)
+        key_len = rng.randint(1, 3)
+        def lowc(n):                     # a short motif over and over, a base in thirty changed: long shared prefixes
+            motif = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 5)))
+            q = list((motif * (n // len(motif) + 1))[:n])
+            for j in range(len(q)):
+                if rng.random() < 0.03:
+                    q[j] = rng.choice(alpha)
+            return "".join(q)
+        pool = [lowc(rng.randint(20, 160)) for _ in range(rng.randint(2, 8))]
+        fas = []
+        for _ in range(rng.randint(2, 4)):
+            seqs = [rng.choice(pool) if rng.random() < 0.6 else lowc(rng.randint(0, 160)) for _ in range(rng.randint(1, 6))]
+            fas.append("".join(">%d\n%s\n" % (rng.randint(1, 5), q) for q in seqs).encode())
+        fq = "".join("@r%d\n%s\n+\n%s\n" % (i, q, "I" * len(q)) for i, q in
+                     enumerate((rng.choice(pool)[:rng.randint(30, 160)] if rng.random() < 0.6 else lowc(rng.randint(0, 90)))
+                               for _ in range(rng.randint(1, 10)))).encode()
+        s_min = rng.randint(min_k, max_k)
+        s_max = rng.randint(s_min, max_k)
+        if rng.random() < 0.5:
+            s_min, s_max = min_k, max_k
+        if s_min == s_max:
+            continue
+        parts = [km.make_reference_db(ctx, fa, max_k, key_len, min_k=min_k) for fa in fas]
+        if sum(d.n_unique for d in parts) == 0:
+            continue
+        rdb = km.make_read_db(ctx, fq, s_max, key_len, min_k=s_min)[0]
+        mset = km.merge_databases(parts)
+        rows, hit = km.match_trie(rdb, mset, s_min)
+        got = km.match_lines(rdb, rows, hit, ref_stored=True)
+        files = [R.build_ref_db(fa, max_k, key_len, min_k=min_k) for fa in fas]
+        o_reads = R.build_read_db(fq, s_max, key_len, min_k=s_min)[0]
+        want = R.near_match_lines(o_reads, R.DB(files), 0, False)
+        assert got == want, (seed, alpha, min_k, max_k, s_min, s_max, key_len, len(fas))
+        lines += len(want)
+        differ += want != R.near_match_lines(o_reads, R.DB(files[::-1]), 0, False)
+        for d in parts + [rdb, mset, rows]:
+            d.close()
+    assert lines > 300 and differ > 3          # (the cases bite: the files' order changes the answers)
