@@ -16,7 +16,8 @@
  * Supported: 1 <= minK <= maxK = k <= 32, 1 <= key_len <= min(minK, 12); the exact join takes k-mers of one
  * length (restrict variable-length databases first, kmg_db_restrict).  k-mers of up to 64 bases ("two-word
  * k-mers", see below; 32 < maxK <= 64, any minK): build, fetch, load, encode, restrict, the exact join, the search over several
- * lengths, the inexact search, TaxaCounts and the per-read tools, the merge of file sets, the RCCL steps.  Anything else returns KMG_EUNSUPPORTED so a shim can fall back to the Java path.
+ * lengths, the inexact search, TaxaCounts and the per-read tools, the merge of file sets, the RCCL steps (every entry point but
+ * kmg_match_keys_dev, which has kmg_match_keys_wide_dev beside it).  Anything else returns KMG_EUNSUPPORTED so a shim can fall back to the Java path.
  *
  * K-mer representation everywhere: uint64, 2 bits per base, code order A=0 C=1 T=2 G=3
  * (Kmers/Base.java:7-10), first base in the top bits, low 64-2k bits zero -- i.e. the bytes of
@@ -273,6 +274,10 @@ int kmg_match_dev(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t
  *   to a device pointer without synchronising.  k = length of the search k-mers (DB.java:78-81 -> KMG_EINVAL). */
 int kmg_match_keys_dev(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run_off, int n_runs, int k,
                        const kmg_db *ref, int64_t *d_hit_index);
+/* kmg_match_keys_wide_dev: the same for two-word k-mers (33 <= k <= 64; Sequence.java:15-35,90-115): d_keys holds the first
+ *   words, d_keys_lo the second, run for run; every run is joined by a launch of its own. */
+int kmg_match_keys_wide_dev(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_keys_lo, const uint64_t *run_off,
+                            int n_runs, int k, const kmg_db *ref, int64_t *d_hit_index);
 
 /* kmg_match_dev_noalloc: kmg_match_dev for callers that cannot allocate.  No counterpart in the reference: it is
  *   for code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same result as
@@ -282,7 +287,8 @@ int kmg_match_keys_dev(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run
  *   k-mers per call (KMG_EINVAL beyond).  Both databases must belong to ctx.  Every call on a GPU shares that GPU's
  *   array; calls from several contexts of one GPU (= several streams) are ordered by the library, each behind the one
  *   queued before it (an event per context, made with the context), so they give the right results but do not
- *   overlap. */
+ *   overlap.  Two-word k-mers: their join finds each tile's piece of the reference inside the kernel, so the array is
+ *   not touched (and nothing is waited for); the limit is the same. */
 #define KMG_MATCH_NOALLOC_MAX_SEARCH 268433408ull   /* 131071 tiles x 2048 k-mers */
 int kmg_match_dev_noalloc(kmg_ctx *ctx, const kmg_db *search, const kmg_db *ref, int64_t *d_hit_index);
 

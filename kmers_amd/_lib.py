@@ -21,7 +21,7 @@ SYMBOLS = [
     "kmg_create", "kmg_destroy", "kmg_last_error", "kmg_stream",
     "kmg_build_begin", "kmg_build_set_filters", "kmg_build_set_min_k", "kmg_build_set_key_range", "kmg_build_add", "kmg_build_add_dev", "kmg_build_finish",
     "kmg_db_info", "kmg_db_fetch", "kmg_db_load", "kmg_db_free", "kmg_db_encode", "kmg_db_merge", "kmg_db_copy_dev", "kmg_db_load_dev", "kmg_db_payload_bits", "kmg_build_add_packed", "kmg_db_min_k", "kmg_db_fetch_lens", "kmg_db_load_var", "kmg_db_restrict", "kmg_db_restrict_range", "kmg_match_trie", "kmg_db_fetch_keys_lo", "kmg_db_load_wide",
-    "kmg_match", "kmg_match_dev", "kmg_match_keys_dev", "kmg_match_dev_noalloc", "kmg_match_near", "kmg_taxacounts", "kmg_collect_by_read", "kmg_classify_reads", "kmg_classify_reads_hits", "kmg_classify_reads_rows",
+    "kmg_match", "kmg_match_dev", "kmg_match_keys_dev", "kmg_match_keys_wide_dev", "kmg_match_dev_noalloc", "kmg_match_near", "kmg_taxacounts", "kmg_collect_by_read", "kmg_classify_reads", "kmg_classify_reads_hits", "kmg_classify_reads_rows",
     "kmg_comm_unique_id", "kmg_comm_create", "kmg_comm_destroy", "kmg_comm_info", "kmg_match_sharded", "kmg_db_exchange_by_key_range",
     "kmg_prof_enable", "kmg_prof_reset", "kmg_prof_get", "kmg_prof_count", "kmg_prof_name", "kmg_calib_copy",
 ]
@@ -88,6 +88,7 @@ def load():
     lib.kmg_match_near.argtypes = [vp, vp, vp, i32, vp, vp, vp, u64, P(u64)]
     lib.kmg_match_dev.argtypes = [vp, vp, vp, vp]
     lib.kmg_match_keys_dev.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.kmg_match_keys_wide_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     lib.kmg_match_dev_noalloc.argtypes = [vp, vp, vp, vp]
     lib.kmg_collect_by_read.argtypes = [vp, vp, vp, P(u64), vp, vp, vp]
     lib.kmg_classify_reads.argtypes = [vp, vp, vp, u64, vp]

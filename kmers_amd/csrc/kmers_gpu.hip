@@ -37,11 +37,6 @@ struct PoolBuf {
     void free() { ctx->pool.release(p); p = nullptr; }
 };
 
-// entry points that take one-word k-mers only: the join from bare device keys, the no-allocation join (two-word k-mers,
-// wide.h, have everything else)
-#define KMG_NO_WIDE(db) \
-    do { if ((db)->k > 32) return fail(ctx, KMG_EUNSUPPORTED, "not built for k-mers of more than 32 bases"); } while (0)
-
 static int fail(kmg_ctx *ctx, int code, const char *msg) {
     if (ctx) ctx->err = msg;
     return code;
@@ -2527,6 +2522,17 @@ static int match_keys_wide_locked(kmg_ctx *ctx, const u64 *d_hi, const u64 *d_lo
     return KMG_OK;
 }
 
+extern "C" int kmg_match_keys_wide_dev(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_keys_lo, const uint64_t *run_off,
+                                       int n_runs, int k, const kmg_db *ref, int64_t *d_hit_index) {
+    if (!ctx || !ref || !run_off) return KMG_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KMG_HIP(hipSetDevice(ctx->device));
+    if (n_runs < 1 || n_runs > MT_MAX_RUNS) return fail(ctx, KMG_EINVAL, "between 1 and 64 runs");
+    if (k <= 32 || !ref->keys_lo) return fail(ctx, KMG_EINVAL, "k-mers of 33 .. 64 bases (kmg_match_keys_dev takes the shorter ones)");
+    if (run_off[n_runs] > run_off[0] && (!d_keys || !d_keys_lo || !d_hit_index)) return fail(ctx, KMG_EINVAL, "null keys / hit_index");
+    return match_keys_wide_locked(ctx, (const u64 *)d_keys, (const u64 *)d_keys_lo, run_off, n_runs, k, ref, d_hit_index);
+}
+
 extern "C" int kmg_match_keys_dev(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run_off, int n_runs, int k,
                                   const kmg_db *ref, int64_t *d_hit_index) {
     if (!ctx || !ref || !run_off) return KMG_EINVAL;
@@ -2538,7 +2544,7 @@ extern "C" int kmg_match_keys_dev(kmg_ctx *ctx, const uint64_t *d_keys, const ui
 static int match_keys_locked(kmg_ctx *ctx, const uint64_t *d_keys, const uint64_t *run_off, int n_runs, int k,
                              const kmg_db *ref, int64_t *d_hit_index) {
     if (ref->ctx->device != ctx->device) return fail(ctx, KMG_EINVAL, "database belongs to another device");
-    KMG_NO_WIDE(ref);
+    if (ref->k > 32) return fail(ctx, KMG_EUNSUPPORTED, "k-mers of more than 32 bases: kmg_match_keys_wide_dev takes both words");
     if (k != ref->k)                                                                             // DB.java:78-81
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
     if (ref->min_k != ref->k) return fail(ctx, KMG_EUNSUPPORTED, "k-mers of several lengths: restrict the database to one length first");
@@ -2615,8 +2621,6 @@ extern "C" int kmg_match_dev_noalloc(kmg_ctx *ctx, const kmg_db *search, const k
     if (!ctx->match_scratch) return fail(ctx, KMG_EDEVICE, "no scratch array on this device");
     // (a foreign database would need an event of its own to order its release: that is an allocation)
     if (search->ctx != ctx || ref->ctx != ctx) return fail(ctx, KMG_EINVAL, "both databases must belong to this context");
-    KMG_NO_WIDE(search);
-    KMG_NO_WIDE(ref);
     if (search->k != ref->k || search->key_len != ref->key_len)                                  // DB.java:78-81
         return fail(ctx, KMG_EINVAL, "Search kmers contain kmers of a length inconsistent with the database");
     if (search->min_k != search->k || ref->min_k != ref->k)
@@ -2624,6 +2628,15 @@ extern "C" int kmg_match_dev_noalloc(kmg_ctx *ctx, const kmg_db *search, const k
     if (search->U > (u64)KMG_MATCH_NOALLOC_MAX_SEARCH)
         return fail(ctx, KMG_EINVAL, "more search k-mers than the no-allocation join holds bounds for (KMG_MATCH_NOALLOC_MAX_SEARCH)");
     if (search->U == 0) return KMG_OK;
+    if (search->k > 32) {
+        // two-word k-mers (wide.h): that join finds every tile's piece of the reference inside the kernel -- no bounds
+        // array, so nothing of the scratch array is touched and no other context has to be waited for
+        hipLaunchKernelGGL(wide_match_kernel, dim3(div_up_u64(search->U, WM_TILE)), dim3(WM_BLOCK), 0, ctx->stream, (const u64 *)search->keys,
+                           (const u64 *)search->keys_lo, search->U, (const u64 *)ref->keys, (const u64 *)ref->keys_lo, ref->U,
+                           (long long *)d_hit_index, (u64 *)nullptr);
+        KMG_HIP(hipGetLastError());
+        return KMG_OK;
+    }
     const u32 ntiles = div_up_u64(search->U, MT_TILE);          // <= KMG_NOALLOC_TILES by the check above
     u64 *bounds = ctx->match_scratch;                            // every word [0, ntiles] is written before it is read
     std::lock_guard<std::mutex> gs(g_match_scratch_mu);          // (queueing order = the order of the waits below)

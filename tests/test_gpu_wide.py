@@ -495,9 +495,17 @@ def test_packed_and_device_resident_input_and_the_second_word_on_the_device(ctx)
     ctx.check(ctx.lib.kmg_match_dev(ctx.h, got.h, again.h, hit.data_ptr()))
     torch.cuda.synchronize()
     assert np.array_equal(hit.cpu().numpy(), np.arange(got.n_unique))
-    with pytest.raises(KmersGpuError) as e:
-        ctx.check(ctx.lib.kmg_match_dev_noalloc(ctx.h, got.h, again.h, hit.data_ptr()))
-    assert e.value.code == KMG_EUNSUPPORTED
+    # the join for callers that cannot allocate takes two-word k-mers too (no bounds array: nothing of its scratch is used)
+    ref_fa = b">7\n%s\n>9\n%s\n" % (seqs[0][:2000].encode(), seqs[4].encode())
+    some = km.make_reference_db(ctx, ref_fa, k, l)
+    for _ in range(2):
+        a_ = torch.full((got.n_unique,), -5, dtype=torch.int64, device=dev)
+        b_ = torch.full((got.n_unique,), -6, dtype=torch.int64, device=dev)
+        ctx.check(ctx.lib.kmg_match_dev(ctx.h, got.h, some.h, a_.data_ptr()))
+        ctx.check(ctx.lib.kmg_match_dev_noalloc(ctx.h, got.h, some.h, b_.data_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(a_, b_) and int((a_ >= 0).sum()) > 0 and int((a_ < 0).sum()) > 0
+    some.close()
     got.close(); again.close()
 
 
@@ -926,3 +934,55 @@ def test_trie_search_over_file_sets_matches_literal_trie(ctx):
         for d in parts + [rdb, mset, rows]:
             d.close()
     assert lines > 300 and differ > 3          # (the cases bite: the files' order changes the answers)
+
+
+@pytest.mark.parametrize("k", [33, 64])
+def test_match_keys_in_runs(ctx, k):
+    """kmg_match_keys_wide_dev: kmg_match_keys_dev for two-word k-mers -- several ascending runs of search k-mers back to
+    back (an empty one among them, run lengths on both sides of a tile), both words on the device; every element's hit
+    index equals the oracle's for that k-mer.  Also the one-run form, the one-word call's answer and the argument checks."""
+    import ctypes as C
+    import torch
+    import kmers_amd as km
+    from kmers_amd import _lib, synth
+    from oracle.c_oracle import OracleDB
+    taxa, genomes = synth.random_genomes(61, 3, 40000, shared_frac=0.2)
+    reads = synth.random_reads(62, genomes, 3000, 130, 0.004)
+    l = 5
+    fa, fq = synth.fasta_bytes(taxa, genomes), synth.fastq_bytes(reads)
+    ref = km.make_reference_db(ctx, fa, k, l)
+    o_ref, o_reads = OracleDB(fa, 0, k, l), OracleDB(fq, 1, k, l)
+    o_hit, _ = o_reads.match(o_ref)
+    rng = np.random.default_rng(5)
+    n = o_reads.U
+    assert n > 5 * 2048 and (o_hit >= 0).sum() > 1000
+    src = rng.integers(0, 5, size=n)
+    src[src == 3] = 4                                  # source 3 sends nothing
+    src[:3] = [0, 1, 2]
+    order = np.concatenate([np.nonzero(src == g)[0] for g in range(5)])
+    off = np.concatenate([[0], np.cumsum([int((src == g).sum()) for g in range(5)])]).astype(np.uint64)
+    dev = torch.device("cuda", 0)
+    d_hi = torch.from_numpy(o_reads.keys[order].view(np.int64).copy()).to(dev)
+    d_lo = torch.from_numpy(o_reads.keys_lo[order].view(np.int64).copy()).to(dev)
+    d_hit = torch.full((n + 1,), -7, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    f = ctx.lib.kmg_match_keys_wide_dev
+    ctx.check(f(ctx.h, d_hi.data_ptr(), d_lo.data_ptr(), off.ctypes.data_as(C.c_void_p), 5, k, ref.h, d_hit.data_ptr()))
+    torch.cuda.ExternalStream(ctx.stream, device=dev).synchronize()
+    got = d_hit.cpu().numpy()
+    assert got[n] == -7 and np.array_equal(got[:n], o_hit[order])
+    one = np.array([0, n], np.uint64)
+    d_hi = torch.from_numpy(o_reads.keys.view(np.int64).copy()).to(dev)
+    d_lo = torch.from_numpy(o_reads.keys_lo.view(np.int64).copy()).to(dev)
+    d_hit.fill_(-7)
+    torch.cuda.synchronize()
+    ctx.check(f(ctx.h, d_hi.data_ptr(), d_lo.data_ptr(), one.ctypes.data_as(C.c_void_p), 1, k, ref.h, d_hit.data_ptr()))
+    torch.cuda.ExternalStream(ctx.stream, device=dev).synchronize()
+    assert np.array_equal(d_hit.cpu().numpy()[:n], o_hit)
+    bad = np.array([5, 0], np.uint64)
+    assert f(ctx.h, d_hi.data_ptr(), d_lo.data_ptr(), bad.ctypes.data_as(C.c_void_p), 1, k, ref.h, d_hit.data_ptr()) == _lib.KMG_EINVAL
+    assert f(ctx.h, d_hi.data_ptr(), d_lo.data_ptr(), one.ctypes.data_as(C.c_void_p), 1, k + 1 if k < 64 else 63, ref.h, d_hit.data_ptr()) == _lib.KMG_EINVAL
+    assert f(ctx.h, d_hi.data_ptr(), d_lo.data_ptr(), one.ctypes.data_as(C.c_void_p), 65, k, ref.h, d_hit.data_ptr()) == _lib.KMG_EINVAL
+    assert f(ctx.h, d_hi.data_ptr(), None, one.ctypes.data_as(C.c_void_p), 1, k, ref.h, d_hit.data_ptr()) == _lib.KMG_EINVAL
+    assert ctx.lib.kmg_match_keys_dev(ctx.h, d_hi.data_ptr(), one.ctypes.data_as(C.c_void_p), 1, k, ref.h, d_hit.data_ptr()) == _lib.KMG_EUNSUPPORTED
+    ref.close()
