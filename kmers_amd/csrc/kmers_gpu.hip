@@ -1206,13 +1206,13 @@ static int finish_variable(kmg_ctx *ctx, std::unique_ptr<kmg_db, void (*)(kmg_db
 // j-th smallest, equal ones in index order (both sorts are stable); his / los = the words in that order; flag[j] = j
 // starts a new k-mer, before[j] = heads before j; U = distinct k-mers, rbits = bits their ranks take.
 struct WideOrder {
-    PoolBuf ka, kb, i0, i1, flag, before, lens;      // lens: the lengths in k-mer order (k-mers of several lengths only)
+    PoolBuf ka, kb, kc, i0, i1, flag, before, lens;      // lens: the lengths in k-mer order (k-mers of several lengths only)
     const u64 *his = nullptr;
     u64 *los = nullptr;
     const u32 *order = nullptr;
     u64 U = 0;
     int rbits = 1;
-    explicit WideOrder(kmg_ctx *c) : ka(c), kb(c), i0(c), i1(c), flag(c), before(c), lens(c) {}
+    explicit WideOrder(kmg_ctx *c) : ka(c), kb(c), kc(c), i0(c), i1(c), flag(c), before(c), lens(c) {}
 };
 static int wide_order(kmg_ctx *ctx, const u64 *hi, const u64 *lo, u32 n, int k, WideOrder &w,
                       const uint8_t *len = nullptr /* k-mers of several lengths: (hi, lo, len) is their order */) {
@@ -1234,6 +1234,37 @@ static int wide_order(kmg_ctx *ctx, const u64 *hi, const u64 *lo, u32 n, int k, 
     hipLaunchKernelGGL(wide_iota_kernel, grid, blk, 0, ctx->stream, w.i0.as<u32>(), n);
     bool in1 = false;
     u32 *perm = w.i0.as<u32>(), *perm_other = w.i1.as<u32>();
+    bool ordered = false;
+    if (!len && lo_bits > 16) {
+        // one length (and second words of more than a digit or two: else their sort is cheap): by hi alone, then every run of equal first words by lo in place (wide_runs_kernel) -- unless a run
+        // is long (low-complexity input), which the two sorts below take
+        PoolBuf longrun(ctx);
+        KMG_ALLOC(longrun, 64);
+        KMG_HIP(hipMemsetAsync(longrun.p, 0, 4, ctx->stream));
+        KMG_HIP(hipMemcpyAsync(w.ka.p, hi, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        KMG_TRY(hybrid_sort_records<u32>(ctx, w.ka.as<u64>(), perm, w.kb.as<u64>(), perm_other, n, 0, none, table.as<u32>(), agg.as<u32>(),
+                                         seg.as<u32>(), whole_space_plan(p_hi), false, &in1, nullptr, false));
+        const u64 *his = in1 ? w.kb.as<u64>() : w.ka.as<u64>();
+        hipLaunchKernelGGL(wide_longrun_kernel, grid, blk, 0, ctx->stream, his, n, longrun.as<u32>());
+        u32 h_long = 0;
+        KMG_HIP(read_back(ctx, &h_long, longrun.p, 4));
+        if (!h_long) {
+            w.his = his;
+            u64 *gathered = in1 ? w.ka.as<u64>() : w.kb.as<u64>();
+            const u32 *order = in1 ? perm_other : perm;
+            u32 *order_out = in1 ? perm : perm_other;
+            KMG_ALLOC(w.kc, (size_t)n * 8);
+            hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, lo, order, n, gathered);
+            hipLaunchKernelGGL(wide_runs_kernel, dim3(div_up_u64(n, WR_TILE)), dim3(WR_BLOCK), 0, ctx->stream, w.his, (const u64 *)gathered, order, n, w.kc.as<u64>(), order_out);
+            w.los = w.kc.as<u64>();
+            w.order = order_out;
+            ordered = true;
+        } else {
+            hipLaunchKernelGGL(wide_iota_kernel, grid, blk, 0, ctx->stream, w.i0.as<u32>(), n);
+            in1 = false;
+        }
+    }
+    if (!ordered) {
     if (len) {
         hipLaunchKernelGGL(wide_lenkey_kernel, grid, blk, 0, ctx->stream, len, n, w.ka.as<u64>());
         KMG_TRY(hybrid_sort_records<u32>(ctx, w.ka.as<u64>(), perm, w.kb.as<u64>(), perm_other, n, 56, none, table.as<u32>(), agg.as<u32>(),
@@ -1251,6 +1282,7 @@ static int wide_order(kmg_ctx *ctx, const u64 *hi, const u64 *lo, u32 n, int k, 
     w.los = in1 ? w.ka.as<u64>() : w.kb.as<u64>();
     w.order = in1 ? perm_other : perm;
     hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, lo, w.order, n, w.los);
+    }
     if (len) {
         KMG_ALLOC(w.lens, (size_t)n + 64);
         hipLaunchKernelGGL(wide_gather8_kernel, grid, blk, 0, ctx->stream, len, w.order, n, w.lens.as<uint8_t>());

@@ -381,6 +381,48 @@ __global__ void wide_gather8_kernel(const uint8_t *__restrict__ src, const u32 *
     if (i < n) out[i] = src[idx[i]];
 }
 // the length as a sort key of its own (k-mers of several lengths: (value, length) is Sequence.compareTo's order)
+// k-mers of one length, ordered by their first words already (a stable sort: equal first words in record order): the
+// runs of equal first words are short in sequencing data (the reads that cover one place), so each run is put
+// in order by the second words where it lies -- stable, as a sort would be -- instead of a
+// whole sort by the second words ahead of the first (every entry counts its place in its run: the run's entries are a few
+// cache lines its neighbours read too).  wide_longrun_kernel says whether a run exceeds WO_RUN (low-complexity
+// input: then the two sorts are taken).
+#define WO_RUN 128
+__global__ void wide_longrun_kernel(const u64 *__restrict__ his, u32 n, u32 *__restrict__ flag) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= WO_RUN && j < n && his[j] == his[j - WO_RUN]) *flag = 1u;
+}
+#define WR_BLOCK 256
+#define WR_TILE 1024
+__global__ __launch_bounds__(WR_BLOCK) void wide_runs_kernel(const u64 *__restrict__ his, const u64 *__restrict__ los,
+                                                             const u32 *__restrict__ order, u32 n, u64 *__restrict__ los_out,
+                                                             u32 *__restrict__ order_out) {
+    // the tile's words and WO_RUN on either side (no run reaches further: wide_longrun_kernel) in LDS
+    __shared__ u64 l_h[WR_TILE + 2 * WO_RUN], l_l[WR_TILE + 2 * WO_RUN];
+    const long long base = (long long)blockIdx.x * WR_TILE - WO_RUN;
+    for (int t = threadIdx.x; t < WR_TILE + 2 * WO_RUN; t += WR_BLOCK) {
+        const long long g = base + t;
+        const bool in = g >= 0 && g < (long long)n;
+        l_h[t] = in ? his[g] : 0ull;
+        l_l[t] = in ? los[g] : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < WR_TILE / WR_BLOCK; r++) {
+        const int t = WO_RUN + r * WR_BLOCK + threadIdx.x;
+        const long long i = base + t;
+        if (i >= (long long)n) break;
+        const u64 h = l_h[t], l = l_l[t];
+        // its place in its run: behind the earlier entries that are not larger and the later ones that are smaller (stable)
+        int s = t, e = t + 1;
+        u32 before = 0;
+        while (base + s > 0 && l_h[s - 1] == h) { s--; before += l_l[s] <= l; }
+        while (base + e < (long long)n && l_h[e] == h) { before += l_l[e] < l; e++; }
+        const long long at = base + s + before;
+        los_out[at] = l;
+        order_out[at] = order[i];
+    }
+}
 __global__ void wide_lenkey_kernel(const uint8_t *__restrict__ len, u32 n, u64 *__restrict__ out) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (u64)len[i] << 56;

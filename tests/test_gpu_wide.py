@@ -986,3 +986,26 @@ def test_match_keys_in_runs(ctx, k):
     assert f(ctx.h, d_hi.data_ptr(), None, one.ctypes.data_as(C.c_void_p), 1, k, ref.h, d_hit.data_ptr()) == _lib.KMG_EINVAL
     assert ctx.lib.kmg_match_keys_dev(ctx.h, d_hi.data_ptr(), one.ctypes.data_as(C.c_void_p), 1, k, ref.h, d_hit.data_ptr()) == _lib.KMG_EUNSUPPORTED
     ref.close()
+
+
+@pytest.mark.parametrize("copies", [2, 127, 128, 129, 300])
+def test_runs_of_equal_first_words_around_the_fast_path_limit(ctx, copies):
+    """K-mers of one length of 41 bases and more are sorted by their first words and every run of equal first words put in
+    order by the second words where it lies (wide_runs_kernel) unless a run is longer than 128 (then: two sorts).  Reads
+    that share their first 32 bases and differ behind them, in descending order, `copies` of them: runs just below, at
+    and above the limit, against the oracle."""
+    import kmers_amd as km
+    from oracle.c_oracle import OracleDB
+    rng = np.random.default_rng(900 + copies)
+    k, l = 50, 4
+    head = "".join("ACGT"[i] for i in rng.integers(0, 4, size=32))
+    tails = sorted({"".join("ACGT"[i] for i in rng.integers(0, 4, size=24)) for _ in range(copies)}, reverse=True)
+    other = ["".join("ACGT"[i] for i in rng.integers(0, 4, size=90)) for _ in range(40)]
+    seqs = [head + t for t in tails] + other + [head + tails[0]] * 3          # (and equal k-mers: several values per k-mer)
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, q.encode(), b"I" * len(q)) for i, q in enumerate(seqs))
+    got, _ = km.make_read_db(ctx, fq, k, l)
+    _same_db(got, OracleDB(fq, 1, k, l))
+    fa = b"".join(b">%d\n%s\n" % (5 + i % 3, q.encode()) for i, q in enumerate(seqs))
+    ref = km.make_reference_db(ctx, fa, k, l)
+    _same_db(ref, OracleDB(fa, 0, k, l))
+    got.close(); ref.close()
