@@ -504,17 +504,28 @@ __global__ __launch_bounds__(WM_BLOCK) void wide_match_kernel(const u64 *__restr
     __shared__ u64 piece[2];
     const int tid = threadIdx.x;
     const u64 i0 = (u64)blockIdx.x * WM_TILE, i1 = min(n, i0 + (u64)WM_TILE);
-    if (tid == 0 || tid == 64) {
-        const bool upper = tid == 64;
+    if (tid < 128) {
+        // two waves find the piece, one bound each: 64 samples of the range a round (the ballot's count of samples still
+        // before the bound names the sixty-fourth that holds it) -- four or five dependent loads where a bisection takes 23
+        const bool upper = tid >= 64;
+        const int lane = tid & 63;
         const u64 kh = upper ? s_hi[i1 - 1] : s_hi[i0], kl = upper ? s_lo[i1 - 1] : s_lo[i0];
         u64 lo = 0, hi = R;
         while (lo < hi) {
-            const u64 mid = (lo + hi) >> 1;
-            const u64 mh = r_hi[mid], ml = r_lo[mid];
-            // lower bound: first reference k-mer >= key; upper bound: first one > key
-            if (upper ? !wide_less(kh, kl, mh, ml) : wide_less(mh, ml, kh, kl)) lo = mid + 1; else hi = mid;
+            const u64 step = (hi - lo) / 64 + 1;
+            const u64 pos = lo + (u64)lane * step;
+            bool before = false;
+            if (pos < hi) {
+                const u64 mh = r_hi[pos], ml = r_lo[pos];
+                // lower bound: first reference k-mer >= key; upper bound: first one > key
+                before = upper ? !wide_less(kh, kl, mh, ml) : wide_less(mh, ml, kh, kl);
+            }
+            const int cnt = __popcll(__ballot(before));
+            const u64 nhi = min(hi, lo + (u64)cnt * step);
+            lo = cnt ? lo + (u64)(cnt - 1) * step + 1 : lo;
+            hi = nhi;
         }
-        piece[upper ? 1 : 0] = lo;
+        if (lane == 0) piece[upper ? 1 : 0] = lo;
     }
     __syncthreads();
     const u64 p0 = piece[0], p1 = piece[1];
@@ -523,34 +534,59 @@ __global__ __launch_bounds__(WM_BLOCK) void wide_match_kernel(const u64 *__restr
     for (u32 j = tid; j < span; j += WM_BLOCK) { l_hi[j] = r_hi[p0 + j]; l_lo[j] = r_lo[p0 + j]; }
     __syncthreads();
     u32 found_n = 0;
+    // a thread's WM_ITEMS search k-mers are neighbours: the place of one bounds the next from below, which lies a step or
+    // two further on (an exponential search from there, then a bisection of the last stride).  All of them are loaded
+    // before the first is looked up (clamped, not guarded: guarded loads wait one by one).
+    u64 kh[WM_ITEMS], kl[WM_ITEMS];
+    long long res[WM_ITEMS];
 #pragma unroll
     for (int r = 0; r < WM_ITEMS; r++) {
-        const u64 i = i0 + (u64)r * WM_BLOCK + tid;
-        if (i >= i1) break;
-        const u64 h = s_hi[i], l = s_lo[i];
-        long long res = -1;
+        const u64 i = i0 + (u64)tid * WM_ITEMS + r;
+        const u64 c = i < i1 ? i : i1 - 1;
+        kh[r] = s_hi[c]; kl[r] = s_lo[c];
+        res[r] = -1;
+    }
+    u32 from = 0;
+    u64 gfrom = p0;
+#pragma unroll
+    for (int r = 0; r < WM_ITEMS; r++) {
+        const u64 h = kh[r], l = kl[r];
         if (in_lds) {
-            u32 a = 0, b = span;
+            u32 a = from, b = from, step = 1;
+            while (b < span && wide_less(l_hi[b], l_lo[b], h, l)) { a = b + 1; b += step; step <<= 1; }
+            b = min(b, span);
             while (a < b) {
                 const u32 mid = (a + b) >> 1;
                 if (wide_less(l_hi[mid], l_lo[mid], h, l)) a = mid + 1; else b = mid;
             }
-            if (a < span && l_hi[a] == h && l_lo[a] == l) res = (long long)(p0 + a);
+            if (a < span && l_hi[a] == h && l_lo[a] == l) res[r] = (long long)(p0 + a);
+            from = a;
         } else {
-            u64 a = p0, b = p1;
+            u64 a = gfrom, b = p1;
             while (a < b) {
                 const u64 mid = (a + b) >> 1;
                 if (wide_less(r_hi[mid], r_lo[mid], h, l)) a = mid + 1; else b = mid;
             }
-            if (a < p1 && r_hi[a] == h && r_lo[a] == l) res = (long long)a;
+            if (a < p1 && r_hi[a] == h && r_lo[a] == l) res[r] = (long long)a;
+            gfrom = a;
         }
-        hit[i] = res;
-        found_n += res >= 0;
     }
-    if (nhits) {
+#pragma unroll
+    for (int r = 0; r < WM_ITEMS; r++) {
+        const u64 i = i0 + (u64)tid * WM_ITEMS + r;
+        if (i < i1) { hit[i] = res[r]; found_n += res[r] >= 0; }
+    }
+    if (nhits) {          // (uniform) one addition a workgroup
+        __shared__ u32 l_found[WM_BLOCK / 64];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) found_n += __shfl_down(found_n, d, 64);
-        if ((tid & 63) == 0 && found_n) atomicAdd((unsigned long long *)nhits, (unsigned long long)found_n);
+        if ((tid & 63) == 0) l_found[tid >> 6] = found_n;
+        __syncthreads();
+        if (tid == 0) {
+            u32 total = 0;
+            for (int w = 0; w < WM_BLOCK / 64; w++) total += l_found[w];
+            if (total) atomicAdd((unsigned long long *)nhits, (unsigned long long)total);
+        }
     }
 }
 
