@@ -157,8 +157,12 @@ def main_wide():
         assert c_reads.encode_blocks()[0] == b"".join(reads[key] for key in range(4 ** l)) and c_reads.names == names, name
         hit, _ = c_reads.match(c_ref)
         assert c_reads.match_lines(c_ref, hit).decode().splitlines() == lines and len(lines) > 20, name
+        near1 = R.near_match_lines(reads, db, 1, False)              # Matcher -n 1 / -n 2 -j: the restated trie
+        near2j = R.near_match_lines(reads, db, 2, True)
+        assert len(near1) >= len(lines), name
         out = {
             "comment": "outputs of oracle/slow_ref.py (restatement of the reference), not of Kmers.jar; see make_golden.py",
+            "near_match_lines_n1": near1, "near_match_lines_n2_just": near2j,
             "k": k, "key_len": l, "fasta": fa.decode(), "fastq": fq.decode(),
             "ref_blocks": {str(key): ref[key].hex() for key in sorted(ref)},
             "read_blocks": {str(key): reads[key].hex() for key in sorted(reads)},
@@ -212,7 +216,9 @@ def main_wide_var():
 
 
 if __name__ == "__main__":
-    main()
-    main_var()
+    import sys
+    if "wide" not in sys.argv[1:]:
+        main()
+        main_var()
     main_wide()
     main_wide_var()

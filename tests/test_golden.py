@@ -210,6 +210,8 @@ def test_restatements_reproduce_wide_golden(path):
     assert lines == g["match_lines"] and R.taxa_counts(db) == g["taxa_counts"]
     collected = R.collect_by_read(lines)
     assert collected == g["collect_by_read"] and R.read_classifier(collected) == g["read_classifier"]
+    assert R.near_match_lines(reads, db, 1, False) == g["near_match_lines_n1"]          # Matcher -n 1 / -n 2 -j: the restated trie
+    assert R.near_match_lines(reads, db, 2, True) == g["near_match_lines_n2_just"]
     c_ref, c_reads = OracleDB(fa, 0, k, l), OracleDB(fq, 1, k, l)
     for c, want in ((c_ref, g["ref_blocks"]), (c_reads, g["read_blocks"])):
         blob, off = c.encode_blocks()
@@ -243,6 +245,9 @@ def test_gpu_reproduces_wide_golden(path):
     assert km.collect_by_read_blocks(reads, ref) == g["collect_by_read"]
     call2, seen = km.classify_reads(reads, ref, len(names), with_hits=True)
     assert km.read_call_blocks(call2, seen) == g["read_classifier"]
+    # inexact search on two words (kmg_match_near's walk + the per-k-mer host steps)
+    assert km.near_match_lines(reads, ref, 1, False) == g["near_match_lines_n1"]
+    assert km.near_match_lines(reads, ref, 2, True) == g["near_match_lines_n2_just"]
     for d in (ref, reads):
         d.close()
     ctx.close()
