@@ -1235,8 +1235,8 @@ static int wide_order(kmg_ctx *ctx, const u64 *hi, const u64 *lo, u32 n, int k, 
     bool in1 = false;
     u32 *perm = w.i0.as<u32>(), *perm_other = w.i1.as<u32>();
     bool ordered = false;
-    if (!len && lo_bits > 16) {
-        // one length (and second words of more than a digit or two: else their sort is cheap): by hi alone, then every run of equal first words by lo in place (wide_runs_kernel) -- unless a run
+    if (!len) {
+        // one length: by hi alone, then every run of equal first words by lo in place (wide_runs_kernel) -- unless a run
         // is long (low-complexity input), which the two sorts below take
         PoolBuf longrun(ctx);
         KMG_ALLOC(longrun, 64);

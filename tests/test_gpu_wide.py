@@ -988,18 +988,18 @@ def test_match_keys_in_runs(ctx, k):
     ref.close()
 
 
-@pytest.mark.parametrize("copies", [2, 127, 128, 129, 300])
-def test_runs_of_equal_first_words_around_the_fast_path_limit(ctx, copies):
-    """K-mers of one length of 41 bases and more are sorted by their first words and every run of equal first words put in
+@pytest.mark.parametrize("copies,k", [(2, 50), (127, 50), (128, 50), (129, 50), (300, 50), (128, 34), (129, 64)])
+def test_runs_of_equal_first_words_around_the_fast_path_limit(ctx, copies, k):
+    """K-mers of one length are sorted by their first words and every run of equal first words put in
     order by the second words where it lies (wide_runs_kernel) unless a run is longer than 128 (then: two sorts).  Reads
     that share their first 32 bases and differ behind them, in descending order, `copies` of them: runs just below, at
     and above the limit, against the oracle."""
     import kmers_amd as km
     from oracle.c_oracle import OracleDB
     rng = np.random.default_rng(900 + copies)
-    k, l = 50, 4
+    l = 4
     head = "".join("ACGT"[i] for i in rng.integers(0, 4, size=32))
-    tails = sorted({"".join("ACGT"[i] for i in rng.integers(0, 4, size=24)) for _ in range(copies)}, reverse=True)
+    tails = sorted({"".join("ACGT"[i] for i in rng.integers(0, 4, size=k - 26)) for _ in range(copies)}, reverse=True)
     other = ["".join("ACGT"[i] for i in rng.integers(0, 4, size=90)) for _ in range(40)]
     seqs = [head + t for t in tails] + other + [head + tails[0]] * 3          # (and equal k-mers: several values per k-mer)
     fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, q.encode(), b"I" * len(q)) for i, q in enumerate(seqs))
