@@ -1235,8 +1235,8 @@ static int wide_order(kmg_ctx *ctx, const u64 *hi, const u64 *lo, u32 n, int k, 
     bool in1 = false;
     u32 *perm = w.i0.as<u32>(), *perm_other = w.i1.as<u32>();
     bool ordered = false;
-    if (!len) {
-        // one length: by hi alone, then every run of equal first words by lo in place (wide_runs_kernel) -- unless a run
+    {
+        // by hi alone, then every run of equal first words by lo in place (wide_runs_kernel) -- unless a run
         // is long (low-complexity input), which the two sorts below take
         PoolBuf longrun(ctx);
         KMG_ALLOC(longrun, 64);
@@ -1255,7 +1255,19 @@ static int wide_order(kmg_ctx *ctx, const u64 *hi, const u64 *lo, u32 n, int k, 
             u32 *order_out = in1 ? perm : perm_other;
             KMG_ALLOC(w.kc, (size_t)n * 8);
             hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, lo, order, n, gathered);
-            hipLaunchKernelGGL(wide_runs_kernel, dim3(div_up_u64(n, WR_TILE)), dim3(WR_BLOCK), 0, ctx->stream, w.his, (const u64 *)gathered, order, n, w.kc.as<u64>(), order_out);
+            if (len) {
+                // several lengths: (hi, lo, length) is the order -- the lengths travel with the second words
+                PoolBuf lens_g(ctx);
+                KMG_ALLOC(lens_g, (size_t)n + 64);
+                KMG_ALLOC(w.lens, (size_t)n + 64);
+                hipLaunchKernelGGL(wide_gather8_kernel, grid, blk, 0, ctx->stream, len, order, n, lens_g.as<uint8_t>());
+                hipLaunchKernelGGL((wide_runs_kernel<true>), dim3(div_up_u64(n, WR_TILE)), dim3(WR_BLOCK), 0, ctx->stream, w.his,
+                                   (const u64 *)gathered, (const uint8_t *)lens_g.as<uint8_t>(), order, n, w.kc.as<u64>(),
+                                   w.lens.as<uint8_t>(), order_out);
+                KMG_HIP(hipGetLastError());          // (lens_g goes back to the pool in stream order)
+            } else
+                hipLaunchKernelGGL((wide_runs_kernel<false>), dim3(div_up_u64(n, WR_TILE)), dim3(WR_BLOCK), 0, ctx->stream, w.his,
+                                   (const u64 *)gathered, (const uint8_t *)nullptr, order, n, w.kc.as<u64>(), (uint8_t *)nullptr, order_out);
             w.los = w.kc.as<u64>();
             w.order = order_out;
             ordered = true;
@@ -1283,7 +1295,7 @@ static int wide_order(kmg_ctx *ctx, const u64 *hi, const u64 *lo, u32 n, int k, 
     w.order = in1 ? perm_other : perm;
     hipLaunchKernelGGL(wide_gather_kernel, grid, blk, 0, ctx->stream, lo, w.order, n, w.los);
     }
-    if (len) {
+    if (len && !ordered) {
         KMG_ALLOC(w.lens, (size_t)n + 64);
         hipLaunchKernelGGL(wide_gather8_kernel, grid, blk, 0, ctx->stream, len, w.order, n, w.lens.as<uint8_t>());
     }

@@ -394,17 +394,22 @@ __global__ void wide_longrun_kernel(const u64 *__restrict__ his, u32 n, u32 *__r
 }
 #define WR_BLOCK 256
 #define WR_TILE 1024
+// LENS: k-mers of several lengths -- inside a run the order is (second word, length), Sequence.compareTo's
+template <bool LENS>
 __global__ __launch_bounds__(WR_BLOCK) void wide_runs_kernel(const u64 *__restrict__ his, const u64 *__restrict__ los,
-                                                             const u32 *__restrict__ order, u32 n, u64 *__restrict__ los_out,
+                                                             const uint8_t *__restrict__ lens, const u32 *__restrict__ order, u32 n,
+                                                             u64 *__restrict__ los_out, uint8_t *__restrict__ lens_out,
                                                              u32 *__restrict__ order_out) {
     // the tile's words and WO_RUN on either side (no run reaches further: wide_longrun_kernel) in LDS
     __shared__ u64 l_h[WR_TILE + 2 * WO_RUN], l_l[WR_TILE + 2 * WO_RUN];
+    __shared__ uint8_t l_n[LENS ? WR_TILE + 2 * WO_RUN : 1];
     const long long base = (long long)blockIdx.x * WR_TILE - WO_RUN;
     for (int t = threadIdx.x; t < WR_TILE + 2 * WO_RUN; t += WR_BLOCK) {
         const long long g = base + t;
         const bool in = g >= 0 && g < (long long)n;
         l_h[t] = in ? his[g] : 0ull;
         l_l[t] = in ? los[g] : 0ull;
+        if (LENS) l_n[t] = in ? lens[g] : (uint8_t)0;
     }
     __syncthreads();
 #pragma unroll
@@ -413,13 +418,21 @@ __global__ __launch_bounds__(WR_BLOCK) void wide_runs_kernel(const u64 *__restri
         const long long i = base + t;
         if (i >= (long long)n) break;
         const u64 h = l_h[t], l = l_l[t];
+        const uint8_t ln = LENS ? l_n[t] : (uint8_t)0;
         // its place in its run: behind the earlier entries that are not larger and the later ones that are smaller (stable)
         int s = t, e = t + 1;
         u32 before = 0;
-        while (base + s > 0 && l_h[s - 1] == h) { s--; before += l_l[s] <= l; }
-        while (base + e < (long long)n && l_h[e] == h) { before += l_l[e] < l; e++; }
+        while (base + s > 0 && l_h[s - 1] == h) {
+            s--;
+            before += LENS ? (l_l[s] < l || (l_l[s] == l && l_n[s] <= ln)) : (l_l[s] <= l);
+        }
+        while (base + e < (long long)n && l_h[e] == h) {
+            before += LENS ? (l_l[e] < l || (l_l[e] == l && l_n[e] < ln)) : (l_l[e] < l);
+            e++;
+        }
         const long long at = base + s + before;
         los_out[at] = l;
+        if (LENS) lens_out[at] = ln;
         order_out[at] = order[i];
     }
 }
